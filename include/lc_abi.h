@@ -1,0 +1,143 @@
+/*
+ * lc_abi.h — C-ABI of libleetcuda_amd.so (MI355X / gfx950 only).
+ *
+ * This is the drop-in boundary for the two hot paths of xlite-dev/LeetCUDA:
+ *   kernels/hgemm      (fp16 GEMM,  C[M,N] = A[M,K] · B[K,N])
+ *   kernels/flash-attn (FlashAttention-2 forward, O = softmax(QKᵀ/√D)·V)
+ *
+ * The reference binds these paths as flat lists of free functions
+ * `void f(torch::Tensor ...)` registered by two pybind modules:
+ *   kernels/hgemm/pybind/hgemm.cc:124-182            (38 exports, module `toy_hgemm` / `hgemm_lib`)
+ *   kernels/flash-attn/pybind/flash_attn.cc:168-224  (26 exports + 3 optional, module `flash_attn_lib`)
+ * Every one of those names is reachable through `lc_hgemm_call` / `lc_attn_call`
+ * (dispatch by the reference's export name) and the typed entry points below.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types; never throws across the boundary
+ *   - all data pointers are DEVICE pointers (HBM); outputs are caller-allocated and written in place
+ *     (same ownership rule as the reference wrappers, e.g. hgemm_mma_stage.cu:2331-2412)
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream, which is what the
+ *     reference's `<<<grid, block, smem>>>` launches use)
+ *   - return value: LC_OK (0) or a negative lc_status code; launches are asynchronous, launch
+ *     failures surface as LC_ERR_LAUNCH, execution faults at the caller's next synchronize
+ *     (same as the reference: no sync after launch)
+ *   - there is NO CPU fallback anywhere behind this ABI.
+ */
+#ifndef LC_ABI_H_
+#define LC_ABI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LC_ABI_VERSION 1
+
+typedef enum lc_status {
+  LC_OK = 0,
+  LC_ERR_ARG = -1,      /* null pointer, unknown enum / entry name                                  */
+  LC_ERR_SHAPE = -2,    /* non-positive dims, misaligned pointer, size overflow                      */
+  LC_ERR_HEADDIM = -3,  /* head dim not supported by this attention family ("headdim not support!")  */
+  LC_ERR_LAUNCH = -4,   /* hipLaunchKernel / hipFuncSetAttribute failed                              */
+  LC_ERR_VENDOR = -5,   /* hipBLASLt comparator unavailable or failed                                */
+  LC_ERR_DEVICE = -6    /* no gfx950 device visible                                                  */
+} lc_status;
+
+/* B operand storage.  NN: B is [K,N] row-major.  TN: B is stored [N,K] row-major (== column-major
+ * [K,N]); the reference still presents it as a [K,N]-shaped tensor (kernels/hgemm/tools/utils.py:152-156)
+ * and takes the layout from the entry-point NAME, never from strides — so does this ABI. */
+typedef enum lc_layout { LC_LAYOUT_NN = 0, LC_LAYOUT_TN = 1 } lc_layout;
+
+/* HGEMM kernel families behind the ABI. */
+typedef enum lc_hgemm_variant {
+  LC_HGEMM_AUTO = 0,     /* best available for the shape                                              */
+  LC_HGEMM_MFMA256 = 1,  /* 256x256x64 WG tile, 8 wave64, LDS-DMA double buffer, one barrier / K-tile */
+  LC_HGEMM_MFMA256P = 2, /* same tile, phase-interleaved ping-pong schedule (counted vmcnt)           */
+  LC_HGEMM_GENERIC = 3   /* 64x64x32 edge-predicated MFMA kernel: any M,N,K                           */
+} lc_hgemm_variant;
+
+/* FlashAttention-2 forward families (resource policies of kernels/flash-attn/mma/basic/ .cu files). */
+typedef enum lc_attn_family {
+  LC_ATTN_SPLIT_Q = 0,     /* flash_attn_mma_split_q.cu:55      K,V tiles staged in LDS, Q in regs   */
+  LC_ATTN_SHARED_QKV = 1,  /* flash_attn_mma_share_qkv.cu:70    one LDS arena time-shared by K and V */
+  LC_ATTN_SHARED_KV = 2,   /* flash_attn_mma_share_kv.cu:70                                          */
+  LC_ATTN_TILING_QK = 3,   /* flash_attn_mma_tiling_qk.cu:76    Q,K streamed in d-slices             */
+  LC_ATTN_TILING_QKV = 4,  /* flash_attn_mma_tiling_qkv.cu:75   Q,K,V streamed in d-slices (FFPA)    */
+  LC_ATTN_SPLIT_KV = 5     /* flash_attn_mma_split_kv.cu:33                                          */
+} lc_attn_family;
+
+int lc_abi_version(void);
+const char* lc_status_string(int status);
+/* 0 when a gfx950 device is current, LC_ERR_DEVICE otherwise. Writes the CU count when non-NULL. */
+int lc_device_check(int* num_cus);
+
+/* ---- HGEMM ------------------------------------------------------------------------------------
+ * Replaces the host launchers + kernels of kernels/hgemm/mma/basic/hgemm_mma_stage.cu:644-1052,2284-2412
+ * (NN) and kernels/hgemm/mma/swizzle/hgemm_mma_stage_tn_swizzle_x4.cu:207,892 (TN).
+ * fp16 in, fp32 MFMA accumulate, fp16 out; no alpha/beta.
+ * `stages` (2..5 in the reference) selects the LDS pipeline depth hint; `swizzle_stride` is the
+ * reference's thread-block-swizzle N-panel width in columns (hgemm.py:198-208): <=1 means no panel
+ * rasterisation. Pointers must be 16-byte aligned; K must be a multiple of 8 for the MFMA kernels
+ * (otherwise LC_ERR_SHAPE). */
+int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int layout,
+                 int variant, int stages, int swizzle_stride, void* stream);
+
+/* Vendor comparator = the reference's cuBLAS entry points (kernels/hgemm/cublas/hgemm_cublas.cu:15-68,
+ * 196-229) on hipBLASLt: init/destroy of a process-global handle + NN/TN GEMM, fp32 compute. */
+int lc_vendor_init(void);
+int lc_vendor_destroy(void);
+int lc_hgemm_vendor_f16(const void* A, const void* B, void* C, int M, int N, int K, int layout,
+                        void* stream);
+
+/* Dispatch by the reference's export name (hgemm.cc:126-181). 3-argument entries ignore
+ * stages/swizzle/swizzle_stride. `init_cublas_handle` / `destroy_cublas_handle` take no tensors
+ * (pass NULLs and zeros). */
+int lc_hgemm_call(const char* entry, const void* A, const void* B, void* C, int M, int N, int K,
+                  int stages, int swizzle, int swizzle_stride, void* stream);
+int lc_hgemm_entry_count(void);
+const char* lc_hgemm_entry_name(int index);
+/* layout (lc_layout), number of reference arguments (0, 3 or 6); returns LC_ERR_ARG if unknown. */
+int lc_hgemm_entry_info(const char* entry, int* layout, int* nargs);
+
+/* ---- FlashAttention-2 forward -------------------------------------------------------------------
+ * Replaces kernels/flash-attn/mma/basic/flash_attn_mma_split_q.cu:55,702,769,
+ * flash_attn_mma_share_qkv.cu:70,772,872, flash_attn_mma_tiling_qkv.cu:75,800,881 and siblings.
+ * Q,K,O: [B,H,N,D] fp16 contiguous.  V: [B,H,N,D], or [B,H,D,N] when v_transposed != 0
+ * (the reference's *_swizzle_qkv share_kv/share_qkv/tiling_qk entries, flash_attn_mma.py:441-442).
+ * Non-causal, scale = 1/sqrt(D), no dropout / mask / LSE output.  fp32 softmax, fp32 MFMA accumulate
+ * (acc_f32 is accepted for signature parity; CDNA4 MFMA has no fp16-accumulate form).
+ * N must be a multiple of 64; D in {32, 64, 96, 128, 256, 512}. */
+int lc_attn_fwd_f16(const void* Q, const void* K, const void* V, void* O, int B, int H, int N, int D,
+                    int v_transposed, int family, int acc_f32, int stages, void* stream);
+
+/* Dispatch by the reference's export name (flash_attn.cc:170-223). */
+int lc_attn_call(const char* entry, const void* Q, const void* K, const void* V, void* O, int B, int H,
+                 int N, int D, int stages, void* stream);
+int lc_attn_entry_count(void);
+const char* lc_attn_entry_name(int index);
+/* family (lc_attn_family), v_transposed, acc_f32, max head dim for stages>1 / stages<=1 and number of
+ * reference arguments (4 for flash_attn_cute, else 5). */
+int lc_attn_entry_info(const char* entry, int* family, int* v_transposed, int* acc_f32,
+                       int* max_d_stage2, int* max_d_stage1, int* nargs);
+
+/* ---- measurement helpers (used by bench.py; HIP events on the launch stream) --------------------
+ * Launch `iters` back-to-back calls between two hipEvents recorded on `stream`; returns average
+ * milliseconds per launch in *ms_per_launch. */
+int lc_hgemm_time(const void* A, const void* B, void* C, int M, int N, int K, int layout, int variant,
+                  int stages, int swizzle_stride, int warmup, int iters, void* stream,
+                  float* ms_per_launch);
+int lc_attn_time(const void* Q, const void* K, const void* V, void* O, int B, int H, int N, int D,
+                 int v_transposed, int family, int stages, int warmup, int iters, void* stream,
+                 float* ms_per_launch);
+
+/* ---- hardware layout probes (tests only; tiny kernels that dump MFMA / LDS-transpose lane maps) -- */
+int lc_probe_mfma16(const void* a16x32, const void* b16x32, float* d16x16, void* stream);
+int lc_probe_mfma32(const void* a32x16, const void* b32x16, float* d32x32, void* stream);
+int lc_probe_tr16(const void* src_64x4_u16, void* dst_64x4_u16, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LC_ABI_H_ */

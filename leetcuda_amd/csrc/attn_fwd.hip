@@ -1,0 +1,232 @@
+// attn_fwd.hip — FlashAttention-2 forward for gfx950 (fp16 in/out, fp32 softmax, fp32 MFMA accumulate).
+//
+// Replaces (from-scratch CDNA4 design) the reference's split-Q forward kernels:
+//   kernels/flash-attn/mma/basic/flash_attn_mma_split_q.cu:55-699      (split_q)
+//   kernels/flash-attn/mma/basic/flash_attn_mma_share_qkv.cu:46-769    (shared_qkv)
+// Semantics (same as the reference): O = softmax(Q Kᵀ / sqrt(D)) V per (batch, head); non-causal;
+// Q,K,V,O [B,H,N,D] contiguous (V optionally [B,H,D,N]); online softmax over KV tiles of 64.
+//
+// MI355X design, per workgroup of NW wave64 (NW*32 query rows), one wave = 32 query rows:
+//   * "swapped" products: Sᵀ = K·Qᵀ and Oᵀ = Vᵀ·Pᵀ with v_mfma_f32_32x32x16_f16, so every lane owns ONE
+//     query row (q = lane & 31): row max / row sum / rescale are lane-local, the only cross-lane op is
+//     one exchange with lane ^ 32 (the reference needs width-4 shuffles per mma quad, utils.h:152-168).
+//   * the C-layout of Sᵀ (lane half `hi` holds kv 4hi+{0..3}, 8+4hi+{0..3}, ...) is used directly as the
+//     k-slot assignment of the Pᵀ operand; the Vᵀ operand is fetched with ds_read_b64_tr_b16 on the same
+//     kv rows, so P never moves between lanes (MFMA contracts over (half, slot) pairs symmetrically).
+//   * Q lives in registers for the whole kernel; K and V tiles are register-staged into a 2-slot LDS
+//     ring (global loads for tile t+1 issued before the math of tile t, LDS writes after it), padded row
+//     strides: K rows +16 B (conflict-free ds_read_b128), V rows so that stride % 256 == 64 (the 4
+//     rows of a tr-read half-wave land on disjoint bank quarters). One barrier per KV tile.
+#pragma once
+#include "lc_common.h"
+
+namespace lc {
+
+constexpr int KVB = 64;  // kv rows per tile
+
+template <int D>
+struct AttnCfg {
+  static constexpr int CH = D / 8;                      // 16-byte chunks per row
+  static constexpr int KSTRIDE = D * 2 + 16;            // bytes
+  static constexpr int VSTRIDE = (D == 32) ? 64 : ((D * 2) % 256 == 0 ? D * 2 + 64 : (D == 64 ? 192 : 320));
+  static constexpr int VT_STRIDE = KVB * 2 + 16;        // Vᵀ tile rows: [D][64 kv] (+16 B pad)
+  static constexpr int KBYTES = KVB * KSTRIDE;
+  static constexpr int VBYTES = KVB * VSTRIDE;
+  static constexpr int VTBYTES = D * VT_STRIDE;
+};
+
+template <int D, bool VT>
+constexpr int attn_lds_bytes() {
+  return 2 * (AttnCfg<D>::KBYTES + (VT ? AttnCfg<D>::VTBYTES : AttnCfg<D>::VBYTES));
+}
+
+template <int D, int NW, bool VT>
+__global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
+    const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
+    half_t* __restrict__ O, int N, float sl2 /* (1/sqrt(D)) * log2(e) */) {
+  using C = AttnCfg<D>;
+  constexpr int NT = NW * 64;
+  constexpr int DT = D / 32;   // 32-wide d tiles of Oᵀ
+  constexpr int DS = D / 16;   // k-steps of the QKᵀ contraction
+  constexpr int VB = VT ? C::VTBYTES : C::VBYTES;
+  constexpr int SLOT = C::KBYTES + VB;
+  constexpr int K_CHUNKS = KVB * C::CH;
+  constexpr int V_CHUNKS = VT ? D * 8 : KVB * C::CH;
+  constexpr int KL = (K_CHUNKS + NT - 1) / NT;
+  constexpr int VL = (V_CHUNKS + NT - 1) / NT;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = wave_id();
+  const int hi = lane >> 5;
+  const int l32 = lane & 31;
+
+  const size_t bh = blockIdx.y;
+  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+  const half_t* Qb = Q + bh * (size_t)N * D;
+  const half_t* Kb = K + bh * (size_t)N * D;
+  const half_t* Vb = V + bh * (size_t)N * D;
+  half_t* Ob = O + bh * (size_t)N * D;
+
+  // ---- Q fragments (B operand of Sᵀ = K·Qᵀ): lane holds Q[q0 + l32][16*s + 8*hi .. +8]
+  half8_t qf[DS];
+#pragma unroll
+  for (int s = 0; s < DS; ++s) {
+    qf[s] = *(const half8_t*)(Qb + (size_t)(q0 + l32) * D + 16 * s + 8 * hi);
+  }
+
+  // ---- register staging of one K/V tile
+  u32x4_t kst[KL], vst[VL];
+  auto load_tile = [&](int t) {
+    const half_t* kp = Kb + (size_t)t * KVB * D;
+#pragma unroll
+    for (int j = 0; j < KL; ++j) {
+      const int idx = tid + j * NT;
+      if (K_CHUNKS % NT == 0 || idx < K_CHUNKS) kst[j] = *(const u32x4_t*)(kp + (size_t)idx * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < VL; ++j) {
+      const int idx = tid + j * NT;
+      if (V_CHUNKS % NT == 0 || idx < V_CHUNKS) {
+        if constexpr (!VT) {
+          vst[j] = *(const u32x4_t*)(Vb + (size_t)t * KVB * D + (size_t)idx * 8);
+        } else {
+          vst[j] = *(const u32x4_t*)(Vb + (size_t)(idx >> 3) * N + (size_t)t * KVB + (idx & 7) * 8);
+        }
+      }
+    }
+  };
+  auto store_tile = [&](char* slot) {
+#pragma unroll
+    for (int j = 0; j < KL; ++j) {
+      const int idx = tid + j * NT;
+      if (K_CHUNKS % NT == 0 || idx < K_CHUNKS) {
+        const int row = idx / C::CH, c = idx % C::CH;
+        *(u32x4_t*)(slot + row * C::KSTRIDE + c * 16) = kst[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VL; ++j) {
+      const int idx = tid + j * NT;
+      if (V_CHUNKS % NT == 0 || idx < V_CHUNKS) {
+        if constexpr (!VT) {
+          const int row = idx / C::CH, c = idx % C::CH;
+          *(u32x4_t*)(slot + C::KBYTES + row * C::VSTRIDE + c * 16) = vst[j];
+        } else {
+          *(u32x4_t*)(slot + C::KBYTES + (idx >> 3) * C::VT_STRIDE + (idx & 7) * 16) = vst[j];
+        }
+      }
+    }
+  };
+
+  // ---- lane-dependent LDS read offsets
+  const int k_rd = l32 * C::KSTRIDE + hi * 16;  // + t*32*KSTRIDE + s*32
+  int v_rd;                                     // V: + (32t+16u)*VSTRIDE [+8*VSTRIDE] + dt*64
+  if constexpr (!VT) {
+    const int i = lane & 15, gi = (lane >> 4) & 1;
+    v_rd = C::KBYTES + (4 * hi + (i >> 2)) * C::VSTRIDE + (16 * gi + 4 * (i & 3)) * 2;
+  } else {
+    v_rd = C::KBYTES + l32 * C::VT_STRIDE + (4 * hi) * 2;  // + dt*32*VT_STRIDE + (32t+16u)*2 [+16]
+  }
+
+  f32x16_t o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int T = N / KVB;
+  load_tile(0);
+  store_tile(smem);
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    char* cur = smem + (t & 1) * SLOT;
+    if (t + 1 < T) load_tile(t + 1);
+
+    // ---- Sᵀ = K·Qᵀ : two 32x32 tiles (kv 0..31, 32..63)
+    f32x16_t s[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[tt][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < DS; ++ks) {
+        const half8_t kf = *(const half8_t*)(cur + k_rd + tt * 32 * C::KSTRIDE + ks * 32);
+        s[tt] = mfma32(kf, qf[ks], s[tt]);
+      }
+    }
+
+    // ---- online softmax (log2 domain): lane owns query row q = l32, kv columns split with lane^32
+    float mx = s[0][0];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[tt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx * sl2);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    half8_t pf[2][2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[tt][8 * u + j], sl2, -m_new));
+          psum += p;
+          pf[tt][u][j] = (half_t)p;
+        }
+      }
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+    // ---- Oᵀ += Vᵀ·Pᵀ
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          half8_t vf;
+          if constexpr (!VT) {
+            const char* p = cur + v_rd + (32 * tt + 16 * u) * C::VSTRIDE + dt * 64;
+            vf = cat4(lds_tr16(p), lds_tr16(p + 8 * C::VSTRIDE));
+          } else {
+            const char* p = cur + v_rd + dt * 32 * C::VT_STRIDE + (32 * tt + 16 * u) * 2;
+            vf = cat4(*(const half4_t*)p, *(const half4_t*)(p + 16));
+          }
+          o[dt] = mfma32(vf, pf[tt][u], o[dt]);
+        }
+      }
+    }
+
+    if (t + 1 < T) store_tile(smem + ((t & 1) ^ 1) * SLOT);
+    __syncthreads();
+  }
+
+  // ---- epilogue: O = Oᵀ / l ; lane holds row q, 4 consecutive d per register quad
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  half_t* orow = Ob + (size_t)(q0 + l32) * D;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      half4_t h;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) h[j] = (half_t)(o[dt][4 * rq + j] * inv);
+      *(half4_t*)(orow + 32 * dt + 8 * rq + 4 * hi) = h;
+    }
+  }
+}
+
+}  // namespace lc

@@ -1,0 +1,250 @@
+// hgemm_pingpong.hip — fp16 GEMM for gfx950, 256x256x64 tile, 8 wave64, phase-interleaved
+// "ping-pong" schedule: the two waves that share a SIMD alternate between an MFMA cluster and a
+// load section (LDS fragment reads + LDS-DMA issue), separated by raw s_barriers; global->LDS DMA
+// stays in flight across barriers behind COUNTED s_waitcnt vmcnt(8) (never 0 inside the K loop).
+//
+// Same contract and LDS swizzles as hgemm_mfma256.hip (reference: kernels/hgemm/mma/basic/
+// hgemm_mma_stage.cu:644-1052 NN, kernels/hgemm/mma/swizzle/hgemm_mma_stage_tn_swizzle_x4.cu:207 TN),
+// v_mfma_f32_32x32x16_f16, swapped operands (accumulator = Cᵀ fragments).
+//
+// Wave (wr, wc) = (wave>>2, wave&3) owns C rows [128wr,+128) x cols [64wc,+64) of the tile as
+// 4 (mt) x 2 (nt) 32x32 accumulators. A K tile (64) is processed in 4 phases of 8 MFMAs = one 64x32
+// quadrant each:   P0: A-half0 x B-half0   P1: A-half0 x B-half1   P2: A-half1 x B-half1   P3: A-half1 x B-half0
+// fragment reads:  P0: A0 (8 b128) + B0 (4)   P1: B1 (4)   P2: A1 (8)   P3: none (B0 stays in registers).
+// "half h" of A = rows with ((row>>6)&1)==h, of B = cols with ((col>>5)&1)==h: 16 KiB = 16 DMA pieces,
+// 2 per wave, so each phase issues exactly 2 global_load_lds per wave:
+//       P0: B1(kt+1)   P1: A1(kt+1)   P2: B0(kt+2)   P3: A0(kt+2)        (tile t lives in ring slot t&1)
+// Hazards (j = global phase index, group-1 waves run one barrier behind group-0):
+//   RAW  a half is read in phase j only after every wave executed vmcnt(8) at the end of phase j-1 and a
+//        barrier: exactly 4 younger issue groups (8 loads) may still be in flight at each of those waits.
+//   WAR  a half last read in phase j is re-staged in phase >= j+2 (B0/A0: read P0, restaged P2/P3;
+//        B1: read P1, restaged next P0; A1: read P2, restaged next P1).
+// Tail: issues past the last K tile re-load tile KT-1 into a dead slot (keeps the vmcnt counts exact).
+#pragma once
+#include "hgemm_mfma256.hip"
+
+namespace lc {
+
+constexpr int HALF_BYTES = TILE_BYTES / 2;  // 16 KiB
+
+#define LC_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <bool B_KN>
+struct PPSrc {
+  const half_t* a[2][2];  // [half][piece]
+  const half_t* b[2][2];
+  int a_lds[2][2];        // LDS byte offset of the piece inside a slot
+  int b_lds[2][2];
+};
+
+template <bool B_KN>
+LC_DEVINL void pp_src_init(PPSrc<B_KN>& s, const half_t* A, const half_t* B, int m0, int n0, int N,
+                           int K, int wave, int lane) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = wave * 2 + i;  // 0..15: this wave's piece inside the half
+      {  // A: 8-row blocks; half h of group g = blocks 16g + 8h + j
+        const int blk = 16 * (q >> 3) + 8 * h + (q & 7);
+        const int row = blk * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        s.a[h][i] = A + (size_t)(m0 + row) * K + c * 8;
+        s.a_lds[h][i] = blk * 1024;
+      }
+      if constexpr (!B_KN) {  // B stored [N][K]: half h of wave-column wc = blocks 8wc + 4h + j
+        const int blk = 8 * (q >> 2) + 4 * h + (q & 3);
+        const int row = blk * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        s.b[h][i] = B + (size_t)(n0 + row) * K + c * 8;
+        s.b_lds[h][i] = TILE_BYTES + blk * 1024;
+      } else {  // B stored [K][N]: sub-image h = [64 k][128 n'] (256 B rows), piece = 4 k rows
+        const int k = q * 4 + (lane >> 4);
+        const int pp = lane & 15;
+        const int pair = (pp >> 1) ^ ((k & 3) << 1);
+        const int nc = pair * 2 + (pp & 1);  // 16-B chunk index inside the sub-image row
+        const int n = 64 * (nc >> 2) + 32 * h + (nc & 3) * 8;
+        s.b[h][i] = B + (size_t)k * N + n0 + n;
+        s.b_lds[h][i] = TILE_BYTES + h * HALF_BYTES + q * 1024;
+      }
+    }
+  }
+}
+
+template <bool B_KN>
+struct PPFrag {
+  int a0;  // A: row (wr*128 + l32), chunk (hi ^ swz); + mt*4096, ^ ks*32
+  int b0;  // TN B: row (wc*64 + l32); + nh*4096, ^ ks*32 ; NN B: tr base; + nh*16384 + ks*4096 (+1024)
+};
+
+template <bool B_KN>
+LC_DEVINL void pp_frag_init(PPFrag<B_KN>& f, int wr, int wc, int lane) {
+  const int l32 = lane & 31, hi = lane >> 5;
+  const int swz = (lane >> 1) & 7;
+  f.a0 = (wr * 128 + l32) * 128 + ((hi ^ swz) * 16);
+  if constexpr (!B_KN) {
+    f.b0 = TILE_BYTES + (wc * 64 + l32) * 128 + ((hi ^ swz) * 16);
+  } else {
+    const int i = lane & 15, gi = (lane >> 4) & 1;
+    const int k = 8 * hi + (i >> 2);
+    f.b0 = TILE_BYTES + k * 256 + (((2 * wc + gi) ^ ((i >> 2) << 1)) * 32) + (i & 3) * 8;
+  }
+}
+
+template <bool B_KN>
+LC_DEVINL void pp_read_a(const char* slot, const PPFrag<B_KN>& f, int mh, half8_t (&af)[2][4]) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      af[m][ks] = *(const half8_t*)(slot + ((f.a0 ^ (ks * 32)) + (mh * 2 + m) * 4096));
+}
+
+template <bool B_KN>
+LC_DEVINL void pp_read_b(const char* slot, const PPFrag<B_KN>& f, int nh, half8_t (&bf)[4]) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    if constexpr (!B_KN) {
+      bf[ks] = *(const half8_t*)(slot + ((f.b0 ^ (ks * 32)) + nh * 4096));
+    } else {
+      const char* p = slot + f.b0 + nh * HALF_BYTES + ks * 4096;
+      bf[ks] = cat4(lds_tr16(p), lds_tr16(p + 1024));
+    }
+  }
+}
+
+LC_DEVINL void pp_mfma(f32x16_t (&acc)[4][2], int mh, int nh, const half8_t (&af)[2][4],
+                       const half8_t (&bf)[4]) {
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[mh * 2 + m][nh] = mfma32(bf[ks], af[m][ks], acc[mh * 2 + m][nh]);
+  __builtin_amdgcn_s_setprio(0);
+}
+
+LC_DEVINL void pp_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Epilogue for the 32x32 swapped-accumulator layout: lane holds C[m = l32][n = 8*(r>>2)+4*hi+(r&3)].
+LC_DEVINL void pp_epilogue(char* smem, f32x16_t (&acc)[4][2], half_t* C, int N, int m0, int n0,
+                           int wave, int wr, int wc, int lane) {
+  char* stg = smem + wave * (64 * EPI_STRIDE);
+  const int l32 = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          half4_t h;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) h[j] = (half_t)acc[pass * 2 + m][nt][4 * rq + j];
+          *(half4_t*)(stg + (m * 32 + l32) * EPI_STRIDE + (nt * 32 + 8 * rq + 4 * hi) * 2) = h;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + (lane >> 3);
+      const u32x4_t v = *(const u32x4_t*)(stg + row * EPI_STRIDE + (lane & 7) * 16);
+      half_t* dst = C + (size_t)(m0 + wr * 128 + pass * 64 + row) * N + n0 + wc * 64 + (lane & 7) * 8;
+      *(u32x4_t*)dst = v;
+    }
+  }
+}
+
+template <bool B_KN>
+__global__ __launch_bounds__(512, 2) void hgemm_pingpong_kernel(const half_t* __restrict__ A,
+                                                                const half_t* __restrict__ B,
+                                                                half_t* __restrict__ C, int M, int N,
+                                                                int K, int tiles_m, int tiles_n,
+                                                                int panel_w) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const TileCoord tc = raster(id, tiles_m, tiles_n, panel_w);
+  const int m0 = tc.tm * BM, n0 = tc.tn * BN;
+
+  PPSrc<B_KN> src;
+  pp_src_init<B_KN>(src, A, B, m0, n0, N, K, wave, lane);
+  PPFrag<B_KN> fr;
+  pp_frag_init<B_KN>(fr, wr, wc, lane);
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int KT = K / BK;
+  const size_t bstep = B_KN ? (size_t)BK * N : (size_t)BK;
+  // issue half `h` of operand A / B of K tile t (clamped) into ring slot t&1
+  auto issue_a = [&](int h, int t) {
+    const int te = t < KT ? t : KT - 1;
+    char* slot = smem + (t & 1) * SLOT_BYTES;
+    glds16(src.a[h][0] + (size_t)te * BK, slot + src.a_lds[h][0]);
+    glds16(src.a[h][1] + (size_t)te * BK, slot + src.a_lds[h][1]);
+  };
+  auto issue_b = [&](int h, int t) {
+    const int te = t < KT ? t : KT - 1;
+    char* slot = smem + (t & 1) * SLOT_BYTES;
+    glds16(src.b[h][0] + (size_t)te * bstep, slot + src.b_lds[h][0]);
+    glds16(src.b[h][1] + (size_t)te * bstep, slot + src.b_lds[h][1]);
+  };
+
+  // prologue: B0(0) A0(0) B1(0) A1(0) B0(1) A0(1); A0(0), B0(0) must have landed
+  issue_b(0, 0); issue_a(0, 0); issue_b(1, 0); issue_a(1, 0); issue_b(0, 1); issue_a(0, 1);
+  LC_VMCNT(8);
+  pp_barrier();
+  if (wr == 1) pp_barrier();  // group 1 runs one barrier behind group 0 (wave-uniform branch)
+
+  half8_t af[2][4], b0f[4], b1f[4];
+  for (int kt = 0; kt < KT; ++kt) {
+    const char* cur = smem + (kt & 1) * SLOT_BYTES;
+    // ---- phase 0
+    pp_read_b<B_KN>(cur, fr, 0, b0f);
+    pp_read_a<B_KN>(cur, fr, 0, af);
+    issue_b(1, kt + 1);
+    LC_VMCNT(8);
+    pp_barrier();
+    pp_mfma(acc, 0, 0, af, b0f);
+    pp_barrier();
+    // ---- phase 1
+    pp_read_b<B_KN>(cur, fr, 1, b1f);
+    issue_a(1, kt + 1);
+    LC_VMCNT(8);
+    pp_barrier();
+    pp_mfma(acc, 0, 1, af, b1f);
+    pp_barrier();
+    // ---- phase 2
+    pp_read_a<B_KN>(cur, fr, 1, af);
+    issue_b(0, kt + 2);
+    pp_barrier();
+    pp_mfma(acc, 1, 1, af, b1f);
+    pp_barrier();
+    // ---- phase 3 (no fragment reads: A1 and B0 are in registers)
+    issue_a(0, kt + 2);
+    LC_VMCNT(8);
+    pp_barrier();
+    pp_mfma(acc, 1, 0, af, b0f);
+    pp_barrier();
+  }
+  if (wr == 0) pp_barrier();
+  LC_VMCNT(0);
+  pp_epilogue(smem, acc, C, N, m0, n0, wave, wr, wc, lane);
+}
+
+}  // namespace lc

@@ -1,0 +1,414 @@
+// lc_abi.hip — the C-ABI of libleetcuda_amd.so (declared in include/lc_abi.h): argument checks,
+// kernel selection, launch geometry, the reference entry-name tables and HIP-event timing helpers.
+// Host side of the reference's L2 layer (the `void f(torch::Tensor...)` wrappers at the tail of every
+// reference .cu, e.g. kernels/hgemm/mma/basic/hgemm_mma_stage.cu:2331-2412 and
+// kernels/flash-attn/mma/basic/flash_attn_mma_split_q.cu:701-815) re-expressed on raw pointers.
+#include "../../include/lc_abi.h"
+
+#include <math.h>
+#include <string.h>
+
+#include "attn_fwd.hip"
+#include "hgemm_generic.hip"
+#include "hgemm_mfma256.hip"
+#include "hgemm_pingpong.hip"
+#include "probe.hip"
+
+using namespace lc;
+
+namespace {
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_launch() { return hipGetLastError() == hipSuccess ? LC_OK : LC_ERR_LAUNCH; }
+
+template <typename KernelT>
+int set_dyn_lds(KernelT kernel, int bytes) {
+  // re-issued on every call like the reference's cudaFuncSetAttribute (hgemm_mma_stage.cu:2284); cheap.
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
+             ? LC_OK
+             : LC_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
+// reference entry tables
+struct HgemmEntry {
+  const char* name;
+  int layout;   // lc_layout
+  int nargs;    // 0, 3 or 6
+  int variant;  // lc_hgemm_variant, -1 = vendor, -2 = handle init, -3 = handle destroy
+};
+
+#define NN LC_LAYOUT_NN
+#define TN LC_LAYOUT_TN
+// kernels/hgemm/pybind/hgemm.cc:126-181, in the reference's registration order.
+const HgemmEntry kHgemmEntries[] = {
+    {"hgemm_naive_f16", NN, 3, LC_HGEMM_GENERIC},
+    {"hgemm_sliced_k_f16", NN, 3, LC_HGEMM_GENERIC},
+    {"hgemm_t_8x8_sliced_k_f16x4", NN, 3, LC_HGEMM_GENERIC},
+    {"hgemm_t_8x8_sliced_k_f16x4_pack", NN, 3, LC_HGEMM_GENERIC},
+    {"hgemm_t_8x8_sliced_k_f16x4_bcf", NN, 3, LC_HGEMM_GENERIC},
+    {"hgemm_t_8x8_sliced_k_f16x4_pack_bcf", NN, 3, LC_HGEMM_GENERIC},
+    {"hgemm_t_8x8_sliced_k_f16x8_pack_bcf", NN, 3, LC_HGEMM_GENERIC},
+    {"hgemm_t_8x8_sliced_k_f16x8_pack_bcf_dbuf", NN, 3, LC_HGEMM_GENERIC},
+    {"hgemm_t_8x8_sliced_k16_f16x8_pack_dbuf", NN, 3, LC_HGEMM_GENERIC},
+    {"hgemm_t_8x8_sliced_k16_f16x8_pack_dbuf_async", NN, 3, LC_HGEMM_GENERIC},
+    {"hgemm_t_8x8_sliced_k32_f16x8_pack_dbuf", NN, 3, LC_HGEMM_GENERIC},
+    {"hgemm_t_8x8_sliced_k32_f16x8_pack_dbuf_async", NN, 3, LC_HGEMM_GENERIC},
+    {"hgemm_t_16x8_sliced_k32_f16x8_pack_dbuf", NN, 3, LC_HGEMM_GENERIC},
+    {"hgemm_t_16x8_sliced_k32_f16x8_pack_dbuf_async", NN, 3, LC_HGEMM_GENERIC},
+    {"init_cublas_handle", NN, 0, -2},
+    {"destroy_cublas_handle", NN, 0, -3},
+    {"hgemm_cublas_tensor_op_nn", NN, 3, -1},
+    {"hgemm_cublas_tensor_op_tn", TN, 3, -1},
+    {"hgemm_wmma_m16n16k16_naive", NN, 3, LC_HGEMM_GENERIC},
+    {"hgemm_wmma_m16n16k16_mma4x2", NN, 3, LC_HGEMM_GENERIC},
+    {"hgemm_wmma_m16n16k16_mma4x2_warp2x4", NN, 3, LC_HGEMM_MFMA256},
+    {"hgemm_wmma_m16n16k16_mma4x2_warp2x4_dbuf_async", NN, 3, LC_HGEMM_MFMA256},
+    {"hgemm_wmma_m32n8k16_mma2x4_warp2x4_dbuf_async", NN, 3, LC_HGEMM_MFMA256},
+    {"hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages", NN, 6, LC_HGEMM_MFMA256},
+    {"hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages_dsmem", NN, 6, LC_HGEMM_MFMA256},
+    {"hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem", NN, 6, LC_HGEMM_AUTO},
+    {"hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", NN, 6, LC_HGEMM_AUTO},
+    {"hgemm_mma_m16n8k16_naive", NN, 3, LC_HGEMM_GENERIC},
+    {"hgemm_mma_m16n8k16_mma2x4_warp4x4", NN, 3, LC_HGEMM_MFMA256},
+    {"hgemm_mma_m16n8k16_mma2x4_warp4x4_stages", NN, 6, LC_HGEMM_MFMA256},
+    {"hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem", NN, 6, LC_HGEMM_MFMA256},
+    {"hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", NN, 6, LC_HGEMM_AUTO},
+    {"hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_x4", NN, 6, LC_HGEMM_AUTO},
+    {"hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_rr", NN, 6, LC_HGEMM_AUTO},
+    {"hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_swizzle", NN, 6, LC_HGEMM_AUTO},
+    {"hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem_tn", TN, 6, LC_HGEMM_MFMA256},
+    {"hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4", TN, 6, LC_HGEMM_AUTO},
+    {"hgemm_mma_stages_block_swizzle_tn_cute", TN, 6, LC_HGEMM_AUTO},
+};
+#undef NN
+#undef TN
+constexpr int kNumHgemmEntries = sizeof(kHgemmEntries) / sizeof(kHgemmEntries[0]);
+
+struct AttnEntry {
+  const char* name;
+  int family, vt, acc_f32, maxd_s2, maxd_s1, nargs;
+};
+// kernels/flash-attn/pybind/flash_attn.cc:170-223; head-dim limits from each wrapper's switch(d)
+// (e.g. flash_attn_mma_split_q.cu:769-815, flash_attn_mma_share_qkv.cu:872-921).
+const AttnEntry kAttnEntries[] = {
+    {"flash_attn_mma_stages_split_kv", LC_ATTN_SPLIT_KV, 0, 0, 128, 128, 5},
+    {"flash_attn_mma_stages_split_q", LC_ATTN_SPLIT_Q, 0, 0, 128, 128, 5},
+    {"flash_attn_mma_stages_split_q_shared_kv", LC_ATTN_SHARED_KV, 0, 0, 128, 256, 5},
+    {"flash_attn_mma_stages_split_q_shared_qkv", LC_ATTN_SHARED_QKV, 0, 0, 128, 256, 5},
+    {"flash_attn_mma_stages_split_q_tiling_qk", LC_ATTN_TILING_QK, 0, 0, 1024, 1024, 5},
+    {"flash_attn_mma_stages_split_q_tiling_qkv", LC_ATTN_TILING_QKV, 0, 0, 1024, 1024, 5},
+    {"flash_attn_mma_stages_split_q_shared_kv_acc_f32", LC_ATTN_SHARED_KV, 0, 1, 128, 256, 5},
+    {"flash_attn_mma_stages_split_q_shared_qkv_acc_f32", LC_ATTN_SHARED_QKV, 0, 1, 128, 256, 5},
+    {"flash_attn_mma_stages_split_q_tiling_qk_acc_f32", LC_ATTN_TILING_QK, 0, 1, 1024, 1024, 5},
+    {"flash_attn_mma_stages_split_q_tiling_qkv_acc_f32", LC_ATTN_TILING_QKV, 0, 1, 1024, 1024, 5},
+    {"flash_attn_mma_stages_split_q_shared_kv_swizzle_q", LC_ATTN_SHARED_KV, 0, 0, 128, 256, 5},
+    {"flash_attn_mma_stages_split_q_shared_kv_swizzle_qk", LC_ATTN_SHARED_KV, 0, 0, 128, 256, 5},
+    {"flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv", LC_ATTN_SHARED_KV, 1, 0, 128, 256, 5},
+    {"flash_attn_mma_stages_split_q_shared_qkv_swizzle_q", LC_ATTN_SHARED_QKV, 0, 0, 128, 256, 5},
+    {"flash_attn_mma_stages_split_q_shared_qkv_swizzle_qk", LC_ATTN_SHARED_QKV, 0, 0, 128, 256, 5},
+    {"flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv", LC_ATTN_SHARED_QKV, 1, 0, 128, 256, 5},
+    {"flash_attn_mma_stages_split_q_tiling_qk_swizzle_q", LC_ATTN_TILING_QK, 0, 0, 1024, 1024, 5},
+    {"flash_attn_mma_stages_split_q_tiling_qk_swizzle_qk", LC_ATTN_TILING_QK, 0, 0, 1024, 1024, 5},
+    {"flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv", LC_ATTN_TILING_QK, 1, 0, 256, 256, 5},
+    {"flash_attn_mma_stages_split_q_tiling_qkv_swizzle_q", LC_ATTN_TILING_QKV, 0, 0, 1024, 1024, 5},
+    {"flash_attn_mma_stages_split_q_tiling_qkv_swizzle_qk", LC_ATTN_TILING_QKV, 0, 0, 1024, 1024, 5},
+    {"flash_attn_mma_stages_split_q_tiling_qkv_swizzle_qkv", LC_ATTN_TILING_QKV, 0, 0, 1024, 1024, 5},
+    {"flash_attn_mma_stages_split_q_tiling_qkv_acc_f32_swizzle_q", LC_ATTN_TILING_QKV, 0, 1, 1024, 1024, 5},
+    {"flash_attn_mma_stages_split_q_tiling_qkv_acc_f32_swizzle_qk", LC_ATTN_TILING_QKV, 0, 1, 1024, 1024, 5},
+    {"flash_attn_mma_stages_split_q_tiling_qkv_acc_f32_swizzle_qkv", LC_ATTN_TILING_QKV, 0, 1, 1024, 1024, 5},
+    {"flash_attn_cute", LC_ATTN_SPLIT_Q, 0, 1, 256, 256, 4},
+    // -DBUILD_FLASH_ATTN_MMA_OTHERS (flash_attn.cc:217-223)
+    {"flash_attn_mma_stages_split_q_shared_qkv_Os2g", LC_ATTN_SHARED_QKV, 0, 0, 128, 256, 5},
+    {"flash_attn_mma_stages_split_q_shared_kv_acc_f32_rr", LC_ATTN_SHARED_KV, 0, 1, 128, 256, 5},
+    {"flash_attn_mma_stages_split_q_shared_qkv_acc_f32_rr", LC_ATTN_SHARED_QKV, 0, 1, 256, 256, 5},
+};
+constexpr int kNumAttnEntries = sizeof(kAttnEntries) / sizeof(kAttnEntries[0]);
+
+const HgemmEntry* find_hgemm(const char* name) {
+  if (!name) return nullptr;
+  for (int i = 0; i < kNumHgemmEntries; ++i)
+    if (strcmp(kHgemmEntries[i].name, name) == 0) return &kHgemmEntries[i];
+  return nullptr;
+}
+const AttnEntry* find_attn(const char* name) {
+  if (!name) return nullptr;
+  for (int i = 0; i < kNumAttnEntries; ++i)
+    if (strcmp(kAttnEntries[i].name, name) == 0) return &kAttnEntries[i];
+  return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// HGEMM launchers
+int panel_tiles(int swizzle_stride, int tiles_n, int tile_n) {
+  if (swizzle_stride <= 1) return tiles_n;  // no thread-block swizzle: plain N-major raster
+  int w = swizzle_stride / tile_n;
+  if (w < 1) w = 1;
+  if (w > tiles_n) w = tiles_n;
+  return w;
+}
+
+template <bool B_KN>
+int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant,
+                   int swizzle_stride, hipStream_t st) {
+  const int tiles_m = M / BM, tiles_n = N / BN;
+  const int pw = panel_tiles(swizzle_stride, tiles_n, BN);
+  const dim3 grid(tiles_m * tiles_n), block(512);
+  if (variant == LC_HGEMM_MFMA256P) {
+    auto kern = hgemm_pingpong_kernel<B_KN>;
+    if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
+    hipLaunchKernelGGL(kern, grid, block, HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
+  } else {
+    auto kern = hgemm_mfma256_kernel<B_KN>;
+    if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
+    hipLaunchKernelGGL(kern, grid, block, HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
+  }
+  return check_launch();
+}
+
+template <bool B_KN>
+int launch_generic(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, hipStream_t st) {
+  const dim3 grid((N + GN - 1) / GN, (M + GM - 1) / GM), block(256);
+  hipLaunchKernelGGL(hgemm_generic_kernel<B_KN>, grid, block, 0, st, A, B, C, M, N, K);
+  return check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention launchers
+template <int D, int NW, bool VT>
+int launch_attn(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
+                hipStream_t st) {
+  auto kern = attn_fwd_kernel<D, NW, VT>;
+  constexpr int lds = attn_lds_bytes<D, VT>();
+  if (int rc = set_dyn_lds(kern, lds)) return rc;
+  const dim3 grid(N / (NW * 32), B * H), block(NW * 64);
+  const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+  hipLaunchKernelGGL(kern, grid, block, lds, st, Q, K, V, O, N, sl2);
+  return check_launch();
+}
+
+template <int D, bool VT>
+int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
+                   hipStream_t st) {
+  if (N % 256 == 0) return launch_attn<D, 8, VT>(Q, K, V, O, B, H, N, st);
+  if (N % 128 == 0) return launch_attn<D, 4, VT>(Q, K, V, O, B, H, N, st);
+  return launch_attn<D, 2, VT>(Q, K, V, O, B, H, N, st);
+}
+
+template <bool VT>
+int launch_attn_d(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
+                  int D, hipStream_t st) {
+  switch (D) {
+    case 32: return launch_attn_nw<32, VT>(Q, K, V, O, B, H, N, st);
+    case 64: return launch_attn_nw<64, VT>(Q, K, V, O, B, H, N, st);
+    case 96: return launch_attn_nw<96, VT>(Q, K, V, O, B, H, N, st);
+    case 128: return launch_attn_nw<128, VT>(Q, K, V, O, B, H, N, st);
+    default: return LC_ERR_HEADDIM;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// vendor comparator (hipBLASLt), resolved lazily with dlopen so the core library has no link-time
+// dependency on it.
+}  // namespace
+
+#include "vendor_gemm.inc"
+
+extern "C" {
+
+int lc_abi_version(void) { return LC_ABI_VERSION; }
+
+const char* lc_status_string(int status) {
+  switch (status) {
+    case LC_OK: return "ok";
+    case LC_ERR_ARG: return "invalid argument";
+    case LC_ERR_SHAPE: return "Tensor size mismatch!";
+    case LC_ERR_HEADDIM: return "headdim not support!";
+    case LC_ERR_LAUNCH: return "kernel launch failed";
+    case LC_ERR_VENDOR: return "vendor GEMM (hipBLASLt) unavailable or failed";
+    case LC_ERR_DEVICE: return "no gfx950 device";
+    default: return "unknown status";
+  }
+}
+
+int lc_device_check(int* num_cus) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return LC_ERR_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return LC_ERR_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return LC_ERR_DEVICE;
+  if (num_cus) *num_cus = prop.multiProcessorCount;
+  return LC_OK;
+}
+
+int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int layout, int variant,
+                 int stages, int swizzle_stride, void* stream) {
+  (void)stages;  // LDS ring depth is fixed per kernel family; accepted for signature parity
+  if (!A || !B || !C) return LC_ERR_ARG;
+  if (layout != LC_LAYOUT_NN && layout != LC_LAYOUT_TN) return LC_ERR_ARG;
+  if (variant < LC_HGEMM_AUTO || variant > LC_HGEMM_GENERIC) return LC_ERR_ARG;
+  if (M <= 0 || N <= 0 || K <= 0) return LC_ERR_SHAPE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const half_t* a = static_cast<const half_t*>(A);
+  const half_t* b = static_cast<const half_t*>(B);
+  half_t* c = static_cast<half_t*>(C);
+  const bool tiles256 = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && aligned16(A) &&
+                        aligned16(B) && aligned16(C);
+  if (variant == LC_HGEMM_AUTO) variant = tiles256 ? LC_HGEMM_MFMA256P : LC_HGEMM_GENERIC;
+  if (variant == LC_HGEMM_MFMA256 || variant == LC_HGEMM_MFMA256P) {
+    if (!tiles256) return LC_ERR_SHAPE;
+    return layout == LC_LAYOUT_NN ? launch_mfma256<true>(a, b, c, M, N, K, variant, swizzle_stride, st)
+                                  : launch_mfma256<false>(a, b, c, M, N, K, variant, swizzle_stride, st);
+  }
+  return layout == LC_LAYOUT_NN ? launch_generic<true>(a, b, c, M, N, K, st)
+                                : launch_generic<false>(a, b, c, M, N, K, st);
+}
+
+int lc_hgemm_entry_count(void) { return kNumHgemmEntries; }
+const char* lc_hgemm_entry_name(int index) {
+  return (index >= 0 && index < kNumHgemmEntries) ? kHgemmEntries[index].name : nullptr;
+}
+int lc_hgemm_entry_info(const char* entry, int* layout, int* nargs) {
+  const HgemmEntry* e = find_hgemm(entry);
+  if (!e) return LC_ERR_ARG;
+  if (layout) *layout = e->layout;
+  if (nargs) *nargs = e->nargs;
+  return LC_OK;
+}
+
+int lc_hgemm_call(const char* entry, const void* A, const void* B, void* C, int M, int N, int K,
+                  int stages, int swizzle, int swizzle_stride, void* stream) {
+  const HgemmEntry* e = find_hgemm(entry);
+  if (!e) return LC_ERR_ARG;
+  if (e->variant == -2) return lc_vendor_init();
+  if (e->variant == -3) return lc_vendor_destroy();
+  if (e->variant == -1) return lc_hgemm_vendor_f16(A, B, C, M, N, K, e->layout, stream);
+  int variant = e->variant;
+  // the tuned kernels need 256-multiples; every reference entry must still accept the reference's own
+  // legal shapes (multiples of 128 / K of 32, hgemm_mma_stage.cu:650,675), so fall back per shape.
+  const bool tiles256 = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && aligned16(A) &&
+                        aligned16(B) && aligned16(C);
+  if (variant != LC_HGEMM_GENERIC && !tiles256) variant = LC_HGEMM_GENERIC;
+  const int stride = (e->nargs == 6 && swizzle) ? swizzle_stride : 1;
+  return lc_hgemm_f16(A, B, C, M, N, K, e->layout, variant, e->nargs == 6 ? stages : 2, stride, stream);
+}
+
+int lc_attn_fwd_f16(const void* Q, const void* K, const void* V, void* O, int B, int H, int N, int D,
+                    int v_transposed, int family, int acc_f32, int stages, void* stream) {
+  (void)acc_f32;
+  (void)stages;
+  if (!Q || !K || !V || !O) return LC_ERR_ARG;
+  if (family < LC_ATTN_SPLIT_Q || family > LC_ATTN_SPLIT_KV) return LC_ERR_ARG;
+  if (B <= 0 || H <= 0 || N <= 0 || D <= 0) return LC_ERR_SHAPE;
+  if (N % KVB != 0) return LC_ERR_SHAPE;
+  if ((size_t)B * H > 65535u * 1ull) {
+    // grid.y limit; the reference has the same implicit bound (grid = (N/Br, B*H), split_q.cu:746)
+    return LC_ERR_SHAPE;
+  }
+  if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O)) return LC_ERR_SHAPE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const half_t* q = static_cast<const half_t*>(Q);
+  const half_t* k = static_cast<const half_t*>(K);
+  const half_t* v = static_cast<const half_t*>(V);
+  half_t* o = static_cast<half_t*>(O);
+  return v_transposed ? launch_attn_d<true>(q, k, v, o, B, H, N, D, st)
+                      : launch_attn_d<false>(q, k, v, o, B, H, N, D, st);
+}
+
+int lc_attn_entry_count(void) { return kNumAttnEntries; }
+const char* lc_attn_entry_name(int index) {
+  return (index >= 0 && index < kNumAttnEntries) ? kAttnEntries[index].name : nullptr;
+}
+int lc_attn_entry_info(const char* entry, int* family, int* v_transposed, int* acc_f32,
+                       int* max_d_stage2, int* max_d_stage1, int* nargs) {
+  const AttnEntry* e = find_attn(entry);
+  if (!e) return LC_ERR_ARG;
+  if (family) *family = e->family;
+  if (v_transposed) *v_transposed = e->vt;
+  if (acc_f32) *acc_f32 = e->acc_f32;
+  if (max_d_stage2) *max_d_stage2 = e->maxd_s2;
+  if (max_d_stage1) *max_d_stage1 = e->maxd_s1;
+  if (nargs) *nargs = e->nargs;
+  return LC_OK;
+}
+
+int lc_attn_call(const char* entry, const void* Q, const void* K, const void* V, void* O, int B, int H,
+                 int N, int D, int stages, void* stream) {
+  const AttnEntry* e = find_attn(entry);
+  if (!e) return LC_ERR_ARG;
+  const int st2 = (e->nargs == 4) ? 2 : stages;
+  const int maxd = st2 > 1 ? e->maxd_s2 : e->maxd_s1;
+  if (D > maxd) return LC_ERR_HEADDIM;  // the reference wrapper's `default:` branch
+  return lc_attn_fwd_f16(Q, K, V, O, B, H, N, D, e->vt, e->family, e->acc_f32, st2, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+int lc_hgemm_time(const void* A, const void* B, void* C, int M, int N, int K, int layout, int variant,
+                  int stages, int swizzle_stride, int warmup, int iters, void* stream,
+                  float* ms_per_launch) {
+  if (!ms_per_launch || iters <= 0 || warmup < 0) return LC_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int i = 0; i < warmup; ++i)
+    if (int rc = lc_hgemm_f16(A, B, C, M, N, K, layout, variant, stages, swizzle_stride, stream)) return rc;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return LC_ERR_LAUNCH;
+  (void)hipEventRecord(e0, st);
+  int rc = LC_OK;
+  for (int i = 0; i < iters && rc == LC_OK; ++i)
+    rc = lc_hgemm_f16(A, B, C, M, N, K, layout, variant, stages, swizzle_stride, stream);
+  (void)hipEventRecord(e1, st);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_launch = ms / iters;
+  return rc;
+}
+
+int lc_attn_time(const void* Q, const void* K, const void* V, void* O, int B, int H, int N, int D,
+                 int v_transposed, int family, int stages, int warmup, int iters, void* stream,
+                 float* ms_per_launch) {
+  if (!ms_per_launch || iters <= 0 || warmup < 0) return LC_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int i = 0; i < warmup; ++i)
+    if (int rc = lc_attn_fwd_f16(Q, K, V, O, B, H, N, D, v_transposed, family, 0, stages, stream)) return rc;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return LC_ERR_LAUNCH;
+  (void)hipEventRecord(e0, st);
+  int rc = LC_OK;
+  for (int i = 0; i < iters && rc == LC_OK; ++i)
+    rc = lc_attn_fwd_f16(Q, K, V, O, B, H, N, D, v_transposed, family, 0, stages, stream);
+  (void)hipEventRecord(e1, st);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_launch = ms / iters;
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+int lc_probe_mfma16(const void* a, const void* b, float* d, void* stream) {
+  if (!a || !b || !d) return LC_ERR_ARG;
+  hipLaunchKernelGGL(probe_mfma16_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const half_t*>(a), static_cast<const half_t*>(b), d);
+  return check_launch();
+}
+int lc_probe_mfma32(const void* a, const void* b, float* d, void* stream) {
+  if (!a || !b || !d) return LC_ERR_ARG;
+  hipLaunchKernelGGL(probe_mfma32_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const half_t*>(a), static_cast<const half_t*>(b), d);
+  return check_launch();
+}
+int lc_probe_tr16(const void* src, void* dst, void* stream) {
+  if (!src || !dst) return LC_ERR_ARG;
+  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const uint16_t*>(src), static_cast<uint16_t*>(dst));
+  return check_launch();
+}
+
+}  // extern "C"
