@@ -159,11 +159,13 @@ static inline float v_at(const float* v, int n, int d, int N, int D, int vt) {
   return vt ? v[(size_t)d * N + n] : v[(size_t)n * D + d];
 }
 
+/* Nq query rows against N keys per (b,h) problem (Nq == N for the plain entry points). */
 static void attn_exact_impl(const uint16_t* Q, const uint16_t* K, const uint16_t* V, void* O, int B,
-                            int H, int N, int D, int vt, int out_f32) {
+                            int H, int Nq, int N, int D, int vt, int out_f32) {
   const size_t per = (size_t)N * D;
+  const size_t perq = (size_t)Nq * D;
   const double scale = 1.0 / sqrt((double)D); /* split_q.cu:79 */
-  float* q = to_f32(Q, per * B * H);
+  float* q = to_f32(Q, perq * B * H);
   float* k = to_f32(K, per * B * H);
   float* v = to_f32(V, per * B * H);
   if (!q || !k || !v) {
@@ -176,8 +178,8 @@ static void attn_exact_impl(const uint16_t* Q, const uint16_t* K, const uint16_t
     double* o = (double*)malloc((size_t)D * sizeof(double));
 #pragma omp for collapse(2) schedule(dynamic, 8)
     for (int bh = 0; bh < B * H; ++bh) {
-      for (int i = 0; i < N; ++i) {
-        const float* qb = q + bh * per + (size_t)i * D;
+      for (int i = 0; i < Nq; ++i) {
+        const float* qb = q + bh * perq + (size_t)i * D;
         const float* kb = k + bh * per;
         const float* vb = v + bh * per;
         double mx = -INFINITY;
@@ -203,9 +205,9 @@ static void attn_exact_impl(const uint16_t* Q, const uint16_t* K, const uint16_t
         for (int d = 0; d < D; ++d) {
           const double r = o[d] / l;
           if (out_f32)
-            ((float*)O)[bh * per + (size_t)i * D + d] = (float)r;
+            ((float*)O)[bh * perq + (size_t)i * D + d] = (float)r;
           else
-            ((uint16_t*)O)[bh * per + (size_t)i * D + d] = lc_d2h(r);
+            ((uint16_t*)O)[bh * perq + (size_t)i * D + d] = lc_d2h(r);
         }
       }
     }
@@ -217,11 +219,15 @@ static void attn_exact_impl(const uint16_t* Q, const uint16_t* K, const uint16_t
 
 void lc_oracle_attn_exact(const uint16_t* Q, const uint16_t* K, const uint16_t* V, uint16_t* O, int B,
                           int H, int N, int D, int v_transposed) {
-  attn_exact_impl(Q, K, V, O, B, H, N, D, v_transposed, 0);
+  attn_exact_impl(Q, K, V, O, B, H, N, N, D, v_transposed, 0);
 }
 void lc_oracle_attn_exact_f32(const uint16_t* Q, const uint16_t* K, const uint16_t* V, float* O, int B,
                               int H, int N, int D, int v_transposed) {
-  attn_exact_impl(Q, K, V, O, B, H, N, D, v_transposed, 1);
+  attn_exact_impl(Q, K, V, O, B, H, N, N, D, v_transposed, 1);
+}
+void lc_oracle_attn_exact_f32_rows(const uint16_t* Qrows, const uint16_t* K, const uint16_t* V, float* O,
+                                   int BH, int Nq, int N, int D, int v_transposed) {
+  attn_exact_impl(Qrows, K, V, O, BH, 1, Nq, N, D, v_transposed, 1);
 }
 
 /* fp16-accumulated dot over `len` elements in steps of 16 (one mma.sync k16 step each). */

@@ -1,0 +1,58 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container (the driver runs -m gpu on an MI355X)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Native artefacts are built in-tree; rebuild only what is missing/stale (hipcc works without a GPU)."""
+    from leetcuda_amd import build
+    abi = build.build_abi()
+    orc = build.build_oracle()
+    return {"abi": abi, "oracle": orc}
+
+
+@pytest.fixture(scope="session")
+def oracle(built):
+    from tests import oracle_lib
+    return oracle_lib.load()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+    g = ROOT / "tests" / "golden"
+    return {
+        "hgemm": np.load(g / "hgemm_small.npz"),
+        "attn": np.load(g / "attn_small.npz"),
+        "colmajor": np.load(g / "as_col_major.npz"),
+        "host": __import__("json").loads((g / "host_helpers.json").read_text()),
+    }

@@ -1,0 +1,60 @@
+"""world_size-2 gloo test (CPU) of the N>1 path of bench.py: rendezvous over 127.0.0.1, sharding of the
+independent attention units, barrier-bracketed timing with MAX over ranks, and the timing gather."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+WORKER = textwrap.dedent("""
+    import json, sys, time
+    sys.path.insert(0, %r)
+    from leetcuda_amd import dist as lcd, host
+    w = lcd.init("gloo")
+    B, H = 4, 6
+    b, h, first = host.attn_shard(B, H, w.size, w.rank)
+    lcd.barrier(w)
+    t0 = time.perf_counter()
+    time.sleep(0.05 * (w.rank + 1))            # rank 1 is the slow shard
+    lcd.barrier(w)
+    dt = time.perf_counter() - t0
+    rows = lcd.gather_row(w, [w.rank, b * h, first, dt])
+    mx = lcd.max_over_ranks(w, 0.05 * (w.rank + 1))
+    if w.rank == 0:
+        print("RESULT " + json.dumps({"rows": rows.tolist(), "max": mx, "size": w.size}))
+    lcd.shutdown(w)
+""") % str(ROOT)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo_shard_and_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT ")][0]
+    import json
+    res = json.loads(line[7:])
+    assert res["size"] == 2
+    rows = res["rows"]
+    assert [r[0] for r in rows] == [0.0, 1.0]
+    assert sum(r[1] for r in rows) == 24 and rows[0][2] == 0 and rows[1][2] == 12   # units partitioned
+    assert abs(res["max"] - 0.10) < 1e-9                                             # MAX over ranks
+    assert min(r[3] for r in rows) >= 0.095        # barrier-bracketed: both ranks waited for the slow one

@@ -1,0 +1,185 @@
+"""GPU parity tests of the FlashAttention-2 forward path through the C-ABI against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests import tol
+
+pytestmark = pytest.mark.gpu
+
+
+def _capi():
+    from leetcuda_amd import capi
+    capi.load()
+    return capi
+
+
+def _check(oracle, q, k, v, o, vt=False, max_abs=tol.ATTN_MAX_ABS):
+    B, H, N, D = q.shape
+    truth = oracle.attn(q, k, v, B, H, N, D, vt=vt, mode="f32")
+    out = o.float().cpu().numpy()
+    assert np.isfinite(out).all()
+    diff = np.abs(out - truth)
+    # the reference's own --check: torch.allclose(ref, out, atol=1e-2) (flash_attn_mma.py:489)
+    assert np.allclose(out, truth, atol=tol.ATTN_ATOL, rtol=1e-5), diff.max()
+    assert diff.max() < max_abs, (diff.max(), diff.mean())
+    return diff.max(), diff.mean()
+
+
+@pytest.mark.parametrize("D", [32, 64, 96, 128])
+@pytest.mark.parametrize("N", [64, 128, 256, 512])
+def test_attn_vs_oracle(oracle, D, N):
+    capi = _capi()
+    B, H = 2, 3
+    torch.manual_seed(D * 1000 + N)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    o = torch.full_like(q, float("nan"))
+    capi.attn_fwd(q, k, v, o)
+    torch.cuda.synchronize()
+    _check(oracle, q, k, v, o)
+    # V handed over transposed ([B,H,D,N], the *_swizzle_qkv convention) gives the same result
+    tv = v.transpose(-2, -1).contiguous()
+    o2 = torch.full_like(q, float("nan"))
+    capi.attn_fwd(q, k, tv, o2, v_transposed=True)
+    torch.cuda.synchronize()
+    _check(oracle, q, k, tv, o2, vt=True)
+    assert (o.float() - o2.float()).abs().max().item() < 1e-3
+
+
+def test_golden_fixtures(oracle, golden):
+    capi = _capi()
+    g = golden["attn"]
+    for i in range(4):
+        q, k, v = (torch.from_numpy(g[f"{n}{i}"].view(np.float16)).cuda() for n in ("q", "k", "v"))
+        o = torch.zeros_like(q)
+        capi.attn_fwd(q, k, v, o)
+        torch.cuda.synchronize()
+        d = np.abs(o.float().cpu().numpy() - g[f"o64_{i}"])     # unfused_standard_attn in fp64
+        assert d.max() < tol.ATTN_MAX_ABS, d.max()
+
+
+def test_forced_rescale_spike(oracle):
+    """One K row matches one Q row so strongly that the running max jumps by >> 8 in the middle of the
+    sequence (tile 5 of 8): every row's accumulator must be rescaled exactly once (rule 26)."""
+    capi = _capi()
+    B, H, N, D = 1, 2, 512, 128
+    torch.manual_seed(42)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k[:, :, 5 * 64 + 17] = 3.0 * q[:, :, 33]          # q33·k337 ~ 3*128 -> score ~ 34 after scaling
+    k[:, :, 2 * 64 + 3] = 1.5 * q[:, :, 400]
+    v[:, :, 5 * 64 + 17] = 7.0
+    o = torch.zeros_like(q)
+    capi.attn_fwd(q, k, v, o)
+    torch.cuda.synchronize()
+    _check(oracle, q, k, v, o, max_abs=6e-3)
+    assert abs(o[0, 0, 33].float().mean().item() - 7.0) < 0.02
+
+
+def test_degenerate_inputs(oracle):
+    capi = _capi()
+    B, H, N, D = 1, 1, 256, 64
+    ones = torch.ones(B, H, N, D, dtype=torch.half, device="cuda")       # --no-rand-qkv
+    o = torch.zeros_like(ones)
+    capi.attn_fwd(ones, ones, ones, o)
+    torch.cuda.synchronize()
+    assert (o.float() - 1).abs().max().item() < 1e-3
+    kr = torch.ones_like(ones)                                            # --range-k: K rows = (i+1)/N
+    for i in range(N):
+        kr[:, :, i, :] = (i + 1) / N
+    torch.manual_seed(1)
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    capi.attn_fwd(ones, kr, v, o)
+    torch.cuda.synchronize()
+    _check(oracle, ones, kr, v, o)
+    z = torch.zeros_like(ones)                                            # uniform softmax -> mean of V
+    capi.attn_fwd(z, z, v, o)
+    torch.cuda.synchronize()
+    assert (o.float() - v.float().mean(dim=2, keepdim=True)).abs().max().item() < 1e-3
+
+
+def test_every_reference_entry_name(oracle):
+    capi = _capi()
+    B, H, N, D = 1, 2, 256, 64
+    torch.manual_seed(3)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    tv = v.transpose(-2, -1).contiguous()
+    truth = oracle.attn(q, k, v, B, H, N, D, mode="f32")
+    for name, fam, vt, acc, d2, d1, nargs in capi.attn_entries():
+        for stages in (1, 2):
+            o = torch.zeros_like(q)
+            capi.attn_call(name, q, k, tv if vt else v, o, stages)
+            torch.cuda.synchronize()
+            d = np.abs(o.float().cpu().numpy() - truth).max()
+            assert d < tol.ATTN_MAX_ABS, (name, stages, d)
+    q512 = torch.zeros(1, 1, 64, 512, dtype=torch.half, device="cuda")
+    with pytest.raises(capi.LcError) as e:
+        capi.attn_call("flash_attn_mma_stages_split_q", q512, q512, q512, q512, 2)
+    assert e.value.status == capi.LC_ERR_HEADDIM
+
+
+def test_torch_extension_module_drop_in(oracle):
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "leetcuda_amd"))
+    import flash_attn_lib
+    B, H, N, D = 1, 4, 512, 128
+    torch.manual_seed(8)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    for fn in (flash_attn_lib.flash_attn_mma_stages_split_q, flash_attn_lib.flash_attn_mma_stages_split_q_shared_qkv):
+        o = torch.zeros_like(q)
+        fn(q, k, v, o, 2)
+        torch.cuda.synchronize()
+        _check(oracle, q, k, v, o)
+    o = torch.zeros_like(q)
+    flash_attn_lib.flash_attn_cute(q, k, v, o)
+    torch.cuda.synchronize()
+    _check(oracle, q, k, v, o)
+    with pytest.raises(RuntimeError, match="headdim not support!"):
+        x = torch.zeros(1, 1, 64, 48, dtype=torch.half, device="cuda")
+        flash_attn_lib.flash_attn_mma_stages_split_q(x, x, x, x, 2)
+
+
+def test_full_size_config3_properties(oracle):
+    """BASELINE config 3: B=4,H=32,S=4096,D=128 randn fp16 (flash_attn_mma.py:417-435)."""
+    capi = _capi()
+    B, H, N, D = 4, 32, 4096, 128
+    torch.manual_seed(0)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    o = torch.zeros_like(q)
+    capi.attn_fwd(q, k, v, o)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o).all()
+    # sampled (b,h) problems x sampled rows against the exact oracle over all 4096 keys
+    heads = [(0, 0), (1, 17), (3, 31), (2, 5)]
+    rows = [0, 31, 32, 255, 256, 2047, 4095]
+    qs = torch.stack([q[b, h, rows] for b, h in heads]).contiguous()
+    ks = torch.stack([k[b, h] for b, h in heads]).contiguous()
+    vs = torch.stack([v[b, h] for b, h in heads]).contiguous()
+    truth = oracle.attn_rows(qs, ks, vs, len(heads), len(rows), N, D)
+    got = torch.stack([o[b, h, rows] for b, h in heads]).float().cpu().numpy()
+    d = np.abs(got - truth)
+    assert d.max() < tol.ATTN_MAX_ABS, d.max()
+    # V = const  =>  O = const for every one of the 524288 rows (softmax weights sum to one)
+    vc = torch.full_like(v, 0.75)
+    capi.attn_fwd(q, k, vc, o)
+    torch.cuda.synchronize()
+    assert (o.float() - 0.75).abs().max().item() < 1e-3
+    # linearity in V: attn(q,k,v1+v2) == attn(q,k,v1) + attn(q,k,v2) on exactly representable values
+    v1 = (torch.randint(-8, 9, v.shape, device="cuda").half() / 8)
+    v2 = (torch.randint(-8, 9, v.shape, device="cuda").half() / 8)
+    o1, o2, o12 = torch.zeros_like(q), torch.zeros_like(q), torch.zeros_like(q)
+    capi.attn_fwd(q, k, v1, o1)
+    capi.attn_fwd(q, k, v2, o2)
+    capi.attn_fwd(q, k, v1 + v2, o12)
+    torch.cuda.synchronize()
+    assert (o12.float() - o1.float() - o2.float()).abs().max().item() < 2e-3

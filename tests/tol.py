@@ -1,0 +1,30 @@
+"""Tolerances of the parity tests, stated once.
+
+north_star: "outputs that match the reference CUDA kernels' results on identical random inputs within
+1e-2 rtol for fp16".  The reference kernels accumulate in fp16 and cannot run here, so parity is judged
+against the exact result of the reference's definition (oracle *_exact):
+
+  HGEMM      |out - truth| <= HGEMM_RTOL*|truth| + hgemm_atol(K, amp)
+             rtol 1e-2 is the north_star figure; the absolute term covers fp32 accumulation noise at
+             truth ~ 0 where a relative bound is ill-posed (K/32 sequential fp32 MFMA accumulations of
+             partial sums ~ amp^2*sqrt(K): <= ~1e-3 at K = 8192, randn inputs).
+  attention  torch.allclose(atol=1e-2) is the reference's own check (flash_attn_mma.py:489); we also hold
+             the README's error envelope "max < ~1e-3" (README.md:130) with ATTN_MAX_ABS.
+"""
+import math
+
+HGEMM_RTOL = 1e-2
+ATTN_ATOL = 1e-2      # the reference's --check threshold
+ATTN_MAX_ABS = 2e-3   # tighter: what fp32-accumulate kernels should hold on randn inputs
+
+
+def hgemm_atol(K: int, amp: float = 1.0) -> float:
+    return amp * amp * (1e-3 + 2.5e-7 * K)
+
+
+def hgemm_close(out_f32, truth_f32, K, amp=1.0):
+    """numpy arrays -> (ok, max_abs_err, worst_excess)."""
+    import numpy as np
+    err = np.abs(out_f32.astype(np.float64) - truth_f32.astype(np.float64))
+    bound = HGEMM_RTOL * np.abs(truth_f32.astype(np.float64)) + hgemm_atol(K, amp)
+    return bool((err <= bound).all()), float(err.max()), float((err - bound).max())

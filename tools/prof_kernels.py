@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Launch the hot kernels a few times with BASELINE-sized inputs — the target command for
+`rocprofv3 --kernel-trace --stats` and the separate `--pmc` passes (profiles/README.md)."""
+import argparse
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+
+from leetcuda_amd import capi, host  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--what", default="all", choices=["all", "hgemm", "attn"])
+ap.add_argument("--iters", type=int, default=5)
+a = ap.parse_args()
+capi.load()
+torch.manual_seed(0)
+if a.what in ("all", "hgemm"):
+    n = 8192
+    A = torch.randn(n, n, dtype=torch.half, device="cuda")
+    B = torch.randn(n, n, dtype=torch.half, device="cuda")
+    C = torch.zeros(n, n, dtype=torch.half, device="cuda")
+    Bt = host.as_col_major(B)
+    for var in (capi.HGEMM_MFMA256P, capi.HGEMM_MFMA256):
+        for lay, bb in ((capi.LAYOUT_TN, Bt), (capi.LAYOUT_NN, B)):
+            for _ in range(a.iters):
+                capi.hgemm(A, bb, C, layout=lay, variant=var, swizzle_stride=2048)
+    torch.cuda.synchronize()
+if a.what in ("all", "attn"):
+    q, k, v, o, tv = host.get_qkvo(4, 32, 4096, 128, seed=0)
+    for _ in range(a.iters):
+        capi.attn_fwd(q, k, v, o)
+    torch.cuda.synchronize()
+print("done")
