@@ -45,6 +45,7 @@ from leetcuda_amd import capi, host  # noqa: E402
 from leetcuda_amd import dist as lcd  # noqa: E402
 
 PEAK = host.MI355X_FP16_DENSE_PEAK_TFLOPS
+PREWARM = 10  # untimed launches before the W warm-up steps (DVFS settles; documented in DESIGN.md §6)
 
 
 def parse():
@@ -54,7 +55,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="hgemm", choices=["hgemm", "attn", "attn_sharded"])
     ap.add_argument("--layout", default="tn", choices=["tn", "nn"])
-    ap.add_argument("--variant", default="auto", choices=["auto", "mfma256", "pingpong", "generic"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "mfma256", "pingpong", "pingpong2", "generic"])
     ap.add_argument("--mnk", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-attention", action="store_true", help="skip the secondary attention measurement")
@@ -63,11 +64,19 @@ def parse():
 
 
 VARIANT = {"auto": capi.HGEMM_AUTO, "mfma256": capi.HGEMM_MFMA256, "pingpong": capi.HGEMM_MFMA256P,
-           "generic": capi.HGEMM_GENERIC}
+           "pingpong2": capi.HGEMM_MFMA256P2, "generic": capi.HGEMM_GENERIC}
+AUTO_KERNEL = "pingpong"   # what LC_HGEMM_AUTO resolves to (lc_abi.hip: g_tune_hgemm_auto)
+
+
+def pmc_key_hgemm(variant: str, layout: str) -> str:
+    v = AUTO_KERNEL if variant == "auto" else variant
+    return f"hgemm_{v}_kernel<{'true' if layout == 'nn' else 'false'}>"
 
 
 def timed_region(w, step, steps, warmup):
     """W untimed + exactly K timed steps, barrier+sync on both sides; returns local seconds."""
+    for _ in range(PREWARM):   # setup: clocks / code objects / allocator, not part of W or K
+        step()
     for _ in range(warmup):
         step()
     lcd.barrier(w)
@@ -78,11 +87,11 @@ def timed_region(w, step, steps, warmup):
     return time.perf_counter() - t0
 
 
-def pmc_traffic(tag: str):
-    """HBM bytes per launch from the committed rocprofv3 --pmc pass (profiles/<tag>_pmc.json), or None."""
-    p = ROOT / "profiles" / f"{tag}_pmc.json"
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
+    (profiles/latest_pmc.json, written by tools/summarize_prof.py: FETCH_SIZE x2 + WRITE_SIZE), or None."""
     try:
-        return json.loads(p.read_text()).get("hbm_bytes_per_launch")
+        return json.loads((ROOT / "profiles" / "latest_pmc.json").read_text())[kernel]["hbm_bytes_per_launch"]
     except Exception:
         return None
 
@@ -112,17 +121,17 @@ def bench_hgemm(w, args):
         "scaling": "weak",
         "roofline": {"bound": "mfma", "achieved": flops / (ms_kernel * 1e-3) * 1e-12, "peak": PEAK,
                      "unit": "TFLOP/s", "kernel_ms": ms_kernel,
-                     "kernel": "hgemm_pingpong_kernel" if args.variant in ("auto", "pingpong") else args.variant,
+                     "kernel": pmc_key_hgemm(args.variant, args.layout),
                      "algorithmic_flops_per_launch": flops,
                      "algorithmic_bytes_per_launch": 3.0 * n * n * 2,
-                     "traffic": pmc_traffic("r01_hgemm")},
+                     "traffic": pmc_traffic(pmc_key_hgemm(args.variant, args.layout))},
     }
     res["roofline"]["frac"] = res["roofline"]["achieved"] / PEAK
     if args.sweep and w.rank == 0:
         capi.vendor_init()
         for lname, l2 in (("tn", capi.LAYOUT_TN), ("nn", capi.LAYOUT_NN)):
             b2 = host.as_col_major(b) if l2 == capi.LAYOUT_TN else b
-            for vn in ("mfma256", "pingpong"):
+            for vn in ("mfma256", "pingpong", "pingpong2"):
                 for st in (1, 1024, 2048, 4096):
                     ms = capi.hgemm_time(a, b2, c, l2, VARIANT[vn], 2, st, warmup=2, iters=20)
                     print(f"[sweep] hgemm {lname} {vn:9s} stride {st:5d}: {ms:.4f} ms  "
@@ -141,6 +150,13 @@ def bench_hgemm(w, args):
                   file=sys.stderr)
             res.setdefault("vendor_tflops", {})[lname] = flops / ms * 1e-9
         capi.vendor_destroy()
+        q, k, v, o, _ = host.get_qkvo(4, 32, 4096, 128)
+        fl = host.mha_matmul_flops(4, 32, 4096, 128)
+        for nw in (8, 4):
+            capi.tune("attn_nw", nw)
+            ms = capi.attn_time(q, k, v, o, False, capi.ATTN_SPLIT_Q, 2, warmup=2, iters=10)
+            print(f"[sweep] attn cfg3 nw={nw}: {ms:.4f} ms  {fl / ms * 1e-9:8.1f} TFLOP/s", file=sys.stderr)
+        capi.tune("attn_nw", 0)
     return res
 
 
@@ -172,26 +188,36 @@ def bench_attn(w, args, sharded_cfg4=False, steps=None, warmup=None):
                      "kernel_ms": ms_kernel, "kernel": "attn_fwd_kernel<128,8,false>",
                      "algorithmic_flops_per_launch": flops_local,
                      "algorithmic_bytes_per_launch": 4.0 * b_loc * h_loc * N * D * 2,
-                     "traffic": pmc_traffic("r01_attn")},
+                     "traffic": pmc_traffic("attn_fwd_kernel<128,8,false>")},
     }
 
 
 # ---------------------------------------------------------------------------------------------------
-def cpu_baseline_hgemm():
-    """torch.matmul on fp16 CPU tensors = the reference's `--torch` baseline callable (hgemm.py:1088),
-    bounded sample: M=N=K=4096 (1/8 of the FLOPs of config 2)."""
-    n = 4096
+def cpu_baseline_hgemm(budget_s: float = 12.0):
+    """torch.matmul on fp16 CPU tensors = the reference's `--torch` baseline callable (hgemm.py:1088).
+    Bounded sample: a 512^3 probe sets the rate, then the largest cube of the 8192^3 problem whose
+    estimated time fits `budget_s` is timed (fp16 CPU matmul speed varies by orders of magnitude
+    between hosts)."""
     torch.manual_seed(0)
-    a = torch.randn(n, n, dtype=torch.half)
-    b = torch.randn(n, n, dtype=torch.half)
-    torch.matmul(a[:512, :512], b[:512, :512])
+    a = torch.randn(512, 512, dtype=torch.half)
+    torch.matmul(a, a)
     t0 = time.perf_counter()
-    torch.matmul(a, b)
-    dt = time.perf_counter() - t0
+    torch.matmul(a, a)
+    probe = max(time.perf_counter() - t0, 1e-6)
+    n, dt = 512, probe
+    for cand in (8192, 4096, 2048, 1024):
+        if probe * (cand / 512) ** 3 <= budget_s:
+            n = cand
+            a = torch.randn(n, n, dtype=torch.half)
+            b = torch.randn(n, n, dtype=torch.half)
+            t0 = time.perf_counter()
+            torch.matmul(a, b)
+            dt = time.perf_counter() - t0
+            break
     out = {"value": 2.0 * n ** 3 / dt * 1e-12, "unit": "TFLOP/s", "cores": torch.get_num_threads(),
            "host_cpus": os.cpu_count(), "kind": "reference",
-           "sample": f"torch.matmul fp16 on CPU tensors, M=N=K={n} ({dt:.2f} s; 1/8 of the 8192^3 work), "
-                     f"the reference bench's own torch baseline callable"}
+           "sample": f"torch.matmul fp16 on CPU tensors, M=N=K={n} ({dt:.2f} s; 1/{(8192 // n) ** 3} of the "
+                     f"8192^3 work), the reference bench's own torch baseline callable (hgemm.py:1088)"}
     try:  # the C oracle ("port"), fp64 accumulate: 128 output rows of the 8192^3 problem
         from tests import oracle_lib
         orc = oracle_lib.load()

@@ -55,7 +55,8 @@ typedef enum lc_hgemm_variant {
   LC_HGEMM_AUTO = 0,     /* best available for the shape                                              */
   LC_HGEMM_MFMA256 = 1,  /* 256x256x64 WG tile, 8 wave64, LDS-DMA double buffer, one barrier / K-tile */
   LC_HGEMM_MFMA256P = 2, /* same tile, phase-interleaved ping-pong schedule (counted vmcnt)           */
-  LC_HGEMM_GENERIC = 3   /* 64x64x32 edge-predicated MFMA kernel: any M,N,K                           */
+  LC_HGEMM_GENERIC = 3,  /* 64x64x32 edge-predicated MFMA kernel: any M,N,K                           */
+  LC_HGEMM_MFMA256P2 = 4 /* ping-pong with 2 phases of 16 MFMAs per K tile, DMA issued inside MFMA clusters */
 } lc_hgemm_variant;
 
 /* FlashAttention-2 forward families (resource policies of kernels/flash-attn/mma/basic/ .cu files). */
@@ -72,6 +73,11 @@ int lc_abi_version(void);
 const char* lc_status_string(int status);
 /* 0 when a gfx950 device is current, LC_ERR_DEVICE otherwise. Writes the CU count when non-NULL. */
 int lc_device_check(int* num_cus);
+
+/* Run-time tuning knobs for experiments / A-B benches (not part of the reference surface):
+ *   "attn_nw"    waves per attention workgroup: 0 = auto (largest that divides N), 8, 4 or 2
+ *   "hgemm_auto" kernel family LC_HGEMM_AUTO resolves to on 256-tileable shapes (1, 2 or 4) */
+int lc_tune_set(const char* key, int value);
 
 /* ---- HGEMM ------------------------------------------------------------------------------------
  * Replaces the host launchers + kernels of kernels/hgemm/mma/basic/hgemm_mma_stage.cu:644-1052,2284-2412

@@ -11,7 +11,7 @@ LIB_PATH = _PKG / "lib" / "libleetcuda_amd.so"
 
 LC_OK, LC_ERR_ARG, LC_ERR_SHAPE, LC_ERR_HEADDIM, LC_ERR_LAUNCH, LC_ERR_VENDOR, LC_ERR_DEVICE = 0, -1, -2, -3, -4, -5, -6
 LAYOUT_NN, LAYOUT_TN = 0, 1
-HGEMM_AUTO, HGEMM_MFMA256, HGEMM_MFMA256P, HGEMM_GENERIC = 0, 1, 2, 3
+HGEMM_AUTO, HGEMM_MFMA256, HGEMM_MFMA256P, HGEMM_GENERIC, HGEMM_MFMA256P2 = 0, 1, 2, 3, 4
 ATTN_SPLIT_Q, ATTN_SHARED_QKV, ATTN_SHARED_KV, ATTN_TILING_QK, ATTN_TILING_QKV, ATTN_SPLIT_KV = range(6)
 
 # every symbol include/lc_abi.h declares: name -> (restype, argtypes)
@@ -20,6 +20,7 @@ SYMBOLS = {
     "lc_abi_version": (_i, []),
     "lc_status_string": (_cp, [_i]),
     "lc_device_check": (_i, [_ip]),
+    "lc_tune_set": (_i, [_cp, _i]),
     "lc_hgemm_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "lc_vendor_init": (_i, []),
     "lc_vendor_destroy": (_i, []),
@@ -98,6 +99,10 @@ def _need_gpu(*tensors):
             raise RuntimeError("leetcuda_amd: tensor must live on the MI355X (no CPU path)")
         if not t.is_contiguous():
             raise RuntimeError("leetcuda_amd: tensor must be contiguous")
+
+
+def tune(key: str, value: int):
+    check(load().lc_tune_set(key.encode(), value), f"lc_tune_set({key})")
 
 
 def device_check() -> int:

@@ -23,6 +23,7 @@
 namespace lc {
 
 constexpr int KVB = 64;  // kv rows per tile
+constexpr float RESCALE_THR = 8.0f;  // log2 units
 
 template <int D>
 struct AttnCfg {
@@ -43,7 +44,7 @@ constexpr int attn_lds_bytes() {
 template <int D, int NW, bool VT>
 __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
-    half_t* __restrict__ O, int N, float sl2 /* (1/sqrt(D)) * log2(e) */) {
+    half_t* __restrict__ O, int N, int nqb /* query blocks per (b,h) */, float sl2 /* (1/sqrt(D))*log2(e) */) {
   using C = AttnCfg<D>;
   constexpr int NT = NW * 64;
   constexpr int DT = D / 32;   // 32-wide d tiles of Oᵀ
@@ -62,8 +63,11 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
   const int hi = lane >> 5;
   const int l32 = lane & 31;
 
-  const size_t bh = blockIdx.y;
-  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+  // XCD-aware placement: each XCD owns a contiguous range of (b,h) problems, so the nqb workgroups that
+  // re-read one head's K/V run on the same XCD (same L2) back to back.
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const size_t bh = id / nqb;
+  const int q0 = (id - (int)bh * nqb) * (NW * 32) + wave * 32;
   const half_t* Qb = Q + bh * (size_t)N * D;
   const half_t* Kb = K + bh * (size_t)N * D;
   const half_t* Vb = V + bh * (size_t)N * D;
@@ -160,16 +164,28 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
     }
 
     // ---- online softmax (log2 domain): lane owns query row q = l32, kv columns split with lane^32
-    float mx = s[0][0];
+    float mt[8];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[tt][r]);
+    for (int r = 0; r < 8; ++r)
+      mt[r] = fmaxf(fmaxf(s[0][r], s[0][r + 8]), fmaxf(s[1][r], s[1][r + 8]));
+    float mx = fmaxf(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3])),
+                     fmaxf(fmaxf(mt[4], mt[5]), fmaxf(mt[6], mt[7])));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx * sl2);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
+    const float m_cand = fmaxf(m_run, mx * sl2);
+    // Deferred rescale: while no row's max grows by more than 2^RESCALE_THR keep the old reference max
+    // (P is then bounded by 2^RESCALE_THR, exact in fp32 sums and far inside fp16 range) and skip the
+    // O / l rescale entirely.  The decision covers ONLY this tile's P, which is exponentiated below, and
+    // the previous tile's P·V is already accumulated -> everything at the old scale is scaled exactly once.
+    if (!__all(m_cand - m_run <= RESCALE_THR)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);
+      m_run = m_cand;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
     half8_t pf[2][2];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
@@ -177,17 +193,13 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
       for (int u = 0; u < 2; ++u) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[tt][8 * u + j], sl2, -m_new));
-          psum += p;
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[tt][8 * u + j], sl2, -m_run));
+          ps[j & 3] += p;
           pf[tt][u][j] = (half_t)p;
         }
       }
     }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
 
     // ---- Oᵀ += Vᵀ·Pᵀ
 #pragma unroll

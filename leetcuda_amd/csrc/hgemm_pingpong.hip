@@ -247,4 +247,112 @@ __global__ __launch_bounds__(512, 2) void hgemm_pingpong_kernel(const half_t* __
   pp_epilogue(smem, acc, C, N, m0, n0, wave, wr, wc, lane);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Two-phase ping-pong (LC_HGEMM_MFMA256P2): 16 MFMAs per phase, 4 barriers per K tile, LDS-DMA issued
+// from INSIDE the MFMA clusters (between MFMAs, where the wave has spare issue slots) instead of from the
+// load sections.
+//   phase A(kt): reads A0 (8 b128), B0 (4), B1 (4)            -> quadrants (0,0), (0,1)
+//                MFMA cluster carries the 2 DMA pieces of A1(kt+1)
+//   phase B(kt): reads A1 (8)                                 -> quadrants (1,0), (1,1)
+//                MFMA cluster carries the 6 DMA pieces of B0, B1, A0 of tile kt+2
+// Waits (issue order ... A0B(kt) | A1(kt) | A0B(kt+1) | A1(kt+1) ...):
+//   end of load A(kt): vmcnt(6) -> A1(kt) landed   (6 younger: B0,B1,A0 of kt+1)
+//   end of load B(kt): vmcnt(2) -> B0,B1,A0(kt+1) landed (2 younger: A1(kt+1))
+// RAW: every half is waited for one phase before it is read (+ a barrier). WAR (slot = barrier interval;
+// group 0 loads phase j in slot 2j and computes in 2j+1, group 1 one slot later): a half last read in
+// load phase j is dead from slot 2j+3; A0/B of tile kt (j = 2kt) are re-staged in MFMA(2kt+1) = slots
+// 4kt+3 / 4kt+4, A1 (j = 2kt+1) in MFMA(2kt+2) = slots 4kt+5 / 4kt+6.
+template <bool B_KN, int NG, typename IssueFn>
+LC_DEVINL void pp2_mfma(f32x16_t (&acc)[4][2], int mh, const half8_t (&af)[2][4], const half8_t (&b0f)[4],
+                        const half8_t (&b1f)[4], IssueFn issue) {
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int nh = g >> 2, ks = g & 3;
+    const half8_t bf = nh ? b1f[ks] : b0f[ks];
+    acc[mh * 2 + 0][nh] = mfma32(bf, af[0][ks], acc[mh * 2 + 0][nh]);
+    acc[mh * 2 + 1][nh] = mfma32(bf, af[1][ks], acc[mh * 2 + 1][nh]);
+    if (g < NG) issue(g);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_s_setprio(0);
+}
+
+template <bool B_KN>
+__global__ __launch_bounds__(512, 2) void hgemm_pingpong2_kernel(const half_t* __restrict__ A,
+                                                                 const half_t* __restrict__ B,
+                                                                 half_t* __restrict__ C, int M, int N,
+                                                                 int K, int tiles_m, int tiles_n,
+                                                                 int panel_w) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const TileCoord tc = raster(id, tiles_m, tiles_n, panel_w);
+  const int m0 = tc.tm * BM, n0 = tc.tn * BN;
+
+  PPSrc<B_KN> src;
+  pp_src_init<B_KN>(src, A, B, m0, n0, N, K, wave, lane);
+  PPFrag<B_KN> fr;
+  pp_frag_init<B_KN>(fr, wr, wc, lane);
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int KT = K / BK;
+  const size_t bstep = B_KN ? (size_t)BK * N : (size_t)BK;
+  // one DMA piece: operand (0 = A, 1 = B), half h, piece i of this wave, K tile t (clamped) -> slot t&1
+  auto piece = [&](int is_b, int h, int i, int t) {
+    const int te = t < KT ? t : KT - 1;
+    char* slot = smem + (t & 1) * SLOT_BYTES;
+    if (is_b)
+      glds16(src.b[h][i] + (size_t)te * bstep, slot + src.b_lds[h][i]);
+    else
+      glds16(src.a[h][i] + (size_t)te * BK, slot + src.a_lds[h][i]);
+  };
+  // g = 0..5 -> B0[0] B0[1] B1[0] B1[1] A0[0] A0[1]
+  auto issue_ab0 = [&](int g, int t) { piece(g < 4, g < 4 ? (g >> 1) : 0, g & 1, t); };
+
+  // prologue: A0B(0) | A1(0) | A0B(1)
+#pragma unroll
+  for (int g = 0; g < 6; ++g) issue_ab0(g, 0);
+  piece(0, 1, 0, 0);
+  piece(0, 1, 1, 0);
+#pragma unroll
+  for (int g = 0; g < 6; ++g) issue_ab0(g, 1);
+  LC_VMCNT(8);
+  pp_barrier();
+  if (wr == 1) pp_barrier();
+
+  half8_t af[2][4], b0f[4], b1f[4];
+  for (int kt = 0; kt < KT; ++kt) {
+    const char* cur = smem + (kt & 1) * SLOT_BYTES;
+    // ---- phase A
+    pp_read_b<B_KN>(cur, fr, 0, b0f);
+    pp_read_a<B_KN>(cur, fr, 0, af);
+    pp_read_b<B_KN>(cur, fr, 1, b1f);
+    LC_VMCNT(6);
+    pp_barrier();
+    pp2_mfma<B_KN, 2>(acc, 0, af, b0f, b1f, [&](int g) { piece(0, 1, g, kt + 1); });
+    pp_barrier();
+    // ---- phase B
+    pp_read_a<B_KN>(cur, fr, 1, af);
+    LC_VMCNT(2);
+    pp_barrier();
+    pp2_mfma<B_KN, 6>(acc, 1, af, b0f, b1f, [&](int g) { issue_ab0(g, kt + 2); });
+    pp_barrier();
+  }
+  if (wr == 0) pp_barrier();
+  LC_VMCNT(0);
+  pp_epilogue(smem, acc, C, N, m0, n0, wave, wr, wc, lane);
+}
+
 }  // namespace lc

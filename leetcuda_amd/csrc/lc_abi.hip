@@ -18,6 +18,10 @@ using namespace lc;
 
 namespace {
 
+// run-time tuning knobs (lc_tune_set): experiments and A/B benches, never required for correctness
+int g_tune_attn_nw = 0;                    // waves per attention workgroup: 0 = auto, 8 / 4 / 2
+int g_tune_hgemm_auto = LC_HGEMM_MFMA256P; // kernel family LC_HGEMM_AUTO resolves to on 256-tileable shapes
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 int check_launch() { return hipGetLastError() == hipSuccess ? LC_OK : LC_ERR_LAUNCH; }
@@ -156,7 +160,11 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   const int tiles_m = M / BM, tiles_n = N / BN;
   const int pw = panel_tiles(swizzle_stride, tiles_n, BN);
   const dim3 grid(tiles_m * tiles_n), block(512);
-  if (variant == LC_HGEMM_MFMA256P) {
+  if (variant == LC_HGEMM_MFMA256P2) {
+    auto kern = hgemm_pingpong2_kernel<B_KN>;
+    if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
+    hipLaunchKernelGGL(kern, grid, block, HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
+  } else if (variant == LC_HGEMM_MFMA256P) {
     auto kern = hgemm_pingpong_kernel<B_KN>;
     if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
     hipLaunchKernelGGL(kern, grid, block, HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
@@ -183,17 +191,19 @@ int launch_attn(const half_t* Q, const half_t* K, const half_t* V, half_t* O, in
   auto kern = attn_fwd_kernel<D, NW, VT>;
   constexpr int lds = attn_lds_bytes<D, VT>();
   if (int rc = set_dyn_lds(kern, lds)) return rc;
-  const dim3 grid(N / (NW * 32), B * H), block(NW * 64);
+  const int nqb = N / (NW * 32);
+  const dim3 grid((unsigned)((size_t)nqb * B * H)), block(NW * 64);
   const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
-  hipLaunchKernelGGL(kern, grid, block, lds, st, Q, K, V, O, N, sl2);
+  hipLaunchKernelGGL(kern, grid, block, lds, st, Q, K, V, O, N, nqb, sl2);
   return check_launch();
 }
 
 template <int D, bool VT>
 int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                    hipStream_t st) {
-  if (N % 256 == 0) return launch_attn<D, 8, VT>(Q, K, V, O, B, H, N, st);
-  if (N % 128 == 0) return launch_attn<D, 4, VT>(Q, K, V, O, B, H, N, st);
+  const int want = g_tune_attn_nw;  // 0 = auto
+  if (N % 256 == 0 && (want == 0 || want == 8)) return launch_attn<D, 8, VT>(Q, K, V, O, B, H, N, st);
+  if (N % 128 == 0 && (want == 0 || want >= 4)) return launch_attn<D, 4, VT>(Q, K, V, O, B, H, N, st);
   return launch_attn<D, 2, VT>(Q, K, V, O, B, H, N, st);
 }
 
@@ -233,6 +243,21 @@ const char* lc_status_string(int status) {
   }
 }
 
+int lc_tune_set(const char* key, int value) {
+  if (!key) return LC_ERR_ARG;
+  if (strcmp(key, "attn_nw") == 0) {
+    if (value != 0 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
+    g_tune_attn_nw = value;
+    return LC_OK;
+  }
+  if (strcmp(key, "hgemm_auto") == 0) {
+    if (value != LC_HGEMM_MFMA256 && value != LC_HGEMM_MFMA256P && value != LC_HGEMM_MFMA256P2) return LC_ERR_ARG;
+    g_tune_hgemm_auto = value;
+    return LC_OK;
+  }
+  return LC_ERR_ARG;
+}
+
 int lc_device_check(int* num_cus) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return LC_ERR_DEVICE;
@@ -248,7 +273,7 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   (void)stages;  // LDS ring depth is fixed per kernel family; accepted for signature parity
   if (!A || !B || !C) return LC_ERR_ARG;
   if (layout != LC_LAYOUT_NN && layout != LC_LAYOUT_TN) return LC_ERR_ARG;
-  if (variant < LC_HGEMM_AUTO || variant > LC_HGEMM_GENERIC) return LC_ERR_ARG;
+  if (variant < LC_HGEMM_AUTO || variant > LC_HGEMM_MFMA256P2) return LC_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0) return LC_ERR_SHAPE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const half_t* a = static_cast<const half_t*>(A);
@@ -256,8 +281,8 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   half_t* c = static_cast<half_t*>(C);
   const bool tiles256 = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && aligned16(A) &&
                         aligned16(B) && aligned16(C);
-  if (variant == LC_HGEMM_AUTO) variant = tiles256 ? LC_HGEMM_MFMA256P : LC_HGEMM_GENERIC;
-  if (variant == LC_HGEMM_MFMA256 || variant == LC_HGEMM_MFMA256P) {
+  if (variant == LC_HGEMM_AUTO) variant = tiles256 ? g_tune_hgemm_auto : LC_HGEMM_GENERIC;
+  if (variant == LC_HGEMM_MFMA256 || variant == LC_HGEMM_MFMA256P || variant == LC_HGEMM_MFMA256P2) {
     if (!tiles256) return LC_ERR_SHAPE;
     return layout == LC_LAYOUT_NN ? launch_mfma256<true>(a, b, c, M, N, K, variant, swizzle_stride, st)
                                   : launch_mfma256<false>(a, b, c, M, N, K, variant, swizzle_stride, st);
@@ -303,10 +328,7 @@ int lc_attn_fwd_f16(const void* Q, const void* K, const void* V, void* O, int B,
   if (family < LC_ATTN_SPLIT_Q || family > LC_ATTN_SPLIT_KV) return LC_ERR_ARG;
   if (B <= 0 || H <= 0 || N <= 0 || D <= 0) return LC_ERR_SHAPE;
   if (N % KVB != 0) return LC_ERR_SHAPE;
-  if ((size_t)B * H > 65535u * 1ull) {
-    // grid.y limit; the reference has the same implicit bound (grid = (N/Br, B*H), split_q.cu:746)
-    return LC_ERR_SHAPE;
-  }
+  if ((size_t)B * H * (size_t)(N / 64) > 0x7fffffffull) return LC_ERR_SHAPE;  // 1-D grid of workgroups
   if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O)) return LC_ERR_SHAPE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const half_t* q = static_cast<const half_t*>(Q);

@@ -38,8 +38,7 @@ __global__ void probe_tr16_kernel(const uint16_t* src, uint16_t* dst) {
   for (int j = 0; j < 4; ++j) buf[lane * 4 + j] = src[lane * 4 + j];
   __syncthreads();
   const half4_t v = lds_tr16(&buf[lane * 4]);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) dst[lane * 4 + j] = __builtin_bit_cast(uint16_t, v[j]);
+  *(u32x2_t*)(dst + lane * 4) = __builtin_bit_cast(u32x2_t, v);  // raw 8 bytes, no per-element casts
 }
 
 }  // namespace lc

@@ -48,6 +48,25 @@ def test_attn_vs_oracle(oracle, D, N):
     assert (o.float() - o2.float()).abs().max().item() < 1e-3
 
 
+@pytest.mark.parametrize("nw", [8, 4, 2])
+def test_workgroup_shapes_agree(oracle, nw):
+    """The same problem through 8-, 4- and 2-wave workgroups (lc_tune_set "attn_nw")."""
+    capi = _capi()
+    B, H, N, D = 1, 3, 512, 128
+    torch.manual_seed(77)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    o = torch.zeros_like(q)
+    capi.tune("attn_nw", nw)
+    try:
+        capi.attn_fwd(q, k, v, o)
+        torch.cuda.synchronize()
+    finally:
+        capi.tune("attn_nw", 0)
+    _check(oracle, q, k, v, o)
+
+
 def test_golden_fixtures(oracle, golden):
     capi = _capi()
     g = golden["attn"]

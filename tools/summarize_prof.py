@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 databases of one gpurun round (gpurun_out/<tag>/prof_stats, pmc_*) into small,
+committed summaries under profiles/:
+
+    profiles/<tag>_kernel_stats.{md,json}   per-kernel calls / avg / min / max duration, VGPR, LDS
+    profiles/<tag>_pmc.json                 per-kernel counter averages + derived HBM bytes per launch
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are collected in
+SEPARATE --pmc passes (TCC slots), both are reported in KiB, and on gfx950 FETCH_SIZE counts a wide
+coalesced 128-B read as 64 B -> the read side is doubled ("fetch_x2") before comparing with a byte count.
+"""
+import json
+import re
+import sqlite3
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def short(name: str) -> str:
+    m = re.match(r"_ZN2lc\d+(\w+?_kernel)I(.*?)EEv", name)
+    if not m:
+        return name[:60]
+    args = m.group(2).replace("Lb0E", "false,").replace("Lb1E", "true,")
+    args = re.sub(r"Li(\d+)E", r"\1,", args).rstrip(",")
+    return f"{m.group(1)}<{args}>"
+
+
+def main(tag: str):
+    src = ROOT / "gpurun_out" / tag
+    out = ROOT / "profiles"
+    out.mkdir(exist_ok=True)
+    stats = {}
+    db = next((src / "prof_stats").glob("*.db"), None)
+    if db:
+        cur = sqlite3.connect(db).cursor()
+        rows = cur.execute("select name, duration, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, grid_x, "
+                           "workgroup_x from kernels where name like '_ZN2lc%'").fetchall()
+        agg = defaultdict(list)
+        meta = {}
+        for name, dur, vg, ag, sg, lds, gx, wx in rows:
+            agg[short(name)].append(dur / 1000.0)
+            meta[short(name)] = {"vgpr": vg, "agpr": ag, "sgpr": sg, "lds_bytes": lds, "grid_x": gx, "wg_x": wx}
+        for k, v in agg.items():
+            v2 = sorted(v)
+            stats[k] = {"calls": len(v), "avg_us": sum(v) / len(v), "min_us": v2[0], "max_us": v2[-1],
+                        "median_us": v2[len(v2) // 2], **meta[k]}
+        (out / f"{tag}_kernel_stats.json").write_text(json.dumps(stats, indent=1))
+        lines = [f"# rocprofv3 --kernel-trace --stats — {tag}", "",
+                 "command: `rocprofv3 --kernel-trace --stats -- python tools/prof_kernels.py --iters 5` "
+                 "(8192^3 HGEMM TN/NN, both schedules; FA-2 fwd B4 H32 S4096 D128; randn inputs)", "",
+                 "| kernel | calls | avg µs | median µs | min µs | max µs | VGPR | LDS B | grid |", "|---|---|---|---|---|---|---|---|---|"]
+        for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["avg_us"]):
+            lines.append(f"| `{k}` | {s['calls']} | {s['avg_us']:.1f} | {s['median_us']:.1f} | {s['min_us']:.1f} | "
+                         f"{s['max_us']:.1f} | {s['vgpr']} | {s['lds_bytes']} | {s['grid_x']} |")
+        (out / f"{tag}_kernel_stats.md").write_text("\n".join(lines) + "\n")
+    pmc = defaultdict(dict)
+    for d in sorted(src.glob("pmc_*")):
+        db = next(d.glob("*.db"), None) if d.is_dir() else None
+        if not db:
+            continue
+        cur = sqlite3.connect(db).cursor()
+        rows = cur.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
+                           "where kernel_name like '_ZN2lc%' group by kernel_name, counter_name").fetchall()
+        for name, cname, val, cnt in rows:
+            pmc[short(name)][cname] = val
+    for k, c in pmc.items():
+        if "FETCH_SIZE" in c:
+            c["hbm_read_bytes_fetch_x2"] = c["FETCH_SIZE"] * 1024 * 2
+        if "WRITE_SIZE" in c:
+            c["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            c["hbm_bytes_per_launch"] = c["hbm_read_bytes_fetch_x2"] + c["hbm_write_bytes"]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"]:
+            # busy cycles are summed over SIMDs (256 CUs x 4); GRBM_GUI_ACTIVE is wall cycles
+            c["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 256 * 4)
+        if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE"):
+            c["lds_conflict_frac"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+    (out / f"{tag}_pmc.json").write_text(json.dumps(pmc, indent=1))
+    if pmc:
+        (out / "latest_pmc.json").write_text(json.dumps(pmc, indent=1))
+    print(json.dumps({"stats": stats, "pmc": pmc}, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01a")
