@@ -56,7 +56,8 @@ typedef enum lc_hgemm_variant {
   LC_HGEMM_MFMA256 = 1,  /* 256x256x64 WG tile, 8 wave64, LDS-DMA double buffer, one barrier / K-tile */
   LC_HGEMM_MFMA256P = 2, /* same tile, phase-interleaved ping-pong schedule (counted vmcnt)           */
   LC_HGEMM_GENERIC = 3,  /* 64x64x32 edge-predicated MFMA kernel: any M,N,K                           */
-  LC_HGEMM_MFMA256P2 = 4 /* ping-pong with 2 phases of 16 MFMAs per K tile, DMA issued inside MFMA clusters */
+  LC_HGEMM_MFMA256P2 = 4, /* ping-pong with 2 phases of 16 MFMAs per K tile, DMA issued inside MFMA clusters */
+  LC_HGEMM_MFMA256P3 = 5  /* same, DMA issued by the load sections (bare MFMA clusters)                     */
 } lc_hgemm_variant;
 
 /* FlashAttention-2 forward families (resource policies of kernels/flash-attn/mma/basic/ .cu files). */
@@ -76,7 +77,7 @@ int lc_device_check(int* num_cus);
 
 /* Run-time tuning knobs for experiments / A-B benches (not part of the reference surface):
  *   "attn_nw"    waves per attention workgroup: 0 = auto (largest that divides N), 8, 4 or 2
- *   "hgemm_auto" kernel family LC_HGEMM_AUTO resolves to on 256-tileable shapes (1, 2 or 4) */
+ *   "hgemm_auto" kernel family LC_HGEMM_AUTO resolves to on 256-tileable shapes (1, 2, 4 or 5) */
 int lc_tune_set(const char* key, int value);
 
 /* ---- HGEMM ------------------------------------------------------------------------------------

@@ -150,18 +150,43 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
     char* cur = smem + (t & 1) * SLOT;
     if (t + 1 < T) load_tile(t + 1);
 
-    // ---- Sᵀ = K·Qᵀ : two 32x32 tiles (kv 0..31, 32..63)
+    // ---- Sᵀ = K·Qᵀ : two 32x32 tiles (kv 0..31, 32..63), 2*DS MFMAs in groups of GQ with the next
+    // group's K fragments (ds_read_b128) in flight behind the current group's MFMAs.
     f32x16_t s[2];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
+    for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[tt][r] = 0.f;
+    {
+      constexpr int GQ = (DS % 4 == 0) ? 4 : 2;    // fragments per group
+      constexpr int NGQ = 2 * DS / GQ;
+      half8_t kf[2][GQ];
+      auto load_k = [&](int g, half8_t (&dst)[GQ]) {
 #pragma unroll
-      for (int ks = 0; ks < DS; ++ks) {
-        const half8_t kf = *(const half8_t*)(cur + k_rd + tt * 32 * C::KSTRIDE + ks * 32);
-        s[tt] = mfma32(kf, qf[ks], s[tt]);
+        for (int i = 0; i < GQ; ++i) {
+          const int idx = g * GQ + i, tt = idx / DS, ks = idx % DS;
+          dst[i] = *(const half8_t*)(cur + k_rd + tt * 32 * C::KSTRIDE + ks * 32);
+        }
+      };
+      load_k(0, kf[0]);
+#pragma unroll
+      for (int g = 0; g < NGQ; ++g) {
+        if (g + 1 < NGQ) load_k(g + 1, kf[(g + 1) & 1]);
+#pragma unroll
+        for (int i = 0; i < GQ; ++i) {
+          const int idx = g * GQ + i, tt = idx / DS, ks = idx % DS;
+          s[tt] = mfma32(kf[g & 1][i], qf[ks], s[tt]);
+        }
+      }
+      // pin the issue order: [GQ reads] then per group [GQ reads of the next group][GQ MFMAs]
+      __builtin_amdgcn_sched_group_barrier(0x100, GQ, 0);
+#pragma unroll
+      for (int g = 0; g < NGQ; ++g) {
+        if (g + 1 < NGQ) __builtin_amdgcn_sched_group_barrier(0x100, GQ, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, GQ, 0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- online softmax (log2 domain): lane owns query row q = l32, kv columns split with lane^32
     float mt[8];
@@ -201,23 +226,29 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
     }
     l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
 
-    // ---- Oᵀ += Vᵀ·Pᵀ
+    // ---- Oᵀ += Vᵀ·Pᵀ : 4 (tt,u) groups of DT MFMAs on independent accumulators; the next group's Vᵀ
+    // fragments (2 transpose reads each) are in flight behind the current group's MFMAs.
+    {
+      half8_t vf[2][DT];
+      auto load_v = [&](int g, half8_t (&dst)[DT]) {
+        const int tt = g >> 1, u = g & 1;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          half8_t vf;
+        for (int dt = 0; dt < DT; ++dt) {
           if constexpr (!VT) {
             const char* p = cur + v_rd + (32 * tt + 16 * u) * C::VSTRIDE + dt * 64;
-            vf = cat4(lds_tr16(p), lds_tr16(p + 8 * C::VSTRIDE));
+            dst[dt] = cat4(lds_tr16(p), lds_tr16(p + 8 * C::VSTRIDE));
           } else {
             const char* p = cur + v_rd + dt * 32 * C::VT_STRIDE + (32 * tt + 16 * u) * 2;
-            vf = cat4(*(const half4_t*)p, *(const half4_t*)(p + 16));
+            dst[dt] = cat4(*(const half4_t*)p, *(const half4_t*)(p + 16));
           }
-          o[dt] = mfma32(vf, pf[tt][u], o[dt]);
         }
+      };
+      load_v(0, vf[0]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (g < 3) load_v(g + 1, vf[(g + 1) & 1]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = mfma32(vf[g & 1][dt], pf[g >> 1][g & 1], o[dt]);
       }
     }
 

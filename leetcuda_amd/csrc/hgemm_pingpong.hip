@@ -279,7 +279,13 @@ LC_DEVINL void pp2_mfma(f32x16_t (&acc)[4][2], int mh, const half8_t (&af)[2][4]
   __builtin_amdgcn_s_setprio(0);
 }
 
-template <bool B_KN>
+// DMA_IN_LOAD = false: DMA pieces ride inside the MFMA clusters (3 slots of flight, but every issue can
+//                      hold the wave's next MFMA back);
+// DMA_IN_LOAD = true : the load sections issue them (A0,B0,B1 of tile T+1 in load A(T), A1(T+1) in load
+//                      B(T); 2 slots of flight; MFMA clusters are bare).  Same vmcnt counts in both forms:
+//                      issue order ... A0B(T) | A1(T) | A0B(T+1) | A1(T+1) ..., WAR: re-stage in load phase
+//                      j+2 of the last read j.
+template <bool B_KN, bool DMA_IN_LOAD>
 __global__ __launch_bounds__(512, 2) void hgemm_pingpong2_kernel(const half_t* __restrict__ A,
                                                                  const half_t* __restrict__ B,
                                                                  half_t* __restrict__ C, int M, int N,
@@ -321,14 +327,18 @@ __global__ __launch_bounds__(512, 2) void hgemm_pingpong2_kernel(const half_t* _
   // g = 0..5 -> B0[0] B0[1] B1[0] B1[1] A0[0] A0[1]
   auto issue_ab0 = [&](int g, int t) { piece(g < 4, g < 4 ? (g >> 1) : 0, g & 1, t); };
 
-  // prologue: A0B(0) | A1(0) | A0B(1)
+  // prologue: A0B(0) | A1(0) [| A0B(1)]
 #pragma unroll
   for (int g = 0; g < 6; ++g) issue_ab0(g, 0);
   piece(0, 1, 0, 0);
   piece(0, 1, 1, 0);
+  if constexpr (!DMA_IN_LOAD) {
 #pragma unroll
-  for (int g = 0; g < 6; ++g) issue_ab0(g, 1);
-  LC_VMCNT(8);
+    for (int g = 0; g < 6; ++g) issue_ab0(g, 1);
+    LC_VMCNT(8);
+  } else {
+    LC_VMCNT(2);
+  }
   pp_barrier();
   if (wr == 1) pp_barrier();
 
@@ -336,18 +346,32 @@ __global__ __launch_bounds__(512, 2) void hgemm_pingpong2_kernel(const half_t* _
   for (int kt = 0; kt < KT; ++kt) {
     const char* cur = smem + (kt & 1) * SLOT_BYTES;
     // ---- phase A
+    if constexpr (DMA_IN_LOAD) {
+#pragma unroll
+      for (int g = 0; g < 6; ++g) issue_ab0(g, kt + 1);
+    }
     pp_read_b<B_KN>(cur, fr, 0, b0f);
     pp_read_a<B_KN>(cur, fr, 0, af);
     pp_read_b<B_KN>(cur, fr, 1, b1f);
     LC_VMCNT(6);
     pp_barrier();
-    pp2_mfma<B_KN, 2>(acc, 0, af, b0f, b1f, [&](int g) { piece(0, 1, g, kt + 1); });
+    if constexpr (DMA_IN_LOAD)
+      pp2_mfma<B_KN, 0>(acc, 0, af, b0f, b1f, [](int) {});
+    else
+      pp2_mfma<B_KN, 2>(acc, 0, af, b0f, b1f, [&](int g) { piece(0, 1, g, kt + 1); });
     pp_barrier();
     // ---- phase B
+    if constexpr (DMA_IN_LOAD) {
+      piece(0, 1, 0, kt + 1);
+      piece(0, 1, 1, kt + 1);
+    }
     pp_read_a<B_KN>(cur, fr, 1, af);
     LC_VMCNT(2);
     pp_barrier();
-    pp2_mfma<B_KN, 6>(acc, 1, af, b0f, b1f, [&](int g) { issue_ab0(g, kt + 2); });
+    if constexpr (DMA_IN_LOAD)
+      pp2_mfma<B_KN, 0>(acc, 1, af, b0f, b1f, [](int) {});
+    else
+      pp2_mfma<B_KN, 6>(acc, 1, af, b0f, b1f, [&](int g) { issue_ab0(g, kt + 2); });
     pp_barrier();
   }
   if (wr == 0) pp_barrier();

@@ -160,8 +160,12 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   const int tiles_m = M / BM, tiles_n = N / BN;
   const int pw = panel_tiles(swizzle_stride, tiles_n, BN);
   const dim3 grid(tiles_m * tiles_n), block(512);
-  if (variant == LC_HGEMM_MFMA256P2) {
-    auto kern = hgemm_pingpong2_kernel<B_KN>;
+  if (variant == LC_HGEMM_MFMA256P3) {
+    auto kern = hgemm_pingpong2_kernel<B_KN, true>;
+    if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
+    hipLaunchKernelGGL(kern, grid, block, HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
+  } else if (variant == LC_HGEMM_MFMA256P2) {
+    auto kern = hgemm_pingpong2_kernel<B_KN, false>;
     if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
     hipLaunchKernelGGL(kern, grid, block, HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
   } else if (variant == LC_HGEMM_MFMA256P) {
@@ -251,7 +255,9 @@ int lc_tune_set(const char* key, int value) {
     return LC_OK;
   }
   if (strcmp(key, "hgemm_auto") == 0) {
-    if (value != LC_HGEMM_MFMA256 && value != LC_HGEMM_MFMA256P && value != LC_HGEMM_MFMA256P2) return LC_ERR_ARG;
+    if (value != LC_HGEMM_MFMA256 && value != LC_HGEMM_MFMA256P && value != LC_HGEMM_MFMA256P2 &&
+        value != LC_HGEMM_MFMA256P3)
+      return LC_ERR_ARG;
     g_tune_hgemm_auto = value;
     return LC_OK;
   }
@@ -273,7 +279,7 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   (void)stages;  // LDS ring depth is fixed per kernel family; accepted for signature parity
   if (!A || !B || !C) return LC_ERR_ARG;
   if (layout != LC_LAYOUT_NN && layout != LC_LAYOUT_TN) return LC_ERR_ARG;
-  if (variant < LC_HGEMM_AUTO || variant > LC_HGEMM_MFMA256P2) return LC_ERR_ARG;
+  if (variant < LC_HGEMM_AUTO || variant > LC_HGEMM_MFMA256P3) return LC_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0) return LC_ERR_SHAPE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const half_t* a = static_cast<const half_t*>(A);
@@ -282,7 +288,8 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   const bool tiles256 = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && aligned16(A) &&
                         aligned16(B) && aligned16(C);
   if (variant == LC_HGEMM_AUTO) variant = tiles256 ? g_tune_hgemm_auto : LC_HGEMM_GENERIC;
-  if (variant == LC_HGEMM_MFMA256 || variant == LC_HGEMM_MFMA256P || variant == LC_HGEMM_MFMA256P2) {
+  if (variant == LC_HGEMM_MFMA256 || variant == LC_HGEMM_MFMA256P || variant == LC_HGEMM_MFMA256P2 ||
+      variant == LC_HGEMM_MFMA256P3) {
     if (!tiles256) return LC_ERR_SHAPE;
     return layout == LC_LAYOUT_NN ? launch_mfma256<true>(a, b, c, M, N, K, variant, swizzle_stride, st)
                                   : launch_mfma256<false>(a, b, c, M, N, K, variant, swizzle_stride, st);

@@ -36,9 +36,12 @@ def init(backend: str | None = None) -> World:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
+        # LC_DIST_BACKEND=gloo lets several ranks share ONE GPU (plumbing tests on a 1-GPU box)
+        backend = os.environ.get("LC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        local = local % torch.cuda.device_count() if backend != "nccl" else local
         torch.cuda.set_device(local)
+    if backend == "nccl":
         dist.init_process_group(backend="nccl", init_method="env://", world_size=size, rank=rank,
                                 device_id=torch.device("cuda", local))
     else:
