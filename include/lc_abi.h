@@ -76,7 +76,8 @@ const char* lc_status_string(int status);
 int lc_device_check(int* num_cus);
 
 /* Run-time tuning knobs for experiments / A-B benches (not part of the reference surface):
- *   "attn_nw"    waves per attention workgroup: 0 = auto (largest that divides N), 8, 4 or 2
+ *   "attn_nw"    attention workgroup shape: 0 = auto, 16 = 8-wave ping-pong kernel (N % 256 == 0),
+ *                8 / 4 / 2 = lock-step kernel with that many waves
  *   "hgemm_auto" kernel family LC_HGEMM_AUTO resolves to on 256-tileable shapes (1, 2, 4 or 5) */
 int lc_tune_set(const char* key, int value);
 

@@ -203,9 +203,23 @@ int launch_attn(const half_t* Q, const half_t* K, const half_t* V, half_t* O, in
 }
 
 template <int D, bool VT>
+int launch_attn_pp(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
+                   hipStream_t st) {
+  auto kern = attn_fwd_pp_kernel<D, VT>;
+  constexpr int lds = attn_lds_bytes<D, VT>();
+  if (int rc = set_dyn_lds(kern, lds)) return rc;
+  const int nqb = N / 256;
+  const dim3 grid((unsigned)((size_t)nqb * B * H)), block(512);
+  const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+  hipLaunchKernelGGL(kern, grid, block, lds, st, Q, K, V, O, N, nqb, sl2);
+  return check_launch();
+}
+
+template <int D, bool VT>
 int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                    hipStream_t st) {
   const int want = g_tune_attn_nw;  // 0 = auto
+  if (N % 256 == 0 && (want == 0 || want == 16)) return launch_attn_pp<D, VT>(Q, K, V, O, B, H, N, st);
   if (N % 256 == 0 && (want == 0 || want == 8)) return launch_attn<D, 8, VT>(Q, K, V, O, B, H, N, st);
   if (N % 128 == 0 && (want == 0 || want >= 4)) return launch_attn<D, 4, VT>(Q, K, V, O, B, H, N, st);
   return launch_attn<D, 2, VT>(Q, K, V, O, B, H, N, st);
@@ -250,7 +264,7 @@ const char* lc_status_string(int status) {
 int lc_tune_set(const char* key, int value) {
   if (!key) return LC_ERR_ARG;
   if (strcmp(key, "attn_nw") == 0) {
-    if (value != 0 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
+    if (value != 0 && value != 16 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
     g_tune_attn_nw = value;
     return LC_OK;
   }

@@ -48,7 +48,7 @@ def test_attn_vs_oracle(oracle, D, N):
     assert (o.float() - o2.float()).abs().max().item() < 1e-3
 
 
-@pytest.mark.parametrize("nw", [8, 4, 2])
+@pytest.mark.parametrize("nw", [16, 8, 4, 2])
 def test_workgroup_shapes_agree(oracle, nw):
     """The same problem through 8-, 4- and 2-wave workgroups (lc_tune_set "attn_nw")."""
     capi = _capi()
