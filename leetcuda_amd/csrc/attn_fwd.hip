@@ -44,7 +44,9 @@ constexpr int attn_lds_bytes() {
   return 2 * (AttnCfg<D>::KBYTES + (VT ? AttnCfg<D>::VTBYTES : AttnCfg<D>::VBYTES));
 }
 
-template <int D, int NW, bool VT>
+// ABL (ablation bits, perf diagnosis only — results are WRONG when non-zero): 1 = no v_exp, 2 = no P·V,
+// 4 = no Q·Kᵀ, 8 = no global loads / LDS staging after the prologue, 16 = no per-tile barrier.
+template <int D, int NW, bool VT, int ABL = 0>
 __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
     half_t* __restrict__ O, int N, int nqb /* query blocks per (b,h) */, float sl2 /* (1/sqrt(D))*log2(e) */) {
@@ -147,11 +149,16 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
   const int T = N / KVB;
   load_tile(0);
   store_tile(smem);
+  // Retire the Q loads HERE: otherwise hipcc carries "qf may still be in flight" into the loop and guards
+  // every Q·Kᵀ MFMA with an in-order vmcnt(N) that also drains the K/V prefetch issued a few instructions
+  // earlier (the whole HBM latency lands inside the MFMA phase of every tile).
+#pragma unroll
+  for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(qf[s]));
   __syncthreads();
 
   for (int t = 0; t < T; ++t) {
-    char* cur = smem + (t & 1) * SLOT;
-    if (t + 1 < T) load_tile(t + 1);
+    char* cur = smem + ((ABL & 8) ? 0 : (t & 1)) * SLOT;
+    if (!(ABL & 8) && t + 1 < T) load_tile(t + 1);
 
     // ---- Sᵀ = K·Qᵀ : two 32x32 tiles (kv 0..31, 32..63), 2*DS MFMAs in groups of GQ with the next
     // group's K fragments (ds_read_b128) in flight behind the current group's MFMAs.
@@ -160,14 +167,19 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[tt][r] = 0.f;
-    {
+    if constexpr (ABL & 4) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[tt][r] = (float)qf[r & (DS - 1)][r & 7] * (float)(t + r);
+    } else {
       constexpr int GQ = (DS % 4 == 0) ? 4 : 2;    // fragments per group
       constexpr int NGQ = 2 * DS / GQ;
       half8_t kf[2][GQ];
       auto load_k = [&](int g, half8_t (&dst)[GQ]) {
 #pragma unroll
         for (int i = 0; i < GQ; ++i) {
-          const int idx = g * GQ + i, tt = idx / DS, ks = idx % DS;
+          const int idx = g * GQ + i, tt = idx & 1, ks = idx >> 1;  // two independent accumulator chains
           dst[i] = *(const half8_t*)(cur + k_rd + tt * 32 * C::KSTRIDE + ks * 32);
         }
       };
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
         if (g + 1 < NGQ) load_k(g + 1, kf[(g + 1) & 1]);
 #pragma unroll
         for (int i = 0; i < GQ; ++i) {
-          const int idx = g * GQ + i, tt = idx / DS, ks = idx % DS;
+          const int idx = g * GQ + i, tt = idx & 1, ks = idx >> 1;  // two independent accumulator chains
           s[tt] = mfma32(kf[g & 1][i], qf[ks], s[tt]);
         }
       }
@@ -221,7 +233,8 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
       for (int u = 0; u < 2; ++u) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[tt][8 * u + j], sl2, -m_run));
+          const float e = __builtin_fmaf(s[tt][8 * u + j], sl2, -m_run);
+          const float p = (ABL & 1) ? e : __builtin_amdgcn_exp2f(e);
           ps[j & 3] += p;
           pf[tt][u][j] = (half_t)p;
         }
@@ -231,7 +244,12 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
 
     // ---- Oᵀ += Vᵀ·Pᵀ : 4 (tt,u) groups of DT MFMAs on independent accumulators; the next group's Vᵀ
     // fragments (2 transpose reads each) are in flight behind the current group's MFMAs.
-    {
+    if constexpr (ABL & 2) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) asm volatile("" ::"v"(pf[tt][u]));
+    } else {
       half8_t vf[2][DT];
       auto load_v = [&](int g, half8_t (&dst)[DT]) {
         const int tt = g >> 1, u = g & 1;
@@ -255,8 +273,8 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
       }
     }
 
-    if (t + 1 < T) store_tile(smem + ((t & 1) ^ 1) * SLOT);
-    __syncthreads();
+    if (!(ABL & 8) && t + 1 < T) store_tile(smem + ((t & 1) ^ 1) * SLOT);
+    if (!(ABL & 16)) __syncthreads();
   }
 
   // ---- epilogue: O = Oᵀ / l ; lane holds row q, 4 consecutive d per register quad
@@ -386,6 +404,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(
   load_v(0);
   store_k(smem);
   store_v(smem);
+#pragma unroll
+  for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(qf[s]));   // retire the Q loads before the loop
   pp_sync();
   if (grp == 1) pp_sync();
 
@@ -406,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(
       auto read_k = [&](int g, half8_t (&dst)[GQ]) {
 #pragma unroll
         for (int i = 0; i < GQ; ++i) {
-          const int idx = g * GQ + i, tt = idx / DS, ks = idx % DS;
+          const int idx = g * GQ + i, tt = idx & 1, ks = idx >> 1;  // two independent accumulator chains
           dst[i] = *(const half8_t*)(cur + k_rd + tt * 32 * C::KSTRIDE + ks * 32);
         }
       };
@@ -417,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(
         if (g + 1 < NGQ) read_k(g + 1, kf[(g + 1) & 1]);
 #pragma unroll
         for (int i = 0; i < GQ; ++i) {
-          const int idx = g * GQ + i, tt = idx / DS, ks = idx % DS;
+          const int idx = g * GQ + i, tt = idx & 1, ks = idx >> 1;  // two independent accumulator chains
           s[tt] = mfma32(kf[g & 1][i], qf[ks], ks == 0 ? zero16 : s[tt]);
         }
       }

@@ -19,6 +19,7 @@ using namespace lc;
 namespace {
 
 // run-time tuning knobs (lc_tune_set): experiments and A/B benches, never required for correctness
+int g_tune_attn_ablate = 0;                // see attn_fwd_kernel ABL (diagnosis only)
 int g_tune_attn_nw = 0;                    // waves per attention workgroup: 0 = auto, 8 / 4 / 2
 int g_tune_hgemm_auto = LC_HGEMM_MFMA256P; // kernel family LC_HGEMM_AUTO resolves to on 256-tileable shapes
 
@@ -189,10 +190,10 @@ int launch_generic(const half_t* A, const half_t* B, half_t* C, int M, int N, in
 
 // ------------------------------------------------------------------------------------------------
 // attention launchers
-template <int D, int NW, bool VT>
+template <int D, int NW, bool VT, int ABL = 0>
 int launch_attn(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                 hipStream_t st) {
-  auto kern = attn_fwd_kernel<D, NW, VT>;
+  auto kern = attn_fwd_kernel<D, NW, VT, ABL>;
   constexpr int lds = attn_lds_bytes<D, VT>();
   if (int rc = set_dyn_lds(kern, lds)) return rc;
   const int nqb = N / (NW * 32);
@@ -218,6 +219,22 @@ int launch_attn_pp(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
 template <int D, bool VT>
 int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                    hipStream_t st) {
+  if constexpr (D == 128 && !VT) {   // perf-diagnosis instantiations (lc_tune_set "attn_ablate")
+    switch (g_tune_attn_ablate) {
+      case 1: return launch_attn<D, 8, VT, 1>(Q, K, V, O, B, H, N, st);
+      case 2: return launch_attn<D, 8, VT, 2>(Q, K, V, O, B, H, N, st);
+      case 3: return launch_attn<D, 8, VT, 3>(Q, K, V, O, B, H, N, st);
+      case 4: return launch_attn<D, 8, VT, 4>(Q, K, V, O, B, H, N, st);
+      case 6: return launch_attn<D, 8, VT, 6>(Q, K, V, O, B, H, N, st);
+      case 7: return launch_attn<D, 8, VT, 7>(Q, K, V, O, B, H, N, st);
+      case 8: return launch_attn<D, 8, VT, 8>(Q, K, V, O, B, H, N, st);
+      case 16: return launch_attn<D, 8, VT, 16>(Q, K, V, O, B, H, N, st);
+      case 24: return launch_attn<D, 8, VT, 24>(Q, K, V, O, B, H, N, st);
+      case 30: return launch_attn<D, 8, VT, 30>(Q, K, V, O, B, H, N, st);
+      case 31: return launch_attn<D, 8, VT, 31>(Q, K, V, O, B, H, N, st);
+      default: break;
+    }
+  }
   const int want = g_tune_attn_nw;  // 0 = auto
   if (N % 256 == 0 && (want == 0 || want == 16)) return launch_attn_pp<D, VT>(Q, K, V, O, B, H, N, st);
   if (N % 256 == 0 && (want == 0 || want == 8)) return launch_attn<D, 8, VT>(Q, K, V, O, B, H, N, st);
@@ -266,6 +283,10 @@ int lc_tune_set(const char* key, int value) {
   if (strcmp(key, "attn_nw") == 0) {
     if (value != 0 && value != 16 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
     g_tune_attn_nw = value;
+    return LC_OK;
+  }
+  if (strcmp(key, "attn_ablate") == 0) {
+    g_tune_attn_ablate = value;
     return LC_OK;
   }
   if (strcmp(key, "hgemm_auto") == 0) {
