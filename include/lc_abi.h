@@ -76,7 +76,8 @@ const char* lc_status_string(int status);
 int lc_device_check(int* num_cus);
 
 /* Run-time tuning knobs for experiments / A-B benches (not part of the reference surface):
- *   "attn_nw"    attention workgroup shape: 0 = auto, 16 = 8-wave ping-pong kernel (N % 256 == 0),
+ *   "attn_nw"    attention workgroup shape: 0 = auto, 32 = 8-wave software-pipelined kernel, 16 = 8-wave
+ *                ping-pong kernel (both need N % 256 == 0),
  *                8 / 4 / 2 = lock-step kernel with that many waves
  *   "hgemm_auto" kernel family LC_HGEMM_AUTO resolves to on 256-tileable shapes (1, 2, 4 or 5) */
 int lc_tune_set(const char* key, int value);
@@ -116,7 +117,7 @@ int lc_hgemm_entry_info(const char* entry, int* layout, int* nargs);
  * (the reference's *_swizzle_qkv share_kv/share_qkv/tiling_qk entries, flash_attn_mma.py:441-442).
  * Non-causal, scale = 1/sqrt(D), no dropout / mask / LSE output.  fp32 softmax, fp32 MFMA accumulate
  * (acc_f32 is accepted for signature parity; CDNA4 MFMA has no fp16-accumulate form).
- * N must be a multiple of 64; D in {32, 64, 96, 128, 256, 512}. */
+ * N must be a multiple of 64; D in {32, 64, 96, 128, 256, 512, 1024} — the head dims of the reference dispatchers. */
 int lc_attn_fwd_f16(const void* Q, const void* K, const void* V, void* O, int B, int H, int N, int D,
                     int v_transposed, int family, int acc_f32, int stages, void* stream);
 

@@ -526,4 +526,473 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined variant (8 waves, N % 256 == 0): inside ONE wave's instruction stream the MFMAs of
+// tile t+1's Sᵀ = K·Qᵀ are issued next to the exp2 / row-sum / fp16-pack VALU work of tile t, and the
+// MFMAs of Oᵀ += Vᵀ·Pᵀ (tile t) next to the row-max tree of tile t+1: every MFMA cluster carries
+// independent VALU work in its shadow (the matrix pipe paces at 32 cycles per MFMA; a wave has ~7 issue
+// slots per MFMA to spend).  Two Sᵀ tiles are live (+32 VGPRs).  K runs one tile ahead of V:
+// iteration t reads K(t+1) and V(t) and stages K(t+2) and V(t+1) (2-slot rings each, one barrier per tile).
+template <int D, bool VT>
+__global__ __launch_bounds__(512, 2) void attn_fwd_swp_kernel(
+    const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
+    half_t* __restrict__ O, int N, int nqb, float sl2) {
+  using C = AttnCfg<D>;
+  constexpr int NW = 8, NT = 512;
+  constexpr int DT = D / 32, DS = D / 16;
+  constexpr int VB = VT ? C::VTBYTES : C::VBYTES;
+  constexpr int K_CHUNKS = KVB * C::CH;
+  constexpr int V_CHUNKS = VT ? D * 8 : KVB * C::CH;
+  constexpr int KL = (K_CHUNKS + NT - 1) / NT;
+  constexpr int VL = (V_CHUNKS + NT - 1) / NT;
+  // LDS: [K slot 0][K slot 1][V slot 0][V slot 1]
+  constexpr int KOFF = 0, VOFF = 2 * C::KBYTES;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = wave_id();
+  const int hi = lane >> 5;
+  const int l32 = lane & 31;
+
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const size_t bh = id / nqb;
+  const int q0 = (id - (int)bh * nqb) * (NW * 32) + wave * 32;
+  const half_t* Qb = Q + bh * (size_t)N * D;
+  const half_t* Kb = K + bh * (size_t)N * D;
+  const half_t* Vb = V + bh * (size_t)N * D;
+  half_t* Ob = O + bh * (size_t)N * D;
+
+  half8_t qf[DS];
+#pragma unroll
+  for (int s = 0; s < DS; ++s) qf[s] = *(const half8_t*)(Qb + (size_t)(q0 + l32) * D + 16 * s + 8 * hi);
+
+  u32x4_t kst[KL], vst[VL];
+  auto load_k = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < KL; ++j) {
+      const int idx = tid + j * NT;
+      if (K_CHUNKS % NT == 0 || idx < K_CHUNKS)
+        kst[j] = *(const u32x4_t*)(Kb + (size_t)t * KVB * D + (size_t)idx * 8);
+    }
+  };
+  auto load_v = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < VL; ++j) {
+      const int idx = tid + j * NT;
+      if (V_CHUNKS % NT == 0 || idx < V_CHUNKS) {
+        if constexpr (!VT)
+          vst[j] = *(const u32x4_t*)(Vb + (size_t)t * KVB * D + (size_t)idx * 8);
+        else
+          vst[j] = *(const u32x4_t*)(Vb + (size_t)(idx >> 3) * N + (size_t)t * KVB + (idx & 7) * 8);
+      }
+    }
+  };
+  auto store_k = [&](int slot) {
+    char* base = smem + KOFF + slot * C::KBYTES;
+#pragma unroll
+    for (int j = 0; j < KL; ++j) {
+      const int idx = tid + j * NT;
+      if (K_CHUNKS % NT == 0 || idx < K_CHUNKS)
+        *(u32x4_t*)(base + (idx / C::CH) * C::KSTRIDE + (idx % C::CH) * 16) = kst[j];
+    }
+  };
+  auto store_v = [&](int slot) {
+    char* base = smem + VOFF + slot * VB;
+#pragma unroll
+    for (int j = 0; j < VL; ++j) {
+      const int idx = tid + j * NT;
+      if (V_CHUNKS % NT == 0 || idx < V_CHUNKS) {
+        if constexpr (!VT)
+          *(u32x4_t*)(base + (idx / C::CH) * C::VSTRIDE + (idx % C::CH) * 16) = vst[j];
+        else
+          *(u32x4_t*)(base + (idx >> 3) * C::VT_STRIDE + (idx & 7) * 16) = vst[j];
+      }
+    }
+  };
+
+  const int k_rd = KOFF + l32 * C::KSTRIDE + hi * 16;
+  int v_rd;
+  if constexpr (!VT) {
+    const int i = lane & 15, gi = (lane >> 4) & 1;
+    v_rd = VOFF + (4 * hi + (i >> 2)) * C::VSTRIDE + (16 * gi + 4 * (i & 3)) * 2;
+  } else {
+    v_rd = VOFF + l32 * C::VT_STRIDE + (4 * hi) * 2;
+  }
+
+  f32x16_t o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16_t zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+
+  // Sᵀ(tile) from K slot `ks_` : 2 x DS MFMAs on two independent accumulators
+  auto qk = [&](int kslot, f32x16_t (&sd)[2]) {
+    const char* kb = smem + kslot * C::KBYTES;
+#pragma unroll
+    for (int ks = 0; ks < DS; ++ks) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const half8_t kf = *(const half8_t*)(kb + k_rd + tt * 32 * C::KSTRIDE + ks * 32);
+        sd[tt] = mfma32(kf, qf[ks], ks == 0 ? zero16 : sd[tt]);
+      }
+    }
+  };
+  auto rowmax = [&](const f32x16_t (&sd)[2]) -> float {
+    float mt[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) mt[r] = fmaxf(fmaxf(sd[0][r], sd[0][r + 8]), fmaxf(sd[1][r], sd[1][r + 8]));
+    float mx = fmaxf(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3])),
+                     fmaxf(fmaxf(mt[4], mt[5]), fmaxf(mt[6], mt[7])));
+    return fmaxf(mx, __shfl_xor(mx, 32));
+  };
+  // rare, wave-uniform: every value at the old scale (O, l) is multiplied exactly once; the pending P tile
+  // is exponentiated AFTER this decision with the new m_run.
+  auto rescale = [&](float mx) {
+    const float m_cand = fmaxf(m_run, mx * sl2);
+    if (!__all(m_cand - m_run <= RESCALE_THR)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);
+      m_run = m_cand;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+  };
+  auto softmax_p = [&](const f32x16_t (&sd)[2], half8_t (&pf)[2][2]) {
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sd[tt][8 * u + j], sl2, -m_run));
+          ps[j & 3] += p;
+          pf[tt][u][j] = (half_t)p;
+        }
+    l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+  };
+  auto pv = [&](int vslot, const half8_t (&pf)[2][2]) {
+    const char* vb = smem + vslot * VB;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int tt = g >> 1, u = g & 1;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        half8_t vf;
+        if constexpr (!VT) {
+          const char* p = vb + v_rd + (32 * tt + 16 * u) * C::VSTRIDE + dt * 64;
+          vf = cat4(lds_tr16(p), lds_tr16(p + 8 * C::VSTRIDE));
+        } else {
+          const char* p = vb + v_rd + dt * 32 * C::VT_STRIDE + (32 * tt + 16 * u) * 2;
+          vf = cat4(*(const half4_t*)p, *(const half4_t*)(p + 16));
+        }
+        o[dt] = mfma32(vf, pf[tt][u], o[dt]);
+      }
+    }
+  };
+
+  const int T = N / KVB;
+  // ---- prologue: K(0), V(0), K(1) staged; Sᵀ(0) and its row max computed
+  load_k(0);
+  load_v(0);
+  store_k(0);
+  store_v(0);
+  if (T > 1) {
+    load_k(1);
+    store_k(1);
+  }
+#pragma unroll
+  for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(qf[s]));   // retire the Q loads before the loop
+  __syncthreads();
+  f32x16_t s_cur[2], s_nxt[2];
+  qk(0, s_cur);
+  rescale(rowmax(s_cur));
+
+  for (int t = 0; t + 1 < T; ++t) {
+    if (t + 2 < T) load_k(t + 2);
+    load_v(t + 1);
+    half8_t pf[2][2];
+    // ---- phase 1: 2*DS chunks of { 1 MFMA of Sᵀ(t+1) | 1 K-fragment read 8 MFMAs ahead | exp2 / sum /
+    //      pack of 32/(2*DS) values of P(t) }; __builtin_amdgcn_sched_barrier(0) pins the chunk order.
+    {
+      constexpr int NM = 2 * DS;                 // MFMAs (and chunks)
+      constexpr int PFD = NM < 8 ? NM : 8;       // K fragments in flight
+      constexpr int VPC = 32 / NM > 0 ? 32 / NM : 1;   // P values per chunk (D=128: 2)
+      const char* kb = smem + ((t + 1) & 1) * C::KBYTES;
+      half8_t kf[PFD];
+      auto kread = [&](int i) -> half8_t {
+        const int tt = i & 1, ks = i >> 1;
+        return *(const half8_t*)(kb + k_rd + tt * 32 * C::KSTRIDE + ks * 32);
+      };
+#pragma unroll
+      for (int i = 0; i < PFD; ++i) kf[i] = kread(i);
+      float ps[4] = {0.f, 0.f, 0.f, 0.f};
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        const int tt = i & 1, ks = i >> 1;
+        s_nxt[tt] = mfma32(kf[i % PFD], qf[ks], ks == 0 ? zero16 : s_nxt[tt]);
+        if (i + PFD < NM) kf[i % PFD] = kread(i + PFD);
+#pragma unroll
+        for (int e = 0; e < VPC; ++e) {
+          const int v = i * VPC + e;             // 0..31 -> (tt, u, j)
+          if (v < 32) {
+            const int ptt = v >> 4, pu = (v >> 3) & 1, pj = v & 7;
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[ptt][8 * pu + pj], sl2, -m_run));
+            ps[pj & 3] += p;
+            pf[ptt][pu][pj] = (half_t)p;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    }
+    // ---- phase 2: 4*DT chunks of { 1 MFMA of Oᵀ += Vᵀ(t)·Pᵀ(t) | 1 V fragment (2 transpose reads) 4 MFMAs
+    //      ahead | a slice of the row-max tree of Sᵀ(t+1) }
+    float mx;
+    {
+      constexpr int NM = 4 * DT;
+      constexpr int PFD = NM < 4 ? NM : 4;
+      const char* vb = smem + (t & 1) * VB;
+      half8_t vf[PFD];
+      auto vread = [&](int i) -> half8_t {
+        const int g = i / DT, dt = i % DT, tt = g >> 1, u = g & 1;
+        if constexpr (!VT) {
+          const char* p = vb + v_rd + (32 * tt + 16 * u) * C::VSTRIDE + dt * 64;
+          return cat4(lds_tr16(p), lds_tr16(p + 8 * C::VSTRIDE));
+        } else {
+          const char* p = vb + v_rd + dt * 32 * C::VT_STRIDE + (32 * tt + 16 * u) * 2;
+          return cat4(*(const half4_t*)p, *(const half4_t*)(p + 16));
+        }
+      };
+#pragma unroll
+      for (int i = 0; i < PFD; ++i) vf[i] = vread(i);
+      float mt[8];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        const int g = i / DT, dt = i % DT;
+        o[dt] = mfma32(vf[i % PFD], pf[g >> 1][g & 1], o[dt]);
+        if (i + PFD < NM) vf[i % PFD] = vread(i + PFD);
+        // row-max tree of s_nxt spread over the chunks (8 leaves, then 4 + 2 + 1 combines)
+        const int c = (i * 8) / NM;              // leaf index handled by this chunk when it is "new"
+        if (((i * 8) % NM) < 8 && c < 8 && (i == 0 || ((i - 1) * 8) / NM != c))
+          mt[c] = fmaxf(fmaxf(s_nxt[0][c], s_nxt[0][c + 8]), fmaxf(s_nxt[1][c], s_nxt[1][c + 8]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mx = fmaxf(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3])),
+                 fmaxf(fmaxf(mt[4], mt[5]), fmaxf(mt[6], mt[7])));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+    }
+    rescale(mx);                         // after P·V(t): O, l at the old scale are complete
+    if (t + 2 < T) store_k(t & 1);       // K(t) was last read in iteration t-1
+    store_v((t + 1) & 1);                // V(t-1) was last read in iteration t-1
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) s_cur[tt] = s_nxt[tt];
+  }
+  {  // last tile: P(T-1), P·V(T-1)
+    half8_t pf[2][2];
+    softmax_p(s_cur, pf);
+    pv((T - 1) & 1, pf);
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  half_t* orow = Ob + (size_t)(q0 + l32) * D;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      half4_t h;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) h[j] = (half_t)(o[dt][4 * rq + j] * inv);
+      *(half4_t*)(orow + 32 * dt + 8 * rq + 4 * hi) = h;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large head dims (D = 256, 512): the FFPA-style fine-grained tiling of the reference's
+// flash_attn_mma_tiling_qkv.cu:75-797 re-thought for CDNA4.  Q, K and V are all streamed through LDS in
+// 64-wide d slices (O(1) LDS in D: 18 + 9 + 12 KiB), Sᵀ is accumulated over the D/64 slices, and the
+// whole Oᵀ tile of a wave (32 rows x D, D/2 fp32 registers: 256 at D = 512) stays in registers — which is
+// why this kernel runs ONE wave per SIMD with the full 512-entry VGPR/AGPR file (the reference keeps O in
+// fp16 registers at d >= 256, tiling_qkv.cu:830-840; here it stays fp32).  Softmax identical to the
+// kernels above.  Correctness-first: single-buffered slices, two barriers per slice.
+// DO = output columns per workgroup: D = 512 is computed as two workgroups of 256 output columns each
+// (both accumulate the full-D Sᵀ: 1.5x the MFMA work, but Oᵀ fits the register file without spills).
+template <int D, int DO, int NW, bool VT>
+__global__ __launch_bounds__(NW * 64, 1) void attn_fwd_bigd_kernel(
+    const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
+    half_t* __restrict__ O, int N, int nqb, float sl2) {
+  constexpr int NT = NW * 64;
+  constexpr int SL = 64;                 // d slice
+  constexpr int NS = D / SL;             // slices of the Q·Kᵀ contraction
+  constexpr int NSO = DO / SL;           // V / O slices owned by this workgroup
+  constexpr int NSPLIT = D / DO;
+  constexpr int QR = NW * 32;            // query rows per workgroup
+  constexpr int QSTR = SL * 2 + 16;      // 144 B rows: conflict-free b128 fragment reads
+  constexpr int VSTR = 192;              // V slice rows [64 kv][64 d]: stride % 256 == 192 (tr-read quarters)
+  constexpr int Q_OFF = 0, K_OFF = QR * QSTR, V_OFF = K_OFF + KVB * QSTR;
+  constexpr int QCH = QR * 8, KCH = KVB * 8;   // 16-byte chunks per slice
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = wave_id();
+  const int hi = lane >> 5;
+  const int l32 = lane & 31;
+
+  const int id0 = xcd_remap(blockIdx.x, gridDim.x);
+  const int dbase = (id0 % NSPLIT) * DO;   // first output column of this workgroup
+  const int id = id0 / NSPLIT;
+  const size_t bh = id / nqb;
+  const int qblk = (id - (int)bh * nqb) * QR;
+  const half_t* Qb = Q + bh * (size_t)N * D + (size_t)qblk * D;
+  const half_t* Kb = K + bh * (size_t)N * D;
+  const half_t* Vb = V + bh * (size_t)N * D;
+  half_t* Ob = O + bh * (size_t)N * D;
+
+  const int q_rd = Q_OFF + (wave * 32 + l32) * QSTR + hi * 16;   // + ks*32
+  const int k_rd = K_OFF + l32 * QSTR + hi * 16;                 // + tt*32*QSTR + ks*32
+  int v_rd;
+  if constexpr (!VT) {
+    const int i = lane & 15, gi = (lane >> 4) & 1;
+    v_rd = V_OFF + (4 * hi + (i >> 2)) * VSTR + (16 * gi + 4 * (i & 3)) * 2;  // + (32tt+16u)*VSTR [+8*VSTR] + dt*64
+  } else {
+    v_rd = V_OFF + l32 * QSTR + (4 * hi) * 2;                                // + dt*32*QSTR + (32tt+16u)*2 [+16]
+  }
+
+  f32x16_t o[DO / 32];
+#pragma unroll
+  for (int dt = 0; dt < DO / 32; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int T = N / KVB;
+  for (int t = 0; t < T; ++t) {
+    f32x16_t s[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[tt][r] = 0.f;
+    // ---- Sᵀ += K[:, slice]·Q[:, slice]ᵀ over the D/64 slices
+#pragma unroll 1
+    for (int sl = 0; sl < NS; ++sl) {
+      __syncthreads();   // previous readers of the Q/K slice buffers are done
+      for (int idx = tid; idx < QCH; idx += NT) {
+        const int row = idx >> 3, c = idx & 7;
+        *(u32x4_t*)(smem + Q_OFF + row * QSTR + c * 16) =
+            *(const u32x4_t*)(Qb + (size_t)row * D + sl * SL + c * 8);
+      }
+      for (int idx = tid; idx < KCH; idx += NT) {
+        const int row = idx >> 3, c = idx & 7;
+        *(u32x4_t*)(smem + K_OFF + row * QSTR + c * 16) =
+            *(const u32x4_t*)(Kb + (size_t)(t * KVB + row) * D + sl * SL + c * 8);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < SL / 16; ++ks) {
+        const half8_t qfr = *(const half8_t*)(smem + q_rd + ks * 32);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const half8_t kfr = *(const half8_t*)(smem + k_rd + tt * 32 * QSTR + ks * 32);
+          s[tt] = mfma32(kfr, qfr, s[tt]);
+        }
+      }
+    }
+    // ---- online softmax (same arithmetic as attn_fwd_kernel)
+    float mt[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) mt[r] = fmaxf(fmaxf(s[0][r], s[0][r + 8]), fmaxf(s[1][r], s[1][r + 8]));
+    float mx = fmaxf(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3])),
+                     fmaxf(fmaxf(mt[4], mt[5]), fmaxf(mt[6], mt[7])));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_cand = fmaxf(m_run, mx * sl2);
+    if (!__all(m_cand - m_run <= RESCALE_THR)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);
+      m_run = m_cand;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < DO / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+    half8_t pf[2][2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[tt][8 * u + j], sl2, -m_run));
+          ps[j & 3] += p;
+          pf[tt][u][j] = (half_t)p;
+        }
+    l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    // ---- Oᵀ[slice] += V[:, slice]ᵀ·Pᵀ, one 64-wide d slice of V at a time (fully unrolled: o[] indices static)
+#pragma unroll
+    for (int sl = 0; sl < NSO; ++sl) {
+      __syncthreads();
+      for (int idx = tid; idx < KCH; idx += NT) {
+        const int row = idx >> 3, c = idx & 7;
+        if constexpr (!VT) {   // row = kv, c = d chunk
+          *(u32x4_t*)(smem + V_OFF + row * VSTR + c * 16) =
+              *(const u32x4_t*)(Vb + (size_t)(t * KVB + row) * D + dbase + sl * SL + c * 8);
+        } else {               // row = d (64 of this slice), c = kv chunk
+          *(u32x4_t*)(smem + V_OFF + row * QSTR + c * 16) =
+              *(const u32x4_t*)(Vb + (size_t)(dbase + sl * SL + row) * N + (size_t)t * KVB + c * 8);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int tt = g >> 1, u = g & 1;
+#pragma unroll
+        for (int d2 = 0; d2 < 2; ++d2) {
+          half8_t vfr;
+          if constexpr (!VT) {
+            const char* p = smem + v_rd + (32 * tt + 16 * u) * VSTR + d2 * 64;
+            vfr = cat4(lds_tr16(p), lds_tr16(p + 8 * VSTR));
+          } else {
+            const char* p = smem + v_rd + d2 * 32 * QSTR + (32 * tt + 16 * u) * 2;
+            vfr = cat4(*(const half4_t*)p, *(const half4_t*)(p + 16));
+          }
+          o[sl * 2 + d2] = mfma32(vfr, pf[tt][u], o[sl * 2 + d2]);
+        }
+      }
+    }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  half_t* orow = Ob + (size_t)(qblk + wave * 32 + l32) * D + dbase;
+#pragma unroll
+  for (int dt = 0; dt < DO / 32; ++dt) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      half4_t h;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) h[j] = (half_t)(o[dt][4 * rq + j] * inv);
+      *(half4_t*)(orow + 32 * dt + 8 * rq + 4 * hi) = h;
+    }
+  }
+}
+
+template <int NW>
+constexpr int attn_bigd_lds_bytes() {
+  return NW * 32 * 144 + KVB * 144 + KVB * 192;
+}
+
 }  // namespace lc

@@ -217,6 +217,19 @@ int launch_attn_pp(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
 }
 
 template <int D, bool VT>
+int launch_attn_swp(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
+                    hipStream_t st) {
+  auto kern = attn_fwd_swp_kernel<D, VT>;
+  constexpr int lds = attn_lds_bytes<D, VT>();
+  if (int rc = set_dyn_lds(kern, lds)) return rc;
+  const int nqb = N / 256;
+  const dim3 grid((unsigned)((size_t)nqb * B * H)), block(512);
+  const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+  hipLaunchKernelGGL(kern, grid, block, lds, st, Q, K, V, O, N, nqb, sl2);
+  return check_launch();
+}
+
+template <int D, bool VT>
 int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                    hipStream_t st) {
   if constexpr (D == 128 && !VT) {   // perf-diagnosis instantiations (lc_tune_set "attn_ablate")
@@ -236,10 +249,32 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
     }
   }
   const int want = g_tune_attn_nw;  // 0 = auto
-  if (N % 256 == 0 && (want == 0 || want == 16)) return launch_attn_pp<D, VT>(Q, K, V, O, B, H, N, st);
+  if (N % 256 == 0 && want == 32) return launch_attn_swp<D, VT>(Q, K, V, O, B, H, N, st);
+  if (N % 256 == 0 && want == 16) return launch_attn_pp<D, VT>(Q, K, V, O, B, H, N, st);
   if (N % 256 == 0 && (want == 0 || want == 8)) return launch_attn<D, 8, VT>(Q, K, V, O, B, H, N, st);
   if (N % 128 == 0 && (want == 0 || want >= 4)) return launch_attn<D, 4, VT>(Q, K, V, O, B, H, N, st);
   return launch_attn<D, 2, VT>(Q, K, V, O, B, H, N, st);
+}
+
+template <int D, int NW, bool VT>
+int launch_attn_bigd(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
+                     hipStream_t st) {
+  constexpr int DO = D > 256 ? 256 : D;   // output columns per workgroup (D = 512: two column halves)
+  auto kern = attn_fwd_bigd_kernel<D, DO, NW, VT>;
+  constexpr int lds = attn_bigd_lds_bytes<NW>();
+  if (int rc = set_dyn_lds(kern, lds)) return rc;
+  const int nqb = N / (NW * 32);
+  const dim3 grid((unsigned)((size_t)nqb * B * H * (D / DO))), block(NW * 64);
+  const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+  hipLaunchKernelGGL(kern, grid, block, lds, st, Q, K, V, O, N, nqb, sl2);
+  return check_launch();
+}
+
+template <int D, bool VT>
+int launch_attn_bigd_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
+                        hipStream_t st) {
+  if (N % 128 == 0) return launch_attn_bigd<D, 4, VT>(Q, K, V, O, B, H, N, st);
+  return launch_attn_bigd<D, 2, VT>(Q, K, V, O, B, H, N, st);
 }
 
 template <bool VT>
@@ -250,6 +285,9 @@ int launch_attn_d(const half_t* Q, const half_t* K, const half_t* V, half_t* O, 
     case 64: return launch_attn_nw<64, VT>(Q, K, V, O, B, H, N, st);
     case 96: return launch_attn_nw<96, VT>(Q, K, V, O, B, H, N, st);
     case 128: return launch_attn_nw<128, VT>(Q, K, V, O, B, H, N, st);
+    case 256: return launch_attn_bigd_nw<256, VT>(Q, K, V, O, B, H, N, st);
+    case 512: return launch_attn_bigd_nw<512, VT>(Q, K, V, O, B, H, N, st);
+    case 1024: return launch_attn_bigd_nw<1024, VT>(Q, K, V, O, B, H, N, st);
     default: return LC_ERR_HEADDIM;
   }
 }
@@ -281,7 +319,7 @@ const char* lc_status_string(int status) {
 int lc_tune_set(const char* key, int value) {
   if (!key) return LC_ERR_ARG;
   if (strcmp(key, "attn_nw") == 0) {
-    if (value != 0 && value != 16 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
+    if (value != 0 && value != 32 && value != 16 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
     g_tune_attn_nw = value;
     return LC_OK;
   }

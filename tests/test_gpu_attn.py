@@ -48,12 +48,14 @@ def test_attn_vs_oracle(oracle, D, N):
     assert (o.float() - o2.float()).abs().max().item() < 1e-3
 
 
-@pytest.mark.parametrize("nw", [16, 8, 4, 2])
-def test_workgroup_shapes_agree(oracle, nw):
-    """The same problem through 8-, 4- and 2-wave workgroups (lc_tune_set "attn_nw")."""
+@pytest.mark.parametrize("nw", [32, 16, 8, 4, 2])
+@pytest.mark.parametrize("D", [128, 64, 96, 32])
+def test_workgroup_shapes_agree(oracle, nw, D):
+    """The same problem through the software-pipelined (32), ping-pong (16) and 8-, 4-, 2-wave lock-step
+    kernels (lc_tune_set "attn_nw")."""
     capi = _capi()
-    B, H, N, D = 1, 3, 512, 128
-    torch.manual_seed(77)
+    B, H, N = 1, 3, 768
+    torch.manual_seed(77 + D)
     q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
@@ -65,6 +67,33 @@ def test_workgroup_shapes_agree(oracle, nw):
     finally:
         capi.tune("attn_nw", 0)
     _check(oracle, q, k, v, o)
+
+
+@pytest.mark.parametrize("D,N", [(256, 128), (256, 192), (512, 256), (512, 64), (1024, 128)])
+def test_large_head_dims_tiling_qkv(oracle, D, N):
+    """D = 256 / 512 / 1024: the fine-grained Q,K,V d-slice tiling (reference: flash_attn_mma_tiling_qkv.cu,
+    dispatcher cases 256, 512, 1024), through the FFPA-ancestor entry names."""
+    capi = _capi()
+    B, H = 1, 2
+    torch.manual_seed(D + N)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    for name in ("flash_attn_mma_stages_split_q_tiling_qkv", "flash_attn_mma_stages_split_q_tiling_qkv_acc_f32"):
+        o = torch.full_like(q, float("nan"))
+        capi.attn_call(name, q, k, v, o, 2)
+        torch.cuda.synchronize()
+        _check(oracle, q, k, v, o)
+    if D <= 256:   # V handed over as [B,H,D,N] (tiling_qk_swizzle_qkv: d <= 256)
+        tv = v.transpose(-2, -1).contiguous()
+        o = torch.full_like(q, float("nan"))
+        capi.attn_call("flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv", q, k, tv, o, 2)
+        torch.cuda.synchronize()
+        _check(oracle, q, k, tv, o, vt=True)
+    else:
+        with pytest.raises(capi.LcError) as e:   # the reference dispatcher stops at 256 for this entry
+            capi.attn_call("flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv", q, k, v, o, 2)
+        assert e.value.status == capi.LC_ERR_HEADDIM
 
 
 def test_golden_fixtures(oracle, golden):
@@ -79,7 +108,8 @@ def test_golden_fixtures(oracle, golden):
         assert d.max() < tol.ATTN_MAX_ABS, d.max()
 
 
-def test_forced_rescale_spike(oracle):
+@pytest.mark.parametrize("nw", [0, 32, 16])
+def test_forced_rescale_spike(oracle, nw):
     """One K row matches one Q row so strongly that the running max jumps by >> 8 in the middle of the
     sequence (tile 5 of 8): every row's accumulator must be rescaled exactly once (rule 26)."""
     capi = _capi()
@@ -92,8 +122,12 @@ def test_forced_rescale_spike(oracle):
     k[:, :, 2 * 64 + 3] = 1.5 * q[:, :, 400]
     v[:, :, 5 * 64 + 17] = 7.0
     o = torch.zeros_like(q)
-    capi.attn_fwd(q, k, v, o)
-    torch.cuda.synchronize()
+    capi.tune("attn_nw", nw)
+    try:
+        capi.attn_fwd(q, k, v, o)
+        torch.cuda.synchronize()
+    finally:
+        capi.tune("attn_nw", 0)
     _check(oracle, q, k, v, o, max_abs=6e-3)
     assert abs(o[0, 0, 33].float().mean().item() - 7.0) < 0.02
 
