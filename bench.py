@@ -65,7 +65,7 @@ def parse():
 
 VARIANT = {"auto": capi.HGEMM_AUTO, "mfma256": capi.HGEMM_MFMA256, "pingpong": capi.HGEMM_MFMA256P,
            "pingpong2": capi.HGEMM_MFMA256P2, "pingpong3": capi.HGEMM_MFMA256P3, "generic": capi.HGEMM_GENERIC}
-AUTO_KERNEL = "pingpong"   # what LC_HGEMM_AUTO resolves to (lc_abi.hip: g_tune_hgemm_auto)
+AUTO_KERNEL = "pingpong2"   # what LC_HGEMM_AUTO resolves to (lc_abi.hip: g_tune_hgemm_auto)
 
 
 def pmc_key_hgemm(variant: str, layout: str) -> str:
@@ -152,7 +152,7 @@ def bench_hgemm(w, args):
         capi.vendor_destroy()
         q, k, v, o, _ = host.get_qkvo(4, 32, 4096, 128)
         fl = host.mha_matmul_flops(4, 32, 4096, 128)
-        for nw in (16, 8, 4):
+        for nw in (32, 16, 8, 4):
             capi.tune("attn_nw", nw)
             ms = capi.attn_time(q, k, v, o, False, capi.ATTN_SPLIT_Q, 2, warmup=2, iters=10)
             print(f"[sweep] attn cfg3 nw={nw}: {ms:.4f} ms  {fl / ms * 1e-9:8.1f} TFLOP/s", file=sys.stderr)

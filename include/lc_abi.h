@@ -52,7 +52,7 @@ typedef enum lc_layout { LC_LAYOUT_NN = 0, LC_LAYOUT_TN = 1 } lc_layout;
 
 /* HGEMM kernel families behind the ABI. */
 typedef enum lc_hgemm_variant {
-  LC_HGEMM_AUTO = 0,     /* best available for the shape                                              */
+  LC_HGEMM_AUTO = 0,     /* best available for the shape (MFMA256P2 when 256-tileable, else GENERIC)  */
   LC_HGEMM_MFMA256 = 1,  /* 256x256x64 WG tile, 8 wave64, LDS-DMA double buffer, one barrier / K-tile */
   LC_HGEMM_MFMA256P = 2, /* same tile, phase-interleaved ping-pong schedule (counted vmcnt)           */
   LC_HGEMM_GENERIC = 3,  /* 64x64x32 edge-predicated MFMA kernel: any M,N,K                           */

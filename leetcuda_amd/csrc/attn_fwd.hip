@@ -163,10 +163,6 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
     // ---- Sᵀ = K·Qᵀ : two 32x32 tiles (kv 0..31, 32..63), 2*DS MFMAs in groups of GQ with the next
     // group's K fragments (ds_read_b128) in flight behind the current group's MFMAs.
     f32x16_t s[2];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[tt][r] = 0.f;
     if constexpr (ABL & 4) {
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
@@ -190,7 +186,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
 #pragma unroll
         for (int i = 0; i < GQ; ++i) {
           const int idx = g * GQ + i, tt = idx & 1, ks = idx >> 1;  // two independent accumulator chains
-          s[tt] = mfma32(kf[g & 1][i], qf[ks], s[tt]);
+          s[tt] = mfma32(kf[g & 1][i], qf[ks], ks == 0 ? (f32x16_t)0.f : s[tt]);
         }
       }
       // pin the issue order: [GQ reads] then per group [GQ reads of the next group][GQ MFMAs]
@@ -395,9 +391,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  f32x16_t zero16;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 
   const int T = N / KVB;
   load_k(0);
@@ -438,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(
 #pragma unroll
         for (int i = 0; i < GQ; ++i) {
           const int idx = g * GQ + i, tt = idx & 1, ks = idx >> 1;  // two independent accumulator chains
-          s[tt] = mfma32(kf[g & 1][i], qf[ks], ks == 0 ? zero16 : s[tt]);
+          s[tt] = mfma32(kf[g & 1][i], qf[ks], ks == 0 ? (f32x16_t)0.f : s[tt]);
         }
       }
       __builtin_amdgcn_s_setprio(0);
@@ -627,9 +620,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_swp_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  f32x16_t zero16;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 
   // Sᵀ(tile) from K slot `ks_` : 2 x DS MFMAs on two independent accumulators
   auto qk = [&](int kslot, f32x16_t (&sd)[2]) {
@@ -639,7 +629,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_swp_kernel(
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const half8_t kf = *(const half8_t*)(kb + k_rd + tt * 32 * C::KSTRIDE + ks * 32);
-        sd[tt] = mfma32(kf, qf[ks], ks == 0 ? zero16 : sd[tt]);
+        sd[tt] = mfma32(kf, qf[ks], ks == 0 ? (f32x16_t)0.f : sd[tt]);
       }
     }
   };
@@ -725,7 +715,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_swp_kernel(
     {
       constexpr int NM = 2 * DS;                 // MFMAs (and chunks)
       constexpr int PFD = NM < 8 ? NM : 8;       // K fragments in flight
-      constexpr int VPC = 32 / NM > 0 ? 32 / NM : 1;   // P values per chunk (D=128: 2)
+      constexpr int VPC = (32 + NM - 1) / NM;    // P values per chunk (D=128: 2)
       const char* kb = smem + ((t + 1) & 1) * C::KBYTES;
       half8_t kf[PFD];
       auto kread = [&](int i) -> half8_t {
@@ -739,7 +729,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_swp_kernel(
 #pragma unroll
       for (int i = 0; i < NM; ++i) {
         const int tt = i & 1, ks = i >> 1;
-        s_nxt[tt] = mfma32(kf[i % PFD], qf[ks], ks == 0 ? zero16 : s_nxt[tt]);
+        s_nxt[tt] = mfma32(kf[i % PFD], qf[ks], ks == 0 ? (f32x16_t)0.f : s_nxt[tt]);
         if (i + PFD < NM) kf[i % PFD] = kread(i + PFD);
 #pragma unroll
         for (int e = 0; e < VPC; ++e) {
@@ -782,10 +772,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_swp_kernel(
         const int g = i / DT, dt = i % DT;
         o[dt] = mfma32(vf[i % PFD], pf[g >> 1][g & 1], o[dt]);
         if (i + PFD < NM) vf[i % PFD] = vread(i + PFD);
-        // row-max tree of s_nxt spread over the chunks (8 leaves, then 4 + 2 + 1 combines)
-        const int c = (i * 8) / NM;              // leaf index handled by this chunk when it is "new"
-        if (((i * 8) % NM) < 8 && c < 8 && (i == 0 || ((i - 1) * 8) / NM != c))
-          mt[c] = fmaxf(fmaxf(s_nxt[0][c], s_nxt[0][c + 8]), fmaxf(s_nxt[1][c], s_nxt[1][c + 8]));
+        // the 8 leaves of the row-max tree of s_nxt, leaf c in chunk (c * NM) / 8
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if ((c * NM) / 8 == i)
+            mt[c] = fmaxf(fmaxf(s_nxt[0][c], s_nxt[0][c + 8]), fmaxf(s_nxt[1][c], s_nxt[1][c + 8]));
         __builtin_amdgcn_sched_barrier(0);
       }
       mx = fmaxf(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3])),

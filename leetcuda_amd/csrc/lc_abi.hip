@@ -21,7 +21,7 @@ namespace {
 // run-time tuning knobs (lc_tune_set): experiments and A/B benches, never required for correctness
 int g_tune_attn_ablate = 0;                // see attn_fwd_kernel ABL (diagnosis only)
 int g_tune_attn_nw = 0;                    // waves per attention workgroup: 0 = auto, 8 / 4 / 2
-int g_tune_hgemm_auto = LC_HGEMM_MFMA256P; // kernel family LC_HGEMM_AUTO resolves to on 256-tileable shapes
+int g_tune_hgemm_auto = LC_HGEMM_MFMA256P2; // kernel family LC_HGEMM_AUTO resolves to on 256-tileable shapes
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
