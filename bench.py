@@ -205,8 +205,8 @@ def cpu_baseline_hgemm(budget_s: float = 12.0):
     torch.matmul(a, a)
     probe = max(time.perf_counter() - t0, 1e-6)
     n, dt = 512, probe
-    for cand in (8192, 4096, 2048, 1024):
-        if probe * (cand / 512) ** 3 <= budget_s:
+    for cand in (4096, 2048, 1024):     # x4 safety: larger cubes fall out of cache and run slower per FLOP
+        if 4.0 * probe * (cand / 512) ** 3 <= budget_s:
             n = cand
             a = torch.randn(n, n, dtype=torch.half)
             b = torch.randn(n, n, dtype=torch.half)

@@ -78,8 +78,11 @@ def main(tag: str):
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             c["hbm_bytes_per_launch"] = c["hbm_read_bytes_fetch_x2"] + c["hbm_write_bytes"]
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"]:
-            # busy cycles are summed over SIMDs (256 CUs x 4); GRBM_GUI_ACTIVE is wall cycles
-            c["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 256 * 4)
+            # busy cycles are summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            # (11.7 M "cycles" for a 0.88 ms kernel = 8 x 1.47 M): wall cycles = GRBM_GUI_ACTIVE / 8
+            wall = c["GRBM_GUI_ACTIVE"] / 8.0
+            c["wall_cycles"] = wall
+            c["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (wall * 256 * 4)
         if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE"):
             c["lds_conflict_frac"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
     (out / f"{tag}_pmc.json").write_text(json.dumps(pmc, indent=1))
