@@ -85,48 +85,45 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
     qf[s] = *(const half8_t*)(Qb + (size_t)(q0 + l32) * D + 16 * s + 8 * hi);
   }
 
-  // ---- register staging of one K/V tile
+  // ---- register staging of one K/V tile; per-lane global / LDS offsets are hoisted out of the KV loop
+  // (the kernel is instruction-issue bound: no per-tile address arithmetic beyond one 64-bit add per load)
   u32x4_t kst[KL], vst[VL];
+  const half_t* kg[KL];
+  const half_t* vg[VL];
+  int kw[KL], vw[VL];
+#pragma unroll
+  for (int j = 0; j < KL; ++j) {
+    const int idx = tid + j * NT;
+    kg[j] = Kb + (size_t)idx * 8;
+    kw[j] = (idx / C::CH) * C::KSTRIDE + (idx % C::CH) * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < VL; ++j) {
+    const int idx = tid + j * NT;
+    if constexpr (!VT) {
+      vg[j] = Vb + (size_t)idx * 8;
+      vw[j] = C::KBYTES + (idx / C::CH) * C::VSTRIDE + (idx % C::CH) * 16;
+    } else {
+      vg[j] = Vb + (size_t)(idx >> 3) * N + (idx & 7) * 8;
+      vw[j] = C::KBYTES + (idx >> 3) * C::VT_STRIDE + (idx & 7) * 16;
+    }
+  }
+  const size_t kstep = (size_t)KVB * D, vstep = VT ? (size_t)KVB : (size_t)KVB * D;
   auto load_tile = [&](int t) {
-    const half_t* kp = Kb + (size_t)t * KVB * D;
 #pragma unroll
-    for (int j = 0; j < KL; ++j) {
-      const int idx = tid + j * NT;
-      if (K_CHUNKS % NT == 0 || idx < K_CHUNKS) kst[j] = *(const u32x4_t*)(kp + (size_t)idx * 8);
-    }
+    for (int j = 0; j < KL; ++j)
+      if (K_CHUNKS % NT == 0 || tid + j * NT < K_CHUNKS) kst[j] = *(const u32x4_t*)(kg[j] + t * kstep);
 #pragma unroll
-    for (int j = 0; j < VL; ++j) {
-      const int idx = tid + j * NT;
-      if (V_CHUNKS % NT == 0 || idx < V_CHUNKS) {
-        if constexpr (!VT) {
-          vst[j] = *(const u32x4_t*)(Vb + (size_t)t * KVB * D + (size_t)idx * 8);
-        } else {
-          vst[j] = *(const u32x4_t*)(Vb + (size_t)(idx >> 3) * N + (size_t)t * KVB + (idx & 7) * 8);
-        }
-      }
-    }
+    for (int j = 0; j < VL; ++j)
+      if (V_CHUNKS % NT == 0 || tid + j * NT < V_CHUNKS) vst[j] = *(const u32x4_t*)(vg[j] + t * vstep);
   };
   auto store_tile = [&](char* slot) {
 #pragma unroll
-    for (int j = 0; j < KL; ++j) {
-      const int idx = tid + j * NT;
-      if (K_CHUNKS % NT == 0 || idx < K_CHUNKS) {
-        const int row = idx / C::CH, c = idx % C::CH;
-        *(u32x4_t*)(slot + row * C::KSTRIDE + c * 16) = kst[j];
-      }
-    }
+    for (int j = 0; j < KL; ++j)
+      if (K_CHUNKS % NT == 0 || tid + j * NT < K_CHUNKS) *(u32x4_t*)(slot + kw[j]) = kst[j];
 #pragma unroll
-    for (int j = 0; j < VL; ++j) {
-      const int idx = tid + j * NT;
-      if (V_CHUNKS % NT == 0 || idx < V_CHUNKS) {
-        if constexpr (!VT) {
-          const int row = idx / C::CH, c = idx % C::CH;
-          *(u32x4_t*)(slot + C::KBYTES + row * C::VSTRIDE + c * 16) = vst[j];
-        } else {
-          *(u32x4_t*)(slot + C::KBYTES + (idx >> 3) * C::VT_STRIDE + (idx & 7) * 16) = vst[j];
-        }
-      }
-    }
+    for (int j = 0; j < VL; ++j)
+      if (V_CHUNKS % NT == 0 || tid + j * NT < V_CHUNKS) *(u32x4_t*)(slot + vw[j]) = vst[j];
   };
 
   // ---- lane-dependent LDS read offsets
@@ -221,22 +218,31 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
     }
-    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+    // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): two values per scale-subtract and per row-sum add
+    f32x2_t ps2[2] = {f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}};
+    const f32x2_t sl2v = {sl2, sl2}, nm = {-m_run, -m_run};
     half8_t pf[2][2];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float e = __builtin_fmaf(s[tt][8 * u + j], sl2, -m_run);
-          const float p = (ABL & 1) ? e : __builtin_amdgcn_exp2f(e);
-          ps[j & 3] += p;
-          pf[tt][u][j] = (half_t)p;
+        for (int j = 0; j < 8; j += 2) {
+          const f32x2_t sv = {s[tt][8 * u + j], s[tt][8 * u + j + 1]};
+          const f32x2_t e = __builtin_elementwise_fma(sv, sl2v, nm);
+          f32x2_t p;
+          p[0] = (ABL & 1) ? e[0] : __builtin_amdgcn_exp2f(e[0]);
+          p[1] = (ABL & 1) ? e[1] : __builtin_amdgcn_exp2f(e[1]);
+          ps2[(j >> 1) & 1] += p;
+          pf[tt][u][j] = (half_t)p[0];
+          pf[tt][u][j + 1] = (half_t)p[1];
         }
       }
     }
-    l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    {
+      const f32x2_t t2 = ps2[0] + ps2[1];
+      l_run += t2[0] + t2[1];
+    }
 
     // ---- Oᵀ += Vᵀ·Pᵀ : 4 (tt,u) groups of DT MFMAs on independent accumulators; the next group's Vᵀ
     // fragments (2 transpose reads each) are in flight behind the current group's MFMAs.
