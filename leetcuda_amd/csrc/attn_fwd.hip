@@ -143,6 +143,10 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
+  // waves 4..7 are dispatched second and lose every issue arbitration to waves 0..3 (priority, then age):
+  // one static s_setprio for the younger half evens the two halves out (measured: the older wave idled
+  // 1200 of 4300 cycles per tile at the barrier waiting for its partner)
+  if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
   const int T = N / KVB;
   load_tile(0);
   store_tile(smem);
@@ -153,9 +157,22 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
   for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(qf[s]));
   __syncthreads();
 
+  // ABL & 32: phase time stamps (s_memtime) of waves 0 and 4 of workgroup 0, tiles 16..19, written as u64
+  // over the first bytes of Q (already in registers by then; diagnosis only, clobbers the input!)
+  unsigned long long* stamp = reinterpret_cast<unsigned long long*>(const_cast<half_t*>(Q));
+  const bool stamping = (ABL & 32) && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0;
+  auto STAMP = [&](int t, int k) {
+    if constexpr (ABL & 32) {
+      if (t >= 16 && t < 20) {
+        const unsigned long long c = __builtin_readcyclecounter();
+        if (stamping) stamp[((wave >> 2) * 4 + (t - 16)) * 8 + k] = c;
+      }
+    }
+  };
   for (int t = 0; t < T; ++t) {
     char* cur = smem + ((ABL & 8) ? 0 : (t & 1)) * SLOT;
-    if (!(ABL & 8) && t + 1 < T) load_tile(t + 1);
+    STAMP(t, 0);
+    const bool more = !(ABL & 8) && t + 1 < T;
 
     // ---- Sᵀ = K·Qᵀ : two 32x32 tiles (kv 0..31, 32..63), 2*DS MFMAs in groups of GQ with the next
     // group's K fragments (ds_read_b128) in flight behind the current group's MFMAs.
@@ -185,17 +202,15 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
           const int idx = g * GQ + i, tt = idx & 1, ks = idx >> 1;  // two independent accumulator chains
           s[tt] = mfma32(kf[g & 1][i], qf[ks], ks == 0 ? (f32x16_t)0.f : s[tt]);
         }
-      }
-      // pin the issue order: [GQ reads] then per group [GQ reads of the next group][GQ MFMAs]
-      __builtin_amdgcn_sched_group_barrier(0x100, GQ, 0);
-#pragma unroll
-      for (int g = 0; g < NGQ; ++g) {
-        if (g + 1 < NGQ) __builtin_amdgcn_sched_group_barrier(0x100, GQ, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, GQ, 0);
+        // the K/V global prefetch of tile t+1 is issued behind the first MFMA group: a VMEM issue holds the
+        // wave for ~80 cycles, which now overlap MFMAs already queued on the matrix pipe
+        __builtin_amdgcn_sched_barrier(0);
+        if (g == 0 && more) load_tile(t + 1);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
 
+    STAMP(t, 1);
     // ---- online softmax (log2 domain): lane owns query row q = l32, kv columns split with lane^32
     float mt[8];
 #pragma unroll
@@ -218,6 +233,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
     }
+    STAMP(t, 2);
     // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): two values per scale-subtract and per row-sum add
     f32x2_t ps2[2] = {f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}};
     const f32x2_t sl2v = {sl2, sl2}, nm = {-m_run, -m_run};
@@ -272,11 +288,19 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
         if (g < 3) load_v(g + 1, vf[(g + 1) & 1]);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = mfma32(vf[g & 1][dt], pf[g >> 1][g & 1], o[dt]);
+        if (g == 1) {   // LDS writes of tile t+1 ride behind the P·V MFMAs (the other ring slot is idle)
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) store_tile(smem + ((t & 1) ^ 1) * SLOT);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
 
-    if (!(ABL & 8) && t + 1 < T) store_tile(smem + ((t & 1) ^ 1) * SLOT);
+    STAMP(t, 3);
+    if ((ABL & 2) && more) store_tile(smem + ((t & 1) ^ 1) * SLOT);   // (P·V ablated: stage here)
+    STAMP(t, 4);
     if (!(ABL & 16)) __syncthreads();
+    STAMP(t, 5);
   }
 
   // ---- epilogue: O = Oᵀ / l ; lane holds row q, 4 consecutive d per register quad

@@ -245,6 +245,7 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
       case 24: return launch_attn<D, 8, VT, 24>(Q, K, V, O, B, H, N, st);
       case 30: return launch_attn<D, 8, VT, 30>(Q, K, V, O, B, H, N, st);
       case 31: return launch_attn<D, 8, VT, 31>(Q, K, V, O, B, H, N, st);
+      case 32: return launch_attn<D, 8, VT, 32>(Q, K, V, O, B, H, N, st);
       default: break;
     }
   }
