@@ -65,7 +65,7 @@ def build_oracle(force: bool = False) -> Path:
     if not force and _newer(out, srcs):
         return out
     cc = shutil.which("gcc") or "cc"
-    _run([cc, "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-o", out,
+    _run([cc, "-O3", "-mavx2", "-mfma", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-o", out,
           ORACLE / "lc_oracle.c", "-lm"])
     return out
 

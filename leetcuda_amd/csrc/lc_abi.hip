@@ -8,6 +8,10 @@
 #include <math.h>
 #include <string.h>
 
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include "attn_fwd.hip"
 #include "hgemm_generic.hip"
 #include "hgemm_mfma256.hip"
@@ -27,13 +31,22 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 int check_launch() { return hipGetLastError() == hipSuccess ? LC_OK : LC_ERR_LAUNCH; }
 
+// The reference re-issues cudaFuncSetAttribute on every call (hgemm_mma_stage.cu:2284); here the attribute is
+// set once per (kernel, device) and remembered.
 template <typename KernelT>
 int set_dyn_lds(KernelT kernel, int bytes) {
-  // re-issued on every call like the reference's cudaFuncSetAttribute (hgemm_mma_stage.cu:2284); cheap.
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
-             ? LC_OK
-             : LC_ERR_LAUNCH;
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> done;
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return LC_ERR_DEVICE;
+  std::lock_guard<std::mutex> g(mu);
+  for (const auto& d : done)
+    if (d.first == fn && d.second == dev) return LC_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+    return LC_ERR_LAUNCH;
+  done.emplace_back(fn, dev);
+  return LC_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
