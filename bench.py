@@ -188,7 +188,7 @@ def bench_attn(w, args, sharded_cfg4=False, steps=None, warmup=None):
                      "kernel_ms": ms_kernel, "kernel": "attn_fwd_kernel<128,8,false>",
                      "algorithmic_flops_per_launch": flops_local,
                      "algorithmic_bytes_per_launch": 4.0 * b_loc * h_loc * N * D * 2,
-                     "traffic": pmc_traffic("attn_fwd_kernel<128,8,false>")},
+                     "traffic": pmc_traffic("attn_fwd_kernel<128,8,false,0>")},
     }
 
 
@@ -253,6 +253,11 @@ def cpu_baseline_attn():
 # ---------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the JSON): park the real stdout and point fd 1 at stderr while
+    # libraries (c10d/gloo/RCCL banners, hipBLASLt) may print, restore it for the final print.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     w = lcd.init()
     if w.size != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={w.size}: launch with torch.distributed.run")
@@ -298,8 +303,12 @@ def main():
         out["cpu_baseline"] = cpu_baseline_hgemm() if args.workload == "hgemm" else cpu_baseline_attn()
         if extra is not None:
             out["attention"]["cpu_baseline"] = cpu_baseline_attn()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
     if w.rank == 0:
         print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
     lcd.shutdown(w)
 
 
