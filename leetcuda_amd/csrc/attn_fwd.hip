@@ -851,6 +851,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_swp_kernel(
 // kernels above.  Correctness-first: single-buffered slices, two barriers per slice.
 // DO = output columns per workgroup: D = 512 is computed as two workgroups of 256 output columns each
 // (both accumulate the full-D Sᵀ: 1.5x the MFMA work, but Oᵀ fits the register file without spills).
+// The D/64 Q·Kᵀ slices and DO/64 P·V slices of a KV tile form one stream of stages; stage i+1's global
+// loads are in flight (registers) while stage i computes from the 2-slot LDS ring: one barrier per stage.
 template <int D, int DO, int NW, bool VT>
 __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_bigd_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
@@ -863,8 +865,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_bigd_kernel(
   constexpr int QR = NW * 32;            // query rows per workgroup
   constexpr int QSTR = SL * 2 + 16;      // 144 B rows: conflict-free b128 fragment reads
   constexpr int VSTR = 192;              // V slice rows [64 kv][64 d]: stride % 256 == 192 (tr-read quarters)
-  constexpr int Q_OFF = 0, K_OFF = QR * QSTR, V_OFF = K_OFF + KVB * QSTR;
-  constexpr int QCH = QR * 8, KCH = KVB * 8;   // 16-byte chunks per slice
+  constexpr int Q_OFF = 0, K_OFF = QR * QSTR, V_OFF = 0;      // the V slice aliases the Q/K area of a slot
+  constexpr int BUF = QR * QSTR + KVB * QSTR;                // one ring slot
+  constexpr int QL = QR * 8 / NT, KL = KVB * 8 / NT;         // 16-byte chunks per thread: Q 4, K/V 2 (NW = 4)
+  static_assert(QR * 8 % NT == 0 && KVB * 8 % NT == 0, "slice chunks must divide evenly");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -893,6 +897,50 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_bigd_kernel(
     v_rd = V_OFF + l32 * QSTR + (4 * hi) * 2;                                // + dt*32*QSTR + (32tt+16u)*2 [+16]
   }
 
+  // ---- register staging of the next stage (Q slice + K slice, or V slice)
+  u32x4_t rq[QL], rk[KL];
+  auto load_qk = [&](int t, int sl) {
+#pragma unroll
+    for (int j = 0; j < QL; ++j) {
+      const int idx = tid + j * NT, row = idx >> 3, c = idx & 7;
+      rq[j] = *(const u32x4_t*)(Qb + (size_t)row * D + sl * SL + c * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < KL; ++j) {
+      const int idx = tid + j * NT, row = idx >> 3, c = idx & 7;
+      rk[j] = *(const u32x4_t*)(Kb + (size_t)(t * KVB + row) * D + sl * SL + c * 8);
+    }
+  };
+  auto commit_qk = [&](char* buf) {
+#pragma unroll
+    for (int j = 0; j < QL; ++j) {
+      const int idx = tid + j * NT, row = idx >> 3, c = idx & 7;
+      *(u32x4_t*)(buf + Q_OFF + row * QSTR + c * 16) = rq[j];
+    }
+#pragma unroll
+    for (int j = 0; j < KL; ++j) {
+      const int idx = tid + j * NT, row = idx >> 3, c = idx & 7;
+      *(u32x4_t*)(buf + K_OFF + row * QSTR + c * 16) = rk[j];
+    }
+  };
+  auto load_v = [&](int t, int sl) {
+#pragma unroll
+    for (int j = 0; j < KL; ++j) {
+      const int idx = tid + j * NT, row = idx >> 3, c = idx & 7;
+      if constexpr (!VT)   // row = kv, c = d chunk
+        rk[j] = *(const u32x4_t*)(Vb + (size_t)(t * KVB + row) * D + dbase + sl * SL + c * 8);
+      else                 // row = d (64 of this slice), c = kv chunk
+        rk[j] = *(const u32x4_t*)(Vb + (size_t)(dbase + sl * SL + row) * N + (size_t)t * KVB + c * 8);
+    }
+  };
+  auto commit_v = [&](char* buf) {
+#pragma unroll
+    for (int j = 0; j < KL; ++j) {
+      const int idx = tid + j * NT, row = idx >> 3, c = idx & 7;
+      *(u32x4_t*)(buf + V_OFF + row * (VT ? QSTR : VSTR) + c * 16) = rk[j];
+    }
+  };
+
   f32x16_t o[DO / 32];
 #pragma unroll
   for (int dt = 0; dt < DO / 32; ++dt)
@@ -901,6 +949,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_bigd_kernel(
   float m_run = -INFINITY, l_run = 0.f;
 
   const int T = N / KVB;
+  int cur = 0;
+  load_qk(0, 0);
+  commit_qk(smem);
+  __syncthreads();
   for (int t = 0; t < T; ++t) {
     f32x16_t s[2];
 #pragma unroll
@@ -910,27 +962,22 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_bigd_kernel(
     // ---- Sᵀ += K[:, slice]·Q[:, slice]ᵀ over the D/64 slices
 #pragma unroll 1
     for (int sl = 0; sl < NS; ++sl) {
-      __syncthreads();   // previous readers of the Q/K slice buffers are done
-      for (int idx = tid; idx < QCH; idx += NT) {
-        const int row = idx >> 3, c = idx & 7;
-        *(u32x4_t*)(smem + Q_OFF + row * QSTR + c * 16) =
-            *(const u32x4_t*)(Qb + (size_t)row * D + sl * SL + c * 8);
-      }
-      for (int idx = tid; idx < KCH; idx += NT) {
-        const int row = idx >> 3, c = idx & 7;
-        *(u32x4_t*)(smem + K_OFF + row * QSTR + c * 16) =
-            *(const u32x4_t*)(Kb + (size_t)(t * KVB + row) * D + sl * SL + c * 8);
-      }
-      __syncthreads();
+      const bool last = sl + 1 == NS;
+      if (!last) load_qk(t, sl + 1); else load_v(t, 0);
+      const char* buf = smem + cur * BUF;
 #pragma unroll
       for (int ks = 0; ks < SL / 16; ++ks) {
-        const half8_t qfr = *(const half8_t*)(smem + q_rd + ks * 32);
+        const half8_t qfr = *(const half8_t*)(buf + q_rd + ks * 32);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-          const half8_t kfr = *(const half8_t*)(smem + k_rd + tt * 32 * QSTR + ks * 32);
+          const half8_t kfr = *(const half8_t*)(buf + k_rd + tt * 32 * QSTR + ks * 32);
           s[tt] = mfma32(kfr, qfr, s[tt]);
         }
       }
+      char* nxt = smem + (cur ^ 1) * BUF;
+      if (!last) commit_qk(nxt); else commit_v(nxt);
+      __syncthreads();
+      cur ^= 1;
     }
     // ---- online softmax (same arithmetic as attn_fwd_kernel)
     float mt[8];
@@ -962,21 +1009,13 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_bigd_kernel(
           pf[tt][u][j] = (half_t)p;
         }
     l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
-    // ---- Oᵀ[slice] += V[:, slice]ᵀ·Pᵀ, one 64-wide d slice of V at a time (fully unrolled: o[] indices static)
+    // ---- Oᵀ[slice] += V[:, slice]ᵀ·Pᵀ, one 64-wide d slice of V per stage (fully unrolled: o[] indices static)
 #pragma unroll
     for (int sl = 0; sl < NSO; ++sl) {
-      __syncthreads();
-      for (int idx = tid; idx < KCH; idx += NT) {
-        const int row = idx >> 3, c = idx & 7;
-        if constexpr (!VT) {   // row = kv, c = d chunk
-          *(u32x4_t*)(smem + V_OFF + row * VSTR + c * 16) =
-              *(const u32x4_t*)(Vb + (size_t)(t * KVB + row) * D + dbase + sl * SL + c * 8);
-        } else {               // row = d (64 of this slice), c = kv chunk
-          *(u32x4_t*)(smem + V_OFF + row * QSTR + c * 16) =
-              *(const u32x4_t*)(Vb + (size_t)(dbase + sl * SL + row) * N + (size_t)t * KVB + c * 8);
-        }
-      }
-      __syncthreads();
+      const bool last = sl + 1 == NSO;
+      const bool more = t + 1 < T;
+      if (!last) load_v(t, sl + 1); else if (more) load_qk(t + 1, 0);
+      const char* buf = smem + cur * BUF;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int tt = g >> 1, u = g & 1;
@@ -984,15 +1023,19 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_bigd_kernel(
         for (int d2 = 0; d2 < 2; ++d2) {
           half8_t vfr;
           if constexpr (!VT) {
-            const char* p = smem + v_rd + (32 * tt + 16 * u) * VSTR + d2 * 64;
+            const char* p = buf + v_rd + (32 * tt + 16 * u) * VSTR + d2 * 64;
             vfr = cat4(lds_tr16(p), lds_tr16(p + 8 * VSTR));
           } else {
-            const char* p = smem + v_rd + d2 * 32 * QSTR + (32 * tt + 16 * u) * 2;
+            const char* p = buf + v_rd + d2 * 32 * QSTR + (32 * tt + 16 * u) * 2;
             vfr = cat4(*(const half4_t*)p, *(const half4_t*)(p + 16));
           }
           o[sl * 2 + d2] = mfma32(vfr, pf[tt][u], o[sl * 2 + d2]);
         }
       }
+      char* nxt = smem + (cur ^ 1) * BUF;
+      if (!last) commit_v(nxt); else if (more) commit_qk(nxt);
+      __syncthreads();
+      cur ^= 1;
     }
   }
 
@@ -1013,7 +1056,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_bigd_kernel(
 
 template <int NW>
 constexpr int attn_bigd_lds_bytes() {
-  return NW * 32 * 144 + KVB * 144 + KVB * 192;
+  return 2 * (NW * 32 * 144 + KVB * 144);   // two ring slots of (Q slice + K slice); V slices alias them
 }
 
 }  // namespace lc
