@@ -267,9 +267,12 @@ template <bool B_KN, int NG, typename IssueFn>
 LC_DEVINL void pp2_mfma(f32x16_t (&acc)[4][2], int mh, const half8_t (&af)[2][4], const half8_t (&b0f)[4],
                         const half8_t (&b1f)[4], IssueFn issue) {
   __builtin_amdgcn_s_setprio(1);
+  // k-step outermost: the 4 accumulators of the phase rotate, so an accumulator is reused only every 4th
+  // MFMA (a dependent v_mfma_f32_32x32x16 issued 2 slots after its producer still stalls ~10 cycles:
+  // measured 676 instead of 512 cycles per 16-MFMA cluster with the 2-accumulator order)
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
-    const int nh = g >> 2, ks = g & 3;
+    const int ks = g >> 1, nh = g & 1;
     const half8_t bf = nh ? b1f[ks] : b0f[ks];
     acc[mh * 2 + 0][nh] = mfma32(bf, af[0][ks], acc[mh * 2 + 0][nh]);
     acc[mh * 2 + 1][nh] = mfma32(bf, af[1][ks], acc[mh * 2 + 1][nh]);
@@ -285,7 +288,7 @@ LC_DEVINL void pp2_mfma(f32x16_t (&acc)[4][2], int mh, const half8_t (&af)[2][4]
 //                      B(T); 2 slots of flight; MFMA clusters are bare).  Same vmcnt counts in both forms:
 //                      issue order ... A0B(T) | A1(T) | A0B(T+1) | A1(T+1) ..., WAR: re-stage in load phase
 //                      j+2 of the last read j.
-template <bool B_KN, bool DMA_IN_LOAD>
+template <bool B_KN, bool DMA_IN_LOAD, bool STAMPS = false>
 __global__ __launch_bounds__(512, 2) void hgemm_pingpong2_kernel(const half_t* __restrict__ A,
                                                                  const half_t* __restrict__ B,
                                                                  half_t* __restrict__ C, int M, int N,
@@ -342,9 +345,22 @@ __global__ __launch_bounds__(512, 2) void hgemm_pingpong2_kernel(const half_t* _
   pp_barrier();
   if (wr == 1) pp_barrier();
 
+  // STAMPS (diagnosis only, clobbers the first bytes of A): cycle stamps of waves 0 and 4 of workgroup 0 at
+  // the phase boundaries of K tiles 32..35
+  unsigned long long* stamp = reinterpret_cast<unsigned long long*>(const_cast<half_t*>(A));
+  const bool stamping = STAMPS && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0;
+  auto STAMP = [&](int kt, int k) {
+    if constexpr (STAMPS) {
+      if (kt >= 32 && kt < 36) {
+        const unsigned long long c = __builtin_readcyclecounter();
+        if (stamping) stamp[((wave >> 2) * 4 + (kt - 32)) * 8 + k] = c;
+      }
+    }
+  };
   half8_t af[2][4], b0f[4], b1f[4];
   for (int kt = 0; kt < KT; ++kt) {
     const char* cur = smem + (kt & 1) * SLOT_BYTES;
+    STAMP(kt, 0);
     // ---- phase A
     if constexpr (DMA_IN_LOAD) {
 #pragma unroll
@@ -353,13 +369,21 @@ __global__ __launch_bounds__(512, 2) void hgemm_pingpong2_kernel(const half_t* _
     pp_read_b<B_KN>(cur, fr, 0, b0f);
     pp_read_a<B_KN>(cur, fr, 0, af);
     pp_read_b<B_KN>(cur, fr, 1, b1f);
+    if constexpr (STAMPS) {   // split "fragment reads returned" from "DMA landed"
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      STAMP(kt, 5);
+    }
     LC_VMCNT(6);
+    STAMP(kt, 1);
     pp_barrier();
+    STAMP(kt, 2);
     if constexpr (DMA_IN_LOAD)
       pp2_mfma<B_KN, 0>(acc, 0, af, b0f, b1f, [](int) {});
     else
       pp2_mfma<B_KN, 2>(acc, 0, af, b0f, b1f, [&](int g) { piece(0, 1, g, kt + 1); });
+    STAMP(kt, 3);
     pp_barrier();
+    STAMP(kt, 4);
     // ---- phase B
     if constexpr (DMA_IN_LOAD) {
       piece(0, 1, 0, kt + 1);
@@ -368,15 +392,18 @@ __global__ __launch_bounds__(512, 2) void hgemm_pingpong2_kernel(const half_t* _
     pp_read_a<B_KN>(cur, fr, 1, af);
     LC_VMCNT(2);
     pp_barrier();
+    STAMP(kt, 6);
     if constexpr (DMA_IN_LOAD)
       pp2_mfma<B_KN, 0>(acc, 1, af, b0f, b1f, [](int) {});
     else
       pp2_mfma<B_KN, 6>(acc, 1, af, b0f, b1f, [&](int g) { issue_ab0(g, kt + 2); });
+    STAMP(kt, 7);
     pp_barrier();
   }
   if (wr == 0) pp_barrier();
   LC_VMCNT(0);
   pp_epilogue(smem, acc, C, N, m0, n0, wave, wr, wc, lane);
 }
+
 
 }  // namespace lc

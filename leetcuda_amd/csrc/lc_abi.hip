@@ -24,6 +24,7 @@ namespace {
 
 // run-time tuning knobs (lc_tune_set): experiments and A/B benches, never required for correctness
 int g_tune_attn_ablate = 0;                // see attn_fwd_kernel ABL (diagnosis only)
+int g_tune_hgemm_stamps = 0;                 // pingpong2 diagnosis build: cycle stamps into A (lc_tune_set "hgemm_stamps")
 int g_tune_attn_nw = 0;                    // waves per attention workgroup: 0 = auto, 8 / 4 / 2
 int g_tune_hgemm_auto = LC_HGEMM_MFMA256P2; // kernel family LC_HGEMM_AUTO resolves to on 256-tileable shapes
 
@@ -174,7 +175,11 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   const int tiles_m = M / BM, tiles_n = N / BN;
   const int pw = panel_tiles(swizzle_stride, tiles_n, BN);
   const dim3 grid(tiles_m * tiles_n), block(512);
-  if (variant == LC_HGEMM_MFMA256P3) {
+  if (variant == LC_HGEMM_MFMA256P2 && g_tune_hgemm_stamps) {
+    auto kern = hgemm_pingpong2_kernel<B_KN, false, true>;
+    if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
+    hipLaunchKernelGGL(kern, grid, block, HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
+  } else if (variant == LC_HGEMM_MFMA256P3) {
     auto kern = hgemm_pingpong2_kernel<B_KN, true>;
     if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
     hipLaunchKernelGGL(kern, grid, block, HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
@@ -335,6 +340,10 @@ int lc_tune_set(const char* key, int value) {
   if (strcmp(key, "attn_nw") == 0) {
     if (value != 0 && value != 32 && value != 16 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
     g_tune_attn_nw = value;
+    return LC_OK;
+  }
+  if (strcmp(key, "hgemm_stamps") == 0) {
+    g_tune_hgemm_stamps = value != 0;
     return LC_OK;
   }
   if (strcmp(key, "attn_ablate") == 0) {
