@@ -100,6 +100,12 @@ int lc_vendor_destroy(void);
 int lc_hgemm_vendor_f16(const void* A, const void* B, void* C, int M, int N, int K, int layout,
                         void* stream);
 
+/* EXTENSION (BASELINE config 5, no reference counterpart — the reference wrappers hard-require kHalf):
+ * fp8 GEMM, OCP e4m3fn inputs, fp32 MFMA accumulate, fp16 output:  C[M,N] = alpha * A8[M,K] * B8^T with B8
+ * stored [N,K] (the TN layout).  M, N multiples of 256, K multiple of 128, 16-byte aligned pointers. */
+int lc_gemm_fp8_e4m3(const void* A, const void* B, void* C, int M, int N, int K, float alpha,
+                     int swizzle_stride, void* stream);
+
 /* Dispatch by the reference's export name (hgemm.cc:126-181). 3-argument entries ignore
  * stages/swizzle/swizzle_stride. `init_cublas_handle` / `destroy_cublas_handle` take no tensors
  * (pass NULLs and zeros). */
@@ -120,6 +126,11 @@ int lc_hgemm_entry_info(const char* entry, int* layout, int* nargs);
  * N must be a multiple of 64; D in {32, 64, 96, 128, 256, 512, 1024} — the head dims of the reference dispatchers. */
 int lc_attn_fwd_f16(const void* Q, const void* K, const void* V, void* O, int B, int H, int N, int D,
                     int v_transposed, int family, int acc_f32, int stages, void* stream);
+
+/* EXTENSION (BASELINE config 5 "FFPA-style QKV fine-grained tiling D=512 bf16"; the reference has no bf16
+ * entry): the large-head-dim d-slice tiling kernel on bfloat16 Q,K,V,O [B,H,N,D], D in {256, 512}. */
+int lc_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, int B, int H, int N, int D,
+                     void* stream);
 
 /* Dispatch by the reference's export name (flash_attn.cc:170-223). */
 int lc_attn_call(const char* entry, const void* Q, const void* K, const void* V, void* O, int B, int H,

@@ -25,11 +25,13 @@ SYMBOLS = {
     "lc_vendor_init": (_i, []),
     "lc_vendor_destroy": (_i, []),
     "lc_hgemm_vendor_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "lc_gemm_fp8_e4m3": (_i, [_vp, _vp, _vp, _i, _i, _i, C.c_float, _i, _vp]),
     "lc_hgemm_call": (_i, [_cp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "lc_hgemm_entry_count": (_i, []),
     "lc_hgemm_entry_name": (_cp, [_i]),
     "lc_hgemm_entry_info": (_i, [_cp, _ip, _ip]),
     "lc_attn_fwd_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "lc_attn_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "lc_attn_call": (_i, [_cp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "lc_attn_entry_count": (_i, []),
     "lc_attn_entry_name": (_cp, [_i]),
@@ -124,6 +126,16 @@ def hgemm(a, b, c, layout=LAYOUT_NN, variant=HGEMM_AUTO, stages=2, swizzle_strid
     return c
 
 
+def gemm_fp8(a8, b8_nk, c, alpha=1.0, swizzle_stride=1):
+    """c[M,N] (fp16) = alpha * a8[M,K] @ b8_nk[N,K]^T; a8/b8 are torch.float8_e4m3fn (or uint8 views)."""
+    _need_gpu(a8, b8_nk, c)
+    M, K = a8.shape
+    N = b8_nk.shape[0]
+    check(load().lc_gemm_fp8_e4m3(_ptr(a8), _ptr(b8_nk), _ptr(c), M, N, K, float(alpha), swizzle_stride, _stream()),
+          "lc_gemm_fp8_e4m3")
+    return c
+
+
 def hgemm_call(entry: str, a, b, c, stages=2, swizzle=False, swizzle_stride=1):
     _need_gpu(a, b, c)
     M, K = a.shape
@@ -181,6 +193,16 @@ def attn_fwd(q, k, v, o, v_transposed=False, family=ATTN_SPLIT_Q, acc_f32=False,
     B, H, N, D = q.shape
     check(load().lc_attn_fwd_f16(_ptr(q), _ptr(k), _ptr(v), _ptr(o), B, H, N, D, int(v_transposed), family,
                                  int(acc_f32), stages, _stream()), "lc_attn_fwd_f16")
+    return o
+
+
+def attn_fwd_bf16(q, k, v, o):
+    """bfloat16 forward for D in {256, 512} (BASELINE config 5 extension)."""
+    import torch
+    _need_gpu(q, k, v, o)
+    assert q.dtype == k.dtype == v.dtype == o.dtype == torch.bfloat16
+    B, H, N, D = q.shape
+    check(load().lc_attn_fwd_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(o), B, H, N, D, _stream()), "lc_attn_fwd_bf16")
     return o
 
 

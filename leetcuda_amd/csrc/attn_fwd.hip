@@ -853,7 +853,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_swp_kernel(
 // (both accumulate the full-D Sᵀ: 1.5x the MFMA work, but Oᵀ fits the register file without spills).
 // The D/64 Q·Kᵀ slices and DO/64 P·V slices of a KV tile form one stream of stages; stage i+1's global
 // loads are in flight (registers) while stage i computes from the 2-slot LDS ring: one barrier per stage.
-template <int D, int DO, int NW, bool VT>
+template <int D, int DO, int NW, bool VT, bool BF16 = false>
 __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_bigd_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
     half_t* __restrict__ O, int N, int nqb, float sl2) {
@@ -971,7 +971,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_bigd_kernel(
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const half8_t kfr = *(const half8_t*)(buf + k_rd + tt * 32 * QSTR + ks * 32);
-          s[tt] = mfma32(kfr, qfr, s[tt]);
+          s[tt] = mfma32_16<BF16>(kfr, qfr, s[tt]);
         }
       }
       char* nxt = smem + (cur ^ 1) * BUF;
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_bigd_kernel(
         for (int j = 0; j < 8; ++j) {
           const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[tt][8 * u + j], sl2, -m_run));
           ps[j & 3] += p;
-          pf[tt][u][j] = (half_t)p;
+          pf[tt][u][j] = cvt16<BF16>(p);
         }
     l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
     // ---- Oᵀ[slice] += V[:, slice]ᵀ·Pᵀ, one 64-wide d slice of V per stage (fully unrolled: o[] indices static)
@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_bigd_kernel(
             const char* p = buf + v_rd + d2 * 32 * QSTR + (32 * tt + 16 * u) * 2;
             vfr = cat4(*(const half4_t*)p, *(const half4_t*)(p + 16));
           }
-          o[sl * 2 + d2] = mfma32(vfr, pf[tt][u], o[sl * 2 + d2]);
+          o[sl * 2 + d2] = mfma32_16<BF16>(vfr, pf[tt][u], o[sl * 2 + d2]);
         }
       }
       char* nxt = smem + (cur ^ 1) * BUF;
@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_bigd_kernel(
     for (int rq = 0; rq < 4; ++rq) {
       half4_t h;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) h[j] = (half_t)(o[dt][4 * rq + j] * inv);
+      for (int j = 0; j < 4; ++j) h[j] = cvt16<BF16>(o[dt][4 * rq + j] * inv);
       *(half4_t*)(orow + 32 * dt + 8 * rq + 4 * hi) = h;
     }
   }

@@ -1,0 +1,152 @@
+// gemm_fp8.hip — fp8 (OCP e4m3fn) GEMM for gfx950: C[M,N] (fp16) = alpha · A8[M,K] · B8ᵀ,  B8 stored [N,K].
+//
+// BASELINE config 5 ("fp8 MFMA HGEMM M=N=K=16384").  The reference has no fp8 GEMM (its wrappers hard-require
+// kHalf) — this is an EXTENSION of the path, parity is defined against the fp64 oracle on the
+// decoded e4m3 values.  Same 256x256 workgroup tile / 8 wave64 / two-phase ping-pong schedule, LDS ring,
+// swizzle and DMA plan as hgemm_pingpong2_kernel — byte for byte: a 128-byte LDS row now holds 128 k-values,
+// so a K tile is 128 deep and every ds_read_b128 fragment feeds TWO v_mfma_f32_32x32x16_fp8_fp8 (low / high
+// 8 bytes; both operands are split the same way, and MFMA contracts over matching (lane-half, slot) pairs, so
+// any consistent k assignment is exact).  32 MFMAs per phase instead of 16: the barrier / load-section
+// overhead per MFMA halves.  Non-scaled fp8 MFMA runs at the fp16 rate (2.5 PF dense); the 5 PF rate needs
+// the MX block-scaled K=128 instructions (next).
+#pragma once
+#include "hgemm_pingpong.hip"
+
+namespace lc {
+
+constexpr int BK8 = 128;  // k elements (= bytes) per K tile
+
+typedef long i64x2_t __attribute__((ext_vector_type(2)));
+
+LC_DEVINL f32x16_t mfma32_fp8(long a, long b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, c, 0, 0, 0);
+}
+
+struct PPSrc8 {
+  const uint8_t* a[2][2];
+  const uint8_t* b[2][2];
+  int a_lds[2][2];
+  int b_lds[2][2];
+};
+
+LC_DEVINL void pp_src8_init(PPSrc8& s, const uint8_t* A, const uint8_t* B, int m0, int n0, int K, int wave,
+                            int lane) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = wave * 2 + i;
+      {
+        const int blk = 16 * (q >> 3) + 8 * h + (q & 7);
+        const int row = blk * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        s.a[h][i] = A + (size_t)(m0 + row) * K + c * 16;
+        s.a_lds[h][i] = blk * 1024;
+      }
+      {
+        const int blk = 8 * (q >> 2) + 4 * h + (q & 3);
+        const int row = blk * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        s.b[h][i] = B + (size_t)(n0 + row) * K + c * 16;
+        s.b_lds[h][i] = TILE_BYTES + blk * 1024;
+      }
+    }
+  }
+}
+
+template <int NG, typename IssueFn>
+LC_DEVINL void pp8_cluster(f32x16_t (&acc)[4][2], int mh, const half8_t (&af)[2][4], const half8_t (&b0f)[4],
+                           const half8_t (&b1f)[4], IssueFn issue) {
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int ks = g >> 1, nh = g & 1;
+    const i64x2_t bv = __builtin_bit_cast(i64x2_t, nh ? b1f[ks] : b0f[ks]);
+    const i64x2_t a0 = __builtin_bit_cast(i64x2_t, af[0][ks]);
+    const i64x2_t a1 = __builtin_bit_cast(i64x2_t, af[1][ks]);
+    acc[mh * 2 + 0][nh] = mfma32_fp8(bv[0], a0[0], acc[mh * 2 + 0][nh]);
+    acc[mh * 2 + 1][nh] = mfma32_fp8(bv[0], a1[0], acc[mh * 2 + 1][nh]);
+    acc[mh * 2 + 0][nh] = mfma32_fp8(bv[1], a0[1], acc[mh * 2 + 0][nh]);
+    acc[mh * 2 + 1][nh] = mfma32_fp8(bv[1], a1[1], acc[mh * 2 + 1][nh]);
+    if (g < NG) issue(g);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_s_setprio(0);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_fp8_pingpong2_kernel(const uint8_t* __restrict__ A,
+                                                                    const uint8_t* __restrict__ B,
+                                                                    half_t* __restrict__ C, int M, int N, int K,
+                                                                    float alpha, int tiles_m, int tiles_n,
+                                                                    int panel_w) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const TileCoord tc = raster(id, tiles_m, tiles_n, panel_w);
+  const int m0 = tc.tm * BM, n0 = tc.tn * BN;
+
+  PPSrc8 src;
+  pp_src8_init(src, A, B, m0, n0, K, wave, lane);
+  PPFrag<false> fr;
+  pp_frag_init<false>(fr, wr, wc, lane);
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int KT = K / BK8;
+  auto piece = [&](int is_b, int h, int i, int t) {
+    const int te = t < KT ? t : KT - 1;
+    char* slot = smem + (t & 1) * SLOT_BYTES;
+    if (is_b)
+      glds16(src.b[h][i] + (size_t)te * BK8, slot + src.b_lds[h][i]);
+    else
+      glds16(src.a[h][i] + (size_t)te * BK8, slot + src.a_lds[h][i]);
+  };
+  auto issue_ab0 = [&](int g, int t) { piece(g < 4, g < 4 ? (g >> 1) : 0, g & 1, t); };
+
+#pragma unroll
+  for (int g = 0; g < 6; ++g) issue_ab0(g, 0);
+  piece(0, 1, 0, 0);
+  piece(0, 1, 1, 0);
+#pragma unroll
+  for (int g = 0; g < 6; ++g) issue_ab0(g, 1);
+  LC_VMCNT(8);
+  pp_barrier();
+  if (wr == 1) pp_barrier();
+
+  half8_t af[2][4], b0f[4], b1f[4];   // 16-byte fragments (16 fp8 values each)
+  for (int kt = 0; kt < KT; ++kt) {
+    const char* cur = smem + (kt & 1) * SLOT_BYTES;
+    pp_read_b<false>(cur, fr, 0, b0f);
+    pp_read_a<false>(cur, fr, 0, af);
+    pp_read_b<false>(cur, fr, 1, b1f);
+    LC_VMCNT(6);
+    pp_barrier();
+    pp8_cluster<2>(acc, 0, af, b0f, b1f, [&](int g) { piece(0, 1, g, kt + 1); });
+    pp_barrier();
+    pp_read_a<false>(cur, fr, 1, af);
+    LC_VMCNT(2);
+    pp_barrier();
+    pp8_cluster<6>(acc, 1, af, b0f, b1f, [&](int g) { issue_ab0(g, kt + 2); });
+    pp_barrier();
+  }
+  if (wr == 0) pp_barrier();
+  LC_VMCNT(0);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] *= alpha;
+  pp_epilogue(smem, acc, C, N, m0, n0, wave, wr, wc, lane);
+}
+
+}  // namespace lc

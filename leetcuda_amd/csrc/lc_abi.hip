@@ -16,6 +16,7 @@
 #include "hgemm_generic.hip"
 #include "hgemm_mfma256.hip"
 #include "hgemm_pingpong.hip"
+#include "gemm_fp8.hip"
 #include "probe.hip"
 
 using namespace lc;
@@ -275,11 +276,11 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   return launch_attn<D, 2, VT>(Q, K, V, O, B, H, N, st);
 }
 
-template <int D, int NW, bool VT>
+template <int D, int NW, bool VT, bool BF16 = false>
 int launch_attn_bigd(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                      hipStream_t st) {
   constexpr int DO = D > 256 ? 256 : D;   // output columns per workgroup (D = 512: two column halves)
-  auto kern = attn_fwd_bigd_kernel<D, DO, NW, VT>;
+  auto kern = attn_fwd_bigd_kernel<D, DO, NW, VT, BF16>;
   constexpr int lds = attn_bigd_lds_bytes<NW>();
   if (int rc = set_dyn_lds(kern, lds)) return rc;
   const int nqb = N / (NW * 32);
@@ -394,6 +395,21 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
                                 : launch_generic<false>(a, b, c, M, N, K, st);
 }
 
+int lc_gemm_fp8_e4m3(const void* A, const void* B, void* C, int M, int N, int K, float alpha,
+                     int swizzle_stride, void* stream) {
+  if (!A || !B || !C) return LC_ERR_ARG;
+  if (M <= 0 || N <= 0 || K <= 0) return LC_ERR_SHAPE;
+  if (M % BM || N % BN || K % BK8 || !aligned16(A) || !aligned16(B) || !aligned16(C)) return LC_ERR_SHAPE;
+  const int tiles_m = M / BM, tiles_n = N / BN;
+  const int pw = panel_tiles(swizzle_stride, tiles_n, BN);
+  auto kern = gemm_fp8_pingpong2_kernel;
+  if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), HGEMM256_LDS, static_cast<hipStream_t>(stream),
+                     static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), static_cast<half_t*>(C), M, N,
+                     K, alpha, tiles_m, tiles_n, pw);
+  return check_launch();
+}
+
 int lc_hgemm_entry_count(void) { return kNumHgemmEntries; }
 const char* lc_hgemm_entry_name(int index) {
   return (index >= 0 && index < kNumHgemmEntries) ? kHgemmEntries[index].name : nullptr;
@@ -440,6 +456,29 @@ int lc_attn_fwd_f16(const void* Q, const void* K, const void* V, void* O, int B,
   half_t* o = static_cast<half_t*>(O);
   return v_transposed ? launch_attn_d<true>(q, k, v, o, B, H, N, D, st)
                       : launch_attn_d<false>(q, k, v, o, B, H, N, D, st);
+}
+
+int lc_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, int B, int H, int N, int D,
+                     void* stream) {
+  if (!Q || !K || !V || !O) return LC_ERR_ARG;
+  if (B <= 0 || H <= 0 || N <= 0 || D <= 0 || N % KVB != 0) return LC_ERR_SHAPE;
+  if ((size_t)B * H * (size_t)(N / 64) * 4 > 0x7fffffffull) return LC_ERR_SHAPE;
+  if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O)) return LC_ERR_SHAPE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const half_t* q = static_cast<const half_t*>(Q);   // raw 16-bit lanes; the kernel flavour decodes bf16
+  const half_t* k = static_cast<const half_t*>(K);
+  const half_t* v = static_cast<const half_t*>(V);
+  half_t* o = static_cast<half_t*>(O);
+  const bool w4 = N % 128 == 0;
+  switch (D) {
+    case 256:
+      return w4 ? launch_attn_bigd<256, 4, false, true>(q, k, v, o, B, H, N, st)
+                : launch_attn_bigd<256, 2, false, true>(q, k, v, o, B, H, N, st);
+    case 512:
+      return w4 ? launch_attn_bigd<512, 4, false, true>(q, k, v, o, B, H, N, st)
+                : launch_attn_bigd<512, 2, false, true>(q, k, v, o, B, H, N, st);
+    default: return LC_ERR_HEADDIM;
+  }
 }
 
 int lc_attn_entry_count(void) { return kNumAttnEntries; }

@@ -48,6 +48,24 @@ LC_DEVINL f32x4_t mfma16(half8_t a, half8_t b, f32x4_t c) {
 LC_DEVINL f32x16_t mfma32(half8_t a, half8_t b, f32x16_t c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
+// 16-bit element flavour of a kernel: fragments travel as raw half8_t (16 bytes), only the MFMA opcode and
+// the fp32 <-> 16-bit conversions differ between fp16 and bf16.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <bool BF16>
+LC_DEVINL f32x16_t mfma32_16(half8_t a, half8_t b, f32x16_t c) {
+  if constexpr (BF16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                   c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+template <bool BF16>
+LC_DEVINL half_t cvt16(float x) {   // round-to-nearest-even to fp16 or bf16, returned as raw 16 bits in a half_t
+  if constexpr (BF16)
+    return __builtin_bit_cast(half_t, (__bf16)x);
+  else
+    return (half_t)x;
+}
 
 // XCD-aware, bijective remap of the hardware block id: block b runs on XCD b%8 (observed, speed
 // only); give every XCD a contiguous chunk of logical tile ids so neighbours share an L2.

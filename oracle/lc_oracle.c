@@ -77,11 +77,21 @@ int lc_oracle_num_threads(void) {
 /* ---------------------------------------------------------------------------------------------- */
 /* HGEMM                                                                                           */
 
+static int g_decode_bf16 = 0; /* set only inside lc_oracle_attn_exact_f32_bf16 (single caller at a time) */
+
+static inline float bf16_to_f32(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
 static float* to_f32(const uint16_t* x, size_t n) {
   float* out = (float*)malloc(n * sizeof(float));
   if (!out) return NULL;
+  const int bf = g_decode_bf16;
 #pragma omp parallel for schedule(static)
-  for (long long i = 0; i < (long long)n; ++i) out[i] = lc_h2f(x[i]);
+  for (long long i = 0; i < (long long)n; ++i) out[i] = bf ? bf16_to_f32(x[i]) : lc_h2f(x[i]);
   return out;
 }
 
@@ -150,6 +160,34 @@ void lc_oracle_hgemm_exact_f32(const uint16_t* A, const uint16_t* B, float* C, i
 void lc_oracle_hgemm_refnum(const uint16_t* A, const uint16_t* B, uint16_t* C, int M, int N, int K,
                             int layout) {
   hgemm_impl(A, B, C, M, N, K, layout, 2);
+}
+
+/* fp8 OCP e4m3fn: 1 sign, 4 exponent (bias 7), 3 mantissa; 0x7f / 0xff = NaN, no infinities. */
+float lc_e4m3_to_f32(uint8_t v) {
+  const int sign = v >> 7, e = (v >> 3) & 0xf, m = v & 7;
+  float r;
+  if (e == 0xf && m == 7) return NAN;
+  if (e == 0)
+    r = ldexpf((float)m, -9);               /* subnormal: m/8 * 2^-6 */
+  else
+    r = ldexpf(1.0f + (float)m / 8.0f, e - 7);
+  return sign ? -r : r;
+}
+
+void lc_oracle_gemm_fp8_exact_f32(const uint8_t* A, const uint8_t* Bnk, float* C, int M, int N, int K,
+                                  float alpha) {
+  float lut[256];
+  for (int i = 0; i < 256; ++i) lut[i] = lc_e4m3_to_f32((uint8_t)i);
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int m = 0; m < M; ++m) {
+    const uint8_t* ar = A + (size_t)m * K;
+    for (int n = 0; n < N; ++n) {
+      const uint8_t* br = Bnk + (size_t)n * K;
+      double acc = 0.0;
+      for (int k = 0; k < K; ++k) acc += (double)lut[ar[k]] * (double)lut[br[k]];
+      C[(size_t)m * N + n] = (float)(acc * (double)alpha);
+    }
+  }
 }
 
 /* ---------------------------------------------------------------------------------------------- */
@@ -228,6 +266,13 @@ void lc_oracle_attn_exact_f32(const uint16_t* Q, const uint16_t* K, const uint16
 void lc_oracle_attn_exact_f32_rows(const uint16_t* Qrows, const uint16_t* K, const uint16_t* V, float* O,
                                    int BH, int Nq, int N, int D, int v_transposed) {
   attn_exact_impl(Qrows, K, V, O, BH, 1, Nq, N, D, v_transposed, 1);
+}
+
+void lc_oracle_attn_exact_f32_bf16(const uint16_t* Q, const uint16_t* K, const uint16_t* V, float* O, int B,
+                                   int H, int N, int D) {
+  g_decode_bf16 = 1;
+  attn_exact_impl(Q, K, V, O, B, H, N, N, D, 0, 1);
+  g_decode_bf16 = 0;
 }
 
 /* fp16-accumulated dot over `len` elements in steps of 16 (one mma.sync k16 step each). */

@@ -34,6 +34,12 @@ class Oracle:
         lib.lc_oracle_block_swizzle_stride.restype = _i
         lib.lc_oracle_block_swizzle_stride.argtypes = [_i, _i, C.c_double]
         lib.lc_oracle_num_threads.restype, lib.lc_oracle_num_threads.argtypes = _i, []
+        lib.lc_oracle_attn_exact_f32_bf16.restype = None
+        lib.lc_oracle_attn_exact_f32_bf16.argtypes = [_u16, _u16, _u16, _f32, _i, _i, _i, _i]
+        lib.lc_e4m3_to_f32.restype, lib.lc_e4m3_to_f32.argtypes = C.c_float, [C.c_uint8]
+        _u8 = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+        lib.lc_oracle_gemm_fp8_exact_f32.restype = None
+        lib.lc_oracle_gemm_fp8_exact_f32.argtypes = [_u8, _u8, _f32, _i, _i, _i, C.c_float]
 
     # ---- numpy-level helpers (uint16 views of fp16 data) -------------------------------------
     @staticmethod
@@ -55,6 +61,16 @@ class Oracle:
         fn(a, b, c, M, N, K, layout)
         return c.view(np.float16)
 
+    def gemm_fp8(self, a8, b8_nk, M, N, K, alpha=1.0):
+        """a8 [M,K], b8_nk [N,K]: uint8 views of e4m3fn data -> fp32 exact result."""
+        if hasattr(a8, "detach"):
+            a8 = a8.detach().cpu().contiguous().view(__import__("torch").uint8).numpy()
+            b8_nk = b8_nk.detach().cpu().contiguous().view(__import__("torch").uint8).numpy()
+        c = np.empty((M, N), np.float32)
+        self.lib.lc_oracle_gemm_fp8_exact_f32(np.ascontiguousarray(a8), np.ascontiguousarray(b8_nk), c, M, N, K,
+                                              float(alpha))
+        return c
+
     def attn(self, q, k, v, B, H, N, D, vt=False, mode="exact", Bc=64, o_f32=False):
         q, k, v = self.u16(q), self.u16(k), self.u16(v)
         if mode == "f32":
@@ -67,6 +83,15 @@ class Oracle:
         else:
             self.lib.lc_oracle_attn_refnum(q, k, v, o, B, H, N, D, Bc, int(o_f32))
         return o.view(np.float16)
+
+    def attn_bf16(self, q, k, v, B, H, N, D):
+        """torch.bfloat16 tensors -> fp32 exact attention."""
+        import torch
+        def u(x):
+            return np.ascontiguousarray(x.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16))
+        o = np.empty((B, H, N, D), np.float32)
+        self.lib.lc_oracle_attn_exact_f32_bf16(u(q), u(k), u(v), o, B, H, N, D)
+        return o
 
     def attn_rows(self, qrows, k, v, BH, Nq, N, D, vt=False):
         o = np.empty((BH, Nq, D), np.float32)

@@ -96,6 +96,25 @@ def test_large_head_dims_tiling_qkv(oracle, D, N):
         assert e.value.status == capi.LC_ERR_HEADDIM
 
 
+@pytest.mark.parametrize("D,N", [(512, 256), (256, 192), (512, 64)])
+def test_bf16_large_head_dim(oracle, D, N):
+    """BASELINE config 5: FFPA-style tiling at D = 512 in bfloat16 (extension; oracle on the bf16 inputs).
+    bf16 has 8 mantissa bits: P and O round 8x coarser than fp16, hence the wider absolute band."""
+    capi = _capi()
+    B, H = 1, 2
+    torch.manual_seed(D * 3 + N)
+    q = torch.randn(B, H, N, D, device="cuda").to(torch.bfloat16)
+    k = torch.randn(B, H, N, D, device="cuda").to(torch.bfloat16)
+    v = torch.randn(B, H, N, D, device="cuda").to(torch.bfloat16)
+    o = torch.full_like(q, float("nan"))
+    capi.attn_fwd_bf16(q, k, v, o)
+    torch.cuda.synchronize()
+    truth = oracle.attn_bf16(q, k, v, B, H, N, D)
+    d = np.abs(o.float().cpu().numpy() - truth)
+    assert np.isfinite(d).all() and d.max() < 1.6e-2, d.max()
+    assert d.mean() < 1.5e-3, d.mean()
+
+
 def test_golden_fixtures(oracle, golden):
     capi = _capi()
     g = golden["attn"]

@@ -134,3 +134,34 @@ def test_flop_accounting_matches_reference(oracle, golden):
     assert oracle.lib.lc_oracle_hgemm_flops(8192, 8192, 8192) == 2.0 * 8192 ** 3
     for N, K, f, want in golden["host"]["swizzle_stride"]:
         assert oracle.lib.lc_oracle_block_swizzle_stride(N, K, -1.0 if f is None else f) == want
+
+
+def test_e4m3_decoder_matches_torch_float8(oracle):
+    """OCP e4m3fn decode pinned on torch's own float8_e4m3fn -> float32 conversion, all 256 codes."""
+    codes = torch.arange(256, dtype=torch.uint8)
+    want = codes.view(torch.float8_e4m3fn).float().numpy()
+    for c in range(256):
+        got = oracle.lib.lc_e4m3_to_f32(c)
+        if np.isnan(want[c]):
+            assert np.isnan(got)
+        else:
+            assert got == want[c], (c, got, want[c])
+
+
+def test_fp8_gemm_oracle_vs_torch(oracle):
+    torch.manual_seed(12)
+    M, N, K = 48, 40, 136
+    a = (torch.randn(M, K) * 0.5).to(torch.float8_e4m3fn)
+    b = (torch.randn(N, K) * 0.5).to(torch.float8_e4m3fn)
+    got = oracle.gemm_fp8(a, b, M, N, K, alpha=0.25)
+    want = 0.25 * (a.double() @ b.double().t())
+    np.testing.assert_allclose(got, want.float().numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_bf16_attention_oracle_vs_torch(oracle):
+    torch.manual_seed(13)
+    B, H, N, D = 1, 2, 64, 256
+    q, k, v = (torch.randn(B, H, N, D).to(torch.bfloat16) for _ in range(3))
+    got = oracle.attn_bf16(q, k, v, B, H, N, D)
+    att = torch.softmax(q.double() @ k.double().transpose(-2, -1) / (D ** 0.5), dim=-1) @ v.double()
+    np.testing.assert_allclose(got, att.float().numpy(), rtol=2e-6, atol=2e-6)
