@@ -157,6 +157,22 @@ def bench_hgemm(w, args):
             ms = capi.attn_time(q, k, v, o, False, capi.ATTN_SPLIT_Q, 2, warmup=2, iters=10)
             print(f"[sweep] attn cfg3 nw={nw}: {ms:.4f} ms  {fl / ms * 1e-9:8.1f} TFLOP/s", file=sys.stderr)
         capi.tune("attn_nw", 0)
+        for nn in (8192, 16384):     # config-5 extension: fp8 e4m3 GEMM (TN), alpha = 1/16
+            a8 = torch.randn(nn, nn, device="cuda").to(torch.float8_e4m3fn)
+            b8 = torch.randn(nn, nn, device="cuda").to(torch.float8_e4m3fn)
+            c8 = torch.zeros(nn, nn, dtype=torch.half, device="cuda")
+            for _ in range(3):
+                capi.gemm_fp8(a8, b8, c8, alpha=1 / 16, swizzle_stride=2048)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                capi.gemm_fp8(a8, b8, c8, alpha=1 / 16, swizzle_stride=2048)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            print(f"[sweep] gemm fp8 e4m3 {nn}^3: {ms:.4f} ms  {2.0 * nn ** 3 / ms * 1e-9:8.1f} TFLOP/s", file=sys.stderr)
+            res.setdefault("fp8_tflops", {})[str(nn)] = 2.0 * nn ** 3 / ms * 1e-9
+            del a8, b8, c8
     return res
 
 
@@ -295,6 +311,8 @@ def main():
     }
     if "vendor_tflops" in main_res:
         out["vendor_tflops"] = main_res["vendor_tflops"]
+    if "fp8_tflops" in main_res:
+        out["fp8_tflops"] = main_res["fp8_tflops"]
     if extra is not None:
         out["attention"] = {k: extra[k] for k in ("value", "ms_per_step", "tflops_reference_formula", "workload",
                                                    "scaling", "roofline")}
