@@ -22,9 +22,15 @@ def hgemm_atol(K: int, amp: float = 1.0) -> float:
     return amp * amp * (1e-3 + 2.5e-7 * K)
 
 
-def hgemm_close(out_f32, truth_f32, K, amp=1.0):
+def fp8_atol(K: int, amp: float = 1.0) -> float:
+    """fp8 MFMA sums its 16 products per instruction with a narrower internal alignment than a chain of fp32
+    FMAs: measured |err| at truth ~ 0 is ~1.7e-3 at K = 2048 (randn e4m3 inputs), ~10x the fp16 kernels'."""
+    return amp * amp * (2e-3 + 1.5e-6 * K)
+
+
+def hgemm_close(out_f32, truth_f32, K, amp=1.0, atol=None):
     """numpy arrays -> (ok, max_abs_err, worst_excess)."""
     import numpy as np
     err = np.abs(out_f32.astype(np.float64) - truth_f32.astype(np.float64))
-    bound = HGEMM_RTOL * np.abs(truth_f32.astype(np.float64)) + hgemm_atol(K, amp)
+    bound = HGEMM_RTOL * np.abs(truth_f32.astype(np.float64)) + (hgemm_atol(K, amp) if atol is None else atol)
     return bool((err <= bound).all()), float(err.max()), float((err - bound).max())
