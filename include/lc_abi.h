@@ -52,12 +52,13 @@ typedef enum lc_layout { LC_LAYOUT_NN = 0, LC_LAYOUT_TN = 1 } lc_layout;
 
 /* HGEMM kernel families behind the ABI. */
 typedef enum lc_hgemm_variant {
-  LC_HGEMM_AUTO = 0,     /* best available for the shape (MFMA256P2 when 256-tileable, else GENERIC)  */
+  LC_HGEMM_AUTO = 0,     /* best available for the shape (MFMA256P2 / MFMA128 / GENERIC by divisibility)  */
   LC_HGEMM_MFMA256 = 1,  /* 256x256x64 WG tile, 8 wave64, LDS-DMA double buffer, one barrier / K-tile */
   LC_HGEMM_MFMA256P = 2, /* same tile, phase-interleaved ping-pong schedule (counted vmcnt)           */
   LC_HGEMM_GENERIC = 3,  /* 64x64x32 edge-predicated MFMA kernel: any M,N,K                           */
   LC_HGEMM_MFMA256P2 = 4, /* ping-pong with 2 phases of 16 MFMAs per K tile, DMA issued inside MFMA clusters */
-  LC_HGEMM_MFMA256P3 = 5  /* same, DMA issued by the load sections (bare MFMA clusters)                     */
+  LC_HGEMM_MFMA256P3 = 5, /* same, DMA issued by the load sections (bare MFMA clusters)                     */
+  LC_HGEMM_MFMA128 = 6    /* 128x128x64 tile, 4 wave64: M, N multiples of 128 (the reference's own tile)     */
 } lc_hgemm_variant;
 
 /* FlashAttention-2 forward families (resource policies of kernels/flash-attn/mma/basic/ .cu files). */

@@ -1,0 +1,130 @@
+// hgemm_mfma128.hip — 128x128x64 workgroup tile, 4 wave64 (2 x 2, wave tile 64x64), LDS-DMA double buffer.
+// The mid-size sibling of hgemm_mfma256.hip (same LDS images, swizzles and one-barrier-per-K-tile schedule)
+// for the shapes the reference itself accepts but a 256 tile does not divide: M, N multiples of 128, K of 64
+// (reference tiles are 128x128, kernels/hgemm/mma/basic/hgemm_mma_stage.cu:644-676).  64 KiB of LDS, two
+// workgroups per CU.
+#pragma once
+#include "hgemm_mfma256.hip"
+
+namespace lc {
+
+constexpr int BM1 = 128, BN1 = 128;
+constexpr int TILE1_BYTES = BM1 * BK * 2;        // 16 KiB (A) == BK * BN1 * 2 (B)
+constexpr int SLOT1_BYTES = 2 * TILE1_BYTES;
+constexpr int HGEMM128_LDS = 2 * SLOT1_BYTES;    // 64 KiB
+
+template <bool B_KN>
+__global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __restrict__ A,
+                                                               const half_t* __restrict__ B,
+                                                               half_t* __restrict__ C, int M, int N, int K,
+                                                               int tiles_m, int tiles_n, int panel_w) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  const int wr = wave >> 1, wc = wave & 1;
+  const int i16 = lane & 15, g = lane >> 4;
+
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const TileCoord tc = raster(id, tiles_m, tiles_n, panel_w);
+  const int m0 = tc.tm * BM1, n0 = tc.tn * BN1;
+
+  // ---- LDS-DMA sources: 16 + 16 pieces of 1 KiB per K tile, 4 + 4 per wave
+  const half_t* sa[4];
+  const half_t* sb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = wave * 4 + i;
+    const int row = p * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    sa[i] = A + (size_t)(m0 + row) * K + c * 8;
+    if constexpr (!B_KN) {
+      sb[i] = B + (size_t)(n0 + row) * K + c * 8;
+    } else {   // [64 k][128 n] image, 256-byte rows = 8 pairs of 16-byte chunks, piece = 4 k rows
+      const int k = p * 4 + (lane >> 4);
+      const int pp = lane & 15;
+      const int h = (k & 3) | (((k >> 3) & 1) << 2);
+      const int nc = (((pp >> 1) ^ h) << 1) | (pp & 1);
+      sb[i] = B + (size_t)k * N + n0 + nc * 8;
+    }
+  }
+  // ---- fragment read offsets
+  const int pc0 = g ^ ((lane >> 1) & 7);
+  const int a0 = (wr * 64 + i16) * 128 + pc0 * 16;
+  int b0 = 0, bt[4];
+  if constexpr (!B_KN) {
+    b0 = (wc * 64 + i16) * 128 + pc0 * 16;
+  } else {
+    const int k = 8 * g + (i16 >> 2);
+    const int h = (i16 >> 2) | ((g & 1) << 2);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bt[ni] = k * 256 + (((wc * 4 + ni) ^ h) * 32) + (i16 & 3) * 8;
+  }
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int KT = K / BK;
+  const size_t bstep = B_KN ? (size_t)BK * N : (size_t)BK;
+  auto issue = [&](int t, char* slot) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(sa[i] + (size_t)t * BK, slot + (wave * 4 + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(sb[i] + (size_t)t * bstep, slot + TILE1_BYTES + (wave * 4 + i) * 1024);
+  };
+  issue(0, smem);
+  for (int kt = 0; kt < KT; ++kt) {
+    const char* cur = smem + (kt & 1) * SLOT1_BYTES;
+    char* nxt = smem + ((kt & 1) ^ 1) * SLOT1_BYTES;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < KT) issue(kt + 1, nxt);
+    const char* la = cur;
+    const char* lb = cur + TILE1_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8_t af[4], bf[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        if constexpr (!B_KN) {
+          bf[ni] = *(const half8_t*)(lb + ((b0 ^ (ks * 64)) + ni * 2048));
+        } else {
+          const half4_t lo = lds_tr16(lb + bt[ni] + ks * (32 * 256));
+          const half4_t hi = lds_tr16(lb + bt[ni] + ks * (32 * 256) + 4 * 256);
+          bf[ni] = cat4(lo, hi);
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) af[mi] = *(const half8_t*)(la + ((a0 ^ (ks * 64)) + mi * 2048));
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(bf[ni], af[mi], acc[mi][ni]);
+    }
+  }
+  // ---- epilogue: each wave stages its 64x64 sub-tile through LDS, stores 128-byte row segments
+  char* stg = smem + wave * (64 * EPI_STRIDE);
+  __syncthreads();
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const f32x4_t v = acc[mi][ni];
+      half4_t h;
+      h[0] = (half_t)v[0]; h[1] = (half_t)v[1]; h[2] = (half_t)v[2]; h[3] = (half_t)v[3];
+      *(half4_t*)(stg + (mi * 16 + i16) * EPI_STRIDE + (ni * 16 + g * 4) * 2) = h;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 8 + (lane >> 3);
+    const u32x4_t v = *(const u32x4_t*)(stg + row * EPI_STRIDE + (lane & 7) * 16);
+    half_t* dst = C + (size_t)(m0 + wr * 64 + row) * N + n0 + wc * 64 + (lane & 7) * 8;
+    *(u32x4_t*)dst = v;
+  }
+}
+
+}  // namespace lc

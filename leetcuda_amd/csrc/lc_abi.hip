@@ -14,6 +14,7 @@
 
 #include "attn_fwd.hip"
 #include "hgemm_generic.hip"
+#include "hgemm_mfma128.hip"
 #include "hgemm_mfma256.hip"
 #include "hgemm_pingpong.hip"
 #include "gemm_fp8.hip"
@@ -201,6 +202,18 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
 }
 
 template <bool B_KN>
+int launch_mfma128(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int swizzle_stride,
+                   hipStream_t st) {
+  const int tiles_m = M / BM1, tiles_n = N / BN1;
+  const int pw = panel_tiles(swizzle_stride, tiles_n, BN1);
+  auto kern = hgemm_mfma128_kernel<B_KN>;
+  if (int rc = set_dyn_lds(kern, HGEMM128_LDS)) return rc;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), HGEMM128_LDS, st, A, B, C, M, N, K, tiles_m,
+                     tiles_n, pw);
+  return check_launch();
+}
+
+template <bool B_KN>
 int launch_generic(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, hipStream_t st) {
   const dim3 grid((N + GN - 1) / GN, (M + GM - 1) / GM), block(256);
   hipLaunchKernelGGL(hgemm_generic_kernel<B_KN>, grid, block, 0, st, A, B, C, M, N, K);
@@ -376,20 +389,27 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   (void)stages;  // LDS ring depth is fixed per kernel family; accepted for signature parity
   if (!A || !B || !C) return LC_ERR_ARG;
   if (layout != LC_LAYOUT_NN && layout != LC_LAYOUT_TN) return LC_ERR_ARG;
-  if (variant < LC_HGEMM_AUTO || variant > LC_HGEMM_MFMA256P3) return LC_ERR_ARG;
+  if (variant < LC_HGEMM_AUTO || variant > LC_HGEMM_MFMA128) return LC_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0) return LC_ERR_SHAPE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const half_t* a = static_cast<const half_t*>(A);
   const half_t* b = static_cast<const half_t*>(B);
   half_t* c = static_cast<half_t*>(C);
-  const bool tiles256 = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && aligned16(A) &&
-                        aligned16(B) && aligned16(C);
-  if (variant == LC_HGEMM_AUTO) variant = tiles256 ? g_tune_hgemm_auto : LC_HGEMM_GENERIC;
+  const bool al = aligned16(A) && aligned16(B) && aligned16(C);
+  const bool tiles256 = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && al;
+  const bool tiles128 = (M % BM1 == 0) && (N % BN1 == 0) && (K % BK == 0) && al;
+  if (variant == LC_HGEMM_AUTO)
+    variant = tiles256 ? g_tune_hgemm_auto : (tiles128 ? LC_HGEMM_MFMA128 : LC_HGEMM_GENERIC);
   if (variant == LC_HGEMM_MFMA256 || variant == LC_HGEMM_MFMA256P || variant == LC_HGEMM_MFMA256P2 ||
       variant == LC_HGEMM_MFMA256P3) {
     if (!tiles256) return LC_ERR_SHAPE;
     return layout == LC_LAYOUT_NN ? launch_mfma256<true>(a, b, c, M, N, K, variant, swizzle_stride, st)
                                   : launch_mfma256<false>(a, b, c, M, N, K, variant, swizzle_stride, st);
+  }
+  if (variant == LC_HGEMM_MFMA128) {
+    if (!tiles128) return LC_ERR_SHAPE;
+    return layout == LC_LAYOUT_NN ? launch_mfma128<true>(a, b, c, M, N, K, swizzle_stride, st)
+                                  : launch_mfma128<false>(a, b, c, M, N, K, swizzle_stride, st);
   }
   return layout == LC_LAYOUT_NN ? launch_generic<true>(a, b, c, M, N, K, st)
                                 : launch_generic<false>(a, b, c, M, N, K, st);
@@ -434,7 +454,7 @@ int lc_hgemm_call(const char* entry, const void* A, const void* B, void* C, int 
   // legal shapes (multiples of 128 / K of 32, hgemm_mma_stage.cu:650,675), so fall back per shape.
   const bool tiles256 = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && aligned16(A) &&
                         aligned16(B) && aligned16(C);
-  if (variant != LC_HGEMM_GENERIC && !tiles256) variant = LC_HGEMM_GENERIC;
+  if (variant != LC_HGEMM_GENERIC && !tiles256) variant = LC_HGEMM_AUTO;   // 128-tile kernel or generic
   const int stride = (e->nargs == 6 && swizzle) ? swizzle_stride : 1;
   return lc_hgemm_f16(A, B, C, M, N, K, e->layout, variant, e->nargs == 6 ? stages : 2, stride, stream);
 }

@@ -60,6 +60,22 @@ def test_tuned_kernels_vs_oracle(oracle, variant, layout, shape):
 
 
 @pytest.mark.parametrize("layout", ["nn", "tn"])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (384, 128, 192), (128, 640, 128), (896, 1152, 512)])
+def test_mfma128_reference_tile_shapes(oracle, layout, shape):
+    """M, N multiples of 128 (the reference's own 128x128 tiles), not of 256: the 128-tile kernel, explicitly
+    and through LC_HGEMM_AUTO."""
+    capi = _capi()
+    M, N, K = shape
+    torch.manual_seed(M * 5 + N + K)
+    a = torch.randn(M, K, dtype=torch.half, device="cuda")
+    b = torch.randn(K, N, dtype=torch.half, device="cuda")
+    lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
+    for var, stride in ((capi.HGEMM_MFMA128, 1), (capi.HGEMM_AUTO, 256)):
+        c, _ = _run(capi, a, b, lay, var, stride)
+        _check(oracle, capi, a, b, c, lay)
+
+
+@pytest.mark.parametrize("layout", ["nn", "tn"])
 @pytest.mark.parametrize("shape", [(64, 64, 64), (128, 128, 32), (100, 72, 50), (1, 1, 1), (257, 129, 65),
                                    (384, 640, 96)])
 def test_generic_kernel_ragged_shapes(oracle, layout, shape):
