@@ -398,8 +398,18 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   const bool al = aligned16(A) && aligned16(B) && aligned16(C);
   const bool tiles256 = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && al;
   const bool tiles128 = (M % BM1 == 0) && (N % BN1 == 0) && (K % BK == 0) && al;
-  if (variant == LC_HGEMM_AUTO)
-    variant = tiles256 ? g_tune_hgemm_auto : (tiles128 ? LC_HGEMM_MFMA128 : LC_HGEMM_GENERIC);
+  if (variant == LC_HGEMM_AUTO) {
+    // measured crossover on MI355X (TN, square): the 256-tile ping-pong kernel wins once its grid has more
+    // than ~128 workgroups (n >= 3072); below that the 128-tile kernel fills the 256 CUs better
+    // (n = 2048: 715 vs 436 TFLOP/s).
+    const long wg256 = (long)(M / BM) * (N / BN);
+    if (tiles256 && wg256 > 128)
+      variant = g_tune_hgemm_auto;
+    else if (tiles128)
+      variant = LC_HGEMM_MFMA128;
+    else
+      variant = LC_HGEMM_GENERIC;
+  }
   if (variant == LC_HGEMM_MFMA256 || variant == LC_HGEMM_MFMA256P || variant == LC_HGEMM_MFMA256P2 ||
       variant == LC_HGEMM_MFMA256P3) {
     if (!tiles256) return LC_ERR_SHAPE;
