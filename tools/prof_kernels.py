@@ -22,7 +22,7 @@ if a.what in ("all", "hgemm"):
     B = torch.randn(n, n, dtype=torch.half, device="cuda")
     C = torch.zeros(n, n, dtype=torch.half, device="cuda")
     Bt = host.as_col_major(B)
-    for var in (capi.HGEMM_MFMA256P3, capi.HGEMM_MFMA256P2, capi.HGEMM_MFMA256P, capi.HGEMM_MFMA256):
+    for var in (capi.HGEMM_MFMA256P2, capi.HGEMM_MFMA256P, capi.HGEMM_MFMA256):
         for lay, bb in ((capi.LAYOUT_TN, Bt), (capi.LAYOUT_NN, B)):
             for _ in range(a.iters):
                 capi.hgemm(A, bb, C, layout=lay, variant=var, swizzle_stride=2048)
@@ -31,5 +31,13 @@ if a.what in ("all", "attn"):
     q, k, v, o, tv = host.get_qkvo(4, 32, 4096, 128, seed=0)
     for _ in range(a.iters):
         capi.attn_fwd(q, k, v, o)
+    torch.cuda.synchronize()
+    del q, k, v, o, tv
+    n = 8192   # config-5 extension: fp8 e4m3 GEMM
+    a8 = torch.randn(n, n, device="cuda").to(torch.float8_e4m3fn)
+    b8 = torch.randn(n, n, device="cuda").to(torch.float8_e4m3fn)
+    c8 = torch.zeros(n, n, dtype=torch.half, device="cuda")
+    for _ in range(a.iters):
+        capi.gemm_fp8(a8, b8, c8, alpha=1 / 16, swizzle_stride=2048)
     torch.cuda.synchronize()
 print("done")

@@ -22,7 +22,8 @@ ROOT = Path(__file__).resolve().parent.parent
 def short(name: str) -> str:
     m = re.match(r"_ZN2lc\d+(\w+?_kernel)I(.*?)EEv", name)
     if not m:
-        return name[:60]
+        m2 = re.match(r"_ZN2lc\d+(\w+?_kernel)E", name)
+        return m2.group(1) if m2 else name[:60]
     args = m.group(2).replace("Lb0E", "false,").replace("Lb1E", "true,")
     if m.group(1) == "hgemm_pingpong2_kernel" and args.endswith("true,"):
         return "hgemm_pingpong3_kernel<" + args.split(",")[0] + ">"   # <B_KN, DMA_IN_LOAD=true>
@@ -53,8 +54,8 @@ def main(tag: str):
                         "median_us": v2[len(v2) // 2], **meta[k]}
         (out / f"{tag}_kernel_stats.json").write_text(json.dumps(stats, indent=1))
         lines = [f"# rocprofv3 --kernel-trace --stats — {tag}", "",
-                 "command: `rocprofv3 --kernel-trace --stats -- python tools/prof_kernels.py --iters 5` "
-                 "(8192^3 HGEMM TN/NN, both schedules; FA-2 fwd B4 H32 S4096 D128; randn inputs)", "",
+                 "command: see profiles/README.md (round r02p: `rocprofv3 --kernel-trace --stats -- python bench.py "
+                 "--steps 20 --warmup 2 --no-cpu-baseline`, i.e. the bench command itself)", "",
                  "| kernel | calls | avg µs | median µs | min µs | max µs | VGPR | LDS B | grid |", "|---|---|---|---|---|---|---|---|---|"]
         for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["avg_us"]):
             lines.append(f"| `{k}` | {s['calls']} | {s['avg_us']:.1f} | {s['median_us']:.1f} | {s['min_us']:.1f} | "
