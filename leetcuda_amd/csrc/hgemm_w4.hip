@@ -1,0 +1,260 @@
+// hgemm_w4.hip — fp16 GEMM for gfx950, 256x256x64 tile, FOUR wave64 (2 x 2), wave tile 128 x 128.
+//
+// Same contract, LDS images and swizzles as hgemm_pingpong.hip (reference: kernels/hgemm/mma/basic/
+// hgemm_mma_stage.cu:644-1052 NN, kernels/hgemm/mma/swizzle/hgemm_mma_stage_tn_swizzle_x4.cu:207 TN).
+// Why a second 256-tile design: the 8-wave kernels run the chip into its POWER limit (80 % MFMA-busy at
+// ~1.6 GHz), so throughput is bought with energy per FLOP, not with more busy cycles.  A 128x128 wave tile
+// reads (128+128) x 16 B per 16 MFMAs = 0.5 KiB of LDS per MFMA instead of 0.75 KiB (128x64), and one wave
+// per SIMD needs no s_setprio ping-pong and only ONE barrier per K tile:
+//   * one wave per SIMD (256 threads, 512-entry register file): 4x4 v_mfma_f32_32x32x16_f16
+//     accumulators = 256 registers (AGPR half), fragments double-buffered in 64 VGPRs;
+//   * the K tile is 4 k-steps of 16 MFMAs; the fragment reads of step s+1 (8 ds_read_b128 / 16 tr reads)
+//     are issued in the first half of step s, behind MFMAs of the same wave (software pipeline inside one
+//     instruction stream, chunked with sched_barrier);
+//   * LDS ring of 2 slots: after step 2 of tile t every read of slot t&1 has been issued ->
+//     s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier  (tile t+1 has landed for everybody, slot t&1 is dead) ->
+//     step 3 carries the 16 LDS-DMA pieces of tile t+2 into slot t&1 (one per MFMA) and the step-0 reads
+//     of tile t+1.  A DMA piece is in flight for >= 3 k-steps (>= 1536 MFMA cycles) before it is needed.
+// DMA source addresses are (wave-uniform 64-bit base) + (32-bit lane offset): 2 offset VGPRs per operand
+// instead of 16 pointers (the swizzle key of a row only depends on the parity of its 8-row block).
+#pragma once
+#include "hgemm_pingpong.hip"
+#include <utility>
+
+namespace lc {
+
+constexpr int W4_EPI_STRIDE = 272;   // bytes per staged C row (128 halves + 16 B pad)
+
+// The 4x4 accumulator tile lives in a[0:255], addressed LITERALLY: hipcc's allocator cannot hold 256 live
+// accumulator registers (as values — builtin or "+a" operands — it emits ~1500 v_accvgpr copies and 250 scratch
+// accesses per K tile).  Every statement names all 256 AGPRs as clobbered, so the compiler never parks a value of
+// its own there (audit: no v_accvgpr_* outside ASMSTART/ASMEND, private_segment_fixed_size 0).
+// Hazards handled here, not by hipcc: accumulate chains (D -> C of the next MFMA on the same registers) need no
+// wait states; A/B fragments come from compiler-visible ds_reads (hipcc waits for them); the first
+// v_accvgpr_read of the epilogue is fenced by w4_mfma_drain() (>= 12 states after an 8-pass MFMA).
+#define LC_AGPR_ALL \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14",  \
+  "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28",  \
+  "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42",  \
+  "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56",  \
+  "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70",  \
+  "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84",  \
+  "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98",  \
+  "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110",  \
+  "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122",  \
+  "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134",  \
+  "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146",  \
+  "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158",  \
+  "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170",  \
+  "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182",  \
+  "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194",  \
+  "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206",  \
+  "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218",  \
+  "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230",  \
+  "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242",  \
+  "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254",  \
+  "a255"
+
+template <int IDX>
+LC_DEVINL void w4_mfma(half8_t a, half8_t b) {   // a[16 IDX .. +15] += a x b
+  asm volatile("v_mfma_f32_32x32x16_f16 a[%2:%3], %0, %1, a[%2:%3]"
+               :: "v"(a), "v"(b), "n"(IDX * 16), "n"(IDX * 16 + 15) : LC_AGPR_ALL);
+}
+template <int R>
+LC_DEVINL void w4_acc_zero() { asm volatile("v_accvgpr_write_b32 a[%0], 0" :: "n"(R) : LC_AGPR_ALL); }
+template <int R>
+LC_DEVINL float w4_acc_read() {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(x) : "n"(R));
+  return x;
+}
+LC_DEVINL void w4_mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
+template <int... Is, typename F>
+LC_DEVINL void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+LC_DEVINL void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+template <bool B_KN>
+__global__ __launch_bounds__(256) void hgemm_w4_kernel(const half_t* __restrict__ A,
+                                                       const half_t* __restrict__ B,
+                                                       half_t* __restrict__ C, int M, int N, int K,
+                                                       int tiles_m, int tiles_n, int panel_w) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l32 = lane & 31, hi = lane >> 5;
+
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const TileCoord tc = raster(id, tiles_m, tiles_n, panel_w);
+  const int m0 = tc.tm * BM, n0 = tc.tn * BN;
+
+  // ---- DMA sources.  A (and TN B): this wave stages the 8-row blocks blk = 8*wave + p, p = 0..7; lane ->
+  // row (lane>>3) of the block, chunk slot (lane&7) holding logical chunk slot ^ ((row>>1)&7), and
+  // (row>>1)&7 = ((lane>>4)&3) | ((p&1)<<2).
+  unsigned a_off[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    a_off[par] = (unsigned)(lane >> 3) * (unsigned)K * 2u +
+                 (unsigned)(((lane & 7) ^ (((lane >> 4) & 3) | (par << 2))) * 16);
+  const char* ua = (const char*)(A + (size_t)(m0 + wave * 64) * K);
+  const char* ub;
+  unsigned b_off[2];
+  if constexpr (!B_KN) {
+    ub = (const char*)(B + (size_t)(n0 + wave * 64) * K);
+    b_off[0] = a_off[0];
+    b_off[1] = a_off[1];
+  } else {
+    // NN: sub-image h = [64 k][128 n'] (256-B rows), piece q = 4 k-rows; this wave stages q = 4*wave + p2
+    // of both sub-images.  lane -> k row (lane>>4), 16-B slot pp = lane&15 holding chunk nc (pair-XOR by k&3).
+    const int pp = lane & 15;
+    const int pair = (pp >> 1) ^ (((lane >> 4) & 3) << 1);
+    const int nc = pair * 2 + (pp & 1);
+    b_off[0] = (unsigned)(lane >> 4) * (unsigned)N * 2u + (unsigned)((64 * (nc >> 2) + (nc & 3) * 8) * 2);
+    b_off[1] = b_off[0];
+    ub = (const char*)(B + (size_t)(wave * 16) * N + n0);
+  }
+  const size_t a_blk = (size_t)8 * K * 2;                        // bytes between consecutive 8-row blocks
+  const size_t a_kt = (size_t)BK * 2;                            // bytes per K tile along a row
+  const size_t b_kt = B_KN ? (size_t)BK * N * 2 : (size_t)BK * 2;
+  const size_t b_q = (size_t)4 * N * 2;                          // NN: bytes between consecutive pieces
+  // piece g = 0..15 of K tile t -> ring slot `slot`
+  auto piece = [&](int g, int t, char* slot) {
+    if (g < 8) {
+      glds16(ua + (size_t)g * a_blk + (size_t)t * a_kt + a_off[g & 1], slot + (wave * 8 + g) * 1024);
+    } else {
+      const int p = g - 8;
+      if constexpr (!B_KN) {
+        glds16(ub + (size_t)p * a_blk + (size_t)t * b_kt + b_off[p & 1],
+               slot + TILE_BYTES + (wave * 8 + p) * 1024);
+      } else {
+        const int h = p >> 2, p2 = p & 3;
+        glds16(ub + (size_t)p2 * b_q + (size_t)(64 * h) + (size_t)t * b_kt + b_off[0],
+               slot + TILE_BYTES + h * HALF_BYTES + (wave * 4 + p2) * 1024);
+      }
+    }
+  };
+
+  // ---- fragment read addresses (one VGPR per k-step: no address arithmetic in the loop)
+  const int swz = (lane >> 1) & 7;
+  int a_ad[4], b_ad[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    a_ad[ks] = (wr * 128 + l32) * 128 + (((2 * ks + hi) ^ swz) * 16);
+    if constexpr (!B_KN) b_ad[ks] = TILE_BYTES + (wc * 128 + l32) * 128 + (((2 * ks + hi) ^ swz) * 16);
+  }
+  if constexpr (B_KN) {
+    const int i = lane & 15, gi = (lane >> 4) & 1;
+    const int k = 8 * hi + (i >> 2);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+      b_ad[jj] = TILE_BYTES + k * 256 + (((4 * wc + 2 * jj + gi) ^ ((i >> 2) << 1)) * 32) + (i & 3) * 8;
+    b_ad[2] = b_ad[3] = 0;
+  }
+  auto read_a = [&](const char* slot, int ks, int i) -> half8_t {
+    return *(const half8_t*)(slot + a_ad[ks] + i * 4096);
+  };
+  auto read_b = [&](const char* slot, int ks, int j) -> half8_t {
+    if constexpr (!B_KN) {
+      return *(const half8_t*)(slot + b_ad[ks] + j * 4096);
+    } else {
+      const char* p = slot + b_ad[j >> 1] + (j & 1) * HALF_BYTES + ks * 4096;
+      return cat4(lds_tr16(p), lds_tr16(p + 1024));
+    }
+  };
+
+  static_for<256>([&](auto r) { w4_acc_zero<decltype(r)::value>(); });   // accumulator (i, j) = a[16(4i+j) ..]
+
+  const int KT = K / BK;
+  // prologue: tiles 0 and 1 in flight, tile 0 landed, step-0 fragments of tile 0 in registers
+#pragma unroll
+  for (int g = 0; g < 16; ++g) piece(g, 0, smem);
+  if (KT > 1) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) piece(g, 1, smem + SLOT_BYTES);
+    LC_VMCNT(16);
+  } else {
+    LC_VMCNT(0);
+  }
+  pp_barrier();
+
+  half8_t af[2][4], bf[2][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) af[0][i] = read_a(smem, 0, i);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bf[0][j] = read_b(smem, 0, j);
+
+  // one k-step: 16 MFMAs from fragment buffer `cb`; the first 4 chunks carry the 8 fragment reads of the
+  // next step into buffer cb^1; every chunk may carry 2 DMA pieces.
+  auto step = [&](auto cbc, const char* rslot, int rks, bool dma, int t2, char* wslot) {
+    constexpr int cb = decltype(cbc)::value;
+    static_for<8>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      // chunk c: accumulators (i, j) = (c>>1, 2(c&1)) , (c>>1, 2(c&1)+1): 16 independent accumulators per step.
+      // MFMAs FIRST: hipcc guards the first asm consumer of the previous step's fragments with lgkmcnt(0); ahead
+      // of this step's reads that wait is free, behind them it would expose a full LDS round trip per step.
+      constexpr int i = c >> 1, j0 = 2 * (c & 1);
+      w4_mfma<4 * i + j0>(bf[cb][j0], af[cb][i]);
+      w4_mfma<4 * i + j0 + 1>(bf[cb][j0 + 1], af[cb][i]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (c < 4) {
+        af[cb ^ 1][c] = read_a(rslot, rks, c);
+        bf[cb ^ 1][c] = read_b(rslot, rks, c);
+      }
+      if (dma) {
+        piece(2 * c, t2, wslot);
+        piece(2 * c + 1, t2, wslot);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  for (int kt = 0; kt < KT; ++kt) {
+    char* cur = smem + (kt & 1) * SLOT_BYTES;
+    char* nxt = smem + ((kt & 1) ^ 1) * SLOT_BYTES;
+    step(I0{}, cur, 1, false, 0, nullptr);
+    step(I1{}, cur, 2, false, 0, nullptr);
+    step(I0{}, cur, 3, false, 0, nullptr);
+    // every read of `cur` is issued; tile kt+1 must have landed before anybody reads `nxt`
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    pp_barrier();
+    if (kt + 2 < KT)
+      step(I1{}, nxt, 0, true, kt + 2, cur);
+    else
+      step(I1{}, nxt, 0, false, 0, nullptr);
+  }
+
+  // ---- epilogue: lane holds C[m = 32i + l32][n = 32j + 8(r>>2) + 4hi + (r&3)]; each wave stages one
+  // 32-row block (32 x 128 halves) at a time in its private LDS area and writes 256-B row segments.
+  w4_mfma_drain();
+  __syncthreads();
+  char* stg = smem + wave * (32 * W4_EPI_STRIDE);
+  half_t* cw = C + (size_t)(m0 + wr * 128) * N + n0 + wc * 128;
+  static_for<4>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    static_for<16>([&](auto qc) {
+      constexpr int j = decltype(qc)::value >> 2, rq = decltype(qc)::value & 3;
+      half4_t h;
+      h[0] = (half_t)w4_acc_read<16 * (4 * i + j) + 4 * rq + 0>();
+      h[1] = (half_t)w4_acc_read<16 * (4 * i + j) + 4 * rq + 1>();
+      h[2] = (half_t)w4_acc_read<16 * (4 * i + j) + 4 * rq + 2>();
+      h[3] = (half_t)w4_acc_read<16 * (4 * i + j) + 4 * rq + 3>();
+      *(half4_t*)(stg + l32 * W4_EPI_STRIDE + (j * 32 + 8 * rq + 4 * hi) * 2) = h;
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + (lane >> 4);
+      const u32x4_t v = *(const u32x4_t*)(stg + row * W4_EPI_STRIDE + (lane & 15) * 16);
+      *(u32x4_t*)(cw + (size_t)(i * 32 + row) * N + (lane & 15) * 8) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  });
+}
+
+}  // namespace lc

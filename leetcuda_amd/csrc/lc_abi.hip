@@ -15,6 +15,7 @@
 #include "attn_fwd.hip"
 #include "hgemm_generic.hip"
 #include "hgemm_mfma128.hip"
+#include "hgemm_w4.hip"
 #include "hgemm_mfma256.hip"
 #include "hgemm_pingpong.hip"
 #include "gemm_fp8.hip"
@@ -177,7 +178,11 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   const int tiles_m = M / BM, tiles_n = N / BN;
   const int pw = panel_tiles(swizzle_stride, tiles_n, BN);
   const dim3 grid(tiles_m * tiles_n), block(512);
-  if (variant == LC_HGEMM_MFMA256P2 && g_tune_hgemm_stamps) {
+  if (variant == LC_HGEMM_MFMA256W4) {
+    auto kern = hgemm_w4_kernel<B_KN>;
+    if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(256), HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
+  } else if (variant == LC_HGEMM_MFMA256P2 && g_tune_hgemm_stamps) {
     auto kern = hgemm_pingpong2_kernel<B_KN, false, true>;
     if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
     hipLaunchKernelGGL(kern, grid, block, HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
@@ -366,7 +371,7 @@ int lc_tune_set(const char* key, int value) {
   }
   if (strcmp(key, "hgemm_auto") == 0) {
     if (value != LC_HGEMM_MFMA256 && value != LC_HGEMM_MFMA256P && value != LC_HGEMM_MFMA256P2 &&
-        value != LC_HGEMM_MFMA256P3)
+        value != LC_HGEMM_MFMA256P3 && value != LC_HGEMM_MFMA256W4)
       return LC_ERR_ARG;
     g_tune_hgemm_auto = value;
     return LC_OK;
@@ -389,7 +394,7 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   (void)stages;  // LDS ring depth is fixed per kernel family; accepted for signature parity
   if (!A || !B || !C) return LC_ERR_ARG;
   if (layout != LC_LAYOUT_NN && layout != LC_LAYOUT_TN) return LC_ERR_ARG;
-  if (variant < LC_HGEMM_AUTO || variant > LC_HGEMM_MFMA128) return LC_ERR_ARG;
+  if (variant < LC_HGEMM_AUTO || variant > LC_HGEMM_MFMA256W4) return LC_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0) return LC_ERR_SHAPE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const half_t* a = static_cast<const half_t*>(A);
@@ -411,7 +416,7 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
       variant = LC_HGEMM_GENERIC;
   }
   if (variant == LC_HGEMM_MFMA256 || variant == LC_HGEMM_MFMA256P || variant == LC_HGEMM_MFMA256P2 ||
-      variant == LC_HGEMM_MFMA256P3) {
+      variant == LC_HGEMM_MFMA256P3 || variant == LC_HGEMM_MFMA256W4) {
     if (!tiles256) return LC_ERR_SHAPE;
     return layout == LC_LAYOUT_NN ? launch_mfma256<true>(a, b, c, M, N, K, variant, swizzle_stride, st)
                                   : launch_mfma256<false>(a, b, c, M, N, K, variant, swizzle_stride, st);
