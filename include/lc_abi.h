@@ -59,7 +59,8 @@ typedef enum lc_hgemm_variant {
   LC_HGEMM_MFMA256P2 = 4, /* ping-pong with 2 phases of 16 MFMAs per K tile, DMA issued inside MFMA clusters */
   LC_HGEMM_MFMA256P3 = 5, /* same, DMA issued by the load sections (bare MFMA clusters)                     */
   LC_HGEMM_MFMA128 = 6,   /* 128x128x64 tile, 4 wave64: M, N multiples of 128 (the reference's own tile)     */
-  LC_HGEMM_MFMA256W4 = 7  /* 256x256x64 tile, FOUR wave64 with 128x128 wave tiles, one barrier per K tile      */
+  LC_HGEMM_MFMA256W4 = 7, /* 256x256x64 tile, FOUR wave64 with 128x128 wave tiles, one barrier per K tile      */
+  LC_HGEMM_MFMA256W4S = 8 /* same wave layout, LDS ring of four 32-k stages (DMA spread one piece per 4 MFMAs) */
 } lc_hgemm_variant;
 
 /* FlashAttention-2 forward families (resource policies of kernels/flash-attn/mma/basic/ .cu files). */

@@ -427,6 +427,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(
   load_v(0);
   store_k(smem);
   store_v(smem);
+  // the global loads run a FULL tile ahead of their LDS store (K(t+1) is issued right after K(t) left the
+  // staging registers, at the end of X(t-1), and stored at the end of X(t)): with the loads issued at the start
+  // of X(t) the store at its end waited for HBM inside every phase.
+  if (T > 1) {
+    load_k(1);
+    load_v(1);
+  }
 #pragma unroll
   for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(qf[s]));   // retire the Q loads before the loop
   pp_sync();
@@ -437,10 +444,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(
     char* nxt = smem + ((t & 1) ^ 1) * SLOT;
     const bool more = t + 1 < T;
     // =========================== X(t) ===========================
-    if (more) {
-      load_k(t + 1);
-      load_v(t + 1);
-    }
     f32x16_t s[2];
     {
       constexpr int GQ = (DS % 4 == 0) ? 4 : 2;
@@ -490,7 +493,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(
           for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
       }
     }
-    if (more) store_k(nxt);
+    if (more) {
+      store_k(nxt);
+      if (t + 2 < T) load_k(t + 2);
+    }
     pp_sync();
     // =========================== Y(t) ===========================
     {
@@ -529,7 +535,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(
         for (int dt = 0; dt < DT; ++dt) o[dt] = mfma32(vf[g & 1][dt], pf[g >> 1][g & 1], o[dt]);
       }
     }
-    if (more) store_v(nxt);
+    if (more) {
+      store_v(nxt);
+      if (t + 2 < T) load_v(t + 2);
+    }
     pp_sync();
   }
   if (grp == 0) pp_sync();

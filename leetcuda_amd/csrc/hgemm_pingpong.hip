@@ -39,7 +39,7 @@ struct PPSrc {
 
 template <bool B_KN>
 LC_DEVINL void pp_src_init(PPSrc<B_KN>& s, const half_t* A, const half_t* B, int m0, int n0, int N,
-                           int K, int wave, int lane) {
+                           int K, int wave, int lane, bool nn_full = false) {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -63,7 +63,11 @@ LC_DEVINL void pp_src_init(PPSrc<B_KN>& s, const half_t* A, const half_t* B, int
         const int pp = lane & 15;
         const int pair = (pp >> 1) ^ ((k & 3) << 1);
         const int nc = pair * 2 + (pp & 1);  // 16-B chunk index inside the sub-image row
-        const int n = 64 * (nc >> 2) + 32 * h + (nc & 3) * 8;
+        // nn_full: sub-image h = the 128 CONTIGUOUS columns [128h, +128) -> every DMA lane group fetches whole
+        // 128-B lines (measured: 64-B source segments double the TA time of a DMA piece); otherwise
+        // sub-image h = the h-th 32-column half of every 64-column wave strip (needed by the 4-phase
+        // schedule, which stages and reads the two halves at different times).
+        const int n = nn_full ? 128 * h + nc * 8 : 64 * (nc >> 2) + 32 * h + (nc & 3) * 8;
         s.b[h][i] = B + (size_t)k * N + n0 + n;
         s.b_lds[h][i] = TILE_BYTES + h * HALF_BYTES + q * 1024;
       }
@@ -74,20 +78,29 @@ LC_DEVINL void pp_src_init(PPSrc<B_KN>& s, const half_t* A, const half_t* B, int
 template <bool B_KN>
 struct PPFrag {
   int a0;  // A: row (wr*128 + l32), chunk (hi ^ swz); + mt*4096, ^ ks*32
-  int b0;  // TN B: row (wc*64 + l32); + nh*4096, ^ ks*32 ; NN B: tr base; + nh*16384 + ks*4096 (+1024)
+  int b0;  // TN B: row (wc*64 + l32); + nh*4096, ^ ks*32 ; NN B: tr base of n-half 0; + ks*4096 (+1024)
+  int b1;  // NN B: tr base of n-half 1
 };
 
 template <bool B_KN>
-LC_DEVINL void pp_frag_init(PPFrag<B_KN>& f, int wr, int wc, int lane) {
+LC_DEVINL void pp_frag_init(PPFrag<B_KN>& f, int wr, int wc, int lane, bool nn_full = false) {
   const int l32 = lane & 31, hi = lane >> 5;
   const int swz = (lane >> 1) & 7;
   f.a0 = (wr * 128 + l32) * 128 + ((hi ^ swz) * 16);
   if constexpr (!B_KN) {
     f.b0 = TILE_BYTES + (wc * 64 + l32) * 128 + ((hi ^ swz) * 16);
+    f.b1 = 0;
   } else {
     const int i = lane & 15, gi = (lane >> 4) & 1;
     const int k = 8 * hi + (i >> 2);
-    f.b0 = TILE_BYTES + k * 256 + (((2 * wc + gi) ^ ((i >> 2) << 1)) * 32) + (i & 3) * 8;
+    if (!nn_full) {
+      f.b0 = TILE_BYTES + k * 256 + (((2 * wc + gi) ^ ((i >> 2) << 1)) * 32) + (i & 3) * 8;
+      f.b1 = f.b0 + HALF_BYTES;
+    } else {   // columns 64wc + 32nh + 16gi.. live in sub-image wc>>1 at 32-B pair 4(wc&1) + 2nh + gi
+      const int base = TILE_BYTES + (wc >> 1) * HALF_BYTES + k * 256 + (i & 3) * 8;
+      f.b0 = base + (((4 * (wc & 1) + gi) ^ ((i >> 2) << 1)) * 32);
+      f.b1 = base + (((4 * (wc & 1) + 2 + gi) ^ ((i >> 2) << 1)) * 32);
+    }
   }
 }
 
@@ -107,7 +120,7 @@ LC_DEVINL void pp_read_b(const char* slot, const PPFrag<B_KN>& f, int nh, half8_
     if constexpr (!B_KN) {
       bf[ks] = *(const half8_t*)(slot + ((f.b0 ^ (ks * 32)) + nh * 4096));
     } else {
-      const char* p = slot + f.b0 + nh * HALF_BYTES + ks * 4096;
+      const char* p = slot + (nh ? f.b1 : f.b0) + ks * 4096;
       bf[ks] = cat4(lds_tr16(p), lds_tr16(p + 1024));
     }
   }
@@ -304,9 +317,9 @@ __global__ __launch_bounds__(512, 2) void hgemm_pingpong2_kernel(const half_t* _
   const int m0 = tc.tm * BM, n0 = tc.tn * BN;
 
   PPSrc<B_KN> src;
-  pp_src_init<B_KN>(src, A, B, m0, n0, N, K, wave, lane);
+  pp_src_init<B_KN>(src, A, B, m0, n0, N, K, wave, lane, true);
   PPFrag<B_KN> fr;
-  pp_frag_init<B_KN>(fr, wr, wc, lane);
+  pp_frag_init<B_KN>(fr, wr, wc, lane, true);
 
   f32x16_t acc[4][2];
 #pragma unroll

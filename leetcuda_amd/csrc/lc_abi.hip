@@ -27,6 +27,7 @@ namespace {
 
 // run-time tuning knobs (lc_tune_set): experiments and A/B benches, never required for correctness
 int g_tune_attn_ablate = 0;                // see attn_fwd_kernel ABL (diagnosis only)
+int g_tune_w4_abl = 0;                       // hgemm_w4 ablation bits (lc_tune_set "w4_abl"), diagnosis only
 int g_tune_hgemm_stamps = 0;                 // pingpong2 diagnosis build: cycle stamps into A (lc_tune_set "hgemm_stamps")
 int g_tune_attn_nw = 0;                    // waves per attention workgroup: 0 = auto, 8 / 4 / 2
 int g_tune_hgemm_auto = LC_HGEMM_MFMA256P2; // kernel family LC_HGEMM_AUTO resolves to on 256-tileable shapes
@@ -178,10 +179,22 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   const int tiles_m = M / BM, tiles_n = N / BN;
   const int pw = panel_tiles(swizzle_stride, tiles_n, BN);
   const dim3 grid(tiles_m * tiles_n), block(512);
-  if (variant == LC_HGEMM_MFMA256W4) {
-    auto kern = hgemm_w4_kernel<B_KN>;
+  if (variant == LC_HGEMM_MFMA256W4S) {
+    auto kern = hgemm_w4s_kernel<B_KN>;
     if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(256), HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
+  } else if (variant == LC_HGEMM_MFMA256W4) {
+#define LC_W4_CASE(ABL)                                                                                   \
+  case ABL: {                                                                                             \
+    auto kern = hgemm_w4_kernel<B_KN, ABL>;                                                               \
+    if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;                                              \
+    hipLaunchKernelGGL(kern, grid, dim3(256), HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);  \
+  } break;
+    switch (g_tune_w4_abl) {
+      LC_W4_CASE(0) LC_W4_CASE(1) LC_W4_CASE(2) LC_W4_CASE(3) LC_W4_CASE(4) LC_W4_CASE(7)
+      default: return LC_ERR_ARG;
+    }
+#undef LC_W4_CASE
   } else if (variant == LC_HGEMM_MFMA256P2 && g_tune_hgemm_stamps) {
     auto kern = hgemm_pingpong2_kernel<B_KN, false, true>;
     if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
@@ -361,6 +374,10 @@ int lc_tune_set(const char* key, int value) {
     g_tune_attn_nw = value;
     return LC_OK;
   }
+  if (strcmp(key, "w4_abl") == 0) {
+    g_tune_w4_abl = value;
+    return LC_OK;
+  }
   if (strcmp(key, "hgemm_stamps") == 0) {
     g_tune_hgemm_stamps = value != 0;
     return LC_OK;
@@ -371,7 +388,7 @@ int lc_tune_set(const char* key, int value) {
   }
   if (strcmp(key, "hgemm_auto") == 0) {
     if (value != LC_HGEMM_MFMA256 && value != LC_HGEMM_MFMA256P && value != LC_HGEMM_MFMA256P2 &&
-        value != LC_HGEMM_MFMA256P3 && value != LC_HGEMM_MFMA256W4)
+        value != LC_HGEMM_MFMA256P3 && value != LC_HGEMM_MFMA256W4 && value != LC_HGEMM_MFMA256W4S)
       return LC_ERR_ARG;
     g_tune_hgemm_auto = value;
     return LC_OK;
@@ -394,7 +411,7 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   (void)stages;  // LDS ring depth is fixed per kernel family; accepted for signature parity
   if (!A || !B || !C) return LC_ERR_ARG;
   if (layout != LC_LAYOUT_NN && layout != LC_LAYOUT_TN) return LC_ERR_ARG;
-  if (variant < LC_HGEMM_AUTO || variant > LC_HGEMM_MFMA256W4) return LC_ERR_ARG;
+  if (variant < LC_HGEMM_AUTO || variant > LC_HGEMM_MFMA256W4S) return LC_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0) return LC_ERR_SHAPE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const half_t* a = static_cast<const half_t*>(A);
@@ -416,7 +433,7 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
       variant = LC_HGEMM_GENERIC;
   }
   if (variant == LC_HGEMM_MFMA256 || variant == LC_HGEMM_MFMA256P || variant == LC_HGEMM_MFMA256P2 ||
-      variant == LC_HGEMM_MFMA256P3 || variant == LC_HGEMM_MFMA256W4) {
+      variant == LC_HGEMM_MFMA256P3 || variant == LC_HGEMM_MFMA256W4 || variant == LC_HGEMM_MFMA256W4S) {
     if (!tiles256) return LC_ERR_SHAPE;
     return layout == LC_LAYOUT_NN ? launch_mfma256<true>(a, b, c, M, N, K, variant, swizzle_stride, st)
                                   : launch_mfma256<false>(a, b, c, M, N, K, variant, swizzle_stride, st);

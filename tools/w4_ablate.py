@@ -1,0 +1,22 @@
+"""hgemm_w4 ablation timing (diagnosis only; ablated variants compute WRONG results)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from leetcuda_amd import capi, host
+n = 8192
+a = torch.randn(n, n, dtype=torch.half, device="cuda")
+b = torch.randn(n, n, dtype=torch.half, device="cuda")
+c = torch.empty(n, n, dtype=torch.half, device="cuda")
+flops = 2.0 * n ** 3
+for lname, lay in (("tn", capi.LAYOUT_TN), ("nn", capi.LAYOUT_NN)):
+    b2 = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
+    for rnd in range(2):
+        for abl in (0, 1, 2, 3, 4, 7):
+            capi.tune("w4_abl", abl)
+            ms = capi.hgemm_time(a, b2, c, lay, capi.HGEMM_MFMA256W4, 2, 2048, warmup=2, iters=20)
+            print(f"{lname} round {rnd} w4_abl {abl}: {ms:.4f} ms {flops / ms * 1e-9:8.1f} TF-equivalent", flush=True)
+        capi.tune("w4_abl", 0)
+        ms = capi.hgemm_time(a, b2, c, lay, capi.HGEMM_MFMA256W4S, 2, 2048, warmup=2, iters=20)
+        print(f"{lname} round {rnd} w4s: {ms:.4f} ms {flops / ms * 1e-9:8.1f} TFLOP/s", flush=True)
+        ms = capi.hgemm_time(a, b2, c, lay, capi.HGEMM_MFMA256P2, 2, 2048, warmup=2, iters=20)
+        print(f"{lname} round {rnd} pingpong2: {ms:.4f} ms {flops / ms * 1e-9:8.1f} TFLOP/s", flush=True)
