@@ -266,6 +266,28 @@ int launch_attn_pp(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   return check_launch();
 }
 
+template <int D>
+int launch_attn_c4(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
+                   hipStream_t st) {
+  constexpr int lds = 4 * KVB * D * 2;   // 2 slots x (K + V), unpadded
+  const int nqb = N / 256;
+  const dim3 grid((unsigned)((size_t)nqb * B * H)), block(512);
+  const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+#define LC_C4_CASE(ABL)                                                         \
+  case ABL: {                                                                   \
+    auto kern = attn_fwd_c4_kernel<D, ABL>;                                     \
+    if (int rc = set_dyn_lds(kern, lds)) return rc;                             \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, Q, K, V, O, N, nqb, sl2);    \
+  } break;
+  switch (g_tune_attn_ablate) {
+    LC_C4_CASE(0) LC_C4_CASE(32) LC_C4_CASE(34) LC_C4_CASE(1) LC_C4_CASE(2) LC_C4_CASE(4) LC_C4_CASE(8)
+    LC_C4_CASE(16) LC_C4_CASE(24) LC_C4_CASE(40) LC_C4_CASE(48)
+    default: return LC_ERR_ARG;
+  }
+#undef LC_C4_CASE
+  return check_launch();
+}
+
 template <int D, bool VT>
 int launch_attn_swp(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                     hipStream_t st) {
@@ -282,6 +304,9 @@ int launch_attn_swp(const half_t* Q, const half_t* K, const half_t* V, half_t* O
 template <int D, bool VT>
 int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                    hipStream_t st) {
+  if constexpr (D == 128 && !VT) {
+    if (N % 256 == 0 && g_tune_attn_nw == 64) return launch_attn_c4<D>(Q, K, V, O, B, H, N, st);
+  }
   if constexpr (D == 128 && !VT) {   // perf-diagnosis instantiations (lc_tune_set "attn_ablate")
     switch (g_tune_attn_ablate) {
       case 1: return launch_attn<D, 8, VT, 1>(Q, K, V, O, B, H, N, st);
@@ -370,7 +395,8 @@ const char* lc_status_string(int status) {
 int lc_tune_set(const char* key, int value) {
   if (!key) return LC_ERR_ARG;
   if (strcmp(key, "attn_nw") == 0) {
-    if (value != 0 && value != 32 && value != 16 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
+    if (value != 0 && value != 64 && value != 32 && value != 16 && value != 8 && value != 4 && value != 2)
+      return LC_ERR_ARG;
     g_tune_attn_nw = value;
     return LC_OK;
   }

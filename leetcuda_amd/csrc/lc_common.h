@@ -67,6 +67,13 @@ LC_DEVINL half_t cvt16(float x) {   // round-to-nearest-even to fp16 or bf16, re
     return (half_t)x;
 }
 
+// raw s_barrier the compiler may not move code across (no implied memory waits: pair it with explicit s_waitcnt)
+LC_DEVINL void raw_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // XCD-aware, bijective remap of the hardware block id: block b runs on XCD b%8 (observed, speed
 // only); give every XCD a contiguous chunk of logical tile ids so neighbours share an L2.
 LC_DEVINL int xcd_remap(int b, int nwg) {
