@@ -159,6 +159,10 @@ int lc_attn_time(const void* Q, const void* K, const void* V, void* O, int B, in
 int lc_probe_mfma16(const void* a16x32, const void* b16x32, float* d16x16, void* stream);
 int lc_probe_mfma32(const void* a32x16, const void* b32x16, float* d32x32, void* stream);
 int lc_probe_tr16(const void* src_64x4_u16, void* dst_64x4_u16, void* stream);
+/* issue-overlap micro-benchmark (tools/coissue_probe.py): 256 x 4 x { 1 MFMA 32x32x16 f16, k fillers }; filler 0 none,
+ * 1 v_fma_f32, 2 v_exp_f32, 3 v_pk_fma_f32, 4 v_cvt_pk_f16_f32, 5 ds_read_b128; mode 0 same wave, 1 SIMD partner wave,
+ * 2 fillers only; out = 16 x u64 (s_memtime cycles per wave).                                                        */
+int lc_probe_coissue(int filler, int k, int mode, void* out_u64x16, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "attn_fwd.hip"
+#include "attn_w4.hip"
 #include "hgemm_generic.hip"
 #include "hgemm_mfma128.hip"
 #include "hgemm_w4.hip"
@@ -288,6 +289,24 @@ int launch_attn_c4(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   return check_launch();
 }
 
+template <int D>
+int launch_attn_w4(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
+                   hipStream_t st) {
+  const int nqb = N / 256;
+  const dim3 grid((unsigned)((size_t)nqb * B * H)), block(256);
+  const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+  if (g_tune_attn_ablate == 32) {
+    auto kern = attn_fwd_w4_kernel<D, true>;
+    if (int rc = set_dyn_lds(kern, AW4_LDS)) return rc;
+    hipLaunchKernelGGL(kern, grid, block, AW4_LDS, st, Q, K, V, O, N, nqb, sl2);
+  } else {
+    auto kern = attn_fwd_w4_kernel<D>;
+    if (int rc = set_dyn_lds(kern, AW4_LDS)) return rc;
+    hipLaunchKernelGGL(kern, grid, block, AW4_LDS, st, Q, K, V, O, N, nqb, sl2);
+  }
+  return check_launch();
+}
+
 template <int D, bool VT>
 int launch_attn_swp(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                     hipStream_t st) {
@@ -306,6 +325,7 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
                    hipStream_t st) {
   if constexpr (D == 128 && !VT) {
     if (N % 256 == 0 && g_tune_attn_nw == 64) return launch_attn_c4<D>(Q, K, V, O, B, H, N, st);
+    if (N % 256 == 0 && g_tune_attn_nw == 128) return launch_attn_w4<D>(Q, K, V, O, B, H, N, st);
   }
   if constexpr (D == 128 && !VT) {   // perf-diagnosis instantiations (lc_tune_set "attn_ablate")
     switch (g_tune_attn_ablate) {
@@ -371,6 +391,25 @@ int launch_attn_d(const half_t* Q, const half_t* K, const half_t* V, half_t* O, 
 // ------------------------------------------------------------------------------------------------
 // vendor comparator (hipBLASLt), resolved lazily with dlopen so the core library has no link-time
 // dependency on it.
+template <int F, int K>
+int probe_coissue_mode(int mode, unsigned long long* out, hipStream_t st) {
+  const int threads = mode == 1 ? 512 : 256;
+  if (mode == 0) hipLaunchKernelGGL((probe_coissue_kernel<F, K, 0>), dim3(1), dim3(threads), 0, st, out, 1.0f);
+  else if (mode == 1) hipLaunchKernelGGL((probe_coissue_kernel<F, K, 1>), dim3(1), dim3(threads), 0, st, out, 1.0f);
+  else if (mode == 3) hipLaunchKernelGGL((probe_coissue_kernel<F, K, 3>), dim3(1), dim3(threads), 0, st, out, 1.0f);
+  else hipLaunchKernelGGL((probe_coissue_kernel<F, K, 2>), dim3(1), dim3(threads), 0, st, out, 1.0f);
+  return check_launch();
+}
+template <int F>
+int probe_coissue_k(int k, int mode, unsigned long long* out, hipStream_t st) {
+  switch (k) {
+    case 1: return probe_coissue_mode<F, 1>(mode, out, st);
+    case 2: return probe_coissue_mode<F, 2>(mode, out, st);
+    case 4: return probe_coissue_mode<F, 4>(mode, out, st);
+    case 8: return probe_coissue_mode<F, 8>(mode, out, st);
+    default: return LC_ERR_ARG;
+  }
+}
 }  // namespace
 
 #include "vendor_gemm.inc"
@@ -395,7 +434,7 @@ const char* lc_status_string(int status) {
 int lc_tune_set(const char* key, int value) {
   if (!key) return LC_ERR_ARG;
   if (strcmp(key, "attn_nw") == 0) {
-    if (value != 0 && value != 64 && value != 32 && value != 16 && value != 8 && value != 4 && value != 2)
+    if (value != 0 && value != 128 && value != 64 && value != 32 && value != 16 && value != 8 && value != 4 && value != 2)
       return LC_ERR_ARG;
     g_tune_attn_nw = value;
     return LC_OK;
@@ -646,6 +685,24 @@ int lc_probe_mfma32(const void* a, const void* b, float* d, void* stream) {
                      static_cast<const half_t*>(a), static_cast<const half_t*>(b), d);
   return check_launch();
 }
+int lc_probe_coissue(int filler, int k, int mode, void* out_u64x16, void* stream) {
+  if (!out_u64x16 || mode < 0 || mode > 3) return LC_ERR_ARG;
+  unsigned long long* out = static_cast<unsigned long long*>(out_u64x16);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (filler) {
+    case 0: return probe_coissue_mode<0, 1>(mode == 2 ? 0 : mode, out, st);
+    case 1: return probe_coissue_k<1>(k, mode, out, st);
+    case 2: return probe_coissue_k<2>(k, mode, out, st);
+    case 3: return probe_coissue_k<3>(k, mode, out, st);
+    case 4: return probe_coissue_k<4>(k, mode, out, st);
+    case 5: return probe_coissue_k<5>(k, mode, out, st);
+    case 6: return probe_coissue_k<6>(k, mode, out, st);
+    case 7: return probe_coissue_k<7>(k, mode, out, st);
+    case 8: return probe_coissue_k<8>(k, mode, out, st);
+    default: return LC_ERR_ARG;
+  }
+}
+
 int lc_probe_tr16(const void* src, void* dst, void* stream) {
   if (!src || !dst) return LC_ERR_ARG;
   hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 
 namespace lc {
 
@@ -36,6 +37,29 @@ LC_DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
 LC_DEVINL half4_t lds_tr16(const void* lds_addr) {
   fp16x4_raw_t r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LC_LDS fp16x4_raw_t*)lds_addr);
   return __builtin_bit_cast(half4_t, r);
+}
+
+// The same transpose read as an asm statement.  Why: hipcc models the builtin as an LDS access that may alias an
+// in-flight LDS-DMA (global_load_lds) and guards EVERY builtin transpose read issued after a DMA with
+// s_waitcnt vmcnt(0) — draining the whole DMA prefetch at each K tile (plain ds_read_b128 loads are not guarded).
+// An asm load is invisible to hipcc's s_waitcnt bookkeeping: the caller must execute lds_tr16_wait*() — which
+// names the destinations — before the first use of the results (in-order LDS returns: lgkmcnt(0) covers them).
+template <int OFF>
+LC_DEVINL half4_t lds_tr16_asm(uint32_t lds_byte_addr) {
+  half4_t r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "n"(OFF));
+  return r;
+}
+LC_DEVINL uint32_t lds_addr32(const void* p) { return (uint32_t)(uintptr_t)(LC_LDS const char*)p; }
+LC_DEVINL void lds_tr16_wait8(half4_t (&a)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+}
+LC_DEVINL void lds_tr16_wait16(half4_t (&a)[16]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                 "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]),
+                 "+v"(a[15]));
 }
 
 LC_DEVINL half8_t cat4(half4_t a, half4_t b) {
@@ -82,4 +106,39 @@ LC_DEVINL int xcd_remap(int b, int nwg) {
   return base + idx;
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{}) — indices usable as
+// template arguments / "n" asm operands (literal AGPR numbers)
+template <int... Is, typename F>
+LC_DEVINL void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+LC_DEVINL void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
 }  // namespace lc
+
+// clobber list naming every AGPR: statements that address accumulators literally (a[N:M]) carry it so that hipcc
+// never parks a value of its own in the accumulator half of the register file
+#define LC_AGPR_ALL \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14",  \
+  "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28",  \
+  "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42",  \
+  "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56",  \
+  "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70",  \
+  "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84",  \
+  "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98",  \
+  "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110",  \
+  "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122",  \
+  "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134",  \
+  "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146",  \
+  "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158",  \
+  "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170",  \
+  "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182",  \
+  "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194",  \
+  "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206",  \
+  "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218",  \
+  "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230",  \
+  "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242",  \
+  "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254",  \
+  "a255"
+

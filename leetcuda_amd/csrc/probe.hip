@@ -41,4 +41,84 @@ __global__ void probe_tr16_kernel(const uint16_t* src, uint16_t* dst) {
   *(u32x2_t*)(dst + lane * 4) = __builtin_bit_cast(u32x2_t, v);  // raw 8 bytes, no per-element casts
 }
 
+
+// Issue-overlap micro-benchmark: 256 iterations of 4 x { one v_mfma_f32_32x32x16_f16, K filler instructions }.
+// FILLER: 1 v_fma_f32, 2 v_exp_f32, 3 v_pk_fma_f32, 4 v_cvt_pk_f16_f32, 5 ds_read_b128, 6 v_accvgpr_read_b32,
+// 7 v_exp_f32 + DEPENDENT v_add_f32 (counts as one filler), 8 ds_read_b64_tr_b16 (0: none).
+// MODE 3: as MODE 0 with the MFMA in the attention form (accumulator and B operand in literal AGPRs).
+// MODE 0: every wave runs MFMAs and fillers interleaved (own-wave shadow); MODE 1: waves 0-3 run only the MFMAs,
+// waves 4-7 (the SIMD partners) only the fillers; MODE 2: fillers only (no MFMA anywhere).
+// out[wave] = s_memtime cycles of the whole loop.
+template <int FILLER, int K, int MODE>
+__global__ __launch_bounds__(512) void probe_coissue_kernel(unsigned long long* out, float seed) {
+  __shared__ __attribute__((aligned(16))) float lbuf[64 * 4 * 8];
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  const bool do_mfma = MODE == 0 || MODE == 3 || (MODE == 1 && wave < 4);
+  const bool do_fill = MODE == 0 || MODE == 3 || MODE == 2 || (MODE == 1 && wave >= 4);
+  half8_t a, b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a[j] = (half_t)(seed + j);
+    b[j] = (half_t)(seed - j);
+  }
+  f32x16_t acc[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  float x[8];
+  f32x2_t x2[8];
+  u32x4_t ld[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    x[j] = seed * 0.01f + j;
+    x2[j] = f32x2_t{seed * 0.01f + j, seed * 0.02f + j};
+    ld[j] = u32x4_t{0, 0, 0, 0};
+    lbuf[lane * 4 + j * 256] = seed;
+  }
+  const float c = 0.999f;
+  const uint32_t la = lds_addr32(&lbuf[lane * 4]);
+  __syncthreads();
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < 256; ++it) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if constexpr (MODE == 3) {
+        if (m == 0) asm volatile("v_mfma_f32_32x32x16_f16 a[0:15], %0, a[192:195], a[0:15]" :: "v"(a) : LC_AGPR_ALL);
+        if (m == 1) asm volatile("v_mfma_f32_32x32x16_f16 a[16:31], %0, a[196:199], a[16:31]" :: "v"(a) : LC_AGPR_ALL);
+        if (m == 2) asm volatile("v_mfma_f32_32x32x16_f16 a[32:47], %0, a[200:203], a[32:47]" :: "v"(a) : LC_AGPR_ALL);
+        if (m == 3) asm volatile("v_mfma_f32_32x32x16_f16 a[48:63], %0, a[204:207], a[48:63]" :: "v"(a) : LC_AGPR_ALL);
+      } else if (do_mfma) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(a), "v"(b));
+      }
+      if (do_fill) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const int i = (m * K + j) & 7;
+          if constexpr (FILLER == 1) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[i]) : "v"(c));
+          if constexpr (FILLER == 2) asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
+          if constexpr (FILLER == 3) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(x2[i]) : "v"(f32x2_t{c, c}));
+          if constexpr (FILLER == 4) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(x[i]) : "v"(c));
+          if constexpr (FILLER == 5) asm volatile("ds_read_b128 %0, %1" : "=v"(ld[i]) : "v"(la));
+          if constexpr (FILLER == 6) asm volatile("v_accvgpr_read_b32 %0, a[128]" : "=v"(x[i]));
+          if constexpr (FILLER == 7)
+            asm volatile("v_exp_f32 %0, %0\n\tv_add_f32 %1, %1, %0" : "+v"(x[i]), "+v"(x2[i][0]));
+          if constexpr (FILLER == 8) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(x2[i]) : "v"(la));
+        }
+      }
+    }
+    if constexpr (FILLER == 5 || FILLER == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float sink = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sink += x[j] + x2[j][0] + x2[j][1] + __builtin_bit_cast(float, ld[j][0]);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) sink += acc[m][0];
+  if (lane == 0) out[wave] = t1 - t0;
+  if (sink == 12345.678f) out[8 + wave] = 1;   // keep everything live
+}
+
 }  // namespace lc
