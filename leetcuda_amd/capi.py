@@ -42,6 +42,7 @@ SYMBOLS = {
     "lc_probe_mfma32": (_i, [_vp, _vp, _vp, _vp]),
     "lc_probe_tr16": (_i, [_vp, _vp, _vp]),
     "lc_probe_coissue": (_i, [_i, _i, _i, _vp, _vp]),
+    "lc_probe_mfma_war": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -410,6 +410,17 @@ int probe_coissue_k(int k, int mode, unsigned long long* out, hipStream_t st) {
     default: return LC_ERR_ARG;
   }
 }
+template <int KIND, int QUEUED>
+int probe_war_delay(int delay, const half_t* a, const half_t* b, float* d, hipStream_t st) {
+#define LC_WAR_CASE(D) case D: hipLaunchKernelGGL((probe_mfma_war_kernel<D, KIND, QUEUED>), dim3(1), dim3(64), 0, st, a, b, d); break;
+  switch (delay) {
+    LC_WAR_CASE(0) LC_WAR_CASE(1) LC_WAR_CASE(2) LC_WAR_CASE(3) LC_WAR_CASE(4) LC_WAR_CASE(6) LC_WAR_CASE(8)
+    LC_WAR_CASE(11) LC_WAR_CASE(15)
+    default: return LC_ERR_ARG;
+  }
+#undef LC_WAR_CASE
+  return check_launch();
+}
 }  // namespace
 
 #include "vendor_gemm.inc"
@@ -701,6 +712,22 @@ int lc_probe_coissue(int filler, int k, int mode, void* out_u64x16, void* stream
     case 8: return probe_coissue_k<8>(k, mode, out, st);
     default: return LC_ERR_ARG;
   }
+}
+
+int lc_probe_mfma_war(int delay, int kind, int queued, const void* a, const void* b, float* d, void* stream) {
+  const half_t* ah = static_cast<const half_t*>(a);
+  const half_t* bh = static_cast<const half_t*>(b);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (kind == 0 && queued == 0) return probe_war_delay<0, 0>(delay, ah, bh, d, st);
+  if (kind == 0 && queued == 1) return probe_war_delay<0, 1>(delay, ah, bh, d, st);
+  if (kind == 1 && queued == 0) return probe_war_delay<1, 0>(delay, ah, bh, d, st);
+  if (kind == 1 && queued == 1) return probe_war_delay<1, 1>(delay, ah, bh, d, st);
+  if (kind == 2 && queued == 0) return probe_war_delay<2, 0>(delay, ah, bh, d, st);
+  if (kind == 2 && queued == 1) return probe_war_delay<2, 1>(delay, ah, bh, d, st);
+  if (kind == 2 && queued == 2) return probe_war_delay<2, 2>(delay, ah, bh, d, st);
+  if (kind == 2 && queued == 4) return probe_war_delay<2, 4>(delay, ah, bh, d, st);
+  if (kind == 0 && queued == 4) return probe_war_delay<0, 4>(delay, ah, bh, d, st);
+  return LC_ERR_ARG;
 }
 
 int lc_probe_tr16(const void* src, void* dst, void* stream) {

@@ -121,4 +121,48 @@ __global__ __launch_bounds__(512) void probe_coissue_kernel(unsigned long long* 
   if (sink == 12345.678f) out[8 + wave] = 1;   // keep everything live
 }
 
+
+// Does an in-flight v_mfma_f32_32x32x16_f16 still read its A operand registers after issue?  One wave: a first MFMA
+// keeps the matrix pipe busy (QUEUED = 1) or not, then the probed MFMA is issued, then DELAY wait states, then VALU
+// (KIND 0: v_mov 0; 1: v_exp_f32; 2: an LDS load of zeros, ds_read_b128) overwrites the A operand registers; QUEUED = number
+// of MFMAs already in the pipe ahead of the probed one.  d = the probed product; the host compares it with a x b.
+template <int DELAY, int KIND, int QUEUED>
+__global__ void probe_mfma_war_kernel(const half_t* a, const half_t* b, float* d) {
+  const int lane = threadIdx.x & 63, l32 = lane & 31, hi = lane >> 5;
+  const half8_t af = *(const half8_t*)(a + l32 * 16 + hi * 8);
+  const half8_t bf = *(const half8_t*)(b + l32 * 16 + hi * 8);
+  f32x16_t c, c0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r] = c0[r] = 0.f;
+  const u32x4_t ar = __builtin_bit_cast(u32x4_t, af);
+  asm volatile("s_nop 7" : "+v"(c), "+v"(c0));
+  __shared__ __attribute__((aligned(16))) uint32_t zeros[64 * 4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) zeros[lane * 4 + j] = 0;
+  __syncthreads();
+  const uint32_t za = lds_addr32(&zeros[lane * 4]);
+#pragma unroll
+  for (int qd = 0; qd < QUEUED; ++qd)
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, %0" : "+v"(c0) : "v"(bf));
+#define LC_WAR_BODY(OVERWRITE)                                                                                   \
+  asm volatile("v_mov_b32 v100, %1\n\tv_mov_b32 v101, %2\n\tv_mov_b32 v102, %3\n\tv_mov_b32 v103, %4\n\ts_nop 4\n\t"  \
+               "v_mfma_f32_32x32x16_f16 %0, v[100:103], %5, %0\n\ts_nop %6\n\t" OVERWRITE                        \
+               : "+v"(c) : "v"(ar[0]), "v"(ar[1]), "v"(ar[2]), "v"(ar[3]), "v"(bf), "n"(DELAY)                    \
+               : "v100", "v101", "v102", "v103")
+  if constexpr (KIND == 0)
+    LC_WAR_BODY("v_mov_b32 v100, 0\n\tv_mov_b32 v101, 0\n\tv_mov_b32 v102, 0\n\tv_mov_b32 v103, 0");
+  else if constexpr (KIND == 2)
+    asm volatile("v_mov_b32 v100, %1\n\tv_mov_b32 v101, %2\n\tv_mov_b32 v102, %3\n\tv_mov_b32 v103, %4\n\ts_nop 4\n\t"
+                 "v_mfma_f32_32x32x16_f16 %0, v[100:103], %5, %0\n\ts_nop %6\n\tds_read_b128 v[100:103], %7\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "+v"(c) : "v"(ar[0]), "v"(ar[1]), "v"(ar[2]), "v"(ar[3]), "v"(bf), "n"(DELAY), "v"(za)
+                 : "v100", "v101", "v102", "v103");
+  else
+    LC_WAR_BODY("v_exp_f32 v100, %1\n\tv_exp_f32 v101, %1\n\tv_exp_f32 v102, %1\n\tv_exp_f32 v103, %1");
+#undef LC_WAR_BODY
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(c), "+v"(c0));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) d[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l32] = c[r] + 0.f * c0[r];
+}
+
 }  // namespace lc
