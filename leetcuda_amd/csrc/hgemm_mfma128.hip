@@ -86,18 +86,25 @@ __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __r
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       half8_t af[4], bf[4];
+      half4_t braw[8];   // NN: asm transpose reads (the builtin form is guarded by s_waitcnt vmcnt(0) after an LDS-DMA,
+                         // which here would serialise the DMA of tile kt+1 with the MFMAs of tile kt)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         if constexpr (!B_KN) {
           bf[ni] = *(const half8_t*)(lb + ((b0 ^ (ks * 64)) + ni * 2048));
         } else {
-          const half4_t lo = lds_tr16(lb + bt[ni] + ks * (32 * 256));
-          const half4_t hi = lds_tr16(lb + bt[ni] + ks * (32 * 256) + 4 * 256);
-          bf[ni] = cat4(lo, hi);
+          const uint32_t a = lds_addr32(lb + bt[ni]) + (uint32_t)(ks * (32 * 256));
+          braw[2 * ni] = lds_tr16_asm<0>(a);
+          braw[2 * ni + 1] = lds_tr16_asm<4 * 256>(a);
         }
       }
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) af[mi] = *(const half8_t*)(la + ((a0 ^ (ks * 64)) + mi * 2048));
+      if constexpr (B_KN) {
+        lds_tr16_wait8(braw);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bf[ni] = cat4(braw[2 * ni], braw[2 * ni + 1]);
+      }
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll

@@ -117,19 +117,25 @@ LC_DEVINL void compute_tile(const char* slot, const FragAddr<B_KN>& f, f32x4_t (
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     half8_t af[8], bf[4];
+    half4_t braw[8];   // NN: asm transpose reads (see lc_common.h lds_tr16_asm)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       if constexpr (!B_KN) {
         bf[ni] = *(const half8_t*)(lb + ((f.b0 ^ (ks * 64)) + ni * 2048));
       } else {
-        const half4_t lo = lds_tr16(lb + f.bt[ni] + ks * (32 * 512));
-        const half4_t hi = lds_tr16(lb + f.bt[ni] + ks * (32 * 512) + 4 * 512);
-        bf[ni] = cat4(lo, hi);
+        const uint32_t a = lds_addr32(lb + f.bt[ni]) + (uint32_t)(ks * (32 * 512));
+        braw[2 * ni] = lds_tr16_asm<0>(a);
+        braw[2 * ni + 1] = lds_tr16_asm<4 * 512>(a);
       }
     }
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
       af[mi] = *(const half8_t*)(la + ((f.a0 ^ (ks * 64)) + mi * 2048));
+    }
+    if constexpr (B_KN) {
+      lds_tr16_wait8(braw);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) bf[ni] = cat4(braw[2 * ni], braw[2 * ni + 1]);
     }
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {

@@ -126,6 +126,27 @@ LC_DEVINL void pp_read_b(const char* slot, const PPFrag<B_KN>& f, int nh, half8_
   }
 }
 
+// NN B fragments with ASM transpose reads (lc_common.h lds_tr16_asm: the builtin form makes hipcc drain the whole
+// LDS-DMA prefetch — s_waitcnt vmcnt(0) — in front of the first transpose read of every K tile).  Two steps: issue
+// the 8 reads of n-half nh into raw[], later pp_b_nn_finish() waits for them and forms the MFMA operands.
+template <int NH>
+LC_DEVINL void pp_read_b_nn_issue(const char* slot, const PPFrag<true>& f, half4_t (&raw)[8]) {
+  const uint32_t a = lds_addr32(slot + (NH ? f.b1 : f.b0));
+  raw[0] = lds_tr16_asm<0>(a);
+  raw[1] = lds_tr16_asm<1024>(a);
+  raw[2] = lds_tr16_asm<4096>(a);
+  raw[3] = lds_tr16_asm<4096 + 1024>(a);
+  raw[4] = lds_tr16_asm<8192>(a);
+  raw[5] = lds_tr16_asm<8192 + 1024>(a);
+  raw[6] = lds_tr16_asm<12288>(a);
+  raw[7] = lds_tr16_asm<12288 + 1024>(a);
+}
+LC_DEVINL void pp_b_nn_finish(half4_t (&raw)[8], half8_t (&bf)[4]) {
+  lds_tr16_wait8(raw);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) bf[ks] = cat4(raw[2 * ks], raw[2 * ks + 1]);
+}
+
 LC_DEVINL void pp_mfma(f32x16_t (&acc)[4][2], int mh, int nh, const half8_t (&af)[2][4],
                        const half8_t (&bf)[4]) {
   __builtin_amdgcn_s_setprio(1);
@@ -228,15 +249,22 @@ __global__ __launch_bounds__(512, 2) void hgemm_pingpong_kernel(const half_t* __
   for (int kt = 0; kt < KT; ++kt) {
     const char* cur = smem + (kt & 1) * SLOT_BYTES;
     // ---- phase 0
-    pp_read_b<B_KN>(cur, fr, 0, b0f);
+    half4_t braw[8];
+    if constexpr (B_KN) pp_read_b_nn_issue<0>(cur, fr, braw); else pp_read_b<B_KN>(cur, fr, 0, b0f);
     pp_read_a<B_KN>(cur, fr, 0, af);
+    if constexpr (B_KN) pp_b_nn_finish(braw, b0f);
     issue_b(1, kt + 1);
     LC_VMCNT(8);
     pp_barrier();
     pp_mfma(acc, 0, 0, af, b0f);
     pp_barrier();
     // ---- phase 1
-    pp_read_b<B_KN>(cur, fr, 1, b1f);
+    if constexpr (B_KN) {
+      pp_read_b_nn_issue<1>(cur, fr, braw);
+      pp_b_nn_finish(braw, b1f);
+    } else {
+      pp_read_b<B_KN>(cur, fr, 1, b1f);
+    }
     issue_a(1, kt + 1);
     LC_VMCNT(8);
     pp_barrier();
@@ -379,9 +407,18 @@ __global__ __launch_bounds__(512, 2) void hgemm_pingpong2_kernel(const half_t* _
 #pragma unroll
       for (int g = 0; g < 6; ++g) issue_ab0(g, kt + 1);
     }
-    pp_read_b<B_KN>(cur, fr, 0, b0f);
-    pp_read_a<B_KN>(cur, fr, 0, af);
-    pp_read_b<B_KN>(cur, fr, 1, b1f);
+    half4_t braw0[8], braw1[8];
+    if constexpr (B_KN) {
+      pp_read_b_nn_issue<0>(cur, fr, braw0);
+      pp_read_a<B_KN>(cur, fr, 0, af);
+      pp_read_b_nn_issue<1>(cur, fr, braw1);
+      pp_b_nn_finish(braw0, b0f);
+      pp_b_nn_finish(braw1, b1f);
+    } else {
+      pp_read_b<B_KN>(cur, fr, 0, b0f);
+      pp_read_a<B_KN>(cur, fr, 0, af);
+      pp_read_b<B_KN>(cur, fr, 1, b1f);
+    }
     if constexpr (STAMPS) {   // split "fragment reads returned" from "DMA landed"
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       STAMP(kt, 5);

@@ -132,12 +132,17 @@ __global__ __launch_bounds__(256) void hgemm_w4_kernel(const half_t* __restrict_
   auto read_a = [&](const char* slot, int ks, int i) -> half8_t {
     return *(const half8_t*)(slot + a_ad[ks] + i * 4096);
   };
+  half4_t braw_lo, braw_hi;          // NN: raw halves of the transpose read just issued
+  half4_t braw[2][8];                // NN: raw B fragments of fragment buffer 0 / 1
   auto read_b = [&](const char* slot, int ks, int j) -> half8_t {
     if constexpr (!B_KN) {
       return *(const half8_t*)(slot + b_ad[ks] + j * 4096);
     } else {
-      const char* p = slot + b_ad[j] + ks * 4096;
-      return cat4(lds_tr16(p), lds_tr16(p + 1024));
+      // (asm transpose reads: hipcc would put s_waitcnt vmcnt(0) in front of the builtin form after every LDS-DMA)
+      const uint32_t a = lds_addr32(slot + b_ad[j]) + (uint32_t)(ks * 4096);
+      braw_lo = lds_tr16_asm<0>(a);
+      braw_hi = lds_tr16_asm<1024>(a);
+      return half8_t{};
     }
   };
 
@@ -160,7 +165,13 @@ __global__ __launch_bounds__(256) void hgemm_w4_kernel(const half_t* __restrict_
 #pragma unroll
   for (int i = 0; i < 4; ++i) af[0][i] = read_a(smem, 0, i);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bf[0][j] = read_b(smem, 0, j);
+  for (int j = 0; j < 4; ++j) {
+    bf[0][j] = read_b(smem, 0, j);
+    if constexpr (B_KN) {
+      braw[0][2 * j] = braw_lo;
+      braw[0][2 * j + 1] = braw_hi;
+    }
+  }
 
   // one k-step: 16 MFMAs from fragment buffer `cb`; the first 4 chunks carry the 8 fragment reads of the
   // next step into buffer cb^1; every chunk may carry 2 DMA pieces.
@@ -169,6 +180,13 @@ __global__ __launch_bounds__(256) void hgemm_w4_kernel(const half_t* __restrict_
   auto step = [&](auto cbc, const char* rslot, int rks, auto dbc, int t2, char* wslot) {
     constexpr int cb = decltype(cbc)::value;
     constexpr int DB = decltype(dbc)::value;
+    if constexpr (B_KN) {   // the asm reads of this buffer were issued >= 8 MFMAs ago
+      lds_tr16_wait8(braw[cb]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[cb][j] = cat4(braw[cb][2 * j], braw[cb][2 * j + 1]);
+      // hipcc may build the operand tuples with v_mov copies right here: VALU write -> (asm) MFMA operand read
+      asm volatile("s_nop 1" : "+v"(bf[cb][0]), "+v"(bf[cb][1]), "+v"(bf[cb][2]), "+v"(bf[cb][3]));
+    }
     static_for<8>([&](auto cc) {
       constexpr int c = decltype(cc)::value;
       // MFMAs FIRST: hipcc guards the first asm consumer of the previous step's fragments with lgkmcnt(0); ahead
@@ -180,6 +198,10 @@ __global__ __launch_bounds__(256) void hgemm_w4_kernel(const half_t* __restrict_
       if constexpr (c < 4 && !(ABL & 4)) {
         af[cb ^ 1][c] = read_a(rslot, rks, c);
         bf[cb ^ 1][c] = read_b(rslot, rks, c);
+        if constexpr (B_KN) {
+          braw[cb ^ 1][2 * c] = braw_lo;
+          braw[cb ^ 1][2 * c + 1] = braw_hi;
+        }
       }
       if constexpr (DB >= 0 && !(ABL & 1)) piece(DB + c, t2, wslot);
       __builtin_amdgcn_sched_barrier(0);
@@ -334,12 +356,17 @@ __global__ __launch_bounds__(256) void hgemm_w4s_kernel(const half_t* __restrict
   auto read_a = [&](const char* slot, int ks, int i) -> half8_t {
     return *(const half8_t*)(slot + a_ad[ks] + i * 2048);
   };
+  half4_t braw_lo, braw_hi;          // NN: raw halves of the transpose read just issued
+  half4_t braw[2][8];                // NN: raw B fragments of fragment buffer 0 / 1
   auto read_b = [&](const char* slot, int ks, int j) -> half8_t {
     if constexpr (!B_KN) {
       return *(const half8_t*)(slot + b_ad[ks] + j * 2048);
     } else {
-      const char* p = slot + b_ad[j] + ks * 4096;
-      return cat4(lds_tr16(p), lds_tr16(p + 1024));
+      // (asm transpose reads: hipcc would put s_waitcnt vmcnt(0) in front of the builtin form after every LDS-DMA)
+      const uint32_t a = lds_addr32(slot + b_ad[j]) + (uint32_t)(ks * 4096);
+      braw_lo = lds_tr16_asm<0>(a);
+      braw_hi = lds_tr16_asm<1024>(a);
+      return half8_t{};
     }
   };
 
@@ -359,12 +386,25 @@ __global__ __launch_bounds__(256) void hgemm_w4s_kernel(const half_t* __restrict
 #pragma unroll
   for (int i = 0; i < 4; ++i) af[0][i] = read_a(smem, 0, i);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bf[0][j] = read_b(smem, 0, j);
+  for (int j = 0; j < 4; ++j) {
+    bf[0][j] = read_b(smem, 0, j);
+    if constexpr (B_KN) {
+      braw[0][2 * j] = braw_lo;
+      braw[0][2 * j + 1] = braw_hi;
+    }
+  }
 
   // one k-step: 16 MFMAs from fragment buffer cb; chunks 0..3 carry the reads of the next k-step into
   // buffer cb^1, chunks 4..7 one DMA piece each (pieces g0..g0+3 of stage dst).
   auto step = [&](auto cbc, const char* rslot, int rks, int g0, int dst) {
     constexpr int cb = decltype(cbc)::value;
+    if constexpr (B_KN) {   // the asm reads of this buffer were issued >= 8 MFMAs ago
+      lds_tr16_wait8(braw[cb]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[cb][j] = cat4(braw[cb][2 * j], braw[cb][2 * j + 1]);
+      // hipcc may build the operand tuples with v_mov copies right here: VALU write -> (asm) MFMA operand read
+      asm volatile("s_nop 1" : "+v"(bf[cb][0]), "+v"(bf[cb][1]), "+v"(bf[cb][2]), "+v"(bf[cb][3]));
+    }
     static_for<8>([&](auto cc) {
       constexpr int c = decltype(cc)::value;
       constexpr int i = c >> 1, j0 = 2 * (c & 1);
@@ -374,6 +414,10 @@ __global__ __launch_bounds__(256) void hgemm_w4s_kernel(const half_t* __restrict
       if constexpr (c < 4) {
         af[cb ^ 1][c] = read_a(rslot, rks, c);
         bf[cb ^ 1][c] = read_b(rslot, rks, c);
+        if constexpr (B_KN) {
+          braw[cb ^ 1][2 * c] = braw_lo;
+          braw[cb ^ 1][2 * c + 1] = braw_hi;
+        }
       } else {
         piece(g0 + c - 4, dst);
       }
