@@ -700,13 +700,18 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_c4_kernel(
     raw_barrier();
     // =========================== SM ===========================
     STAMP(t, 4);
+    // asm transpose reads (lc_common.h lds_tr16_asm): the builtin form is guarded by s_waitcnt vmcnt(0) after an LDS-DMA
+    half4_t vlo[16], vhi[16];
+    {
+      uint32_t va[DT];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const char* p = cur + v_rd + (32 * (g >> 1) + 16 * (g & 1)) * 256 + ((dt ^ v_sw) << 6);
-        fr[g * DT + dt] = cat4(lds_tr16(p), lds_tr16(p + 8 * 256));
-      }
+      for (int dt = 0; dt < DT; ++dt) va[dt] = lds_addr32(cur + v_rd + ((dt ^ v_sw) << 6));
+      static_for<16>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, g = i >> 2, dt = i & 3;
+        constexpr int ro = (32 * (g >> 1) + 16 * (g & 1)) * 256;
+        vlo[i] = lds_tr16_asm<ro>(va[dt]);
+        vhi[i] = lds_tr16_asm<ro + 8 * 256>(va[dt]);
+      });
     }
     __builtin_amdgcn_sched_barrier(0);
     half8_t pf[2][2];
@@ -774,7 +779,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_c4_kernel(
     }
     }
     if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lds_tr16_wait16(vlo);
+    lds_tr16_wait16(vhi);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) fr[i] = cat4(vlo[i], vhi[i]);
     STAMP(t, 5);
     raw_barrier();
     // =========================== C2 ===========================
