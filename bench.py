@@ -201,10 +201,10 @@ def bench_attn(w, args, sharded_cfg4=False, steps=None, warmup=None):
                     f"randn inputs, {b_loc}x{h_loc} (batch,head) problems per rank",
         "scaling": "strong",
         "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK, "unit": "TFLOP/s", "frac": ach / PEAK,
-                     "kernel_ms": ms_kernel, "kernel": "attn_fwd_kernel<128,8,false>",
+                     "kernel_ms": ms_kernel, "kernel": "attn_fwd_c4_kernel<128,0>",
                      "algorithmic_flops_per_launch": flops_local,
                      "algorithmic_bytes_per_launch": 4.0 * b_loc * h_loc * N * D * 2,
-                     "traffic": pmc_traffic("attn_fwd_kernel<128,8,false,0>")},
+                     "traffic": pmc_traffic("attn_fwd_c4_kernel<128,0>")},
     }
 
 

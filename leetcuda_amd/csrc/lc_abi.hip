@@ -324,7 +324,9 @@ template <int D, bool VT>
 int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                    hipStream_t st) {
   if constexpr (D == 128 && !VT) {
-    if (N % 256 == 0 && g_tune_attn_nw == 64) return launch_attn_c4<D>(Q, K, V, O, B, H, N, st);
+    // default for D = 128: the four-cluster LDS-DMA kernel (measured 2-3 % ahead of the lock-step kernel at config 3)
+    if (N % 256 == 0 && (g_tune_attn_nw == 64 || (g_tune_attn_nw == 0 && g_tune_attn_ablate == 0)))
+      return launch_attn_c4<D>(Q, K, V, O, B, H, N, st);
     if (N % 256 == 0 && g_tune_attn_nw == 128) return launch_attn_w4<D>(Q, K, V, O, B, H, N, st);
   }
   if constexpr (D == 128 && !VT) {   // perf-diagnosis instantiations (lc_tune_set "attn_ablate")
