@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Variant x size table (square fp16 GEMM, TN and NN) incl. hipBLASLt: data for the LC_HGEMM_AUTO heuristic."""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+from leetcuda_amd import capi, host  # noqa: E402
+
+capi.load()
+capi.vendor_init()
+sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1024, 2048, 3072, 4096, 6144, 8192]
+V = {"mfma128": capi.HGEMM_MFMA128, "mfma256": capi.HGEMM_MFMA256, "pingpong2": capi.HGEMM_MFMA256P2,
+     "w4": capi.HGEMM_MFMA256W4, "auto": capi.HGEMM_AUTO}
+for n in sizes:
+    a = torch.randn(n, n, dtype=torch.half, device="cuda")
+    b = torch.randn(n, n, dtype=torch.half, device="cuda")
+    c = torch.empty(n, n, dtype=torch.half, device="cuda")
+    fl = 2.0 * n ** 3
+    st = host.make_block_swizzle_stride(n, n)
+    for lname, lay in (("tn", capi.LAYOUT_TN), ("nn", capi.LAYOUT_NN)):
+        b2 = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
+        row = []
+        for name, var in V.items():
+            if name != "mfma128" and name != "auto" and n % 256:
+                continue
+            ms = min(capi.hgemm_time(a, b2, c, lay, var, 2, st, warmup=3, iters=20) for _ in range(2))
+            row.append(f"{name} {fl / ms * 1e-9:7.1f}")
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            capi.hgemm_vendor(a, b2, c, lay)
+        t0.record()
+        for _ in range(20):
+            capi.hgemm_vendor(a, b2, c, lay)
+        t1.record(); torch.cuda.synchronize()
+        ms = t0.elapsed_time(t1) / 20
+        row.append(f"hipBLASLt {fl / ms * 1e-9:7.1f}")
+        print(f"n={n:5d} {lname}: " + " | ".join(row), flush=True)
+capi.vendor_destroy()

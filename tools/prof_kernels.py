@@ -22,15 +22,18 @@ if a.what in ("all", "hgemm"):
     B = torch.randn(n, n, dtype=torch.half, device="cuda")
     C = torch.zeros(n, n, dtype=torch.half, device="cuda")
     Bt = host.as_col_major(B)
-    for var in (capi.HGEMM_MFMA256P2, capi.HGEMM_MFMA256P, capi.HGEMM_MFMA256):
+    for var in (capi.HGEMM_MFMA256P2, capi.HGEMM_MFMA256W4, capi.HGEMM_MFMA256):
         for lay, bb in ((capi.LAYOUT_TN, Bt), (capi.LAYOUT_NN, B)):
             for _ in range(a.iters):
                 capi.hgemm(A, bb, C, layout=lay, variant=var, swizzle_stride=2048)
     torch.cuda.synchronize()
 if a.what in ("all", "attn"):
     q, k, v, o, tv = host.get_qkvo(4, 32, 4096, 128, seed=0)
-    for _ in range(a.iters):
-        capi.attn_fwd(q, k, v, o)
+    for nw in (0, 8, 128):     # default (four-cluster LDS-DMA), lock-step, 4-wave x 64-row
+        capi.tune("attn_nw", nw)
+        for _ in range(a.iters):
+            capi.attn_fwd(q, k, v, o)
+    capi.tune("attn_nw", 0)
     torch.cuda.synchronize()
     del q, k, v, o, tv
     n = 8192   # config-5 extension: fp8 e4m3 GEMM

@@ -54,7 +54,7 @@ def main(tag: str):
                         "median_us": v2[len(v2) // 2], **meta[k]}
         (out / f"{tag}_kernel_stats.json").write_text(json.dumps(stats, indent=1))
         lines = [f"# rocprofv3 --kernel-trace --stats — {tag}", "",
-                 "command: see profiles/README.md (round r02p: `rocprofv3 --kernel-trace --stats -- python bench.py "
+                 "command: see profiles/README.md (rounds r02p / r03z: `rocprofv3 --kernel-trace --stats -- python bench.py "
                  "--steps 20 --warmup 2 --no-cpu-baseline`, i.e. the bench command itself)", "",
                  "| kernel | calls | avg µs | median µs | min µs | max µs | VGPR | LDS B | grid |", "|---|---|---|---|---|---|---|---|---|"]
         for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["avg_us"]):
