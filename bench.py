@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="hgemm", choices=["hgemm", "attn", "attn_sharded"])
     ap.add_argument("--layout", default="tn", choices=["tn", "nn"])
-    ap.add_argument("--variant", default="auto", choices=["auto", "mfma256", "pingpong", "pingpong2", "pingpong3", "w4", "w4s", "generic"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "mfma256", "pingpong", "pingpong2", "pingpong3", "w4", "w4s", "w4b", "w4c", "generic"])
     ap.add_argument("--mnk", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-attention", action="store_true", help="skip the secondary attention measurement")
@@ -64,13 +64,18 @@ def parse():
 
 
 VARIANT = {"auto": capi.HGEMM_AUTO, "mfma256": capi.HGEMM_MFMA256, "pingpong": capi.HGEMM_MFMA256P,
-           "pingpong2": capi.HGEMM_MFMA256P2, "pingpong3": capi.HGEMM_MFMA256P3, "w4": capi.HGEMM_MFMA256W4, "w4s": capi.HGEMM_MFMA256W4S, "generic": capi.HGEMM_GENERIC}
-AUTO_KERNEL = "pingpong2"   # what LC_HGEMM_AUTO resolves to (lc_abi.hip: g_tune_hgemm_auto)
+           "pingpong2": capi.HGEMM_MFMA256P2, "pingpong3": capi.HGEMM_MFMA256P3, "w4": capi.HGEMM_MFMA256W4, "w4s": capi.HGEMM_MFMA256W4S, "w4b": capi.HGEMM_MFMA256W4B, "w4c": capi.HGEMM_MFMA256W4C, "generic": capi.HGEMM_GENERIC}
+AUTO_KERNEL = "w4c"   # what LC_HGEMM_AUTO resolves to (lc_abi.hip: g_tune_hgemm_auto)
 
 
 def pmc_key_hgemm(variant: str, layout: str) -> str:
     v = AUTO_KERNEL if variant == "auto" else variant
-    return f"hgemm_{v}_kernel<{'true' if layout == 'nn' else 'false'}>"
+    nn = 'true' if layout == 'nn' else 'false'
+    if v in ("w4b", "w4c"):
+        return f"hgemm_w4b_kernel<{nn},{'true' if v == 'w4c' else 'false'}>"
+    if v == "w4":
+        return f"hgemm_w4_kernel<{nn},0>"
+    return f"hgemm_{v}_kernel<{nn}>"
 
 
 def timed_region(w, step, steps, warmup):
@@ -131,7 +136,7 @@ def bench_hgemm(w, args):
         capi.vendor_init()
         for lname, l2 in (("tn", capi.LAYOUT_TN), ("nn", capi.LAYOUT_NN)):
             b2 = host.as_col_major(b) if l2 == capi.LAYOUT_TN else b
-            for vn in ("mfma256", "pingpong", "pingpong2", "pingpong3", "w4", "w4s"):
+            for vn in ("mfma256", "pingpong", "pingpong2", "pingpong3", "w4", "w4s", "w4b", "w4c"):
                 for st in (1, 1024, 2048):
                     ms = capi.hgemm_time(a, b2, c, l2, VARIANT[vn], 2, st, warmup=2, iters=20)
                     print(f"[sweep] hgemm {lname} {vn:9s} stride {st:5d}: {ms:.4f} ms  "

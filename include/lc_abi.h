@@ -52,7 +52,7 @@ typedef enum lc_layout { LC_LAYOUT_NN = 0, LC_LAYOUT_TN = 1 } lc_layout;
 
 /* HGEMM kernel families behind the ABI. */
 typedef enum lc_hgemm_variant {
-  LC_HGEMM_AUTO = 0,     /* best available for the shape (MFMA256P2 / MFMA128 / GENERIC by divisibility)  */
+  LC_HGEMM_AUTO = 0,     /* best available for the shape (MFMA256W4C / MFMA128 / GENERIC by divisibility) */
   LC_HGEMM_MFMA256 = 1,  /* 256x256x64 WG tile, 8 wave64, LDS-DMA double buffer, one barrier / K-tile */
   LC_HGEMM_MFMA256P = 2, /* same tile, phase-interleaved ping-pong schedule (counted vmcnt)           */
   LC_HGEMM_GENERIC = 3,  /* 64x64x32 edge-predicated MFMA kernel: any M,N,K                           */
@@ -60,7 +60,9 @@ typedef enum lc_hgemm_variant {
   LC_HGEMM_MFMA256P3 = 5, /* same, DMA issued by the load sections (bare MFMA clusters)                     */
   LC_HGEMM_MFMA128 = 6,   /* 128x128x64 tile, 4 wave64: M, N multiples of 128 (the reference's own tile)     */
   LC_HGEMM_MFMA256W4 = 7, /* 256x256x64 tile, FOUR wave64 with 128x128 wave tiles, one barrier per K tile      */
-  LC_HGEMM_MFMA256W4S = 8 /* same wave layout, LDS ring of four 32-k stages (DMA spread one piece per 4 MFMAs) */
+  LC_HGEMM_MFMA256W4S = 8, /* same wave layout, LDS ring of four 32-k stages (DMA spread one piece per 4 MFMAs) */
+  LC_HGEMM_MFMA256W4B = 9, /* same wave layout, A ring of 2 + B ring of 3 K tiles (160 KiB): no DMA piece < 3 k-steps ahead */
+  LC_HGEMM_MFMA256W4C = 10 /* W4B with buffer_load ... lds (descriptor + scalar offset) DMA instead of global_load_lds   */
 } lc_hgemm_variant;
 
 /* FlashAttention-2 forward families (resource policies of kernels/flash-attn/mma/basic/ .cu files). */

@@ -11,7 +11,7 @@ LIB_PATH = _PKG / "lib" / "libleetcuda_amd.so"
 
 LC_OK, LC_ERR_ARG, LC_ERR_SHAPE, LC_ERR_HEADDIM, LC_ERR_LAUNCH, LC_ERR_VENDOR, LC_ERR_DEVICE = 0, -1, -2, -3, -4, -5, -6
 LAYOUT_NN, LAYOUT_TN = 0, 1
-HGEMM_AUTO, HGEMM_MFMA256, HGEMM_MFMA256P, HGEMM_GENERIC, HGEMM_MFMA256P2, HGEMM_MFMA256P3, HGEMM_MFMA128, HGEMM_MFMA256W4, HGEMM_MFMA256W4S = 0, 1, 2, 3, 4, 5, 6, 7, 8
+HGEMM_AUTO, HGEMM_MFMA256, HGEMM_MFMA256P, HGEMM_GENERIC, HGEMM_MFMA256P2, HGEMM_MFMA256P3, HGEMM_MFMA128, HGEMM_MFMA256W4, HGEMM_MFMA256W4S, HGEMM_MFMA256W4B, HGEMM_MFMA256W4C = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 ATTN_SPLIT_Q, ATTN_SHARED_QKV, ATTN_SHARED_KV, ATTN_TILING_QK, ATTN_TILING_QKV, ATTN_SPLIT_KV = range(6)
 
 # every symbol include/lc_abi.h declares: name -> (restype, argtypes)

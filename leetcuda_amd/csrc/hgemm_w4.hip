@@ -26,6 +26,7 @@
 
 namespace lc {
 
+constexpr int W4B_LDS = 5 * TILE_BYTES;   // A ring 2 x 32 KiB + B ring 3 x 32 KiB
 constexpr int W4_EPI_STRIDE = 272;   // bytes per staged C row (128 halves + 16 B pad)
 
 // The 4x4 accumulator tile lives in a[0:255], addressed LITERALLY: hipcc's allocator cannot hold 256 live
@@ -232,6 +233,226 @@ __global__ __launch_bounds__(256) void hgemm_w4_kernel(const half_t* __restrict_
     else
       step(I1{}, nxt, 0, NoDma{}, 0, nullptr);
   }
+
+  // ---- epilogue: lane holds C[m = 32i + l32][n = 32j + 8(r>>2) + 4hi + (r&3)]; each wave stages one
+  // 32-row block (32 x 128 halves) at a time in its private LDS area and writes 256-B row segments.
+  w4_mfma_drain();
+  __syncthreads();
+  char* stg = smem + wave * (32 * W4_EPI_STRIDE);
+  half_t* cw = C + (size_t)(m0 + wr * 128) * N + n0 + wc * 128;
+  static_for<4>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    static_for<16>([&](auto qc) {
+      constexpr int j = decltype(qc)::value >> 2, rq = decltype(qc)::value & 3;
+      half4_t h;
+      h[0] = (half_t)w4_acc_read<16 * (4 * i + j) + 4 * rq + 0>();
+      h[1] = (half_t)w4_acc_read<16 * (4 * i + j) + 4 * rq + 1>();
+      h[2] = (half_t)w4_acc_read<16 * (4 * i + j) + 4 * rq + 2>();
+      h[3] = (half_t)w4_acc_read<16 * (4 * i + j) + 4 * rq + 3>();
+      *(half4_t*)(stg + l32 * W4_EPI_STRIDE + (j * 32 + 8 * rq + 4 * hi) * 2) = h;
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + (lane >> 4);
+      const u32x4_t v = *(const u32x4_t*)(stg + row * W4_EPI_STRIDE + (lane & 15) * 16);
+      *(u32x4_t*)(cw + (size_t)(i * 32 + row) * N + (lane & 15) * 8) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  });
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// hgemm_w4b_kernel — hgemm_w4_kernel with a THREE-slot ring for B (A 2 x 32 KiB + B 3 x 32 KiB = 160 KiB, all of
+// a CU's LDS): the B pieces of tile t+2 go out during steps 1-2 of tile t (their slot has been dead since the end of
+// tile t-1), one per 4 MFMAs, and are in flight for >= 5 k-steps; the A pieces of tile t+2 follow in step 3 behind the
+// barrier (3 k-steps of flight) — no DMA piece is issued less than 1500 MFMA cycles before it is needed, and the wait
+// in front of the barrier is a counted vmcnt(8) (the 8 B pieces of tile t+2 stay in flight across it).
+// issue order  ... | B(t+1): steps 1-2 of t-1 | A(t+1): step 3 of t-1 | B(t+2): steps 1-2 of t | A(t+2): step 3 of t ...
+// BUF: the DMA pieces are buffer_load ... lds (descriptor + scalar offset) instead of global_load_lds (64-bit lane address)
+template <bool B_KN, bool BUF = false>
+__global__ __launch_bounds__(256) void hgemm_w4b_kernel(const half_t* __restrict__ A,
+                                                       const half_t* __restrict__ B,
+                                                       half_t* __restrict__ C, int M, int N, int K,
+                                                       int tiles_m, int tiles_n, int panel_w) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l32 = lane & 31, hi = lane >> 5;
+
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const TileCoord tc = raster(id, tiles_m, tiles_n, panel_w);
+  const int m0 = tc.tm * BM, n0 = tc.tn * BN;
+
+  // ---- DMA sources.  A (and TN B): this wave stages the 8-row blocks blk = 8*wave + p, p = 0..7; lane ->
+  // row (lane>>3) of the block, chunk slot (lane&7) holding logical chunk slot ^ ((row>>1)&7), and
+  // (row>>1)&7 = ((lane>>4)&3) | ((p&1)<<2).
+  unsigned a_off[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    a_off[par] = (unsigned)(lane >> 3) * (unsigned)K * 2u +
+                 (unsigned)(((lane & 7) ^ (((lane >> 4) & 3) | (par << 2))) * 16);
+  const char* ua = (const char*)(A + (size_t)(m0 + wave * 64) * K);
+  const char* ub;
+  unsigned b_off[2];
+  if constexpr (!B_KN) {
+    ub = (const char*)(B + (size_t)(n0 + wave * 64) * K);
+    b_off[0] = a_off[0];
+    b_off[1] = a_off[1];
+  } else {
+    // NN: sub-image h = columns [128h, +128) as [64 k][256 B], piece q = 4 k-rows; this wave stages
+    // q = 4*wave + p2 of both sub-images.  lane -> k row (lane>>4), 16-B slot pp = lane&15 holding chunk nc
+    // (32-B pairs XOR-ed by (k&3)<<1).
+    const int pp = lane & 15;
+    const int pair = (pp >> 1) ^ (((lane >> 4) & 3) << 1);
+    const int nc = pair * 2 + (pp & 1);
+    b_off[0] = (unsigned)(lane >> 4) * (unsigned)N * 2u + (unsigned)(nc * 16);
+    b_off[1] = b_off[0];
+    ub = (const char*)(B + (size_t)(wave * 16) * N + n0);
+  }
+  const size_t a_blk = (size_t)8 * K * 2;                        // bytes between consecutive 8-row blocks
+  const size_t a_kt = (size_t)BK * 2;                            // bytes per K tile along a row
+  const size_t b_kt = B_KN ? (size_t)BK * N * 2 : (size_t)BK * 2;
+  const size_t b_q = (size_t)4 * N * 2;                          // NN: bytes between consecutive pieces
+  // piece g = 0..15 of K tile t (clamped: past the end the last tile is staged again into a dead slot, which keeps
+  // the vmcnt counts exact) -> `slot` = the A slot (g < 8) or the B slot (g >= 8) of that tile
+  const int KT = K / BK;
+  const buf_rsrc_t ra = make_rsrc(ua), rb = make_rsrc(ub);
+  auto dma = [&](buf_rsrc_t r, const char* base, size_t uoff, unsigned loff, char* dst) {
+    if constexpr (BUF) blds16(r, loff, (unsigned)uoff, dst);
+    else glds16(base + uoff + loff, dst);
+  };
+  auto piece = [&](int g, int t, char* slot) {
+    const int te = t < KT ? t : KT - 1;
+    if (g < 8) {
+      dma(ra, ua, (size_t)g * a_blk + (size_t)te * a_kt, a_off[g & 1], slot + (wave * 8 + g) * 1024);
+    } else {
+      const int p = g - 8;
+      if constexpr (!B_KN) {
+        dma(rb, ub, (size_t)p * a_blk + (size_t)te * b_kt, b_off[p & 1], slot + (wave * 8 + p) * 1024);
+      } else {
+        const int h = p >> 2, p2 = p & 3;
+        dma(rb, ub, (size_t)p2 * b_q + (size_t)(256 * h) + (size_t)te * b_kt, b_off[0],
+            slot + h * HALF_BYTES + (wave * 4 + p2) * 1024);
+      }
+    }
+  };
+  auto a_slot = [&](int t) -> char* { return smem + (t & 1) * TILE_BYTES; };
+  auto b_slot = [&](int bi) -> char* { return smem + (2 + bi) * TILE_BYTES; };   // bi = t % 3, tracked by the caller
+
+  // ---- fragment read addresses (one VGPR per k-step: no address arithmetic in the loop)
+  const int swz = (lane >> 1) & 7;
+  int a_ad[4], b_ad[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    a_ad[ks] = (wr * 128 + l32) * 128 + (((2 * ks + hi) ^ swz) * 16);
+    if constexpr (!B_KN) b_ad[ks] = (wc * 128 + l32) * 128 + (((2 * ks + hi) ^ swz) * 16);
+  }
+  if constexpr (B_KN) {
+    const int i = lane & 15, gi = (lane >> 4) & 1;
+    const int k = 8 * hi + (i >> 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)   // n-block j = columns 128wc + 32j + 16gi.. = pair 2j + gi of sub-image wc
+      b_ad[j] = wc * HALF_BYTES + k * 256 + (((2 * j + gi) ^ ((i >> 2) << 1)) * 32) + (i & 3) * 8;
+  }
+  auto read_a = [&](const char* slot, int ks, int i) -> half8_t {
+    return *(const half8_t*)(slot + a_ad[ks] + i * 4096);
+  };
+  half4_t braw_lo, braw_hi;          // NN: raw halves of the transpose read just issued
+  half4_t braw[2][8];                // NN: raw B fragments of fragment buffer 0 / 1
+  auto read_b = [&](const char* slot, int ks, int j) -> half8_t {
+    if constexpr (!B_KN) {
+      return *(const half8_t*)(slot + b_ad[ks] + j * 4096);
+    } else {
+      // (asm transpose reads: hipcc would put s_waitcnt vmcnt(0) in front of the builtin form after every LDS-DMA)
+      const uint32_t a = lds_addr32(slot + b_ad[j]) + (uint32_t)(ks * 4096);
+      braw_lo = lds_tr16_asm<0>(a);
+      braw_hi = lds_tr16_asm<1024>(a);
+      return half8_t{};
+    }
+  };
+
+  static_for<256>([&](auto r) { w4_acc_zero<decltype(r)::value>(); });   // accumulator (i, j) = a[16(4i+j) ..]
+
+  // prologue: B(0) A(0) B(1) A(1); tile 0 landed, step-0 fragments of tile 0 in registers
+#pragma unroll
+  for (int g = 8; g < 16; ++g) piece(g, 0, b_slot(0));
+#pragma unroll
+  for (int g = 0; g < 8; ++g) piece(g, 0, a_slot(0));
+#pragma unroll
+  for (int g = 8; g < 16; ++g) piece(g, 1, b_slot(1));
+#pragma unroll
+  for (int g = 0; g < 8; ++g) piece(g, 1, a_slot(1));
+  LC_VMCNT(16);
+  pp_barrier();
+
+  half8_t af[2][4], bf[2][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) af[0][i] = read_a(a_slot(0), 0, i);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bf[0][j] = read_b(b_slot(0), 0, j);
+    if constexpr (B_KN) {
+      braw[0][2 * j] = braw_lo;
+      braw[0][2 * j + 1] = braw_hi;
+    }
+  }
+
+  // one k-step: 16 MFMAs from fragment buffer cb; chunks 0..3 carry the 8 fragment reads of the next step into
+  // buffer cb^1; DMA: NP pieces g0.. of tile t2 into wslot, one per 8/NP chunks (NP = 0, 4 or 8)
+  auto step = [&](auto cbc, const char* ra, const char* rb, int rks, auto npc, int g0, int t2, char* wslot) {
+    constexpr int cb = decltype(cbc)::value;
+    constexpr int NP = decltype(npc)::value;
+    if constexpr (B_KN) {   // the asm reads of this buffer were issued >= 8 MFMAs ago
+      lds_tr16_wait8(braw[cb]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[cb][j] = cat4(braw[cb][2 * j], braw[cb][2 * j + 1]);
+      asm volatile("s_nop 1" : "+v"(bf[cb][0]), "+v"(bf[cb][1]), "+v"(bf[cb][2]), "+v"(bf[cb][3]));
+    }
+    static_for<8>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      constexpr int i = c >> 1, j0 = 2 * (c & 1);
+      w4_mfma<4 * i + j0>(bf[cb][j0], af[cb][i]);
+      w4_mfma<4 * i + j0 + 1>(bf[cb][j0 + 1], af[cb][i]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (c < 4) {
+        af[cb ^ 1][c] = read_a(ra, rks, c);
+        bf[cb ^ 1][c] = read_b(rb, rks, c);
+        if constexpr (B_KN) {
+          braw[cb ^ 1][2 * c] = braw_lo;
+          braw[cb ^ 1][2 * c + 1] = braw_hi;
+        }
+      }
+      if constexpr (NP == 8) piece(g0 + c, t2, wslot);
+      if constexpr (NP == 4 && (c & 1) == 1) piece(g0 + (c >> 1), t2, wslot);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using P0 = std::integral_constant<int, 0>;
+  using P4 = std::integral_constant<int, 4>;
+  using P8 = std::integral_constant<int, 8>;
+
+  int b0 = 0, b1 = 1, b2 = 2;   // B slot indices of tiles kt, kt+1, kt+2 (rotating, kt % 3)
+  for (int kt = 0; kt < KT; ++kt) {
+    const char* ca = a_slot(kt);
+    const char* cbs = b_slot(b0);
+    step(I0{}, ca, cbs, 1, P0{}, 0, 0, nullptr);
+    step(I1{}, ca, cbs, 2, P4{}, 8, kt + 2, b_slot(b2));
+    step(I0{}, ca, cbs, 3, P4{}, 12, kt + 2, b_slot(b2));
+    // every read of tile kt is issued; A(kt+1), B(kt+1) must have landed (the 8 B pieces of tile kt+2 stay in flight)
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    pp_barrier();
+    step(I1{}, a_slot(kt + 1), b_slot(b1), 0, P8{}, 0, kt + 2, a_slot(kt));
+    const int t = b0;
+    b0 = b1;
+    b1 = b2;
+    b2 = t;
+  }
+  LC_VMCNT(0);
 
   // ---- epilogue: lane holds C[m = 32i + l32][n = 32j + 8(r>>2) + 4hi + (r&3)]; each wave stages one
   // 32-row block (32 x 128 halves) at a time in its private LDS area and writes 256-B row segments.

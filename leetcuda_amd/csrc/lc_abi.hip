@@ -31,7 +31,7 @@ int g_tune_attn_ablate = 0;                // see attn_fwd_kernel ABL (diagnosis
 int g_tune_w4_abl = 0;                       // hgemm_w4 ablation bits (lc_tune_set "w4_abl"), diagnosis only
 int g_tune_hgemm_stamps = 0;                 // pingpong2 diagnosis build: cycle stamps into A (lc_tune_set "hgemm_stamps")
 int g_tune_attn_nw = 0;                    // waves per attention workgroup: 0 = auto, 8 / 4 / 2
-int g_tune_hgemm_auto = LC_HGEMM_MFMA256P2; // kernel family LC_HGEMM_AUTO resolves to on 256-tileable shapes
+int g_tune_hgemm_auto = LC_HGEMM_MFMA256W4C;   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -180,7 +180,15 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   const int tiles_m = M / BM, tiles_n = N / BN;
   const int pw = panel_tiles(swizzle_stride, tiles_n, BN);
   const dim3 grid(tiles_m * tiles_n), block(512);
-  if (variant == LC_HGEMM_MFMA256W4S) {
+  if (variant == LC_HGEMM_MFMA256W4C) {
+    auto kern = hgemm_w4b_kernel<B_KN, true>;
+    if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
+  } else if (variant == LC_HGEMM_MFMA256W4B) {
+    auto kern = hgemm_w4b_kernel<B_KN>;
+    if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
+  } else if (variant == LC_HGEMM_MFMA256W4S) {
     auto kern = hgemm_w4s_kernel<B_KN>;
     if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(256), HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
@@ -466,7 +474,7 @@ int lc_tune_set(const char* key, int value) {
   }
   if (strcmp(key, "hgemm_auto") == 0) {
     if (value != LC_HGEMM_MFMA256 && value != LC_HGEMM_MFMA256P && value != LC_HGEMM_MFMA256P2 &&
-        value != LC_HGEMM_MFMA256P3 && value != LC_HGEMM_MFMA256W4 && value != LC_HGEMM_MFMA256W4S)
+        value != LC_HGEMM_MFMA256P3 && value != LC_HGEMM_MFMA256W4 && value != LC_HGEMM_MFMA256W4S && value != LC_HGEMM_MFMA256W4B && value != LC_HGEMM_MFMA256W4C)
       return LC_ERR_ARG;
     g_tune_hgemm_auto = value;
     return LC_OK;
@@ -489,7 +497,7 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   (void)stages;  // LDS ring depth is fixed per kernel family; accepted for signature parity
   if (!A || !B || !C) return LC_ERR_ARG;
   if (layout != LC_LAYOUT_NN && layout != LC_LAYOUT_TN) return LC_ERR_ARG;
-  if (variant < LC_HGEMM_AUTO || variant > LC_HGEMM_MFMA256W4S) return LC_ERR_ARG;
+  if (variant < LC_HGEMM_AUTO || variant > LC_HGEMM_MFMA256W4C) return LC_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0) return LC_ERR_SHAPE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const half_t* a = static_cast<const half_t*>(A);
@@ -511,7 +519,7 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
       variant = LC_HGEMM_GENERIC;
   }
   if (variant == LC_HGEMM_MFMA256 || variant == LC_HGEMM_MFMA256P || variant == LC_HGEMM_MFMA256P2 ||
-      variant == LC_HGEMM_MFMA256P3 || variant == LC_HGEMM_MFMA256W4 || variant == LC_HGEMM_MFMA256W4S) {
+      variant == LC_HGEMM_MFMA256P3 || variant == LC_HGEMM_MFMA256W4 || variant == LC_HGEMM_MFMA256W4S || variant == LC_HGEMM_MFMA256W4B || variant == LC_HGEMM_MFMA256W4C) {
     if (!tiles256) return LC_ERR_SHAPE;
     return layout == LC_LAYOUT_NN ? launch_mfma256<true>(a, b, c, M, N, K, variant, swizzle_stride, st)
                                   : launch_mfma256<false>(a, b, c, M, N, K, variant, swizzle_stride, st);

@@ -32,6 +32,19 @@ LC_DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const LC_GLOBAL void*)gsrc, (LC_LDS void*)lds_wave_base, 16, 0, 0);
 }
 
+// LDS-DMA through a buffer descriptor: address = rsrc.base + soffset (SGPR, wave-uniform) + voffset (per lane, 32 bit) —
+// no 64-bit per-lane address arithmetic per piece (buffer_load_dwordx4 ... offen lds).
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+LC_DEVINL buf_rsrc_t make_rsrc(const void* base_wave_uniform) {
+  // readfirstlane the pointer: a descriptor hipcc cannot PROVE wave-uniform gets a waterfall loop around every use
+  const uint64_t p = (uint64_t)base_wave_uniform;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), (short)0, 0x7fffffff, 0x00020000);
+}
+LC_DEVINL void blds16(buf_rsrc_t rsrc, unsigned voffset, unsigned soffset, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LC_LDS void*)lds_wave_base, 16, (int)voffset, (int)soffset, 0, 0);
+}
+
 // 16-lane-group hardware transpose read: lane i of a group supplies the address of 4 consecutive
 // halves = row (i>>2), cols 4*(i&3).. of a 4x16 block; lane i receives column i (4 rows).
 LC_DEVINL half4_t lds_tr16(const void* lds_addr) {
