@@ -180,6 +180,12 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   const int tiles_m = M / BM, tiles_n = N / BN;
   const int pw = panel_tiles(swizzle_stride, tiles_n, BN);
   const dim3 grid(tiles_m * tiles_n), block(512);
+  // buffer-descriptor DMA addresses are 32-bit offsets from the wave's first row: fall back to the 64-bit global form
+  // when an offset could reach 2 GiB (NN: K tiles step through the whole of B)
+  if (variant == LC_HGEMM_MFMA256W4C) {
+    const size_t max_off = B_KN ? (size_t)K * N * 2 + (size_t)N * 64 : (size_t)K * 2 * 130;
+    if (max_off >= ((size_t)1 << 31)) variant = LC_HGEMM_MFMA256W4B;
+  }
   if (variant == LC_HGEMM_MFMA256W4C) {
     auto kern = hgemm_w4b_kernel<B_KN, true>;
     if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;

@@ -231,3 +231,21 @@ def test_full_size_config2_properties(oracle, layout):
         assert ok, mx
     finally:
         capi.vendor_destroy()
+
+
+def test_auto_large_nn_b_uses_64bit_dma_addresses():
+    """B of 2 GiB (NN): the buffer-descriptor DMA of the AUTO kernel (32-bit offsets) must hand over to the 64-bit
+    global form; the result has to agree with the independently scheduled 8-wave kernel on every element."""
+    capi = _capi()
+    M, N, K = 512, 32768, 32768
+    torch.manual_seed(5)
+    a = torch.randn(M, K, dtype=torch.half, device="cuda")
+    b = torch.randn(K, N, dtype=torch.half, device="cuda")
+    c1, _ = _run(capi, a, b, capi.LAYOUT_NN, VARIANTS["w4c"], 2048)      # falls back to w4b internally
+    c2, _ = _run(capi, a, b, capi.LAYOUT_NN, VARIANTS["pingpong2"], 2048)
+    ulp = torch.clamp(c2.float().abs(), min=64.0) * 2.0 ** -10
+    assert ((c1.float() - c2.float()).abs() <= ulp).all()
+    # and the last K tile really contributed: perturbing the last row of B changes C
+    b[-1].add_(1.0)
+    c3, _ = _run(capi, a, b, capi.LAYOUT_NN, 0, 2048)
+    assert (c3.float() - c1.float()).abs().max().item() > 0.1
