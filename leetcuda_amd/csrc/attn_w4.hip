@@ -38,72 +38,20 @@
 
 namespace lc {
 
-#if defined(AW4_DEBUG_SERIAL)   // debugging aid: every MFMA statement waits for all memory ops and drains the matrix pipe
-#define AW4_PRE "s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\t"
-#define AW4_POST "\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
-#elif defined(AW4_DEBUG_PRE_LGKM)
-#define AW4_PRE "s_waitcnt lgkmcnt(0)\n\ts_nop 1\n\t"
-#define AW4_POST ""
-#elif defined(AW4_DEBUG_PRE_NOP)
-#define AW4_PRE "s_nop 7\n\t"
-#define AW4_POST ""
-#elif defined(AW4_DEBUG_POST)
-#define AW4_PRE "s_nop 1\n\t"
-#define AW4_POST "\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
-#elif defined(AW4_DEBUG_POST_QK) || defined(AW4_DEBUG_POST_PV) || defined(AW4_DEBUG_POST16) || defined(AW4_DEBUG_Q7) || defined(AW4_DEBUG_Q3) || defined(AW4_DEBUG_QZ) || defined(AW4_DEBUG_QN)
-#define AW4_PRE "s_nop 1\n\t"
-#define AW4_POST ""
-#else
-#define AW4_PRE "s_nop 1\n\t"
-#define AW4_POST ""
-#endif
+#define AW4_PRE "s_nop 1\n\t"   // VALU write -> MFMA operand read (hipcc reloads spilled operand pieces right in front)
 
 constexpr int AW4_TILE = KVB * 128 * 2;     // 16 KiB: one K or V tile
 constexpr int AW4_SLOT = 2 * AW4_TILE;      // K + V
 constexpr int AW4_NSLOT = 4;
 constexpr int AW4_LDS = AW4_NSLOT * AW4_SLOT;   // 128 KiB
 
-#if defined(AW4_DEBUG_POST_QK)
-#define AW4_POSTQ "\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
-#define AW4_POSTP ""
-#elif defined(AW4_DEBUG_POST_PV)
-#define AW4_POSTQ ""
-#define AW4_POSTP "\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
-#elif defined(AW4_DEBUG_POST16)
-#define AW4_POSTQ "\n\ts_nop 15"
-#define AW4_POSTP "\n\ts_nop 15"
-#elif defined(AW4_DEBUG_Q7)
-#define AW4_POSTQ "\n\ts_nop 7"
-#define AW4_POSTP ""
-#elif defined(AW4_DEBUG_Q3)
-#define AW4_POSTQ "\n\ts_nop 3"
-#define AW4_POSTP ""
-#elif defined(AW4_DEBUG_QZ) || defined(AW4_DEBUG_QN)
-#define AW4_POSTQ ""
-#define AW4_POSTP ""
-#else
-#define AW4_POSTQ ""
-#define AW4_POSTP ""
-#endif
-#if defined(AW4_DEBUG_QZ)
-#define AW4_POSTQZ "\n\ts_nop 15"
-#define AW4_POSTQN ""
-#elif defined(AW4_DEBUG_QN)
-#define AW4_POSTQZ ""
-#define AW4_POSTQN "\n\ts_nop 15"
-#else
-#define AW4_POSTQZ ""
-// EMPIRICAL (tools/_w4dbg bisect, r03 round): with Sᵀ accumulated in VGPRs (SrcC = vDst = arch VGPR tuple) the
+// EMPIRICAL (bisected on hardware with per-statement drains, round 1): with Sᵀ accumulated in VGPRs (SrcC = vDst = arch VGPR tuple) the
 // instruction stream right behind an ACCUMULATING Q·Kᵀ MFMA corrupts results unless >= 4 wait states follow it
 // (s_nop 3 fixes, s_nop 7 used; the C = 0 form and the AGPR-accumulating P·V MFMAs need nothing; operands
 // overwritten right after issue are safe — tools/mfma_war_probe.py).  Consistent with the documented XDL
 // SrcC-read window (the MFMA is still reading its 16 SrcC VGPRs while the following VALU/TRANS op issues).
-#ifndef AW4_NO_NOP_AFTER_QK      // (define to reproduce the failure: ~1.04 PFLOP/s but wrong rows)
+// (without it: ~1.04 PFLOP/s but wrong rows in the second query block, varying from launch to launch)
 #define AW4_POSTQN "\n\ts_nop 7"
-#else
-#define AW4_POSTQN ""
-#endif
-#endif
 // Sᵀ block (VGPRs) (+)= K fragment x Q fragment (literal AGPRs);  ZERO: first k-step, C = 0.
 // Hazards owned here (hipcc pads nothing around asm): the next MFMA on the same block comes 4 MFMAs later; VALU
 // reads of a block start >= 3 MFMAs after its last write (phase 2 processes the blocks in write order); an
@@ -114,16 +62,16 @@ constexpr int AW4_LDS = AW4_NSLOT * AW4_SLOT;   // 128 KiB
 template <int QREG, bool ZERO>
 LC_DEVINL void aw4_qk(f32x16_t& s, half8_t k) {
   if constexpr (ZERO)
-    asm volatile(AW4_PRE "v_mfma_f32_32x32x16_f16 %0, %1, a[%2:%3], 0" AW4_POST AW4_POSTQ AW4_POSTQZ
+    asm volatile(AW4_PRE "v_mfma_f32_32x32x16_f16 %0, %1, a[%2:%3], 0"
                  : "=&v"(s) : "v"(k), "n"(QREG), "n"(QREG + 3) : LC_AGPR_ATTN);
   else
-    asm volatile(AW4_PRE "v_mfma_f32_32x32x16_f16 %0, %1, a[%2:%3], %0" AW4_POST AW4_POSTQ AW4_POSTQN
+    asm volatile(AW4_PRE "v_mfma_f32_32x32x16_f16 %0, %1, a[%2:%3], %0" AW4_POSTQN
                  : "+v"(s) : "v"(k), "n"(QREG), "n"(QREG + 3) : LC_AGPR_ATTN);
 }
 // Oᵀ(qb,dt) += Vᵀ fragment x Pᵀ fragment
 template <int OACC>
 LC_DEVINL void aw4_pv(half8_t v, half8_t p) {
-  asm volatile(AW4_PRE "v_mfma_f32_32x32x16_f16 a[%2:%3], %0, %1, a[%2:%3]" AW4_POST AW4_POSTP
+  asm volatile(AW4_PRE "v_mfma_f32_32x32x16_f16 a[%2:%3], %0, %1, a[%2:%3]"
                :: "v"(v), "v"(p), "n"(OACC), "n"(OACC + 15) : LC_AGPR_ATTN);
 }
 template <int R>
@@ -362,11 +310,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4_kernel(
         read_v_half(cc);          // the 32 transpose reads of Vᵀ(t), one per MFMA
         if constexpr (c < 16 && (c & 1) == 0) read_k(8 + (c >> 1), k1);   // K(t+1) fragments of k-steps 4..7
         if constexpr ((c & 3) == 3) {
-#ifdef AW4_DEBUG_NOCLAMP
-          if (t + 3 < T) issue_piece(c >> 2, t + 3);
-#else
           issue_piece(c >> 2, t3, t + 3);
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         // exps of P pair c: fragment f = c>>2 (g = f>>1, query block f&1), values j, j+1
@@ -384,19 +328,12 @@ __global__ __launch_bounds__(256) void attn_fwd_w4_kernel(
     // =========================== phase 2: Oᵀ += Vᵀ(t)·Pᵀ(t) MFMAs | row max of Sᵀ(t+1), decision, E(t+1) | K(t+2) reads
     lds_tr16_wait16(vlo);
     lds_tr16_wait16(vhi);
-#ifdef AW4_DEBUG_DRAIN
-    aw4_drain();
-#endif
     static_for<32>([&](auto cc) {
       constexpr int c = decltype(cc)::value, g = c >> 3, dt = (c >> 1) & 3, qb = c & 1;
       aw4_pv<16 * (4 * qb + dt)>(cat4(vlo[4 * g + dt], vhi[4 * g + dt]), pf[qb][g]);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr ((c & 3) == 1) read_k(c >> 2, k2);   // K(t+2) fragments of k-steps 0..3, one per 4 MFMAs
-#ifdef AW4_DEBUG_RT
-      if (t + 1 < T) {
-#else
       if constexpr (has_next) {
-#endif
         if constexpr (c < 8) {             // partial maxima, blocks in the order they were completed by phase 1
           max_block(sb, c >> 1, c & 1);
         } else if constexpr (c == 8) {

@@ -271,7 +271,9 @@ __global__ __launch_bounds__(256) void hgemm_w4_kernel(const half_t* __restrict_
 // in front of the barrier is a counted vmcnt(8) (the 8 B pieces of tile t+2 stay in flight across it).
 // issue order  ... | B(t+1): steps 1-2 of t-1 | A(t+1): step 3 of t-1 | B(t+2): steps 1-2 of t | A(t+2): step 3 of t ...
 // BUF: the DMA pieces are buffer_load ... lds (descriptor + scalar offset) instead of global_load_lds (64-bit lane address)
-template <bool B_KN, bool BUF = false>
+// STAMPS (diagnosis only; clobbers the first bytes of A): s_memtime of wave 0 of workgroup 0 at the step boundaries of
+// K tiles 32..35 (lc_tune_set "hgemm_stamps", tools/hgemm_stamps.py).
+template <bool B_KN, bool BUF = false, bool STAMPS = false>
 __global__ __launch_bounds__(256) void hgemm_w4b_kernel(const half_t* __restrict__ A,
                                                        const half_t* __restrict__ B,
                                                        half_t* __restrict__ C, int M, int N, int K,
@@ -417,6 +419,7 @@ __global__ __launch_bounds__(256) void hgemm_w4b_kernel(const half_t* __restrict
       w4_mfma<4 * i + j0>(bf[cb][j0], af[cb][i]);
       w4_mfma<4 * i + j0 + 1>(bf[cb][j0 + 1], af[cb][i]);
       __builtin_amdgcn_sched_barrier(0);
+      // (one read per chunk over all 8 chunks instead of two in chunks 0..3 measures the same: A/B run r04c)
       if constexpr (c < 4) {
         af[cb ^ 1][c] = read_a(ra, rks, c);
         bf[cb ^ 1][c] = read_b(rb, rks, c);
@@ -436,17 +439,34 @@ __global__ __launch_bounds__(256) void hgemm_w4b_kernel(const half_t* __restrict
   using P4 = std::integral_constant<int, 4>;
   using P8 = std::integral_constant<int, 8>;
 
+  unsigned long long* stamp = reinterpret_cast<unsigned long long*>(const_cast<half_t*>(A));
+  const bool stamping = STAMPS && blockIdx.x == 0 && wave == 0 && lane == 0;
+  auto STAMP = [&](int kt, int k) {
+    if constexpr (STAMPS) {
+      if (kt >= 32 && kt < 36) {
+        const unsigned long long c = __builtin_readcyclecounter();
+        if (stamping) stamp[(kt - 32) * 8 + k] = c;
+      }
+    }
+  };
   int b0 = 0, b1 = 1, b2 = 2;   // B slot indices of tiles kt, kt+1, kt+2 (rotating, kt % 3)
   for (int kt = 0; kt < KT; ++kt) {
     const char* ca = a_slot(kt);
     const char* cbs = b_slot(b0);
+    STAMP(kt, 0);
     step(I0{}, ca, cbs, 1, P0{}, 0, 0, nullptr);
+    STAMP(kt, 1);
     step(I1{}, ca, cbs, 2, P4{}, 8, kt + 2, b_slot(b2));
+    STAMP(kt, 2);
     step(I0{}, ca, cbs, 3, P4{}, 12, kt + 2, b_slot(b2));
+    STAMP(kt, 3);
     // every read of tile kt is issued; A(kt+1), B(kt+1) must have landed (the 8 B pieces of tile kt+2 stay in flight)
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    STAMP(kt, 4);
     pp_barrier();
+    STAMP(kt, 5);
     step(I1{}, a_slot(kt + 1), b_slot(b1), 0, P8{}, 0, kt + 2, a_slot(kt));
+    STAMP(kt, 6);
     const int t = b0;
     b0 = b1;
     b1 = b2;

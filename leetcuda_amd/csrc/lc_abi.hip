@@ -186,7 +186,11 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
     const size_t max_off = B_KN ? (size_t)K * N * 2 + (size_t)N * 64 : (size_t)K * 2 * 130;
     if (max_off >= ((size_t)1 << 31)) variant = LC_HGEMM_MFMA256W4B;
   }
-  if (variant == LC_HGEMM_MFMA256W4C) {
+  if (variant == LC_HGEMM_MFMA256W4C && g_tune_hgemm_stamps) {
+    auto kern = hgemm_w4b_kernel<B_KN, true, true>;
+    if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
+  } else if (variant == LC_HGEMM_MFMA256W4C) {
     auto kern = hgemm_w4b_kernel<B_KN, true>;
     if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
