@@ -7,8 +7,10 @@
 // so a K tile is 128 deep and every ds_read_b128 fragment feeds TWO v_mfma_f32_32x32x16_fp8_fp8 (low / high
 // 8 bytes; both operands are split the same way, and MFMA contracts over matching (lane-half, slot) pairs, so
 // any consistent k assignment is exact).  32 MFMAs per phase instead of 16: the barrier / load-section
-// overhead per MFMA halves.  Non-scaled fp8 MFMA runs at the fp16 rate (2.5 PF dense); the 5 PF rate needs
-// the MX block-scaled K=128 instructions (next).
+// overhead per MFMA halves.  Non-scaled fp8 MFMA runs at the fp16 rate (2.5 PF dense).
+// MX = true: the same data through v_mfma_scale_f32_32x32x64_f8f6f4 with both block scales = 2^0 (E8M0 0x7F): one
+// instruction contracts 64 k-values (two 16-byte fragments per operand), at twice the MAC rate of the non-scaled
+// form; e4m3 x e4m3 products are exact in fp32 either way, only the accumulation order differs.
 #pragma once
 #include "hgemm_pingpong.hip"
 
@@ -54,6 +56,32 @@ LC_DEVINL void pp_src8_init(PPSrc8& s, const uint8_t* A, const uint8_t* B, int m
   }
 }
 
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+LC_DEVINL i32x8_t cat8(half8_t a, half8_t b) {
+  typedef int i32x4_t __attribute__((ext_vector_type(4)));
+  return __builtin_shufflevector(__builtin_bit_cast(i32x4_t, a), __builtin_bit_cast(i32x4_t, b), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+LC_DEVINL f32x16_t mfma32_fp8_mx(i32x8_t a, i32x8_t b, f32x16_t c) {   // formats 0 = e4m3, scales 1.0
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
+// MX form of the cluster: 8 MFMAs of K = 64 (fragments ks = 2k', 2k'+1 of both operands form one 32-byte operand)
+template <int NG, typename IssueFn>
+LC_DEVINL void pp8_cluster_mx(f32x16_t (&acc)[4][2], int mh, const half8_t (&af)[2][4], const half8_t (&b0f)[4],
+                              const half8_t (&b1f)[4], IssueFn issue) {
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int kp = g >> 2, nh = (g >> 1) & 1, m = g & 1;
+    const i32x8_t bv = nh ? cat8(b1f[2 * kp], b1f[2 * kp + 1]) : cat8(b0f[2 * kp], b0f[2 * kp + 1]);
+    const i32x8_t av = cat8(af[m][2 * kp], af[m][2 * kp + 1]);
+    acc[mh * 2 + m][nh] = mfma32_fp8_mx(bv, av, acc[mh * 2 + m][nh]);
+    if (g < NG) issue(g);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_s_setprio(0);
+}
+
 template <int NG, typename IssueFn>
 LC_DEVINL void pp8_cluster(f32x16_t (&acc)[4][2], int mh, const half8_t (&af)[2][4], const half8_t (&b0f)[4],
                            const half8_t (&b1f)[4], IssueFn issue) {
@@ -74,6 +102,7 @@ LC_DEVINL void pp8_cluster(f32x16_t (&acc)[4][2], int mh, const half8_t (&af)[2]
   __builtin_amdgcn_s_setprio(0);
 }
 
+template <bool MX>
 __global__ __launch_bounds__(512, 2) void gemm_fp8_pingpong2_kernel(const uint8_t* __restrict__ A,
                                                                     const uint8_t* __restrict__ B,
                                                                     half_t* __restrict__ C, int M, int N, int K,
@@ -130,12 +159,14 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pingpong2_kernel(const uint8_
     pp_read_b<false>(cur, fr, 1, b1f);
     LC_VMCNT(6);
     pp_barrier();
-    pp8_cluster<2>(acc, 0, af, b0f, b1f, [&](int g) { piece(0, 1, g, kt + 1); });
+    if constexpr (MX) pp8_cluster_mx<2>(acc, 0, af, b0f, b1f, [&](int g) { piece(0, 1, g, kt + 1); });
+    else pp8_cluster<2>(acc, 0, af, b0f, b1f, [&](int g) { piece(0, 1, g, kt + 1); });
     pp_barrier();
     pp_read_a<false>(cur, fr, 1, af);
     LC_VMCNT(2);
     pp_barrier();
-    pp8_cluster<6>(acc, 1, af, b0f, b1f, [&](int g) { issue_ab0(g, kt + 2); });
+    if constexpr (MX) pp8_cluster_mx<6>(acc, 1, af, b0f, b1f, [&](int g) { issue_ab0(g, kt + 2); });
+    else pp8_cluster<6>(acc, 1, af, b0f, b1f, [&](int g) { issue_ab0(g, kt + 2); });
     pp_barrier();
   }
   if (wr == 0) pp_barrier();

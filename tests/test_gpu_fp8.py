@@ -14,8 +14,18 @@ def _capi():
     return capi
 
 
+@pytest.fixture(params=[1, 0], ids=["mx_scaled_k64", "plain_k16"])
+def mx(request):
+    """Both MFMA forms of the fp8 kernel: v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (default) and
+    v_mfma_f32_32x32x16_fp8_fp8 (lc_tune_set "fp8_mx")."""
+    capi = _capi()
+    capi.tune("fp8_mx", request.param)
+    yield request.param
+    capi.tune("fp8_mx", 1)
+
+
 @pytest.mark.parametrize("shape", [(256, 256, 128), (512, 256, 384), (256, 768, 1024), (1024, 1024, 2048)])
-def test_fp8_gemm_vs_oracle(oracle, shape):
+def test_fp8_gemm_vs_oracle(oracle, shape, mx):
     capi = _capi()
     M, N, K = shape
     torch.manual_seed(M + N + K)
@@ -30,7 +40,7 @@ def test_fp8_gemm_vs_oracle(oracle, shape):
         assert ok, (mx, ex)
 
 
-def test_fp8_identity_detects_transposes():
+def test_fp8_identity_detects_transposes(mx):
     capi = _capi()
     n = 512
     eye = torch.eye(n, device="cuda").to(torch.float8_e4m3fn)
@@ -45,7 +55,7 @@ def test_fp8_identity_detects_transposes():
     assert torch.equal(c, b.float().half())
 
 
-def test_fp8_config5_16384_properties(oracle):
+def test_fp8_config5_16384_properties(oracle, mx):
     """BASELINE config 5: M=N=K=16384 fp8: sampled rows vs the exact oracle + C*x == A*(B^T*x)."""
     capi = _capi()
     n = 16384

@@ -10,7 +10,7 @@ capi.load()
 capi.vendor_init()
 sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1024, 2048, 3072, 4096, 6144, 8192]
 V = {"mfma128": capi.HGEMM_MFMA128, "mfma256": capi.HGEMM_MFMA256, "pingpong2": capi.HGEMM_MFMA256P2,
-     "w4": capi.HGEMM_MFMA256W4, "auto": capi.HGEMM_AUTO}
+     "w4c": capi.HGEMM_MFMA256W4C, "auto": capi.HGEMM_AUTO}
 for n in sizes:
     a = torch.randn(n, n, dtype=torch.half, device="cuda")
     b = torch.randn(n, n, dtype=torch.half, device="cuda")
