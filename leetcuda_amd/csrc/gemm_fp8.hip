@@ -65,16 +65,34 @@ LC_DEVINL f32x16_t mfma32_fp8_mx(i32x8_t a, i32x8_t b, f32x16_t c) {   // format
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
 
-// MX form of the cluster: 8 MFMAs of K = 64 (fragments ks = 2k', 2k'+1 of both operands form one 32-byte operand)
+// MX form of the cluster: 8 MFMAs of K = 64 (fragments ks = 2k', 2k'+1 of both operands form one 32-byte operand,
+// read straight into the two halves of an 8-register tuple: no concatenation copies)
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+LC_DEVINL void pp8_read_a(const char* slot, const PPFrag<false>& f, int mh, i32x8_t (&af)[2][2]) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) {
+      af[m][kp].lo = *(const i32x4_t*)(slot + ((f.a0 ^ ((2 * kp) * 32)) + (mh * 2 + m) * 4096));
+      af[m][kp].hi = *(const i32x4_t*)(slot + ((f.a0 ^ ((2 * kp + 1) * 32)) + (mh * 2 + m) * 4096));
+    }
+}
+LC_DEVINL void pp8_read_b(const char* slot, const PPFrag<false>& f, int nh, i32x8_t (&bf)[2]) {
+#pragma unroll
+  for (int kp = 0; kp < 2; ++kp) {
+    bf[kp].lo = *(const i32x4_t*)(slot + ((f.b0 ^ ((2 * kp) * 32)) + nh * 4096));
+    bf[kp].hi = *(const i32x4_t*)(slot + ((f.b0 ^ ((2 * kp + 1) * 32)) + nh * 4096));
+  }
+}
 template <int NG, typename IssueFn>
-LC_DEVINL void pp8_cluster_mx(f32x16_t (&acc)[4][2], int mh, const half8_t (&af)[2][4], const half8_t (&b0f)[4],
-                              const half8_t (&b1f)[4], IssueFn issue) {
+LC_DEVINL void pp8_cluster_mx(f32x16_t (&acc)[4][2], int mh, const i32x8_t (&af)[2][2], const i32x8_t (&b0f)[2],
+                              const i32x8_t (&b1f)[2], IssueFn issue) {
   __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     const int kp = g >> 2, nh = (g >> 1) & 1, m = g & 1;
-    const i32x8_t bv = nh ? cat8(b1f[2 * kp], b1f[2 * kp + 1]) : cat8(b0f[2 * kp], b0f[2 * kp + 1]);
-    const i32x8_t av = cat8(af[m][2 * kp], af[m][2 * kp + 1]);
+    const i32x8_t bv = nh ? b1f[kp] : b0f[kp];
+    const i32x8_t av = af[m][kp];
     acc[mh * 2 + m][nh] = mfma32_fp8_mx(bv, av, acc[mh * 2 + m][nh]);
     if (g < NG) issue(g);
     __builtin_amdgcn_sched_barrier(0);
@@ -152,20 +170,27 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pingpong2_kernel(const uint8_
   if (wr == 1) pp_barrier();
 
   half8_t af[2][4], b0f[4], b1f[4];   // 16-byte fragments (16 fp8 values each)
+  i32x8_t af2[2][2], b0f2[2], b1f2[2];   // MX: 32-byte operands
   for (int kt = 0; kt < KT; ++kt) {
     const char* cur = smem + (kt & 1) * SLOT_BYTES;
-    pp_read_b<false>(cur, fr, 0, b0f);
-    pp_read_a<false>(cur, fr, 0, af);
-    pp_read_b<false>(cur, fr, 1, b1f);
+    if constexpr (MX) {
+      pp8_read_b(cur, fr, 0, b0f2);
+      pp8_read_a(cur, fr, 0, af2);
+      pp8_read_b(cur, fr, 1, b1f2);
+    } else {
+      pp_read_b<false>(cur, fr, 0, b0f);
+      pp_read_a<false>(cur, fr, 0, af);
+      pp_read_b<false>(cur, fr, 1, b1f);
+    }
     LC_VMCNT(6);
     pp_barrier();
-    if constexpr (MX) pp8_cluster_mx<2>(acc, 0, af, b0f, b1f, [&](int g) { piece(0, 1, g, kt + 1); });
+    if constexpr (MX) pp8_cluster_mx<2>(acc, 0, af2, b0f2, b1f2, [&](int g) { piece(0, 1, g, kt + 1); });
     else pp8_cluster<2>(acc, 0, af, b0f, b1f, [&](int g) { piece(0, 1, g, kt + 1); });
     pp_barrier();
-    pp_read_a<false>(cur, fr, 1, af);
+    if constexpr (MX) pp8_read_a(cur, fr, 1, af2); else pp_read_a<false>(cur, fr, 1, af);
     LC_VMCNT(2);
     pp_barrier();
-    if constexpr (MX) pp8_cluster_mx<6>(acc, 1, af, b0f, b1f, [&](int g) { issue_ab0(g, kt + 2); });
+    if constexpr (MX) pp8_cluster_mx<6>(acc, 1, af2, b0f2, b1f2, [&](int g) { issue_ab0(g, kt + 2); });
     else pp8_cluster<6>(acc, 1, af, b0f, b1f, [&](int g) { issue_ab0(g, kt + 2); });
     pp_barrier();
   }
