@@ -13,6 +13,7 @@
 // form; e4m3 x e4m3 products are exact in fp32 either way, only the accumulation order differs.
 #pragma once
 #include "hgemm_pingpong.hip"
+#include "hgemm_w4.hip"
 
 namespace lc {
 
@@ -203,6 +204,151 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pingpong2_kernel(const uint8_
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] *= alpha;
   pp_epilogue(smem, acc, C, N, m0, n0, wave, wr, wc, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// gemm_fp8_w4_kernel — the fp8 GEMM on the structure of hgemm_w4b_kernel<TN, BUF> (four waves, 128x128 wave tiles,
+// 4x4 accumulators in literal AGPRs, A ring of 2 + B ring of 3 K tiles, buffer_load..lds DMA, one barrier per K tile)
+// with the MX-scaled K = 64 MFMA (unit block scales).  A K tile is 128 k = 128 bytes per row = TWO k-steps of 64; a
+// k-step is 16 MFMAs (64 cycles each) from 4 + 4 operands of 32 bytes per lane (two ds_read_b128 each, read straight
+// into the halves of an 8-register tuple), double-buffered:
+//   step 0: MFMAs on k-step 0 | reads of k-step 1            | DMA B(t+2): 8 pieces
+//           s_waitcnt vmcnt(8) lgkmcnt(0); s_barrier          (A(t+1), B(t+1) landed; 8 B pieces stay in flight)
+//   step 1: MFMAs on k-step 1 | reads of k-step 0 of tile t+1 | DMA A(t+2): 8 pieces
+template <int IDX>
+LC_DEVINL void w4_mfma_fp8mx(i32x8_t a, i32x8_t b, int scale) {   // a[16 IDX .. +15] += a x b   (formats e4m3, scales 2^0)
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 a[%3:%4], %0, %1, a[%3:%4], %2, %2 op_sel_hi:[0,0,0]"
+               :: "v"(a), "v"(b), "v"(scale), "n"(IDX * 16), "n"(IDX * 16 + 15) : LC_AGPR_ALL);
+}
+
+__global__ __launch_bounds__(256) void gemm_fp8_w4_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
+                                                          half_t* __restrict__ C, int M, int N, int K, float alpha,
+                                                          int tiles_m, int tiles_n, int panel_w) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l32 = lane & 31, hi = lane >> 5;
+
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const TileCoord tc = raster(id, tiles_m, tiles_n, panel_w);
+  const int m0 = tc.tm * BM, n0 = tc.tn * BN;
+  const int KT = K / BK8;
+
+  // DMA: 8-row blocks blk = 8*wave + p of the A / B tile; lane -> row lane>>3, 16-byte slot lane&7 (swizzle as hgemm_w4)
+  unsigned a_off[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    a_off[par] = (unsigned)(lane >> 3) * (unsigned)K + (unsigned)(((lane & 7) ^ (((lane >> 4) & 3) | (par << 2))) * 16);
+  const buf_rsrc_t ra = make_rsrc(A + (size_t)(m0 + wave * 64) * K);
+  const buf_rsrc_t rb = make_rsrc(B + (size_t)(n0 + wave * 64) * K);
+  const unsigned blk_bytes = 8u * (unsigned)K;
+  auto piece = [&](int g, int t, char* slot) {   // g < 8: A pieces, else B pieces; clamped past the end
+    const int te = t < KT ? t : KT - 1;
+    const int p = g & 7;
+    blds16(g < 8 ? ra : rb, a_off[p & 1], (unsigned)p * blk_bytes + (unsigned)te * BK8, slot + (wave * 8 + p) * 1024);
+  };
+  auto a_slot = [&](int t) -> char* { return smem + (t & 1) * TILE_BYTES; };
+  auto b_slot = [&](int bi) -> char* { return smem + (2 + bi) * TILE_BYTES; };
+
+  // fragment addresses: 16-byte chunk c = 2ks + hi of row r at slot c ^ ((r>>1)&7); ks = 0..3 (16 bytes of k each)
+  const int swz = (lane >> 1) & 7;
+  int a_ad[4], b_ad[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    a_ad[ks] = (wr * 128 + l32) * 128 + (((2 * ks + hi) ^ swz) * 16);
+    b_ad[ks] = (wc * 128 + l32) * 128 + (((2 * ks + hi) ^ swz) * 16);
+  }
+  auto read_op = [&](const char* slot, const int (&ad)[4], int kp, int i) -> i32x8_t {   // k-step kp, 32-row block i
+    i32x8_t v;
+    v.lo = *(const i32x4_t*)(slot + ad[2 * kp] + i * 4096);
+    v.hi = *(const i32x4_t*)(slot + ad[2 * kp + 1] + i * 4096);
+    return v;
+  };
+
+  static_for<256>([&](auto r) { w4_acc_zero<decltype(r)::value>(); });
+  int scale = 0x7f7f7f7f;
+  asm volatile("" : "+v"(scale));
+
+  // prologue: B(0) A(0) B(1) A(1)
+#pragma unroll
+  for (int g = 8; g < 16; ++g) piece(g, 0, b_slot(0));
+#pragma unroll
+  for (int g = 0; g < 8; ++g) piece(g, 0, a_slot(0));
+#pragma unroll
+  for (int g = 8; g < 16; ++g) piece(g, 1, b_slot(1));
+#pragma unroll
+  for (int g = 0; g < 8; ++g) piece(g, 1, a_slot(1));
+  LC_VMCNT(16);
+  pp_barrier();
+
+  i32x8_t af[2][4], bf[2][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    af[0][i] = read_op(a_slot(0), a_ad, 0, i);
+    bf[0][i] = read_op(b_slot(0), b_ad, 0, i);
+  }
+
+  auto step = [&](auto cbc, const char* ra_, const char* rb_, int rkp, int g0, int t2, char* wslot) {
+    constexpr int cb = decltype(cbc)::value;
+    static_for<8>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      constexpr int i = c >> 1, j0 = 2 * (c & 1);
+      w4_mfma_fp8mx<4 * i + j0>(bf[cb][j0], af[cb][i], scale);
+      w4_mfma_fp8mx<4 * i + j0 + 1>(bf[cb][j0 + 1], af[cb][i], scale);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (c < 4) {
+        af[cb ^ 1][c] = read_op(ra_, a_ad, rkp, c);
+        bf[cb ^ 1][c] = read_op(rb_, b_ad, rkp, c);
+      }
+      piece(g0 + c, t2, wslot);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  int b0 = 0, b1 = 1, b2 = 2;
+  for (int kt = 0; kt < KT; ++kt) {
+    step(I0{}, a_slot(kt), b_slot(b0), 1, 8, kt + 2, b_slot(b2));
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    pp_barrier();
+    step(I1{}, a_slot(kt + 1), b_slot(b1), 0, 0, kt + 2, a_slot(kt));
+    const int t = b0;
+    b0 = b1;
+    b1 = b2;
+    b2 = t;
+  }
+  LC_VMCNT(0);
+
+  // epilogue (as hgemm_w4): each wave stages 32 x 128 halves at a time, alpha applied in fp32
+  w4_mfma_drain();
+  w4_mfma_drain();
+  w4_mfma_drain();   // a K = 64 MFMA is 16 passes
+  __syncthreads();
+  char* stg = smem + wave * (32 * W4_EPI_STRIDE);
+  half_t* cw = C + (size_t)(m0 + wr * 128) * N + n0 + wc * 128;
+  static_for<4>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    static_for<16>([&](auto qc) {
+      constexpr int j = decltype(qc)::value >> 2, rq = decltype(qc)::value & 3;
+      half4_t h;
+      h[0] = (half_t)(w4_acc_read<16 * (4 * i + j) + 4 * rq + 0>() * alpha);
+      h[1] = (half_t)(w4_acc_read<16 * (4 * i + j) + 4 * rq + 1>() * alpha);
+      h[2] = (half_t)(w4_acc_read<16 * (4 * i + j) + 4 * rq + 2>() * alpha);
+      h[3] = (half_t)(w4_acc_read<16 * (4 * i + j) + 4 * rq + 3>() * alpha);
+      *(half4_t*)(stg + l32 * W4_EPI_STRIDE + (j * 32 + 8 * rq + 4 * hi) * 2) = h;
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + (lane >> 4);
+      const u32x4_t v = *(const u32x4_t*)(stg + row * W4_EPI_STRIDE + (lane & 15) * 16);
+      *(u32x4_t*)(cw + (size_t)(i * 32 + row) * N + (lane & 15) * 8) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  });
 }
 
 }  // namespace lc

@@ -28,7 +28,7 @@ namespace {
 
 // run-time tuning knobs (lc_tune_set): experiments and A/B benches, never required for correctness
 int g_tune_attn_ablate = 0;                // see attn_fwd_kernel ABL (diagnosis only)
-int g_tune_fp8_mx = 1;                       // fp8 GEMM through the MX-scaled K=64 MFMA with unit scales (lc_tune_set "fp8_mx")
+int g_tune_fp8_mx = 1;                       // fp8 GEMM: 1 = MX-scaled K=64 MFMA, 4-wave kernel; 2 = MX, 8-wave kernel; 0 = plain K=16 MFMA
 int g_tune_w4_abl = 0;                       // hgemm_w4 ablation bits (lc_tune_set "w4_abl"), diagnosis only
 int g_tune_hgemm_stamps = 0;                 // pingpong2 diagnosis build: cycle stamps into A (lc_tune_set "hgemm_stamps")
 int g_tune_attn_nw = 0;                    // waves per attention workgroup: 0 = auto, 8 / 4 / 2
@@ -472,7 +472,8 @@ int lc_tune_set(const char* key, int value) {
     return LC_OK;
   }
   if (strcmp(key, "fp8_mx") == 0) {
-    g_tune_fp8_mx = value != 0;
+    if (value < 0 || value > 2) return LC_ERR_ARG;
+    g_tune_fp8_mx = value;
     return LC_OK;
   }
   if (strcmp(key, "w4_abl") == 0) {
@@ -555,7 +556,14 @@ int lc_gemm_fp8_e4m3(const void* A, const void* B, void* C, int M, int N, int K,
   if (M % BM || N % BN || K % BK8 || !aligned16(A) || !aligned16(B) || !aligned16(C)) return LC_ERR_SHAPE;
   const int tiles_m = M / BM, tiles_n = N / BN;
   const int pw = panel_tiles(swizzle_stride, tiles_n, BN);
-  if (g_tune_fp8_mx) {
+  // MX + 4-wave kernel (default, fp8_mx = 1) unless a buffer offset could reach 2 GiB; fp8_mx = 2: MX 8-wave kernel
+  if (g_tune_fp8_mx == 1 && (size_t)K * 130 < ((size_t)1 << 31)) {
+    auto kern = gemm_fp8_w4_kernel;
+    if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), W4B_LDS, static_cast<hipStream_t>(stream),
+                       static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), static_cast<half_t*>(C), M, N,
+                       K, alpha, tiles_m, tiles_n, pw);
+  } else if (g_tune_fp8_mx) {
     auto kern = gemm_fp8_pingpong2_kernel<true>;
     if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), HGEMM256_LDS, static_cast<hipStream_t>(stream),

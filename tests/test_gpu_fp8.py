@@ -14,7 +14,7 @@ def _capi():
     return capi
 
 
-@pytest.fixture(params=[1, 0], ids=["mx_scaled_k64", "plain_k16"])
+@pytest.fixture(params=[1, 2, 0], ids=["mx_k64_4wave", "mx_k64_8wave", "plain_k16"])
 def mx(request):
     """Both MFMA forms of the fp8 kernel: v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (default) and
     v_mfma_f32_32x32x16_fp8_fp8 (lc_tune_set "fp8_mx")."""
