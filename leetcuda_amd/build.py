@@ -54,7 +54,7 @@ def build_abi(force: bool = False) -> Path:
     if not force and _newer(out, srcs):
         return out
     _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-          "-Wno-unused-result", "-fno-honor-nans", "-mno-amdgpu-ieee", f"-I{ROOT / 'include'}", "-o", out, CSRC / "lc_abi.hip", "-ldl"])
+          "-Wno-unused-result", "-fno-honor-nans", "-mno-amdgpu-ieee", *(["-DLC_DIAG"] if os.environ.get("LC_DIAG") == "1" else []), f"-I{ROOT / 'include'}", "-o", out, CSRC / "lc_abi.hip", "-ldl"])
     return out
 
 

@@ -187,11 +187,14 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
     const size_t max_off = B_KN ? (size_t)K * N * 2 + (size_t)N * 64 : (size_t)K * 2 * 130;
     if (max_off >= ((size_t)1 << 31)) variant = LC_HGEMM_MFMA256W4B;
   }
+#ifdef LC_DIAG
   if (variant == LC_HGEMM_MFMA256W4C && g_tune_hgemm_stamps) {
     auto kern = hgemm_w4b_kernel<B_KN, true, true>;
     if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
-  } else if (variant == LC_HGEMM_MFMA256W4C) {
+  } else
+#endif
+  if (variant == LC_HGEMM_MFMA256W4C) {
     auto kern = hgemm_w4b_kernel<B_KN, true>;
     if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
@@ -211,14 +214,19 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
     hipLaunchKernelGGL(kern, grid, dim3(256), HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);  \
   } break;
     switch (g_tune_w4_abl) {
-      LC_W4_CASE(0) LC_W4_CASE(1) LC_W4_CASE(2) LC_W4_CASE(3) LC_W4_CASE(4) LC_W4_CASE(7)
+      LC_W4_CASE(0)
+#ifdef LC_DIAG
+      LC_W4_CASE(1) LC_W4_CASE(2) LC_W4_CASE(3) LC_W4_CASE(4) LC_W4_CASE(7)
+#endif
       default: return LC_ERR_ARG;
     }
 #undef LC_W4_CASE
+#ifdef LC_DIAG
   } else if (variant == LC_HGEMM_MFMA256P2 && g_tune_hgemm_stamps) {
     auto kern = hgemm_pingpong2_kernel<B_KN, false, true>;
     if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
     hipLaunchKernelGGL(kern, grid, block, HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
+#endif
   } else if (variant == LC_HGEMM_MFMA256P3) {
     auto kern = hgemm_pingpong2_kernel<B_KN, true>;
     if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
@@ -300,8 +308,10 @@ int launch_attn_c4(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
     hipLaunchKernelGGL(kern, grid, block, lds, st, Q, K, V, O, N, nqb, sl2);    \
   } break;
   switch (g_tune_attn_ablate) {
-    LC_C4_CASE(0) LC_C4_CASE(32) LC_C4_CASE(34) LC_C4_CASE(1) LC_C4_CASE(2) LC_C4_CASE(4) LC_C4_CASE(8)
-    LC_C4_CASE(16) LC_C4_CASE(24) LC_C4_CASE(40) LC_C4_CASE(48)
+    LC_C4_CASE(0)
+#ifdef LC_DIAG
+    LC_C4_CASE(32) LC_C4_CASE(4) LC_C4_CASE(8) LC_C4_CASE(16)
+#endif
     default: return LC_ERR_ARG;
   }
 #undef LC_C4_CASE
@@ -314,11 +324,14 @@ int launch_attn_w4(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   const int nqb = N / 256;
   const dim3 grid((unsigned)((size_t)nqb * B * H)), block(256);
   const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+#ifdef LC_DIAG
   if (g_tune_attn_ablate == 32) {
     auto kern = attn_fwd_w4_kernel<D, true>;
     if (int rc = set_dyn_lds(kern, AW4_LDS)) return rc;
     hipLaunchKernelGGL(kern, grid, block, AW4_LDS, st, Q, K, V, O, N, nqb, sl2);
-  } else {
+  } else
+#endif
+  {
     auto kern = attn_fwd_w4_kernel<D>;
     if (int rc = set_dyn_lds(kern, AW4_LDS)) return rc;
     hipLaunchKernelGGL(kern, grid, block, AW4_LDS, st, Q, K, V, O, N, nqb, sl2);
@@ -350,6 +363,7 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   }
   if constexpr (D == 128 && !VT) {   // perf-diagnosis instantiations (lc_tune_set "attn_ablate")
     switch (g_tune_attn_ablate) {
+#ifdef LC_DIAG
       case 1: return launch_attn<D, 8, VT, 1>(Q, K, V, O, B, H, N, st);
       case 2: return launch_attn<D, 8, VT, 2>(Q, K, V, O, B, H, N, st);
       case 3: return launch_attn<D, 8, VT, 3>(Q, K, V, O, B, H, N, st);
@@ -362,6 +376,7 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
       case 30: return launch_attn<D, 8, VT, 30>(Q, K, V, O, B, H, N, st);
       case 31: return launch_attn<D, 8, VT, 31>(Q, K, V, O, B, H, N, st);
       case 32: return launch_attn<D, 8, VT, 32>(Q, K, V, O, B, H, N, st);
+#endif
       default: break;
     }
   }
@@ -416,7 +431,7 @@ template <int F, int K>
 int probe_coissue_mode(int mode, unsigned long long* out, hipStream_t st) {
   const int threads = mode == 1 ? 512 : 256;
   if (mode == 0) hipLaunchKernelGGL((probe_coissue_kernel<F, K, 0>), dim3(1), dim3(threads), 0, st, out, 1.0f);
-  else if (mode == 1) hipLaunchKernelGGL((probe_coissue_kernel<F, K, 1>), dim3(1), dim3(threads), 0, st, out, 1.0f);
+  else if (mode == 1) return LC_ERR_ARG;   // (cross-wave mode removed: its per-instruction branches dominated the result)
   else if (mode == 3) hipLaunchKernelGGL((probe_coissue_kernel<F, K, 3>), dim3(1), dim3(threads), 0, st, out, 1.0f);
   else hipLaunchKernelGGL((probe_coissue_kernel<F, K, 2>), dim3(1), dim3(threads), 0, st, out, 1.0f);
   return check_launch();

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Ablation timing of the lock-step attention kernel at config 3 (results are wrong by design when a bit
-is set): which phase carries the time? bits: 1 no exp, 2 no PV, 4 no QK, 8 no staging, 16 no barrier."""
+is set): which phase carries the time? bits: 1 no exp, 2 no PV, 4 no QK, 8 no staging, 16 no barrier.
+Needs the diagnostic kernel instantiations: `LC_DIAG=1 python -m leetcuda_amd.build --force` first."""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

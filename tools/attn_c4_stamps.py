@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Segment cycle stamps of the four-cluster attention kernel (diagnosis; attn_nw=64 + attn_ablate=32)."""
+"""Segment cycle stamps of the four-cluster attention kernel (diagnosis; attn_nw=64 + attn_ablate=32).
+Needs the diagnostic kernel instantiations: `LC_DIAG=1 python -m leetcuda_amd.build --force` first."""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -26,7 +27,7 @@ for abl in (32,):
             d.append(int(st[w, t + 1, 0] - r[7]) if t < 3 else -1)
             print(f"abl {abl} wave{w*4} tile{16+t}: start={int(r[0]-st[0,0,0]):6d} " + " ".join(f"{n}={x:5d}" for n, x in zip(names, d)))
 fl = host.mha_matmul_flops(4, 32, 4096, 128)
-for abl in (0, 4, 8, 16, 0, 4):
+for abl in (0, 4, 8, 16):
     q.copy_(q0)
     capi.tune("attn_ablate", abl)
     ms = capi.attn_time(q, k, v, o, False, capi.ATTN_SPLIT_Q, 2, warmup=3, iters=20)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-phase cycle stamps of the lock-step attention kernel (diagnosis; lc_tune_set attn_ablate=32)."""
+"""Per-phase cycle stamps of the lock-step attention kernel (diagnosis; lc_tune_set attn_ablate=32).
+Needs the diagnostic kernel instantiations: `LC_DIAG=1 python -m leetcuda_amd.build --force` first."""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Phase cycle stamps of the 4-wave x 64-row attention kernel (attn_nw=128 + attn_ablate=32)."""
+"""Phase cycle stamps of the 4-wave x 64-row attention kernel (attn_nw=128 + attn_ablate=32).
+Needs the diagnostic kernel instantiations: `LC_DIAG=1 python -m leetcuda_amd.build --force` first."""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

@@ -23,8 +23,6 @@ def run(f, k, mode):
 
 base = run(0, 1, 0)
 print(f"MFMA only, 1 wave/SIMD: {base[0] / 1024:.1f} cycles per MFMA")
-base2 = run(0, 1, 1)
-print(f"MFMA only (waves 0-3 of 8): {base2[0] / 1024:.1f} cycles per MFMA")
 base3 = run(0, 1, 3)
 print(f"MFMA only, AGPR accumulator + AGPR B operand: {base3[0] / 1024:.1f} cycles per MFMA")
 for f in (1, 2, 3, 4, 5, 6, 7, 8):

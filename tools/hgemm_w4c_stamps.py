@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Step cycle stamps of the AUTO HGEMM kernel (hgemm_w4b_kernel<.., BUF=true>; lc_tune_set hgemm_stamps=1 clobbers A)."""
+"""Step cycle stamps of the AUTO HGEMM kernel (hgemm_w4b_kernel<.., BUF=true>; lc_tune_set hgemm_stamps=1 clobbers A).
+Needs the diagnostic kernel instantiations: `LC_DIAG=1 python -m leetcuda_amd.build --force` first."""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

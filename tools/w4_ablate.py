@@ -1,4 +1,5 @@
-"""hgemm_w4 ablation timing (diagnosis only; ablated variants compute WRONG results)."""
+"""hgemm_w4 ablation timing (diagnosis only; ablated variants compute WRONG results).
+Needs the diagnostic kernel instantiations: `LC_DIAG=1 python -m leetcuda_amd.build --force` first."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
