@@ -81,10 +81,13 @@ const char* lc_status_string(int status);
 int lc_device_check(int* num_cus);
 
 /* Run-time tuning knobs for experiments / A-B benches (not part of the reference surface):
- *   "attn_nw"    attention workgroup shape: 0 = auto, 32 = 8-wave software-pipelined kernel, 16 = 8-wave
- *                ping-pong kernel (both need N % 256 == 0),
- *                8 / 4 / 2 = lock-step kernel with that many waves
- *   "hgemm_auto" kernel family LC_HGEMM_AUTO resolves to on 256-tileable shapes (1, 2, 4 or 5) */
+ *   "attn_nw"      attention kernel for D = 128 (N % 256 == 0 unless noted): 0 = auto (four-cluster LDS-DMA kernel),
+ *                  128 = 4 waves x 64 query rows (software-pipelined, literal AGPRs), 64 = four-cluster kernel,
+ *                  32 = 8-wave software-pipelined kernel, 16 = 8-wave ping-pong kernel,
+ *                  8 / 4 / 2 = lock-step kernel with that many waves (any N % (32 x waves) == 0, every D <= 128)
+ *   "hgemm_auto"   kernel LC_HGEMM_AUTO launches on large 256-tileable shapes (a 256-tile lc_hgemm_variant value)
+ *   "fp8_mx"       fp8 GEMM: 1 = MX-scaled K = 64 MFMA, 4-wave kernel (default); 2 = MX, 8-wave kernel; 0 = plain K = 16
+ *   "attn_ablate", "hgemm_stamps", "w4_abl"   diagnosis builds only (library built with LC_DIAG=1; results may be WRONG) */
 int lc_tune_set(const char* key, int value);
 
 /* ---- HGEMM ------------------------------------------------------------------------------------
