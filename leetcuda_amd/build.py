@@ -53,8 +53,26 @@ def build_abi(force: bool = False) -> Path:
     srcs.append(ROOT / "include" / "lc_abi.h")
     if not force and _newer(out, srcs):
         return out
-    _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-          "-Wno-unused-result", "-fno-honor-nans", "-mno-amdgpu-ieee", *(["-DLC_DIAG"] if os.environ.get("LC_DIAG") == "1" else []), f"-I{ROOT / 'include'}", "-o", out, CSRC / "lc_abi.hip", "-ldl"])
+    # four translation units (lc_abi.hip + the compile-heavy literal-AGPR kernels in tu_*.hip), compiled in parallel
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-fno-honor-nans",
+             "-mno-amdgpu-ieee", *(["-DLC_DIAG"] if os.environ.get("LC_DIAG") == "1" else []), f"-I{ROOT / 'include'}"]
+    objdir = LIBDIR / "obj"
+    objdir.mkdir(exist_ok=True)
+    units = [CSRC / "lc_abi.hip"] + sorted(CSRC.glob("tu_*.hip"))
+    procs = []
+    for u in units:
+        obj = objdir / (u.stem + ".o")
+        cmd = [hipcc(), *flags, "-c", "-o", str(obj), str(u)]
+        print("[build] " + " ".join(cmd), flush=True)
+        procs.append((u, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    objs = []
+    for u, obj, pr in procs:
+        log, _ = pr.communicate()
+        if pr.returncode != 0:
+            sys.stdout.write(log)
+            raise subprocess.CalledProcessError(pr.returncode, pr.args)
+        objs.append(obj)
+    _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, "-ldl"])
     return out
 
 

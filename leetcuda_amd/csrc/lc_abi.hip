@@ -12,49 +12,30 @@
 #include <utility>
 #include <vector>
 
+#include "lc_launch.h"
 #include "attn_fwd.hip"
-#include "attn_w4.hip"
 #include "hgemm_generic.hip"
 #include "hgemm_mfma128.hip"
-#include "hgemm_w4.hip"
 #include "hgemm_mfma256.hip"
 #include "hgemm_pingpong.hip"
-#include "gemm_fp8.hip"
 #include "probe.hip"
 
 using namespace lc;
 
+namespace lc {
+int g_tune_attn_ablate = 0;      // attention ablation / stamp builds (diagnosis only, LC_DIAG)
+int g_tune_w4_abl = 0;           // hgemm_w4 ablation bits (diagnosis only, LC_DIAG)
+int g_tune_hgemm_stamps = 0;     // GEMM cycle-stamp builds (diagnosis only, LC_DIAG)
+}  // namespace lc
+
 namespace {
 
 // run-time tuning knobs (lc_tune_set): experiments and A/B benches, never required for correctness
-int g_tune_attn_ablate = 0;                // see attn_fwd_kernel ABL (diagnosis only)
 int g_tune_fp8_mx = 1;                       // fp8 GEMM: 1 = MX-scaled K=64 MFMA, 4-wave kernel; 2 = MX, 8-wave kernel; 0 = plain K=16 MFMA
-int g_tune_w4_abl = 0;                       // hgemm_w4 ablation bits (lc_tune_set "w4_abl"), diagnosis only
-int g_tune_hgemm_stamps = 0;                 // pingpong2 diagnosis build: cycle stamps into A (lc_tune_set "hgemm_stamps")
 int g_tune_attn_nw = 0;                    // waves per attention workgroup: 0 = auto, 8 / 4 / 2
 int g_tune_hgemm_auto = LC_HGEMM_MFMA256W4C;   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
-int check_launch() { return hipGetLastError() == hipSuccess ? LC_OK : LC_ERR_LAUNCH; }
-
-// The reference re-issues cudaFuncSetAttribute on every call (hgemm_mma_stage.cu:2284); here the attribute is
-// set once per (kernel, device) and remembered.
-template <typename KernelT>
-int set_dyn_lds(KernelT kernel, int bytes) {
-  static std::mutex mu;
-  static std::vector<std::pair<const void*, int>> done;
-  const void* fn = reinterpret_cast<const void*>(kernel);
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return LC_ERR_DEVICE;
-  std::lock_guard<std::mutex> g(mu);
-  for (const auto& d : done)
-    if (d.first == fn && d.second == dev) return LC_OK;
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
-    return LC_ERR_LAUNCH;
-  done.emplace_back(fn, dev);
-  return LC_OK;
-}
 
 // ------------------------------------------------------------------------------------------------
 // reference entry tables
@@ -181,46 +162,10 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   const int tiles_m = M / BM, tiles_n = N / BN;
   const int pw = panel_tiles(swizzle_stride, tiles_n, BN);
   const dim3 grid(tiles_m * tiles_n), block(512);
-  // buffer-descriptor DMA addresses are 32-bit offsets from the wave's first row: fall back to the 64-bit global form
-  // when an offset could reach 2 GiB (NN: K tiles step through the whole of B)
-  if (variant == LC_HGEMM_MFMA256W4C) {
-    const size_t max_off = B_KN ? (size_t)K * N * 2 + (size_t)N * 64 : (size_t)K * 2 * 130;
-    if (max_off >= ((size_t)1 << 31)) variant = LC_HGEMM_MFMA256W4B;
-  }
-#ifdef LC_DIAG
-  if (variant == LC_HGEMM_MFMA256W4C && g_tune_hgemm_stamps) {
-    auto kern = hgemm_w4b_kernel<B_KN, true, true>;
-    if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
-  } else
-#endif
-  if (variant == LC_HGEMM_MFMA256W4C) {
-    auto kern = hgemm_w4b_kernel<B_KN, true>;
-    if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
-  } else if (variant == LC_HGEMM_MFMA256W4B) {
-    auto kern = hgemm_w4b_kernel<B_KN>;
-    if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
-  } else if (variant == LC_HGEMM_MFMA256W4S) {
-    auto kern = hgemm_w4s_kernel<B_KN>;
-    if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(256), HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
-  } else if (variant == LC_HGEMM_MFMA256W4) {
-#define LC_W4_CASE(ABL)                                                                                   \
-  case ABL: {                                                                                             \
-    auto kern = hgemm_w4_kernel<B_KN, ABL>;                                                               \
-    if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;                                              \
-    hipLaunchKernelGGL(kern, grid, dim3(256), HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);  \
-  } break;
-    switch (g_tune_w4_abl) {
-      LC_W4_CASE(0)
-#ifdef LC_DIAG
-      LC_W4_CASE(1) LC_W4_CASE(2) LC_W4_CASE(3) LC_W4_CASE(4) LC_W4_CASE(7)
-#endif
-      default: return LC_ERR_ARG;
-    }
-#undef LC_W4_CASE
+  if (variant == LC_HGEMM_MFMA256W4 || variant == LC_HGEMM_MFMA256W4S || variant == LC_HGEMM_MFMA256W4B ||
+      variant == LC_HGEMM_MFMA256W4C)
+    return launch_w4_family(A, B, C, M, N, K, variant, B_KN, tiles_m, tiles_n, pw, st);
+  if (false) {
 #ifdef LC_DIAG
   } else if (variant == LC_HGEMM_MFMA256P2 && g_tune_hgemm_stamps) {
     auto kern = hgemm_pingpong2_kernel<B_KN, false, true>;
@@ -318,27 +263,6 @@ int launch_attn_c4(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   return check_launch();
 }
 
-template <int D>
-int launch_attn_w4(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
-                   hipStream_t st) {
-  const int nqb = N / 256;
-  const dim3 grid((unsigned)((size_t)nqb * B * H)), block(256);
-  const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
-#ifdef LC_DIAG
-  if (g_tune_attn_ablate == 32) {
-    auto kern = attn_fwd_w4_kernel<D, true>;
-    if (int rc = set_dyn_lds(kern, AW4_LDS)) return rc;
-    hipLaunchKernelGGL(kern, grid, block, AW4_LDS, st, Q, K, V, O, N, nqb, sl2);
-  } else
-#endif
-  {
-    auto kern = attn_fwd_w4_kernel<D>;
-    if (int rc = set_dyn_lds(kern, AW4_LDS)) return rc;
-    hipLaunchKernelGGL(kern, grid, block, AW4_LDS, st, Q, K, V, O, N, nqb, sl2);
-  }
-  return check_launch();
-}
-
 template <int D, bool VT>
 int launch_attn_swp(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                     hipStream_t st) {
@@ -359,7 +283,7 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
     // default for D = 128: the four-cluster LDS-DMA kernel (measured 2-3 % ahead of the lock-step kernel at config 3)
     if (N % 256 == 0 && (g_tune_attn_nw == 64 || (g_tune_attn_nw == 0 && g_tune_attn_ablate == 0)))
       return launch_attn_c4<D>(Q, K, V, O, B, H, N, st);
-    if (N % 256 == 0 && g_tune_attn_nw == 128) return launch_attn_w4<D>(Q, K, V, O, B, H, N, st);
+    if (N % 256 == 0 && g_tune_attn_nw == 128) return launch_attn_w4_d128(Q, K, V, O, B, H, N, st);
   }
   if constexpr (D == 128 && !VT) {   // perf-diagnosis instantiations (lc_tune_set "attn_ablate")
     switch (g_tune_attn_ablate) {
@@ -568,30 +492,11 @@ int lc_gemm_fp8_e4m3(const void* A, const void* B, void* C, int M, int N, int K,
                      int swizzle_stride, void* stream) {
   if (!A || !B || !C) return LC_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0) return LC_ERR_SHAPE;
-  if (M % BM || N % BN || K % BK8 || !aligned16(A) || !aligned16(B) || !aligned16(C)) return LC_ERR_SHAPE;
+  if (M % BM || N % BN || K % 128 || !aligned16(A) || !aligned16(B) || !aligned16(C)) return LC_ERR_SHAPE;
   const int tiles_m = M / BM, tiles_n = N / BN;
   const int pw = panel_tiles(swizzle_stride, tiles_n, BN);
-  // MX + 4-wave kernel (default, fp8_mx = 1) unless a buffer offset could reach 2 GiB; fp8_mx = 2: MX 8-wave kernel
-  if (g_tune_fp8_mx == 1 && (size_t)K * 130 < ((size_t)1 << 31)) {
-    auto kern = gemm_fp8_w4_kernel;
-    if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), W4B_LDS, static_cast<hipStream_t>(stream),
-                       static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), static_cast<half_t*>(C), M, N,
-                       K, alpha, tiles_m, tiles_n, pw);
-  } else if (g_tune_fp8_mx) {
-    auto kern = gemm_fp8_pingpong2_kernel<true>;
-    if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), HGEMM256_LDS, static_cast<hipStream_t>(stream),
-                       static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), static_cast<half_t*>(C), M, N,
-                       K, alpha, tiles_m, tiles_n, pw);
-  } else {
-    auto kern = gemm_fp8_pingpong2_kernel<false>;
-    if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), HGEMM256_LDS, static_cast<hipStream_t>(stream),
-                       static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), static_cast<half_t*>(C), M, N,
-                       K, alpha, tiles_m, tiles_n, pw);
-  }
-  return check_launch();
+  return launch_gemm_fp8(static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), static_cast<half_t*>(C), M, N, K,
+                         alpha, tiles_m, tiles_n, pw, g_tune_fp8_mx, static_cast<hipStream_t>(stream));
 }
 
 int lc_hgemm_entry_count(void) { return kNumHgemmEntries; }

@@ -1,0 +1,49 @@
+// lc_launch.h — pieces shared by the translation units of libleetcuda_amd.so (lc_abi.hip + the tu_*.hip files that
+// hold the compile-heavy literal-AGPR kernels, built in parallel by leetcuda_amd/build.py).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <utility>
+#include <vector>
+
+#include "../../include/lc_abi.h"
+#include "lc_common.h"
+
+namespace lc {
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? LC_OK : LC_ERR_LAUNCH; }
+
+// The reference re-issues cudaFuncSetAttribute on every call (hgemm_mma_stage.cu:2284); here the attribute is
+// set once per (kernel, device) and remembered.
+template <typename KernelT>
+int set_dyn_lds(KernelT kernel, int bytes) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> done;
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return LC_ERR_DEVICE;
+  std::lock_guard<std::mutex> g(mu);
+  for (const auto& d : done)
+    if (d.first == fn && d.second == dev) return LC_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+    return LC_ERR_LAUNCH;
+  done.emplace_back(fn, dev);
+  return LC_OK;
+}
+
+// tuning globals (defined in lc_abi.hip, lc_tune_set)
+extern int g_tune_attn_ablate, g_tune_w4_abl, g_tune_hgemm_stamps;
+
+// launchers living in their own translation units
+// tu_w4.hip: LC_HGEMM_MFMA256W4 / W4S / W4B / W4C (M, N % 256 == 0, K % 64 == 0 checked by the caller)
+int launch_w4_family(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant, bool b_kn,
+                     int tiles_m, int tiles_n, int panel_w, hipStream_t st);
+// tu_attn_w4.hip: 4-wave x 64-row attention kernel, D = 128, N % 256 == 0
+int launch_attn_w4_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
+                        hipStream_t st);
+// tu_fp8.hip: fp8 e4m3 GEMM, mx = 1 (MX, 4 waves) / 2 (MX, 8 waves) / 0 (plain K = 16)
+int launch_gemm_fp8(const uint8_t* A, const uint8_t* B, half_t* C, int M, int N, int K, float alpha, int tiles_m,
+                    int tiles_n, int panel_w, int mx, hipStream_t st);
+
+}  // namespace lc
