@@ -614,13 +614,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_c4_kernel(
   const unsigned k_off = (unsigned)(r4 * 256 + ((cs ^ (4 * (wave & 3) + r4)) * 16));   // (row & 15) = 4(p&3) + r4
   const unsigned v_off = (unsigned)(r4 * 256 + ((cs ^ (r4 << 2)) * 16));               // (row & 3) = r4
   // piece i = 0..3 of this wave for tile t: K pieces wave, wave+8, then V pieces wave, wave+8
+  // buffer_load..lds: descriptor per (b,h) + scalar offset + one 32-bit lane offset (no 64-bit lane address per piece)
+  const buf_rsrc_t rk = make_rsrc(Kb), rv = make_rsrc(Vb);
   auto issue_piece = [&](int i, int t, char* slot) {
-    const size_t tb = (size_t)t * TILE;
+    const unsigned tb = (unsigned)t * TILE;
     const int p = wave + 8 * (i & 1);
     if (i < 2)
-      glds16(Kb + tb + (size_t)p * 1024 + k_off, slot + p * 1024);
+      blds16(rk, k_off, tb + (unsigned)p * 1024, slot + p * 1024);
     else
-      glds16(Vb + tb + (size_t)p * 1024 + v_off, slot + TILE + p * 1024);
+      blds16(rv, v_off, tb + (unsigned)p * 1024, slot + TILE + p * 1024);
   };
   auto issue_tile = [&](int t, char* slot) {
 #pragma unroll
