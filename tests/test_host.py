@@ -97,3 +97,25 @@ def test_attn_shard_prefers_batch_axis():
     assert (b, h, first) == (1, 12, 12)
     with pytest.raises(ValueError):
         host.shard_bounds(4, 2, 2)
+
+
+def test_bench_traffic_keys_exist_in_committed_pmc_summary():
+    """bench.py looks the dominant kernels' HBM bytes up in profiles/latest_pmc.json (written by
+    tools/summarize_prof.py from the separate rocprofv3 --pmc passes): the keys it asks for must be there, otherwise
+    `roofline.traffic` silently degrades to null."""
+    import importlib.util
+    import json
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("lc_bench", root / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pmc = json.loads((root / "profiles" / "latest_pmc.json").read_text())
+    for layout in ("tn", "nn"):
+        key = bench.pmc_key_hgemm("auto", layout)
+        assert key in pmc and pmc[key]["hbm_bytes_per_launch"] > 0, key
+        assert bench.pmc_traffic(key) == pmc[key]["hbm_bytes_per_launch"]
+    src = (root / "bench.py").read_text()
+    m = re.search(r'pmc_traffic\("(attn_[^"]+)"\)', src)
+    assert m and m.group(1) in pmc, m and m.group(1)
+    # algorithmic bytes of the 8192^3 HGEMM are 3 * 8192^2 * 2; fabric traffic is a small multiple of it, never less
+    assert pmc[bench.pmc_key_hgemm("auto", "tn")]["hbm_bytes_per_launch"] >= 3 * 8192 * 8192 * 2
