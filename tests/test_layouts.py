@@ -1,0 +1,109 @@
+"""LDS layout algebra of the kernels, restated in Python (CPU): the XOR swizzles applied to the LDS-DMA source
+addresses must be (1) permutations inside a row and (2) conflict-free for the read instruction's lane groups, using
+the bank model of /opt/skills/guides/MI355X_MICROARCH.md §LDS: 64 banks x 4 B (256 B per clock) for ds_read_b128 /
+ds_read_b64_tr_b16, lane groups of one LDS cycle each:
+    ds_read_b128        {0-3,12-15,20-27} {4-11,16-19,28-31} {32-35,44-47,52-59} {36-43,48-51,60-63}
+    ds_read_b64_tr_b16  {0-31} {32-63}
+A group is conflict-free when its lanes touch pairwise different banks (or identical addresses).
+These are the formulas of hgemm_pingpong.hip / hgemm_w4.hip (st_2x8, 128-B rows; 64-B rows of the w4s variant) and of
+attn_fwd.hip / attn_w4.hip (K: chunk ^ (row & 15) on 256-B rows; V: 64-B unit ^ (row & 3) for the transpose reads)."""
+import itertools
+
+B128_GROUPS = [
+    [0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+    [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31],
+    [32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59],
+    [36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63],
+]
+TR_GROUPS = [list(range(0, 32)), list(range(32, 64))]
+
+
+def banks(addr, nbytes):
+    return {(addr + b) // 4 % 64 for b in range(0, nbytes, 4)}
+
+
+def conflict_free(addrs, nbytes):
+    seen = {}
+    for a in addrs:
+        for bk in banks(a, nbytes):
+            if bk in seen and seen[bk] != a:
+                return False
+            seen[bk] = a
+    return True
+
+
+def test_gemm_st2x8_swizzle_is_conflict_free_for_b128_fragment_reads():
+    # 128-B rows; 16-B chunk c of row r at slot c ^ ((r >> 1) & 7); lane -> row l32 (+32 per block), chunk 2ks + hi
+    for ks in range(4):
+        for grp in B128_GROUPS:
+            addrs = []
+            for lane in grp:
+                l32, hi = lane & 31, lane >> 5
+                addrs.append(l32 * 128 + (((2 * ks + hi) ^ ((l32 >> 1) & 7)) * 16))
+            assert conflict_free(addrs, 16), (ks, grp)
+    for r in range(16):   # a permutation of the 8 chunk slots in every row
+        assert sorted(c ^ ((r >> 1) & 7) for c in range(8)) == list(range(8))
+
+
+def test_gemm_64_byte_row_swizzle_of_the_four_stage_ring():
+    # 64-B rows (hgemm_w4s): chunk c of row r at slot c ^ ((r >> 2) & 3)
+    for ks in range(2):
+        for grp in B128_GROUPS:
+            addrs = []
+            for lane in grp:
+                l32, hi = lane & 31, lane >> 5
+                addrs.append(l32 * 64 + (((2 * ks + hi) ^ ((l32 >> 2) & 3)) * 16))
+            assert conflict_free(addrs, 16), (ks, grp)
+
+
+def test_attention_k_tile_swizzle_256_byte_rows():
+    # K tile [64 kv][256 B]: chunk c of row r at slot c ^ (r & 15); fragment lane -> row tt*32 + l32, chunk 2ks + hi
+    for ks, tt in itertools.product(range(8), range(2)):
+        for grp in B128_GROUPS:
+            addrs = []
+            for lane in grp:
+                l32, hi = lane & 31, lane >> 5
+                row = tt * 32 + l32
+                addrs.append(row * 256 + (((2 * ks + hi) ^ (row & 15)) * 16))
+            assert conflict_free(addrs, 16), (ks, tt, grp)
+
+
+def test_attention_v_tile_unit_swizzle_for_transpose_reads():
+    # V tile [64 kv][256 B]: 64-B unit u of row r at unit u ^ (r & 3).  A transpose read: lane i of a 16-lane group
+    # supplies row (i >> 2), 8 bytes at column 4 (i & 3) of a 16-column block; lanes 16..31 take the next 16 columns;
+    # lane half hi takes rows +4.
+    for g, x, dt in itertools.product(range(4), range(2), range(4)):
+        for grp in TR_GROUPS:
+            addrs = []
+            for lane in grp:
+                i, gi, hi = lane & 15, (lane >> 4) & 1, lane >> 5
+                row = 32 * (g >> 1) + 16 * (g & 1) + 8 * x + 4 * hi + (i >> 2)
+                unit = dt ^ (row & 3)
+                addrs.append(row * 256 + unit * 64 + 32 * gi + 8 * (i & 3))
+            assert conflict_free(addrs, 8), (g, x, dt)
+
+
+def test_nn_b_image_pair_swizzle_for_transpose_reads():
+    # NN B sub-image [k][256 B] = 128 contiguous columns; 32-B pair P of row k at pair slot P ^ ((k & 3) << 1)
+    for j, ks, x in itertools.product(range(4), range(4), range(2)):
+        for grp in TR_GROUPS:
+            addrs = []
+            for lane in grp:
+                i, gi, hi = lane & 15, (lane >> 4) & 1, lane >> 5
+                k = 16 * ks + 8 * hi + (i >> 2) + 4 * x
+                pair = (2 * j + gi) ^ ((k & 3) << 1)
+                addrs.append(k * 256 + pair * 32 + (i & 3) * 8)
+            assert conflict_free(addrs, 8), (j, ks, x)
+    for k in range(4):
+        assert sorted(p ^ ((k & 3) << 1) for p in range(8)) == list(range(8))
+
+
+def test_dma_source_permutation_is_the_inverse_of_the_read_mapping():
+    # LDS-DMA writes lane-linearly: the lane that fills slot s of row r must FETCH logical chunk s ^ key(r); reading
+    # logical chunk c then finds it at slot c ^ key(r) (XOR is an involution) — for every key used above
+    for key in (lambda r: (r >> 1) & 7, lambda r: r & 15, lambda r: (r >> 2) & 3):
+        width = 16 if key(15) == 15 else (8 if key(15) == 7 else 4)
+        for r in range(64):
+            image = {s: s ^ key(r) for s in range(width)}          # slot -> logical chunk stored there
+            for c in range(width):
+                assert image[c ^ key(r)] == c
