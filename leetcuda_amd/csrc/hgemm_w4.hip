@@ -41,6 +41,12 @@ LC_DEVINL void w4_mfma(half8_t a, half8_t b) {   // a[16 IDX .. +15] += a x b
   asm volatile("v_mfma_f32_32x32x16_f16 a[%2:%3], %0, %1, a[%2:%3]"
                :: "v"(a), "v"(b), "n"(IDX * 16), "n"(IDX * 16 + 15) : LC_AGPR_ALL);
 }
+template <int IDX0, int IDX1>
+LC_DEVINL void w4_mfma2(half8_t a0, half8_t a1, half8_t b) {   // two MFMAs sharing operand b, one statement (no pad between)
+  asm volatile("v_mfma_f32_32x32x16_f16 a[%3:%4], %0, %2, a[%3:%4]\n\tv_mfma_f32_32x32x16_f16 a[%5:%6], %1, %2, a[%5:%6]"
+               :: "v"(a0), "v"(a1), "v"(b), "n"(IDX0 * 16), "n"(IDX0 * 16 + 15), "n"(IDX1 * 16), "n"(IDX1 * 16 + 15)
+               : LC_AGPR_ALL);
+}
 template <int R>
 LC_DEVINL void w4_acc_zero() { asm volatile("v_accvgpr_write_b32 a[%0], 0" :: "n"(R) : LC_AGPR_ALL); }
 template <int R>
@@ -416,8 +422,7 @@ __global__ __launch_bounds__(256) void hgemm_w4b_kernel(const half_t* __restrict
     static_for<8>([&](auto cc) {
       constexpr int c = decltype(cc)::value;
       constexpr int i = c >> 1, j0 = 2 * (c & 1);
-      w4_mfma<4 * i + j0>(bf[cb][j0], af[cb][i]);
-      w4_mfma<4 * i + j0 + 1>(bf[cb][j0 + 1], af[cb][i]);
+      w4_mfma2<4 * i + j0, 4 * i + j0 + 1>(bf[cb][j0], bf[cb][j0 + 1], af[cb][i]);
       __builtin_amdgcn_sched_barrier(0);
       // (one read per chunk over all 8 chunks instead of two in chunks 0..3 measures the same: A/B run r04c)
       if constexpr (c < 4) {
