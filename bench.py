@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hgemm|attn|attn_sharded]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hgemm|attn|attn_cfg4|attn_d512]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment SELF-SPAWNS the N ranks
+(torch.multiprocessing.spawn, one process per GPU, RCCL; LC_DIST_BACKEND=gloo lets the ranks share one GPU) — the
+launch idiom SURVEY.md section 8(e) names (reference: others/pytorch/distributed/test_dist_all.py:189-234).
 
 Metric (BASELINE.json): achieved fp16 TFLOPS vs MI355X MFMA peak — HGEMM 8192^3; FA-2 fwd S=4096 D=128.
 A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
@@ -13,18 +17,24 @@ A "step" is one pass of the hot path over one batch of synthetic input already r
                     N > 1: N independent replicas (HGEMM does not shard in north_star) -> "weak".
   attn              FlashAttention-2 forward B=4,H=32,S=4096,D=128 (config 3); N > 1: the 128 (batch,head)
                     problems are split across ranks -> "strong".
-  attn_sharded      config 4: B=32,H=32,S=8192,D=128 batch-sharded over N ranks -> "strong".
+  attn_cfg4         config 4: B=32,H=32,S=8192,D=128 through the shared-QKV entry, batch-sharded over N ranks -> "strong".
+  attn_d512         config 5a: (1,48,8192,512) through the tiling-QKV entry (fp16) and lc_attn_fwd_bf16; heads sharded.
 
-The default run reports HGEMM as `value` and carries the config-3 attention numbers in "attention".
-No data-path collective exists: the only collectives are the barrier bracketing the timed region and
-the gather of per-rank timings (RCCL when N > 1).  W warm-up steps, then EXACTLY K timed steps between
-barrier + torch.cuda.synchronize() on both sides; time = MAX over ranks; rank 0 prints ONE JSON line.
+The default run reports HGEMM as `value` and carries, in the same JSON line: "vendor_tflops" (same-run hipBLASLt TN /
+NN = the reference's cuBLAS comparator), "uniform_tflops" (the same kernel on uniform[-1,1) operands, the fill the
+programming guide quotes), "sustained" (>= 2 s of back-to-back launches with the effective shader clock),
+"attention" (config 3), "attention_cfg4" (config 4, aggregate over ranks) and "attention_d512" (config 5a).
+No data-path collective exists: the only collectives are the barrier bracketing the timed region and the gather of
+per-rank timings.  W warm-up steps, then EXACTLY K timed steps between barrier + torch.cuda.synchronize() on both
+sides; time = MAX over ranks; rank 0 prints ONE JSON line.
 
-"roofline": achieved = algorithmic FLOPs per launch / average launch duration from HIP events recorded on
-the launch stream (lc_hgemm_time / lc_attn_time); peak = 2500 TFLOP/s dense fp16 MFMA.
+"roofline": achieved = algorithmic FLOPs per launch / average launch duration from HIP events recorded on the launch
+stream (lc_hgemm_time / lc_attn_time / lc_timer_*); peak = 2500 TFLOP/s dense fp16 MFMA; "kernel" comes from the
+dispatcher itself (lc_*_kernel_name); "traffic" = fabric bytes per launch from the COMMITTED rocprofv3 --pmc passes
+("traffic_source" names the file: it is not a same-run counter).
 "cpu_baseline": the reference benches' own CPU-capable baseline callables (torch.matmul, hgemm.py:1088;
-F.scaled_dot_product_attention, flash_attn_mma.py:455-462) timed on this box's host cores, rank 0, N=1,
-on a bounded sample — a reported baseline, not the target.
+F.scaled_dot_product_attention and the unfused formula, flash_attn_mma.py:448-462) on this box's host cores, rank 0,
+N=1: 1 warm-up + 3 timed runs on bounded samples, thread count stated — a reported baseline, not the target.
 """
 from __future__ import annotations
 
@@ -46,41 +56,37 @@ from leetcuda_amd import dist as lcd  # noqa: E402
 
 PEAK = host.MI355X_FP16_DENSE_PEAK_TFLOPS
 PREWARM = 10  # untimed launches before the W warm-up steps (DVFS settles; documented in DESIGN.md §6)
+PMC_FILE = "profiles/latest_pmc.json"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="hgemm", choices=["hgemm", "attn", "attn_sharded"])
+    ap.add_argument("--workload", default="hgemm", choices=["hgemm", "attn", "attn_cfg4", "attn_sharded", "attn_d512"])
     ap.add_argument("--layout", default="tn", choices=["tn", "nn"])
-    ap.add_argument("--variant", default="auto", choices=["auto", "mfma256", "pingpong", "pingpong2", "pingpong3", "w4", "w4s", "w4b", "w4c", "generic"])
+    ap.add_argument("--variant", default="auto", choices=sorted(VARIANT))
     ap.add_argument("--mnk", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-attention", action="store_true", help="skip the secondary attention measurement")
+    ap.add_argument("--no-attention", action="store_true", help="skip the attention blocks of the default line")
+    ap.add_argument("--quick", action="store_true", help="headline + config-3 attention only (plumbing tests)")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0)
     ap.add_argument("--sweep", action="store_true", help="also print a per-variant table to stderr")
-    return ap.parse_args()
+    a = ap.parse_args(argv)
+    if a.workload == "attn_sharded":     # round-1 name of config 4
+        a.workload = "attn_cfg4"
+    return a
 
 
-VARIANT = {"auto": capi.HGEMM_AUTO, "mfma256": capi.HGEMM_MFMA256, "pingpong": capi.HGEMM_MFMA256P,
-           "pingpong2": capi.HGEMM_MFMA256P2, "pingpong3": capi.HGEMM_MFMA256P3, "w4": capi.HGEMM_MFMA256W4, "w4s": capi.HGEMM_MFMA256W4S, "w4b": capi.HGEMM_MFMA256W4B, "w4c": capi.HGEMM_MFMA256W4C, "generic": capi.HGEMM_GENERIC}
-AUTO_KERNEL = "w4c"   # what LC_HGEMM_AUTO resolves to (lc_abi.hip: g_tune_hgemm_auto)
+VARIANT = {"auto": capi.HGEMM_AUTO, "mfma256": capi.HGEMM_MFMA256, "pingpong2": capi.HGEMM_MFMA256P2,
+           "w4b": capi.HGEMM_MFMA256W4B, "w4c": capi.HGEMM_MFMA256W4C, "w4d": capi.HGEMM_MFMA256W4D,
+           "mfma128": capi.HGEMM_MFMA128, "generic": capi.HGEMM_GENERIC}
 
 
-def pmc_key_hgemm(variant: str, layout: str) -> str:
-    v = AUTO_KERNEL if variant == "auto" else variant
-    nn = 'true' if layout == 'nn' else 'false'
-    if v in ("w4b", "w4c"):
-        return f"hgemm_w4b_kernel<{nn},{'true' if v == 'w4c' else 'false'}>"
-    if v == "w4":
-        return f"hgemm_w4_kernel<{nn},0>"
-    return f"hgemm_{v}_kernel<{nn}>"
-
-
-def timed_region(w, step, steps, warmup):
+def timed_region(w, step, steps, warmup, prewarm=PREWARM):
     """W untimed + exactly K timed steps, barrier+sync on both sides; returns local seconds."""
-    for _ in range(PREWARM):   # setup: clocks / code objects / allocator, not part of W or K
+    for _ in range(prewarm):   # setup: clocks / code objects / allocator, not part of W or K
         step()
     for _ in range(warmup):
         step()
@@ -93,12 +99,44 @@ def timed_region(w, step, steps, warmup):
 
 
 def pmc_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
-    (profiles/latest_pmc.json, written by tools/summarize_prof.py: FETCH_SIZE x2 + WRITE_SIZE), or None."""
+    """Fabric bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (written by
+    tools/summarize_prof.py: FETCH_SIZE x2 + WRITE_SIZE), or None when that kernel was not profiled."""
     try:
-        return json.loads((ROOT / "profiles" / "latest_pmc.json").read_text())[kernel]["hbm_bytes_per_launch"]
+        return json.loads((ROOT / PMC_FILE).read_text())[kernel]["hbm_bytes_per_launch"]
     except Exception:
         return None
+
+
+def roofline(kernel, flops, nbytes, ms_kernel):
+    ach = flops / (ms_kernel * 1e-3) * 1e-12
+    t = pmc_traffic(kernel)
+    return {"bound": "mfma", "achieved": ach, "peak": PEAK, "unit": "TFLOP/s", "frac": ach / PEAK,
+            "kernel_ms": ms_kernel, "kernel": kernel, "algorithmic_flops_per_launch": flops,
+            "algorithmic_bytes_per_launch": nbytes, "traffic": t,
+            "traffic_source": (PMC_FILE + " (committed rocprofv3 --pmc passes, not a same-run counter)") if t else None}
+
+
+def sustained(step, flops, seconds):
+    """>= `seconds` of back-to-back launches; effective shader clock from two lc_clock_probe stamps around them."""
+    stamps = torch.zeros(4, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    with capi.Timer() as tm:          # calibrate: launches per second
+        for _ in range(20):
+            step()
+    n = max(20, int(seconds / (tm.ms / 20 * 1e-3)) + 1)
+    capi.clock_probe(stamps[0:2])
+    with capi.Timer() as tm:
+        for _ in range(n):
+            step()
+    capi.clock_probe(stamps[2:4])
+    torch.cuda.synchronize()
+    s = stamps.cpu().tolist()
+    d_cyc, d_ref = s[2] - s[0], s[3] - s[1]
+    return {"seconds": tm.ms * 1e-3, "launches": n, "tflops": flops * n / (tm.ms * 1e-3) * 1e-12,
+            "eff_clock_ghz": (d_cyc / (d_ref / 100e6) * 1e-9) if d_ref > 0 else None,
+            "eff_clock_method": "s_memtime / s_memrealtime (100 MHz) deltas of lc_clock_probe around the batch"}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -118,131 +156,172 @@ def bench_hgemm(w, args):
     flops = 2.0 * n * n * n
     ms_kernel = capi.hgemm_time(a, bb, c, lay, var, 2, stride, warmup=2, iters=max(10, args.steps))
     ms_kernel = lcd.max_over_ranks(w, ms_kernel)
+    kname = capi.hgemm_kernel_name(n, n, n, lay, var)
     res = {
         "value": w.size * flops * args.steps / secs * 1e-12,
         "ms_per_step": secs / args.steps * 1e3,
         "workload": f"HGEMM M=N=K={n} fp16 {args.layout.upper()} (BASELINE config 2), randn inputs, "
                     f"variant={args.variant}, block-swizzle stride {stride}",
         "scaling": "weak",
-        "roofline": {"bound": "mfma", "achieved": flops / (ms_kernel * 1e-3) * 1e-12, "peak": PEAK,
-                     "unit": "TFLOP/s", "kernel_ms": ms_kernel,
-                     "kernel": pmc_key_hgemm(args.variant, args.layout),
-                     "algorithmic_flops_per_launch": flops,
-                     "algorithmic_bytes_per_launch": 3.0 * n * n * 2,
-                     "traffic": pmc_traffic(pmc_key_hgemm(args.variant, args.layout))},
+        "roofline": roofline(kname, flops, 3.0 * n * n * 2, ms_kernel),
     }
-    res["roofline"]["frac"] = res["roofline"]["achieved"] / PEAK
-    if args.sweep and w.rank == 0:
-        capi.vendor_init()
+    if w.rank == 0 and w.size == 1 and not args.quick:
+        # same-run comparator: hipBLASLt behind the reference's cuBLAS entry points (config 2: "rocprof vs rocBLAS")
+        ven = {}
         for lname, l2 in (("tn", capi.LAYOUT_TN), ("nn", capi.LAYOUT_NN)):
             b2 = host.as_col_major(b) if l2 == capi.LAYOUT_TN else b
-            for vn in ("mfma256", "pingpong", "pingpong2", "pingpong3", "w4", "w4s", "w4b", "w4c"):
+            try:
+                for _ in range(5):
+                    capi.hgemm_vendor(a, b2, c, l2)
+                with capi.Timer() as tm:
+                    for _ in range(20):
+                        capi.hgemm_vendor(a, b2, c, l2)
+                ven[lname] = flops / (tm.ms / 20) * 1e-9
+            except Exception as e:   # a missing hipBLASLt only disables the comparator
+                ven[lname] = None
+                ven["error"] = repr(e)
+            ours = capi.hgemm_time(a, b2, c, l2, var, 2, stride, warmup=2, iters=20)
+            ven[lname + "_ours"] = flops / ours * 1e-9
+        capi.vendor_destroy()
+        res["vendor_tflops"] = ven
+        # uniform[-1,1) operands: the fill /opt/skills/guides/cdna_hip_programming.md quotes its 8192^3 figures on
+        au = (torch.rand((n, n), device="cuda") * 2 - 1).half()
+        bu = (torch.rand((n, n), device="cuda") * 2 - 1).half()
+        ms_u = capi.hgemm_time(au, bu, c, lay, var, 2, stride, warmup=5, iters=max(10, args.steps))
+        res["uniform_tflops"] = flops / ms_u * 1e-9
+        del au, bu
+        res["sustained"] = sustained(step, flops, args.sustain_seconds)
+    if args.sweep and w.rank == 0:
+        for lname, l2 in (("tn", capi.LAYOUT_TN), ("nn", capi.LAYOUT_NN)):
+            b2 = host.as_col_major(b) if l2 == capi.LAYOUT_TN else b
+            for vn in ("mfma256", "pingpong2", "w4b", "w4c", "w4d"):
                 for st in (1, 1024, 2048):
                     ms = capi.hgemm_time(a, b2, c, l2, VARIANT[vn], 2, st, warmup=2, iters=20)
                     print(f"[sweep] hgemm {lname} {vn:9s} stride {st:5d}: {ms:.4f} ms  "
                           f"{flops / ms * 1e-9:8.1f} TFLOP/s", file=sys.stderr)
-            t0 = torch.cuda.Event(enable_timing=True)
-            t1 = torch.cuda.Event(enable_timing=True)
-            for _ in range(3):
-                capi.hgemm_vendor(a, b2, c, l2)
-            t0.record()
-            for _ in range(20):
-                capi.hgemm_vendor(a, b2, c, l2)
-            t1.record()
-            torch.cuda.synchronize()
-            ms = t0.elapsed_time(t1) / 20
-            print(f"[sweep] hgemm {lname} hipBLASLt            : {ms:.4f} ms  {flops / ms * 1e-9:8.1f} TFLOP/s",
-                  file=sys.stderr)
-            res.setdefault("vendor_tflops", {})[lname] = flops / ms * 1e-9
-        capi.vendor_destroy()
-        q, k, v, o, _ = host.get_qkvo(4, 32, 4096, 128)
-        fl = host.mha_matmul_flops(4, 32, 4096, 128)
-        for nw in (32, 16, 8, 4):
-            capi.tune("attn_nw", nw)
-            ms = capi.attn_time(q, k, v, o, False, capi.ATTN_SPLIT_Q, 2, warmup=2, iters=10)
-            print(f"[sweep] attn cfg3 nw={nw}: {ms:.4f} ms  {fl / ms * 1e-9:8.1f} TFLOP/s", file=sys.stderr)
-        capi.tune("attn_nw", 0)
         for nn in (8192, 16384):     # config-5 extension: fp8 e4m3 GEMM (TN), alpha = 1/16
             a8 = torch.randn(nn, nn, device="cuda").to(torch.float8_e4m3fn)
             b8 = torch.randn(nn, nn, device="cuda").to(torch.float8_e4m3fn)
             c8 = torch.zeros(nn, nn, dtype=torch.half, device="cuda")
             for _ in range(3):
                 capi.gemm_fp8(a8, b8, c8, alpha=1 / 16, swizzle_stride=2048)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                capi.gemm_fp8(a8, b8, c8, alpha=1 / 16, swizzle_stride=2048)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 10
+            with capi.Timer() as tm:
+                for _ in range(10):
+                    capi.gemm_fp8(a8, b8, c8, alpha=1 / 16, swizzle_stride=2048)
+            ms = tm.ms / 10
             print(f"[sweep] gemm fp8 e4m3 {nn}^3: {ms:.4f} ms  {2.0 * nn ** 3 / ms * 1e-9:8.1f} TFLOP/s", file=sys.stderr)
             res.setdefault("fp8_tflops", {})[str(nn)] = 2.0 * nn ** 3 / ms * 1e-9
             del a8, b8, c8
     return res
 
 
-def bench_attn(w, args, sharded_cfg4=False, steps=None, warmup=None):
+def bench_attn(w, args, cfg4=False, steps=None, warmup=None, prewarm=PREWARM):
     steps = steps or args.steps
     warmup = args.warmup if warmup is None else warmup
-    B, H, N, D = (32, 32, 8192, 128) if sharded_cfg4 else (4, 32, 4096, 128)
+    B, H, N, D = (32, 32, 8192, 128) if cfg4 else (4, 32, 4096, 128)
     b_loc, h_loc, _ = host.attn_shard(B, H, w.size, w.rank)
     torch.manual_seed(0 + w.rank)
     q, k, v, o, _ = host.get_qkvo(b_loc, h_loc, N, D)            # flash_attn_mma.py:417-435
-    fam = capi.ATTN_SHARED_QKV if sharded_cfg4 else capi.ATTN_SPLIT_Q
-    step = lambda: capi.attn_fwd(q, k, v, o, family=fam, stages=2)  # noqa: E731
-    secs = timed_region(w, step, steps, warmup)
+    entry = "flash_attn_mma_stages_split_q_shared_qkv" if cfg4 else "flash_attn_mma_stages_split_q"
+    fam = capi.ATTN_SHARED_QKV if cfg4 else capi.ATTN_SPLIT_Q
+    step = lambda: capi.attn_call(entry, q, k, v, o, 2)          # noqa: E731   the reference's entry NAME
+    secs = timed_region(w, step, steps, warmup, prewarm)
     secs = lcd.max_over_ranks(w, secs)
     flops_total = host.mha_matmul_flops(B, H, N, D)               # whole job, all ranks
     flops_local = host.mha_matmul_flops(b_loc, h_loc, N, D)
-    ms_kernel = capi.attn_time(q, k, v, o, False, fam, 2, warmup=1, iters=max(5, steps))
+    ms_kernel = capi.attn_time(q, k, v, o, False, fam, 2, warmup=1, iters=max(3, steps))
     ms_kernel = lcd.max_over_ranks(w, ms_kernel)
-    ach = flops_local / (ms_kernel * 1e-3) * 1e-12
     return {
         "value": flops_total * steps / secs * 1e-12,
         "ms_per_step": secs / steps * 1e3,
+        "steps": steps,
         "tflops_reference_formula": host.get_mha_tflops(B, H, N, D, secs / steps),
         "workload": f"FlashAttention-2 fwd B={B} H={H} S={N} D={D} fp16 "
-                    f"({'config 4, shared-QKV entry, batch-sharded' if sharded_cfg4 else 'config 3, split-Q entry'}), "
-                    f"randn inputs, {b_loc}x{h_loc} (batch,head) problems per rank",
+                    f"({'config 4, shared-QKV entry, batch-sharded' if cfg4 else 'config 3, split-Q entry'}), "
+                    f"randn inputs, {b_loc}x{h_loc} (batch,head) problems per rank, entry {entry}",
         "scaling": "strong",
-        "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK, "unit": "TFLOP/s", "frac": ach / PEAK,
-                     "kernel_ms": ms_kernel, "kernel": "attn_fwd_c4_kernel<128,0>",
-                     "algorithmic_flops_per_launch": flops_local,
-                     "algorithmic_bytes_per_launch": 4.0 * b_loc * h_loc * N * D * 2,
-                     "traffic": pmc_traffic("attn_fwd_c4_kernel<128,0>")},
+        "n_ranks": w.size,
+        "roofline": roofline(capi.attn_kernel_name(N, D), flops_local, 4.0 * b_loc * h_loc * N * D * 2, ms_kernel),
     }
 
 
+def bench_attn_d512(w, args, steps=3):
+    """Config 5a, the reference's published FFPA shape (1,48,8192,512): fp16 through the tiling-QKV entry and bf16
+    through lc_attn_fwd_bf16; the 48 heads are sharded over the ranks."""
+    B, H, N, D = 1, 48, 8192, 512
+    lo, hi = host.shard_bounds(H, w.size, w.rank)
+    h_loc = hi - lo
+    torch.manual_seed(5 + w.rank)
+    out = {"workload": f"FlashAttention-2 fwd B={B} H={H} S={N} D={D} (config 5a, FFPA shape), randn inputs, "
+                       f"{h_loc} heads per rank", "scaling": "strong", "n_ranks": w.size}
+    flops_total = host.mha_matmul_flops(B, H, N, D)
+    flops_local = host.mha_matmul_flops(B, h_loc, N, D)
+    for dt, name in ((torch.half, "fp16"), (torch.bfloat16, "bf16")):
+        q = torch.randn(B, h_loc, N, D, device="cuda").to(dt)
+        k = torch.randn(B, h_loc, N, D, device="cuda").to(dt)
+        v = torch.randn(B, h_loc, N, D, device="cuda").to(dt)
+        o = torch.zeros_like(q)
+        if dt == torch.half:
+            step = lambda: capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, o, 2)  # noqa: E731
+        else:
+            step = lambda: capi.attn_fwd_bf16(q, k, v, o)  # noqa: E731
+        secs = lcd.max_over_ranks(w, timed_region(w, step, steps, 1, prewarm=2))
+        with capi.Timer() as tm:
+            for _ in range(steps):
+                step()
+        ms_kernel = lcd.max_over_ranks(w, tm.ms / steps)
+        out[name] = {"value": flops_total * steps / secs * 1e-12, "ms_per_step": secs / steps * 1e3, "steps": steps,
+                     "roofline": roofline(capi.attn_kernel_name(N, D, False, dt == torch.bfloat16), flops_local,
+                                          4.0 * B * h_loc * N * D * 2, ms_kernel)}
+        del q, k, v, o
+    out["value"] = out["fp16"]["value"]
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------
-def cpu_baseline_hgemm(budget_s: float = 12.0):
-    """torch.matmul on fp16 CPU tensors = the reference's `--torch` baseline callable (hgemm.py:1088).
-    Bounded sample: a 512^3 probe sets the rate, then the largest cube of the 8192^3 problem whose
-    estimated time fits `budget_s` is timed (fp16 CPU matmul speed varies by orders of magnitude
-    between hosts)."""
+def _timed3(fn):
+    """1 warm-up + 3 timed runs -> (median seconds, [seconds])."""
+    fn()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[1], ts
+
+
+def cpu_baseline_hgemm(budget_s: float = 10.0):
+    """torch.matmul on fp16 CPU tensors = the reference's `--torch` baseline callable (hgemm.py:1088), SURVEY §8(d):
+    all host cores (thread count stated), 1 warm-up + 3 timed at 1024^3 (config 1's size) and at the largest cube of
+    the 8192^3 problem whose 4 runs fit `budget_s`."""
+    threads = torch.get_num_threads()
     torch.manual_seed(0)
-    a = torch.randn(512, 512, dtype=torch.half)
-    torch.matmul(a, a)
-    t0 = time.perf_counter()
-    torch.matmul(a, a)
-    probe = max(time.perf_counter() - t0, 1e-6)
-    n, dt = 512, probe
-    for cand in (4096, 2048, 1024):     # x4 safety: larger cubes fall out of cache and run slower per FLOP
-        if 4.0 * probe * (cand / 512) ** 3 <= budget_s:
-            n = cand
-            a = torch.randn(n, n, dtype=torch.half)
-            b = torch.randn(n, n, dtype=torch.half)
-            t0 = time.perf_counter()
-            torch.matmul(a, b)
-            dt = time.perf_counter() - t0
+    runs = {}
+    n = 1024
+    a = torch.randn(n, n, dtype=torch.half)
+    b = torch.randn(n, n, dtype=torch.half)
+    med, ts = _timed3(lambda: torch.matmul(a, b))
+    runs[str(n)] = {"median_s": med, "runs_s": ts, "tflops": 2.0 * n ** 3 / med * 1e-12}
+    big = n
+    for cand in (8192, 4096, 2048):     # x1.5 safety: larger cubes fall out of cache and run slower per FLOP
+        if 4 * 1.5 * med * (cand / n) ** 3 <= budget_s:
+            big = cand
             break
-    out = {"value": 2.0 * n ** 3 / dt * 1e-12, "unit": "TFLOP/s", "cores": torch.get_num_threads(),
-           "host_cpus": os.cpu_count(), "kind": "reference",
-           "sample": f"torch.matmul fp16 on CPU tensors, M=N=K={n} ({dt:.2f} s; 1/{(8192 // n) ** 3} of the "
-                     f"8192^3 work), the reference bench's own torch baseline callable (hgemm.py:1088)"}
-    try:  # the C oracle ("port"), fp64 accumulate: 128 output rows of the 8192^3 problem
+    if big != n:
+        a = torch.randn(big, big, dtype=torch.half)
+        b = torch.randn(big, big, dtype=torch.half)
+        med2, ts2 = _timed3(lambda: torch.matmul(a, b))
+        runs[str(big)] = {"median_s": med2, "runs_s": ts2, "tflops": 2.0 * big ** 3 / med2 * 1e-12}
+    head = runs[str(big)]
+    out = {"value": head["tflops"], "unit": "TFLOP/s", "cores": threads, "host_cpus": os.cpu_count(),
+           "kind": "reference", "runs": runs,
+           "sample": f"torch.matmul fp16 on CPU tensors, {threads} threads, 1 warm-up + 3 timed (median), M=N=K={big} "
+                     f"(1/{(8192 // big) ** 3} of the 8192^3 work) and 1024^3; the reference bench's own torch "
+                     f"baseline callable (hgemm.py:1088)"}
+    try:  # the C oracle ("port"), fp64 accumulate: 64 output rows of the 8192^3 problem
         from tests import oracle_lib
         orc = oracle_lib.load()
-        m, nn = 128, 8192
+        m, nn = 64, 8192
         a2 = torch.randn(m, nn, dtype=torch.half)
         b2 = torch.randn(nn, nn, dtype=torch.half)
         t0 = time.perf_counter()
@@ -257,23 +336,31 @@ def cpu_baseline_hgemm(budget_s: float = 12.0):
 
 
 def cpu_baseline_attn():
+    """F.scaled_dot_product_attention and the unfused formula (flash_attn_mma.py:448-462) on fp16 CPU tensors:
+    4 of the 128 (batch, head) problems of config 3, 1 warm-up + 3 timed."""
     import torch.nn.functional as F
+    threads = torch.get_num_threads()
     B, H, N, D = 1, 4, 4096, 128
     torch.manual_seed(0)
     q, k, v = (torch.randn(B, H, N, D, dtype=torch.half) for _ in range(3))
-    F.scaled_dot_product_attention(q[:, :1, :512], k[:, :1, :512], v[:, :1, :512])
-    t0 = time.perf_counter()
-    F.scaled_dot_product_attention(q, k, v)
-    dt = time.perf_counter() - t0
-    return {"value": host.mha_matmul_flops(B, H, N, D) / dt * 1e-12, "unit": "TFLOP/s",
-            "cores": torch.get_num_threads(), "kind": "reference",
-            "sample": f"F.scaled_dot_product_attention fp16 on CPU tensors, B={B} H={H} S={N} D={D} "
-                      f"({dt:.2f} s; 1/32 of config 3), the reference bench's sdpa baseline callable"}
+    fl = host.mha_matmul_flops(B, H, N, D)
+    med, ts = _timed3(lambda: F.scaled_dot_product_attention(q, k, v))
+
+    def unfused():   # flash_attn_mma.py:448-452
+        att = (q @ k.transpose(-2, -1)) * (1.0 / (D ** 0.5))
+        att = F.softmax(att, dim=-1)
+        return att @ v
+    med_u, ts_u = _timed3(unfused)
+    return {"value": fl / med * 1e-12, "unit": "TFLOP/s", "cores": threads, "host_cpus": os.cpu_count(),
+            "kind": "reference", "runs_s": ts,
+            "unfused": {"value": fl / med_u * 1e-12, "runs_s": ts_u},
+            "sample": f"F.scaled_dot_product_attention (and unfused_standard_attn) fp16 on CPU tensors, {threads} "
+                      f"threads, 1 warm-up + 3 timed (median), B={B} H={H} S={N} D={D} = 1/32 of config 3; the "
+                      f"reference bench's own baseline callables (flash_attn_mma.py:448-462)"}
 
 
 # ---------------------------------------------------------------------------------------------------
-def main():
-    args = parse()
+def run(args):
     # stdout carries exactly ONE line (the JSON): park the real stdout and point fd 1 at stderr while
     # libraries (c10d/gloo/RCCL banners, hipBLASLt) may print, restore it for the final print.
     sys.stdout.flush()
@@ -281,21 +368,28 @@ def main():
     os.dup2(2, 1)
     w = lcd.init()
     if w.size != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={w.size}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={w.size}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path for the HIP kernels")
     capi.load()
+    capi.require_production()        # a LC_DIAG=1 library can produce WRONG results
     capi.device_check()
 
+    blocks = {}
     if args.workload == "hgemm":
         main_res = bench_hgemm(w, args)
-        extra = None
         if not args.no_attention:
-            extra = bench_attn(w, args, sharded_cfg4=False, steps=max(5, args.steps // 5), warmup=1)
+            blocks["attention"] = bench_attn(w, args, cfg4=False, steps=max(5, args.steps // 5), warmup=1)
+            if not args.quick:
+                blocks["attention_cfg4"] = bench_attn(w, args, cfg4=True, steps=3, warmup=1, prewarm=1)
+                blocks["attention_d512"] = bench_attn_d512(w, args)
     elif args.workload == "attn":
-        main_res, extra = bench_attn(w, args, sharded_cfg4=False), None
+        main_res = bench_attn(w, args, cfg4=False)
+    elif args.workload == "attn_cfg4":
+        main_res = bench_attn(w, args, cfg4=True, prewarm=1)
     else:
-        main_res, extra = bench_attn(w, args, sharded_cfg4=True), None
+        main_res = bench_attn_d512(w, args, steps=max(3, args.steps))
+        main_res.update({"ms_per_step": main_res["fp16"]["ms_per_step"], "roofline": main_res["fp16"]["roofline"]})
 
     out = {
         "metric": "achieved fp16 TFLOPS vs MI355X MFMA peak: HGEMM 8192^3; FA-2 fwd S=4096 D=128",
@@ -310,21 +404,23 @@ def main():
         "vs_baseline": None,          # BASELINE.md holds no published number for this metric on MI355X
         "dtype": "f16 (fp32 MFMA accumulate)",
         "data": "synthetic",
-        "config": {"workload": main_res["workload"], "parallelism": f"{w.size} independent rank(s), no data-path collective"},
+        "config": {"workload": main_res["workload"],
+                   "parallelism": f"{w.size} rank(s), one process per GPU, no data-path collective"
+                                  + (f" (backend {w.backend})" if w.backend else "")},
         "frac_of_peak": main_res["value"] / (PEAK * w.size),
         "roofline": main_res["roofline"],
+        "library": capi.build_info()[0],
     }
-    if "vendor_tflops" in main_res:
-        out["vendor_tflops"] = main_res["vendor_tflops"]
-    if "fp8_tflops" in main_res:
-        out["fp8_tflops"] = main_res["fp8_tflops"]
-    if extra is not None:
-        out["attention"] = {k: extra[k] for k in ("value", "ms_per_step", "tflops_reference_formula", "workload",
-                                                   "scaling", "roofline")}
-        out["attention"]["frac_of_peak"] = extra["value"] / (PEAK * w.size)
-    if w.rank == 0 and w.size == 1 and not args.no_cpu_baseline:
+    for key in ("vendor_tflops", "uniform_tflops", "sustained", "fp8_tflops", "fp16", "bf16"):
+        if key in main_res:
+            out[key] = main_res[key]
+    for name, blk in blocks.items():
+        blk = dict(blk)
+        blk["frac_of_peak"] = blk["value"] / (PEAK * w.size)
+        out[name] = blk
+    if w.rank == 0 and w.size == 1 and not args.no_cpu_baseline and not args.quick:
         out["cpu_baseline"] = cpu_baseline_hgemm() if args.workload == "hgemm" else cpu_baseline_attn()
-        if extra is not None:
+        if "attention" in out:
             out["attention"]["cpu_baseline"] = cpu_baseline_attn()
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
@@ -333,6 +429,20 @@ def main():
         print(json.dumps(out), flush=True)
     os.dup2(2, 1)
     lcd.shutdown(w)
+
+
+def _rank_main(argv):
+    run(parse(argv))
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: one process per GPU, spawned here
+        lcd.spawn(_rank_main, args.gpus, (list(argv),))
+        return
+    run(args)
 
 
 if __name__ == "__main__":

@@ -33,12 +33,12 @@
 extern "C" {
 #endif
 
-#define LC_ABI_VERSION 1
+#define LC_ABI_VERSION 2   /* 2: retired round-1 kernel variants, lc_build_info, lc_timer_*, probes moved to lc_diag.h */
 
 typedef enum lc_status {
   LC_OK = 0,
   LC_ERR_ARG = -1,      /* null pointer, unknown enum / entry name                                  */
-  LC_ERR_SHAPE = -2,    /* non-positive dims, misaligned pointer, size overflow                      */
+  LC_ERR_SHAPE = -2,    /* non-positive dims, shape / alignment the requested kernel family cannot tile  */
   LC_ERR_HEADDIM = -3,  /* head dim not supported by this attention family ("headdim not support!")  */
   LC_ERR_LAUNCH = -4,   /* hipLaunchKernel / hipFuncSetAttribute failed                              */
   LC_ERR_VENDOR = -5,   /* hipBLASLt comparator unavailable or failed                                */
@@ -50,19 +50,18 @@ typedef enum lc_status {
  * and takes the layout from the entry-point NAME, never from strides — so does this ABI. */
 typedef enum lc_layout { LC_LAYOUT_NN = 0, LC_LAYOUT_TN = 1 } lc_layout;
 
-/* HGEMM kernel families behind the ABI. */
+/* HGEMM kernel families behind the ABI (numeric values are stable; 2, 5, 7, 8 were round-1 experiments that
+ * measured slower and were retired — passing them returns LC_ERR_ARG). */
 typedef enum lc_hgemm_variant {
-  LC_HGEMM_AUTO = 0,     /* best available for the shape (MFMA256W4C / MFMA128 / GENERIC by divisibility) */
-  LC_HGEMM_MFMA256 = 1,  /* 256x256x64 WG tile, 8 wave64, LDS-DMA double buffer, one barrier / K-tile */
-  LC_HGEMM_MFMA256P = 2, /* same tile, phase-interleaved ping-pong schedule (counted vmcnt)           */
-  LC_HGEMM_GENERIC = 3,  /* 64x64x32 edge-predicated MFMA kernel: any M,N,K                           */
-  LC_HGEMM_MFMA256P2 = 4, /* ping-pong with 2 phases of 16 MFMAs per K tile, DMA issued inside MFMA clusters */
-  LC_HGEMM_MFMA256P3 = 5, /* same, DMA issued by the load sections (bare MFMA clusters)                     */
-  LC_HGEMM_MFMA128 = 6,   /* 128x128x64 tile, 4 wave64: M, N multiples of 128 (the reference's own tile)     */
-  LC_HGEMM_MFMA256W4 = 7, /* 256x256x64 tile, FOUR wave64 with 128x128 wave tiles, one barrier per K tile      */
-  LC_HGEMM_MFMA256W4S = 8, /* same wave layout, LDS ring of four 32-k stages (DMA spread one piece per 4 MFMAs) */
-  LC_HGEMM_MFMA256W4B = 9, /* same wave layout, A ring of 2 + B ring of 3 K tiles (160 KiB): no DMA piece < 3 k-steps ahead */
-  LC_HGEMM_MFMA256W4C = 10 /* W4B with buffer_load ... lds (descriptor + scalar offset) DMA instead of global_load_lds   */
+  LC_HGEMM_AUTO = 0,       /* best available for the shape (MFMA256W4C / MFMA128 / GENERIC by divisibility)            */
+  LC_HGEMM_MFMA256 = 1,    /* 256x256x64 WG tile, 8 wave64, LDS-DMA double buffer, one barrier / K-tile (simplest)      */
+  LC_HGEMM_GENERIC = 3,    /* 64x64x32 edge-predicated MFMA kernel: any M,N,K                                           */
+  LC_HGEMM_MFMA256P2 = 4,  /* 8-wave ping-pong, 2 phases of 16 MFMAs per K tile, DMA issued inside the MFMA clusters:
+                              the independently scheduled cross-check of the default kernel                            */
+  LC_HGEMM_MFMA128 = 6,    /* 128x128x64 tile, 4 wave64: M, N multiples of 128 (the reference's own tile)               */
+  LC_HGEMM_MFMA256W4B = 9, /* 256x256x64 tile, FOUR wave64 with 128x128 wave tiles, A ring of 2 + B ring of 3 K tiles   */
+  LC_HGEMM_MFMA256W4C = 10, /* W4B with buffer_load ... lds (descriptor + scalar offset) DMA: the AUTO kernel            */
+  LC_HGEMM_MFMA256W4D = 11  /* W4C with the A pieces spread over two k-steps (one DMA piece per 4 MFMAs everywhere)      */
 } lc_hgemm_variant;
 
 /* FlashAttention-2 forward families (resource policies of kernels/flash-attn/mma/basic/ .cu files). */
@@ -80,24 +79,32 @@ const char* lc_status_string(int status);
 /* 0 when a gfx950 device is current, LC_ERR_DEVICE otherwise. Writes the CU count when non-NULL. */
 int lc_device_check(int* num_cus);
 
-/* Run-time tuning knobs for experiments / A-B benches (not part of the reference surface):
- *   "attn_nw"      attention kernel for D = 128 (N % 256 == 0 unless noted): 0 = auto (four-cluster LDS-DMA kernel),
- *                  128 = 4 waves x 64 query rows (software-pipelined, literal AGPRs), 64 = four-cluster kernel,
- *                  32 = 8-wave software-pipelined kernel, 16 = 8-wave ping-pong kernel,
+/* Build identification: the compile flags of this library as one string (e.g. "gfx950 -O3 LC_DIAG=0"); *is_diag = 1
+ * when it was built with LC_DIAG=1 (ablation / stamp instantiations compiled in — bench.py and the tests refuse such a
+ * library, its diagnosis knobs can make results WRONG).  Never fails. */
+const char* lc_build_info(int* is_diag);
+
+/* Run-time selection knobs for A-B benches (not part of the reference surface; correctness never depends on them):
+ *   "attn_nw"      attention kernel for D = 128: 0 = auto, 128 = 4 waves x 64 query rows (one wave per SIMD, literal
+ *                  AGPRs; N % 256 == 0), 64 = 8-wave four-cluster kernel (N % 256 == 0),
  *                  8 / 4 / 2 = lock-step kernel with that many waves (any N % (32 x waves) == 0, every D <= 128)
  *   "hgemm_auto"   kernel LC_HGEMM_AUTO launches on large 256-tileable shapes (a 256-tile lc_hgemm_variant value)
  *   "fp8_mx"       fp8 GEMM: 1 = MX-scaled K = 64 MFMA, 4-wave kernel (default); 2 = MX, 8-wave kernel; 0 = plain K = 16
- *   "attn_ablate", "hgemm_stamps", "w4_abl"   diagnosis builds only (library built with LC_DIAG=1; results may be WRONG) */
+ *   "attn_d512"    D = 512 kernel: 0 = auto (one workgroup owns all 512 output columns), 1 = round-1 column-split kernel
+ * Diagnosis keys (include/lc_diag.h) are rejected with LC_ERR_ARG unless the library was built with LC_DIAG=1. */
 int lc_tune_set(const char* key, int value);
 
 /* ---- HGEMM ------------------------------------------------------------------------------------
  * Replaces the host launchers + kernels of kernels/hgemm/mma/basic/hgemm_mma_stage.cu:644-1052,2284-2412
  * (NN) and kernels/hgemm/mma/swizzle/hgemm_mma_stage_tn_swizzle_x4.cu:207,892 (TN).
  * fp16 in, fp32 MFMA accumulate, fp16 out; no alpha/beta.
- * `stages` (2..5 in the reference) selects the LDS pipeline depth hint; `swizzle_stride` is the
- * reference's thread-block-swizzle N-panel width in columns (hgemm.py:198-208): <=1 means no panel
- * rasterisation. Pointers must be 16-byte aligned; K must be a multiple of 8 for the MFMA kernels
- * (otherwise LC_ERR_SHAPE). */
+ * `stages` (2..5 in the reference, anything else falls back to 2: hgemm_mma_stage.cu:2388-2391) is ACCEPTED AND
+ * IGNORED: the LDS ring depth is a fixed property of each kernel family here (2-slot rings; 2 + 3 slots for the W4
+ * kernels that fill the CU's 160 KiB) — results never depend on it, exactly as in the reference.
+ * `swizzle_stride` is the reference's thread-block-swizzle N-panel width in columns (hgemm.py:198-208): <= 1 means no
+ * panel rasterisation.  Shapes: the tuned variants need M, N multiples of 256 (128 for MFMA128), K a multiple of 64
+ * and 16-byte aligned pointers, else LC_ERR_SHAPE; LC_HGEMM_AUTO and LC_HGEMM_GENERIC accept ANY positive M, N, K and
+ * 2-byte alignment (the edge-predicated kernel serves what the tiles do not divide; all address arithmetic is 64-bit). */
 int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int layout,
                  int variant, int stages, int swizzle_stride, void* stream);
 
@@ -150,28 +157,31 @@ const char* lc_attn_entry_name(int index);
 int lc_attn_entry_info(const char* entry, int* family, int* v_transposed, int* acc_f32,
                        int* max_d_stage2, int* max_d_stage1, int* nargs);
 
+/* ---- introspection (bench.py labels its roofline / rocprof rows with these; never launches) ------
+ * Name of the kernel the dispatcher would launch for this call with the current lc_tune_set selection, in the form
+ * rocprofv3 demangles it to (e.g. "hgemm_w4b_kernel<false,true,false,0>"), written NUL-terminated into buf.
+ * Pointers are assumed 16-byte aligned.  Returns LC_OK, LC_ERR_ARG / LC_ERR_SHAPE / LC_ERR_HEADDIM as the call would. */
+int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf, int buflen);
+int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int buflen);
+
 /* ---- measurement helpers (used by bench.py; HIP events on the launch stream) --------------------
  * Launch `iters` back-to-back calls between two hipEvents recorded on `stream`; returns average
- * milliseconds per launch in *ms_per_launch. */
+ * milliseconds per launch in *ms_per_launch.  Any HIP failure (event, launch, execution fault) -> LC_ERR_LAUNCH. */
 int lc_hgemm_time(const void* A, const void* B, void* C, int M, int N, int K, int layout, int variant,
                   int stages, int swizzle_stride, int warmup, int iters, void* stream,
                   float* ms_per_launch);
 int lc_attn_time(const void* Q, const void* K, const void* V, void* O, int B, int H, int N, int D,
                  int v_transposed, int family, int stages, int warmup, int iters, void* stream,
                  float* ms_per_launch);
-
-/* ---- hardware layout probes (tests only; tiny kernels that dump MFMA / LDS-transpose lane maps) -- */
-int lc_probe_mfma16(const void* a16x32, const void* b16x32, float* d16x16, void* stream);
-int lc_probe_mfma32(const void* a32x16, const void* b32x16, float* d32x32, void* stream);
-int lc_probe_tr16(const void* src_64x4_u16, void* dst_64x4_u16, void* stream);
-/* issue-overlap micro-benchmark (tools/coissue_probe.py): 256 x 4 x { 1 MFMA 32x32x16 f16, k fillers }; filler 0 none,
- * 1 v_fma_f32, 2 v_exp_f32, 3 v_pk_fma_f32, 4 v_cvt_pk_f16_f32, 5 ds_read_b128; mode 0 same wave, 1 SIMD partner wave,
- * 2 fillers only; out = 16 x u64 (s_memtime cycles per wave).                                                        */
-int lc_probe_coissue(int filler, int k, int mode, void* out_u64x16, void* stream);
-/* does an in-flight 32x32x16 MFMA still read its A operand after issue? (tools/mfma_war_probe.py): the A registers are
- * overwritten by VALU `delay`+1 wait states after the MFMA (kind 0 v_mov, 1 v_exp_f32; queued: behind another MFMA).  */
-int lc_probe_mfma_war(int delay, int kind, int queued, const void* a32x16, const void* b32x16, float* d32x32,
-                      void* stream);
+/* Generic form: bracket ANY sequence of launches on `stream` with HIP events.  lc_timer_start records the first
+ * event and returns an opaque timer; lc_timer_stop records the second, waits for it, writes the elapsed
+ * milliseconds and frees the timer (also on failure). */
+int lc_timer_start(void* stream, void** timer);
+int lc_timer_stop(void* timer, float* elapsed_ms);
+/* Effective shader clock without a profiler: a one-wave kernel writes {s_memtime (shader cycles), s_memrealtime
+ * (constant 100 MHz)} into out_u64x2 (device memory).  Two probes around a timed batch on the same stream give
+ * eff_clock = d(memtime) / (d(memrealtime) / 100e6). */
+int lc_clock_probe(void* out_u64x2, void* stream);
 
 #ifdef __cplusplus
 }

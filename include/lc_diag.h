@@ -1,0 +1,40 @@
+/*
+ * lc_diag.h — diagnosis surface of the MI355X kernels.  NOT part of the drop-in boundary (include/lc_abi.h):
+ * nothing here is needed to run the reference's entry points.
+ *
+ * 1. Hardware layout probes: tiny kernels that dump MFMA / LDS-transpose lane maps and issue-overlap timings.
+ *    They live in their own library, leetcuda_amd/lib/liblc_diag.so (csrc/diag/lc_diag.hip), used by
+ *    tests/test_gpu_probe.py and tools/{coissue,mfma_war}_probe.py only.
+ * 2. Diagnosis keys of lc_tune_set(): compiled into libleetcuda_amd.so only when it is built with LC_DIAG=1
+ *    (`LC_DIAG=1 python -m leetcuda_amd.build --force`); a production library rejects them with LC_ERR_ARG and
+ *    lc_build_info() reports which kind a given .so is.  With an ablation key set, results are WRONG by design
+ *    (work is skipped to price it) and the stamp keys overwrite the first bytes of A / Q with cycle counters.
+ *      "attn_ablate"   attention ablation / stamp instantiations (tools/attn_ablate.py, tools/attn_*_stamps.py)
+ *      "w4_abl"        4-wave HGEMM: 2 = no DMA after the prologue, 4 = no per-tile wait + barrier, 8 = no fragment
+ *                      reads, 14 = MFMA issue only (tools/w4_ablate.py)
+ *      "hgemm_stamps"  s_memtime stamps of one wave at the k-step boundaries (tools/hgemm_w4c_stamps.py)
+ */
+#ifndef LC_DIAG_H_
+#define LC_DIAG_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes as in lc_abi.h (0 = ok, -1 = bad argument, -4 = launch failed) */
+int lc_probe_mfma16(const void* a16x32, const void* b16x32, float* d16x16, void* stream);
+int lc_probe_mfma32(const void* a32x16, const void* b32x16, float* d32x32, void* stream);
+int lc_probe_tr16(const void* src_64x4_u16, void* dst_64x4_u16, void* stream);
+/* issue-overlap micro-benchmark (tools/coissue_probe.py): 256 x 4 x { 1 MFMA 32x32x16 f16, k fillers }; filler 0 none,
+ * 1 v_fma_f32, 2 v_exp_f32, 3 v_pk_fma_f32, 4 v_cvt_pk_f16_f32, 5 ds_read_b128; mode 0 same wave, 2 fillers only;
+ * out = 16 x u64 (s_memtime cycles per wave). */
+int lc_probe_coissue(int filler, int k, int mode, void* out_u64x16, void* stream);
+/* does an in-flight 32x32x16 MFMA still read its A operand after issue? (tools/mfma_war_probe.py): the A registers are
+ * overwritten by VALU `delay`+1 wait states after the MFMA (kind 0 v_mov, 1 v_exp_f32; queued: behind another MFMA). */
+int lc_probe_mfma_war(int delay, int kind, int queued, const void* a32x16, const void* b32x16, float* d32x32,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LC_DIAG_H_ */

@@ -8,6 +8,7 @@ hipcc cross-compiles gfx950 without a GPU, so this runs in the CPU-only dev cont
 from __future__ import annotations
 
 import argparse
+import json
 import os
 import shutil
 import subprocess
@@ -45,34 +46,100 @@ def hipcc() -> str:
     return exe
 
 
-def build_abi(force: bool = False) -> Path:
-    """hipcc --offload-arch=gfx950 -> leetcuda_amd/lib/libleetcuda_amd.so (the C-ABI, include/lc_abi.h)."""
+def _flags():
+    diag = os.environ.get("LC_DIAG") == "1"
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-fno-honor-nans",
+            "-mno-amdgpu-ieee", *(["-DLC_DIAG"] if diag else []), f"-I{ROOT / 'include'}"]
+
+
+def _stamp_ok(stamp: Path, flags) -> bool:
+    """The .so is only current if it was built with THESE flags (toggling LC_DIAG must rebuild: a diagnosis library
+    cannot be told from a production one by mtimes)."""
+    try:
+        return json.loads(stamp.read_text())["flags"] == [str(f) for f in flags]
+    except Exception:
+        return False
+
+
+def _unit_current(obj: Path, asm, dep: Path) -> bool:
+    if not obj.exists() or not dep.exists() or (asm is not None and not asm.exists()):
+        return False
+    txt = dep.read_text().replace("\\\n", " ")
+    deps = txt.split(":", 1)[1].split() if ":" in txt else []
+    t = min(obj.stat().st_mtime, asm.stat().st_mtime) if asm is not None else obj.stat().st_mtime
+    return bool(deps) and all(Path(d).exists() and Path(d).stat().st_mtime <= t for d in deps)
+
+
+def build_abi(force: bool = False, audit: bool = True) -> Path:
+    """hipcc --offload-arch=gfx950 -> leetcuda_amd/lib/libleetcuda_amd.so (the C-ABI, include/lc_abi.h), then the
+    ISA audit of leetcuda_amd/isa_audit.py on the device assembly of every translation unit (same flags)."""
     LIBDIR.mkdir(parents=True, exist_ok=True)
     out = LIBDIR / LIB_NAME
+    stamp = LIBDIR / "build_stamp.json"
     srcs = sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.inc"))
     srcs.append(ROOT / "include" / "lc_abi.h")
-    if not force and _newer(out, srcs):
+    srcs.append(PKG / "isa_audit.py")
+    flags = _flags()
+    if not force and _newer(out, srcs) and _stamp_ok(stamp, flags):
         return out
-    # four translation units (lc_abi.hip + the compile-heavy literal-AGPR kernels in tu_*.hip), compiled in parallel
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-fno-honor-nans",
-             "-mno-amdgpu-ieee", *(["-DLC_DIAG"] if os.environ.get("LC_DIAG") == "1" else []), f"-I{ROOT / 'include'}"]
+    # translation units (lc_abi.hip + the compile-heavy literal-AGPR kernels in tu_*.hip), compiled in parallel; each
+    # is compiled twice: to an object and (device side only) to assembly for the audit
     objdir = LIBDIR / "obj"
     objdir.mkdir(exist_ok=True)
     units = [CSRC / "lc_abi.hip"] + sorted(CSRC.glob("tu_*.hip"))
+    flags_ok = _stamp_ok(stamp, flags)
     procs = []
     for u in units:
         obj = objdir / (u.stem + ".o")
-        cmd = [hipcc(), *flags, "-c", "-o", str(obj), str(u)]
+        asm = objdir / (u.stem + ".s")
+        dep = objdir / (u.stem + ".d")
+        # per-unit staleness from the compiler's own dependency file (-MD): only units whose sources changed rebuild
+        if not force and flags_ok and _unit_current(obj, asm if audit else None, dep):
+            procs.append((u, obj, None))
+            continue
+        cmd = [hipcc(), *flags, "-MD", "-MF", str(dep), "-c", "-o", str(obj), str(u)]
         print("[build] " + " ".join(cmd), flush=True)
         procs.append((u, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        if audit:
+            cmd = [hipcc(), *flags, "-S", "--cuda-device-only", "-Wno-unused-command-line-argument", "-o", str(asm), str(u)]
+            procs.append((u, None, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     objs = []
     for u, obj, pr in procs:
-        log, _ = pr.communicate()
-        if pr.returncode != 0:
-            sys.stdout.write(log)
-            raise subprocess.CalledProcessError(pr.returncode, pr.args)
-        objs.append(obj)
+        if pr is not None:
+            log, _ = pr.communicate()
+            if pr.returncode != 0:
+                sys.stdout.write(log[-8000:])
+                raise subprocess.CalledProcessError(pr.returncode, pr.args)
+        if obj is not None:
+            objs.append(obj)
+    if audit:
+        from leetcuda_amd import isa_audit
+        reps, bad = isa_audit.audit_files([objdir / (u.stem + ".s") for u in units])
+        for r in reps:
+            print(f"[audit] {r.name}: vgpr {r.vgpr_count} agpr {r.agpr_count} scratch {r.scratch} "
+                  f"asm loads {r.asm_loads} compiler v_accvgpr {r.compiler_accvgpr}", flush=True)
+        (objdir / "isa_audit.json").write_text(json.dumps(
+            [{"kernel": r.name, "vgpr": r.vgpr_count, "agpr": r.agpr_count, "scratch": r.scratch,
+              "asm_loads": r.asm_loads, "compiler_accvgpr": r.compiler_accvgpr, "violations": r.violations}
+             for r in reps], indent=1))
+        if bad:
+            if out.exists():
+                out.unlink()     # never leave a library around whose hidden-state invariants do not hold
+            raise RuntimeError("ISA audit failed (leetcuda_amd/isa_audit.py):\n  " + "\n  ".join(bad))
     _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, "-ldl"])
+    stamp.write_text(json.dumps({"flags": [str(f) for f in flags]}))
+    return out
+
+
+def build_diag(force: bool = False) -> Path:
+    """liblc_diag.so: the hardware probes of include/lc_diag.h (tests / tools only; not part of the drop-in library)."""
+    LIBDIR.mkdir(parents=True, exist_ok=True)
+    out = LIBDIR / "liblc_diag.so"
+    srcs = sorted((CSRC / "diag").glob("*.hip")) + [CSRC / "lc_common.h", ROOT / "include" / "lc_diag.h"]
+    if not force and _newer(out, srcs):
+        return out
+    _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-Wno-inline-asm",
+          f"-I{ROOT / 'include'}", "-o", out, CSRC / "diag" / "lc_diag.hip"])
     return out
 
 
@@ -122,6 +189,7 @@ def build_torch_ext(force: bool = False):
 
 def build_all(force: bool = False, torch_ext: bool = True):
     abi = build_abi(force)
+    build_diag(force)
     orc = build_oracle(force)
     ext = build_torch_ext(force) if torch_ext else []
     return abi, orc, ext

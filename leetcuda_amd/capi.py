@@ -8,10 +8,13 @@ from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "lib" / "libleetcuda_amd.so"
+DIAG_LIB_PATH = _PKG / "lib" / "liblc_diag.so"   # probes of include/lc_diag.h (tests / tools only)
 
 LC_OK, LC_ERR_ARG, LC_ERR_SHAPE, LC_ERR_HEADDIM, LC_ERR_LAUNCH, LC_ERR_VENDOR, LC_ERR_DEVICE = 0, -1, -2, -3, -4, -5, -6
 LAYOUT_NN, LAYOUT_TN = 0, 1
-HGEMM_AUTO, HGEMM_MFMA256, HGEMM_MFMA256P, HGEMM_GENERIC, HGEMM_MFMA256P2, HGEMM_MFMA256P3, HGEMM_MFMA128, HGEMM_MFMA256W4, HGEMM_MFMA256W4S, HGEMM_MFMA256W4B, HGEMM_MFMA256W4C = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+# lc_hgemm_variant (values 2, 5, 7, 8 were retired round-1 experiments: LC_ERR_ARG)
+HGEMM_AUTO, HGEMM_MFMA256, HGEMM_GENERIC, HGEMM_MFMA256P2, HGEMM_MFMA128 = 0, 1, 3, 4, 6
+HGEMM_MFMA256W4B, HGEMM_MFMA256W4C, HGEMM_MFMA256W4D = 9, 10, 11
 ATTN_SPLIT_Q, ATTN_SHARED_QKV, ATTN_SHARED_KV, ATTN_TILING_QK, ATTN_TILING_QKV, ATTN_SPLIT_KV = range(6)
 
 # every symbol include/lc_abi.h declares: name -> (restype, argtypes)
@@ -20,6 +23,7 @@ SYMBOLS = {
     "lc_abi_version": (_i, []),
     "lc_status_string": (_cp, [_i]),
     "lc_device_check": (_i, [_ip]),
+    "lc_build_info": (_cp, [_ip]),
     "lc_tune_set": (_i, [_cp, _i]),
     "lc_hgemm_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "lc_vendor_init": (_i, []),
@@ -38,6 +42,14 @@ SYMBOLS = {
     "lc_attn_entry_info": (_i, [_cp, _ip, _ip, _ip, _ip, _ip, _ip]),
     "lc_hgemm_time": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _fp]),
     "lc_attn_time": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _fp]),
+    "lc_hgemm_kernel_name": (_i, [_i, _i, _i, _i, _i, _cp, _i]),
+    "lc_attn_kernel_name": (_i, [_i, _i, _i, _i, _cp, _i]),
+    "lc_timer_start": (_i, [_vp, C.POINTER(_vp)]),
+    "lc_timer_stop": (_i, [_vp, _fp]),
+    "lc_clock_probe": (_i, [_vp, _vp]),
+}
+# every symbol include/lc_diag.h declares (liblc_diag.so)
+DIAG_SYMBOLS = {
     "lc_probe_mfma16": (_i, [_vp, _vp, _vp, _vp]),
     "lc_probe_mfma32": (_i, [_vp, _vp, _vp, _vp]),
     "lc_probe_tr16": (_i, [_vp, _vp, _vp]),
@@ -46,6 +58,7 @@ SYMBOLS = {
 }
 
 _lib = None
+_diag = None
 
 
 class LcError(RuntimeError):
@@ -79,6 +92,36 @@ def load() -> C.CDLL:
     return lib
 
 
+def load_diag() -> C.CDLL:
+    """dlopen liblc_diag.so (hardware probes; tests and tools only)."""
+    global _diag
+    if _diag is not None:
+        return _diag
+    if not DIAG_LIB_PATH.exists():
+        raise RuntimeError(f"{DIAG_LIB_PATH} is missing: build it with `python -m leetcuda_amd.build`")
+    import torch  # noqa: F401  (maps libamdhip64 first)
+    lib = C.CDLL(str(DIAG_LIB_PATH), mode=C.RTLD_GLOBAL)
+    for name, (res, args) in DIAG_SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _diag = lib
+    return lib
+
+
+def build_info():
+    """(flags string, is_diag) of the loaded library."""
+    d = C.c_int(0)
+    return load().lc_build_info(C.byref(d)).decode(), bool(d.value)
+
+
+def require_production():
+    """bench.py and the parity tests refuse a LC_DIAG=1 library: its diagnosis knobs can make results WRONG."""
+    info, diag = build_info()
+    if diag:
+        raise RuntimeError(f"libleetcuda_amd.so is a DIAGNOSIS build ({info}); rebuild with "
+                           "`python -m leetcuda_amd.build --force` (LC_DIAG unset)")
+
+
 def status_string(status: int) -> str:
     return load().lc_status_string(status).decode()
 
@@ -95,6 +138,43 @@ def _ptr(t) -> int:
 def _stream() -> int:
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def _shape_err(what: str):
+    # the reference wrappers' message (hgemm_mma_stage.cu:2048-2057 CHECK_TORCH_TENSOR_SHAPE)
+    raise RuntimeError(f"Tensor size mismatch! ({what})")
+
+
+def _gemm_dims(a, b, c, layout=LAYOUT_NN, b_is_nk=False):
+    """(M, N, K) after checking a [M,K], b and c [M,N] — a mismatched tensor must fail here with the reference's
+    message, not as an out-of-bounds access on the device.  b: NN -> [K,N]; TN -> the reference presents a
+    [K,N]-shaped tensor whose STORAGE is [N,K] (tools/utils.py:152-156), so either orientation is accepted;
+    b_is_nk (fp8 entry) -> [N,K]."""
+    if a.dim() != 2 or b.dim() != 2 or c.dim() != 2:
+        _shape_err("2-D tensors expected")
+    M, K = a.shape
+    N = c.shape[1]
+    if c.shape[0] != M:
+        _shape_err(f"c {tuple(c.shape)} vs a {tuple(a.shape)}")
+    if b_is_nk:
+        ok = tuple(b.shape) == (N, K)
+    elif layout == LAYOUT_TN:
+        ok = tuple(b.shape) in ((K, N), (N, K))
+    else:
+        ok = tuple(b.shape) == (K, N)
+    if not ok:
+        _shape_err(f"b {tuple(b.shape)} vs K={K}, N={N}")
+    return M, N, K
+
+
+def _attn_dims(q, k, v, o, v_transposed=False):
+    if q.dim() != 4:
+        _shape_err("4-D [B,H,N,D] tensors expected")
+    B, H, N, D = q.shape
+    vshape = (B, H, D, N) if v_transposed else (B, H, N, D)
+    if tuple(k.shape) != (B, H, N, D) or tuple(o.shape) != (B, H, N, D) or tuple(v.shape) != vshape:
+        _shape_err(f"q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)} o {tuple(o.shape)}")
+    return B, H, N, D
 
 
 def _need_gpu(*tensors):
@@ -121,8 +201,7 @@ def hgemm(a, b, c, layout=LAYOUT_NN, variant=HGEMM_AUTO, stages=2, swizzle_strid
     import torch
     _need_gpu(a, b, c)
     assert a.dtype == b.dtype == c.dtype == torch.half
-    M, K = a.shape
-    N = c.shape[1]
+    M, N, K = _gemm_dims(a, b, c, layout)
     check(load().lc_hgemm_f16(_ptr(a), _ptr(b), _ptr(c), M, N, K, layout, variant, stages, swizzle_stride,
                               _stream()), "lc_hgemm_f16")
     return c
@@ -131,8 +210,7 @@ def hgemm(a, b, c, layout=LAYOUT_NN, variant=HGEMM_AUTO, stages=2, swizzle_strid
 def gemm_fp8(a8, b8_nk, c, alpha=1.0, swizzle_stride=1):
     """c[M,N] (fp16) = alpha * a8[M,K] @ b8_nk[N,K]^T; a8/b8 are torch.float8_e4m3fn (or uint8 views)."""
     _need_gpu(a8, b8_nk, c)
-    M, K = a8.shape
-    N = b8_nk.shape[0]
+    M, N, K = _gemm_dims(a8, b8_nk, c, b_is_nk=True)
     check(load().lc_gemm_fp8_e4m3(_ptr(a8), _ptr(b8_nk), _ptr(c), M, N, K, float(alpha), swizzle_stride, _stream()),
           "lc_gemm_fp8_e4m3")
     return c
@@ -140,8 +218,9 @@ def gemm_fp8(a8, b8_nk, c, alpha=1.0, swizzle_stride=1):
 
 def hgemm_call(entry: str, a, b, c, stages=2, swizzle=False, swizzle_stride=1):
     _need_gpu(a, b, c)
-    M, K = a.shape
-    N = c.shape[1]
+    lay = C.c_int(LAYOUT_NN)
+    load().lc_hgemm_entry_info(entry.encode(), C.byref(lay), None)   # unknown names fail in lc_hgemm_call below
+    M, N, K = _gemm_dims(a, b, c, lay.value)
     check(load().lc_hgemm_call(entry.encode(), _ptr(a), _ptr(b), _ptr(c), M, N, K, stages, int(swizzle),
                                swizzle_stride, _stream()), entry)
     return c
@@ -149,8 +228,7 @@ def hgemm_call(entry: str, a, b, c, stages=2, swizzle=False, swizzle_stride=1):
 
 def hgemm_vendor(a, b, c, layout=LAYOUT_NN):
     _need_gpu(a, b, c)
-    M, K = a.shape
-    N = c.shape[1]
+    M, N, K = _gemm_dims(a, b, c, layout)
     check(load().lc_hgemm_vendor_f16(_ptr(a), _ptr(b), _ptr(c), M, N, K, layout, _stream()),
           "lc_hgemm_vendor_f16")
     return c
@@ -168,8 +246,7 @@ def hgemm_time(a, b, c, layout=LAYOUT_NN, variant=HGEMM_AUTO, stages=2, swizzle_
                iters=10) -> float:
     """Average ms per launch, HIP events on the launch stream."""
     _need_gpu(a, b, c)
-    M, K = a.shape
-    N = c.shape[1]
+    M, N, K = _gemm_dims(a, b, c, layout)
     ms = C.c_float(0)
     check(load().lc_hgemm_time(_ptr(a), _ptr(b), _ptr(c), M, N, K, layout, variant, stages, swizzle_stride,
                                warmup, iters, _stream(), C.byref(ms)), "lc_hgemm_time")
@@ -192,7 +269,7 @@ def attn_fwd(q, k, v, o, v_transposed=False, family=ATTN_SPLIT_Q, acc_f32=False,
     import torch
     _need_gpu(q, k, v, o)
     assert q.dtype == k.dtype == v.dtype == o.dtype == torch.half
-    B, H, N, D = q.shape
+    B, H, N, D = _attn_dims(q, k, v, o, v_transposed)
     check(load().lc_attn_fwd_f16(_ptr(q), _ptr(k), _ptr(v), _ptr(o), B, H, N, D, int(v_transposed), family,
                                  int(acc_f32), stages, _stream()), "lc_attn_fwd_f16")
     return o
@@ -203,14 +280,16 @@ def attn_fwd_bf16(q, k, v, o):
     import torch
     _need_gpu(q, k, v, o)
     assert q.dtype == k.dtype == v.dtype == o.dtype == torch.bfloat16
-    B, H, N, D = q.shape
+    B, H, N, D = _attn_dims(q, k, v, o)
     check(load().lc_attn_fwd_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(o), B, H, N, D, _stream()), "lc_attn_fwd_bf16")
     return o
 
 
 def attn_call(entry: str, q, k, v, o, stages=2):
     _need_gpu(q, k, v, o)
-    B, H, N, D = q.shape
+    vt = C.c_int(0)
+    load().lc_attn_entry_info(entry.encode(), None, C.byref(vt), None, None, None, None)
+    B, H, N, D = _attn_dims(q, k, v, o, bool(vt.value))
     check(load().lc_attn_call(entry.encode(), _ptr(q), _ptr(k), _ptr(v), _ptr(o), B, H, N, D, stages,
                               _stream()), entry)
     return o
@@ -218,7 +297,7 @@ def attn_call(entry: str, q, k, v, o, stages=2):
 
 def attn_time(q, k, v, o, v_transposed=False, family=ATTN_SPLIT_Q, stages=2, warmup=1, iters=5) -> float:
     _need_gpu(q, k, v, o)
-    B, H, N, D = q.shape
+    B, H, N, D = _attn_dims(q, k, v, o, v_transposed)
     ms = C.c_float(0)
     check(load().lc_attn_time(_ptr(q), _ptr(k), _ptr(v), _ptr(o), B, H, N, D, int(v_transposed), family,
                               stages, warmup, iters, _stream(), C.byref(ms)), "lc_attn_time")
@@ -234,3 +313,39 @@ def attn_entries():
         lib.lc_attn_entry_info(name, *[C.byref(x) for x in v])
         out.append((name.decode(),) + tuple(x.value for x in v))
     return out
+
+
+# ---- measurement ------------------------------------------------------------------------------------
+class Timer:
+    """HIP events on the launch stream around any sequence of ABI launches (lc_timer_start / lc_timer_stop)."""
+
+    def __enter__(self):
+        self._t = C.c_void_p()
+        check(load().lc_timer_start(_stream(), C.byref(self._t)), "lc_timer_start")
+        self.ms = None
+        return self
+
+    def __exit__(self, et, ev, tb):
+        ms = C.c_float(0)
+        rc = load().lc_timer_stop(self._t, C.byref(ms))
+        if et is None:
+            check(rc, "lc_timer_stop")
+            self.ms = ms.value
+        return False
+
+
+def hgemm_kernel_name(M, N, K, layout=LAYOUT_NN, variant=HGEMM_AUTO) -> str:
+    buf = C.create_string_buffer(128)
+    check(load().lc_hgemm_kernel_name(M, N, K, layout, variant, buf, 128), "lc_hgemm_kernel_name")
+    return buf.value.decode()
+
+
+def attn_kernel_name(N, D, v_transposed=False, bf16=False) -> str:
+    buf = C.create_string_buffer(128)
+    check(load().lc_attn_kernel_name(N, D, int(v_transposed), int(bf16), buf, 128), "lc_attn_kernel_name")
+    return buf.value.decode()
+
+
+def clock_probe(out_u64x2):
+    """Enqueue the {shader cycles, 100 MHz ticks} probe on the current stream (out: int64 cuda tensor of 2)."""
+    check(load().lc_clock_probe(_ptr(out_u64x2), _stream()), "lc_clock_probe")

@@ -321,245 +321,6 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
 
 
 // ------------------------------------------------------------------------------------------------
-// Ping-pong variant (8 waves, N % 256 == 0): the per-tile work of a wave is cut into
-//   X(t) = Sᵀ = K·Qᵀ (16 MFMAs) + row max + (rare) rescale of O/l     — MFMA first, light VALU
-//   Y(t) = P = exp2(...) / row sums / fp16 pack (VALU + transcendental) + Oᵀ += Vᵀ·Pᵀ (16 MFMAs)
-// and the two waves that share a SIMD (wave w and w+4) run one barrier apart, so on every SIMD an X
-// phase always faces a Y phase: the exp/VALU work of one wave hides behind the MFMAs of the other
-// (in the lock-step kernel above both waves hit the matrix pipe and the VALU at the same moments).
-// K(t+1) is written to the LDS ring at the end of X(t), V(t+1) at the end of Y(t); with group 1 one slot
-// behind group 0 every write lands >= 1 barrier after the last read of the slot it replaces and >= 1
-// barrier before its first read (K is only read in X phases, V only in Y phases).
-template <int D, bool VT>
-__global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(
-    const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
-    half_t* __restrict__ O, int N, int nqb, float sl2) {
-  using C = AttnCfg<D>;
-  constexpr int NW = 8, NT = 512;
-  constexpr int DT = D / 32, DS = D / 16;
-  constexpr int VB = VT ? C::VTBYTES : C::VBYTES;
-  constexpr int SLOT = C::KBYTES + VB;
-  constexpr int K_CHUNKS = KVB * C::CH;
-  constexpr int V_CHUNKS = VT ? D * 8 : KVB * C::CH;
-  constexpr int KL = (K_CHUNKS + NT - 1) / NT;
-  constexpr int VL = (V_CHUNKS + NT - 1) / NT;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = wave_id();
-  const int grp = wave >> 2;   // 0: leads, 1: one barrier behind (waves w and w+4 share a SIMD)
-  const int hi = lane >> 5;
-  const int l32 = lane & 31;
-
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const size_t bh = id / nqb;
-  const int q0 = (id - (int)bh * nqb) * (NW * 32) + wave * 32;
-  const half_t* Qb = Q + bh * (size_t)N * D;
-  const half_t* Kb = K + bh * (size_t)N * D;
-  const half_t* Vb = V + bh * (size_t)N * D;
-  half_t* Ob = O + bh * (size_t)N * D;
-
-  half8_t qf[DS];
-#pragma unroll
-  for (int s = 0; s < DS; ++s) qf[s] = *(const half8_t*)(Qb + (size_t)(q0 + l32) * D + 16 * s + 8 * hi);
-
-  u32x4_t kst[KL], vst[VL];
-  auto load_k = [&](int t) {
-#pragma unroll
-    for (int j = 0; j < KL; ++j) {
-      const int idx = tid + j * NT;
-      if (K_CHUNKS % NT == 0 || idx < K_CHUNKS)
-        kst[j] = *(const u32x4_t*)(Kb + (size_t)t * KVB * D + (size_t)idx * 8);
-    }
-  };
-  auto load_v = [&](int t) {
-#pragma unroll
-    for (int j = 0; j < VL; ++j) {
-      const int idx = tid + j * NT;
-      if (V_CHUNKS % NT == 0 || idx < V_CHUNKS) {
-        if constexpr (!VT)
-          vst[j] = *(const u32x4_t*)(Vb + (size_t)t * KVB * D + (size_t)idx * 8);
-        else
-          vst[j] = *(const u32x4_t*)(Vb + (size_t)(idx >> 3) * N + (size_t)t * KVB + (idx & 7) * 8);
-      }
-    }
-  };
-  auto store_k = [&](char* slot) {
-#pragma unroll
-    for (int j = 0; j < KL; ++j) {
-      const int idx = tid + j * NT;
-      if (K_CHUNKS % NT == 0 || idx < K_CHUNKS)
-        *(u32x4_t*)(slot + (idx / C::CH) * C::KSTRIDE + (idx % C::CH) * 16) = kst[j];
-    }
-  };
-  auto store_v = [&](char* slot) {
-#pragma unroll
-    for (int j = 0; j < VL; ++j) {
-      const int idx = tid + j * NT;
-      if (V_CHUNKS % NT == 0 || idx < V_CHUNKS) {
-        if constexpr (!VT)
-          *(u32x4_t*)(slot + C::KBYTES + (idx / C::CH) * C::VSTRIDE + (idx % C::CH) * 16) = vst[j];
-        else
-          *(u32x4_t*)(slot + C::KBYTES + (idx >> 3) * C::VT_STRIDE + (idx & 7) * 16) = vst[j];
-      }
-    }
-  };
-
-  const int k_rd = l32 * C::KSTRIDE + hi * 16;
-  int v_rd;
-  if constexpr (!VT) {
-    const int i = lane & 15, gi = (lane >> 4) & 1;
-    v_rd = C::KBYTES + (4 * hi + (i >> 2)) * C::VSTRIDE + (16 * gi + 4 * (i & 3)) * 2;
-  } else {
-    v_rd = C::KBYTES + l32 * C::VT_STRIDE + (4 * hi) * 2;
-  }
-
-  f32x16_t o[DT];
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  const int T = N / KVB;
-  load_k(0);
-  load_v(0);
-  store_k(smem);
-  store_v(smem);
-  // the global loads run a FULL tile ahead of their LDS store (K(t+1) is issued right after K(t) left the
-  // staging registers, at the end of X(t-1), and stored at the end of X(t)): with the loads issued at the start
-  // of X(t) the store at its end waited for HBM inside every phase.
-  if (T > 1) {
-    load_k(1);
-    load_v(1);
-  }
-#pragma unroll
-  for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(qf[s]));   // retire the Q loads before the loop
-  pp_sync();
-  if (grp == 1) pp_sync();
-
-  for (int t = 0; t < T; ++t) {
-    char* cur = smem + (t & 1) * SLOT;
-    char* nxt = smem + ((t & 1) ^ 1) * SLOT;
-    const bool more = t + 1 < T;
-    // =========================== X(t) ===========================
-    f32x16_t s[2];
-    {
-      constexpr int GQ = (DS % 4 == 0) ? 4 : 2;
-      constexpr int NGQ = 2 * DS / GQ;
-      half8_t kf[2][GQ];
-      auto read_k = [&](int g, half8_t (&dst)[GQ]) {
-#pragma unroll
-        for (int i = 0; i < GQ; ++i) {
-          const int idx = g * GQ + i, tt = idx & 1, ks = idx >> 1;  // two independent accumulator chains
-          dst[i] = *(const half8_t*)(cur + k_rd + tt * 32 * C::KSTRIDE + ks * 32);
-        }
-      };
-      read_k(0, kf[0]);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int g = 0; g < NGQ; ++g) {
-        if (g + 1 < NGQ) read_k(g + 1, kf[(g + 1) & 1]);
-#pragma unroll
-        for (int i = 0; i < GQ; ++i) {
-          const int idx = g * GQ + i, tt = idx & 1, ks = idx >> 1;  // two independent accumulator chains
-          s[tt] = mfma32(kf[g & 1][i], qf[ks], ks == 0 ? (f32x16_t)0.f : s[tt]);
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_group_barrier(0x100, GQ, 0);
-#pragma unroll
-      for (int g = 0; g < NGQ; ++g) {
-        if (g + 1 < NGQ) __builtin_amdgcn_sched_group_barrier(0x100, GQ, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, GQ, 0);
-      }
-    }
-    {
-      float mt[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) mt[r] = fmaxf(fmaxf(s[0][r], s[0][r + 8]), fmaxf(s[1][r], s[1][r + 8]));
-      float mx = fmaxf(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3])),
-                       fmaxf(fmaxf(mt[4], mt[5]), fmaxf(mt[6], mt[7])));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_cand = fmaxf(m_run, mx * sl2);
-      if (!__all(m_cand - m_run <= RESCALE_THR)) {   // PV(t-1) is complete: O, l are all at the old scale
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);
-        m_run = m_cand;
-        l_run *= alpha;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-      }
-    }
-    if (more) {
-      store_k(nxt);
-      if (t + 2 < T) load_k(t + 2);
-    }
-    pp_sync();
-    // =========================== Y(t) ===========================
-    {
-      float ps[4] = {0.f, 0.f, 0.f, 0.f};
-      half8_t pf[2][2];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[tt][8 * u + j], sl2, -m_run));
-            ps[j & 3] += p;
-            pf[tt][u][j] = (half_t)p;
-          }
-      l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
-      half8_t vf[2][DT];
-      auto read_v = [&](int g, half8_t (&dst)[DT]) {
-        const int tt = g >> 1, u = g & 1;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          if constexpr (!VT) {
-            const char* p = cur + v_rd + (32 * tt + 16 * u) * C::VSTRIDE + dt * 64;
-            dst[dt] = cat4(lds_tr16(p), lds_tr16(p + 8 * C::VSTRIDE));
-          } else {
-            const char* p = cur + v_rd + dt * 32 * C::VT_STRIDE + (32 * tt + 16 * u) * 2;
-            dst[dt] = cat4(*(const half4_t*)p, *(const half4_t*)(p + 16));
-          }
-        }
-      };
-      read_v(0, vf[0]);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (g < 3) read_v(g + 1, vf[(g + 1) & 1]);
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) o[dt] = mfma32(vf[g & 1][dt], pf[g >> 1][g & 1], o[dt]);
-      }
-    }
-    if (more) {
-      store_v(nxt);
-      if (t + 2 < T) load_v(t + 2);
-    }
-    pp_sync();
-  }
-  if (grp == 0) pp_sync();
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
-  half_t* orow = Ob + (size_t)(q0 + l32) * D;
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      half4_t h;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) h[j] = (half_t)(o[dt][4 * rq + j] * inv);
-      *(half4_t*)(orow + 32 * dt + 8 * rq + 4 * hi) = h;
-    }
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------------
 // Four-cluster role-split variant (8 waves, D = 128, N % 256 == 0): per KV tile every wave runs four
 // barrier-separated segments
 //     L1: K fragments LDS -> registers (16 ds_read_b128) + LDS-DMA issue of K/V(t+1)
@@ -821,296 +582,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_c4_kernel(
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Software-pipelined variant (8 waves, N % 256 == 0): inside ONE wave's instruction stream the MFMAs of
-// tile t+1's Sᵀ = K·Qᵀ are issued next to the exp2 / row-sum / fp16-pack VALU work of tile t, and the
-// MFMAs of Oᵀ += Vᵀ·Pᵀ (tile t) next to the row-max tree of tile t+1: every MFMA cluster carries
-// independent VALU work in its shadow (the matrix pipe paces at 32 cycles per MFMA; a wave has ~7 issue
-// slots per MFMA to spend).  Two Sᵀ tiles are live (+32 VGPRs).  K runs one tile ahead of V:
-// iteration t reads K(t+1) and V(t) and stages K(t+2) and V(t+1) (2-slot rings each, one barrier per tile).
-template <int D, bool VT>
-__global__ __launch_bounds__(512, 2) void attn_fwd_swp_kernel(
-    const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
-    half_t* __restrict__ O, int N, int nqb, float sl2) {
-  using C = AttnCfg<D>;
-  constexpr int NW = 8, NT = 512;
-  constexpr int DT = D / 32, DS = D / 16;
-  constexpr int VB = VT ? C::VTBYTES : C::VBYTES;
-  constexpr int K_CHUNKS = KVB * C::CH;
-  constexpr int V_CHUNKS = VT ? D * 8 : KVB * C::CH;
-  constexpr int KL = (K_CHUNKS + NT - 1) / NT;
-  constexpr int VL = (V_CHUNKS + NT - 1) / NT;
-  // LDS: [K slot 0][K slot 1][V slot 0][V slot 1]
-  constexpr int KOFF = 0, VOFF = 2 * C::KBYTES;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = wave_id();
-  const int hi = lane >> 5;
-  const int l32 = lane & 31;
-
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const size_t bh = id / nqb;
-  const int q0 = (id - (int)bh * nqb) * (NW * 32) + wave * 32;
-  const half_t* Qb = Q + bh * (size_t)N * D;
-  const half_t* Kb = K + bh * (size_t)N * D;
-  const half_t* Vb = V + bh * (size_t)N * D;
-  half_t* Ob = O + bh * (size_t)N * D;
-
-  half8_t qf[DS];
-#pragma unroll
-  for (int s = 0; s < DS; ++s) qf[s] = *(const half8_t*)(Qb + (size_t)(q0 + l32) * D + 16 * s + 8 * hi);
-
-  u32x4_t kst[KL], vst[VL];
-  auto load_k = [&](int t) {
-#pragma unroll
-    for (int j = 0; j < KL; ++j) {
-      const int idx = tid + j * NT;
-      if (K_CHUNKS % NT == 0 || idx < K_CHUNKS)
-        kst[j] = *(const u32x4_t*)(Kb + (size_t)t * KVB * D + (size_t)idx * 8);
-    }
-  };
-  auto load_v = [&](int t) {
-#pragma unroll
-    for (int j = 0; j < VL; ++j) {
-      const int idx = tid + j * NT;
-      if (V_CHUNKS % NT == 0 || idx < V_CHUNKS) {
-        if constexpr (!VT)
-          vst[j] = *(const u32x4_t*)(Vb + (size_t)t * KVB * D + (size_t)idx * 8);
-        else
-          vst[j] = *(const u32x4_t*)(Vb + (size_t)(idx >> 3) * N + (size_t)t * KVB + (idx & 7) * 8);
-      }
-    }
-  };
-  auto store_k = [&](int slot) {
-    char* base = smem + KOFF + slot * C::KBYTES;
-#pragma unroll
-    for (int j = 0; j < KL; ++j) {
-      const int idx = tid + j * NT;
-      if (K_CHUNKS % NT == 0 || idx < K_CHUNKS)
-        *(u32x4_t*)(base + (idx / C::CH) * C::KSTRIDE + (idx % C::CH) * 16) = kst[j];
-    }
-  };
-  auto store_v = [&](int slot) {
-    char* base = smem + VOFF + slot * VB;
-#pragma unroll
-    for (int j = 0; j < VL; ++j) {
-      const int idx = tid + j * NT;
-      if (V_CHUNKS % NT == 0 || idx < V_CHUNKS) {
-        if constexpr (!VT)
-          *(u32x4_t*)(base + (idx / C::CH) * C::VSTRIDE + (idx % C::CH) * 16) = vst[j];
-        else
-          *(u32x4_t*)(base + (idx >> 3) * C::VT_STRIDE + (idx & 7) * 16) = vst[j];
-      }
-    }
-  };
-
-  const int k_rd = KOFF + l32 * C::KSTRIDE + hi * 16;
-  int v_rd;
-  if constexpr (!VT) {
-    const int i = lane & 15, gi = (lane >> 4) & 1;
-    v_rd = VOFF + (4 * hi + (i >> 2)) * C::VSTRIDE + (16 * gi + 4 * (i & 3)) * 2;
-  } else {
-    v_rd = VOFF + l32 * C::VT_STRIDE + (4 * hi) * 2;
-  }
-
-  f32x16_t o[DT];
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  // Sᵀ(tile) from K slot `ks_` : 2 x DS MFMAs on two independent accumulators
-  auto qk = [&](int kslot, f32x16_t (&sd)[2]) {
-    const char* kb = smem + kslot * C::KBYTES;
-#pragma unroll
-    for (int ks = 0; ks < DS; ++ks) {
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const half8_t kf = *(const half8_t*)(kb + k_rd + tt * 32 * C::KSTRIDE + ks * 32);
-        sd[tt] = mfma32(kf, qf[ks], ks == 0 ? (f32x16_t)0.f : sd[tt]);
-      }
-    }
-  };
-  auto rowmax = [&](const f32x16_t (&sd)[2]) -> float {
-    float mt[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) mt[r] = fmaxf(fmaxf(sd[0][r], sd[0][r + 8]), fmaxf(sd[1][r], sd[1][r + 8]));
-    float mx = fmaxf(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3])),
-                     fmaxf(fmaxf(mt[4], mt[5]), fmaxf(mt[6], mt[7])));
-    return fmaxf(mx, __shfl_xor(mx, 32));
-  };
-  // rare, wave-uniform: every value at the old scale (O, l) is multiplied exactly once; the pending P tile
-  // is exponentiated AFTER this decision with the new m_run.
-  auto rescale = [&](float mx) {
-    const float m_cand = fmaxf(m_run, mx * sl2);
-    if (!__all(m_cand - m_run <= RESCALE_THR)) {
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);
-      m_run = m_cand;
-      l_run *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-    }
-  };
-  auto softmax_p = [&](const f32x16_t (&sd)[2], half8_t (&pf)[2][2]) {
-    float ps[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sd[tt][8 * u + j], sl2, -m_run));
-          ps[j & 3] += p;
-          pf[tt][u][j] = (half_t)p;
-        }
-    l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
-  };
-  auto pv = [&](int vslot, const half8_t (&pf)[2][2]) {
-    const char* vb = smem + vslot * VB;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int tt = g >> 1, u = g & 1;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        half8_t vf;
-        if constexpr (!VT) {
-          const char* p = vb + v_rd + (32 * tt + 16 * u) * C::VSTRIDE + dt * 64;
-          vf = cat4(lds_tr16(p), lds_tr16(p + 8 * C::VSTRIDE));
-        } else {
-          const char* p = vb + v_rd + dt * 32 * C::VT_STRIDE + (32 * tt + 16 * u) * 2;
-          vf = cat4(*(const half4_t*)p, *(const half4_t*)(p + 16));
-        }
-        o[dt] = mfma32(vf, pf[tt][u], o[dt]);
-      }
-    }
-  };
-
-  const int T = N / KVB;
-  // ---- prologue: K(0), V(0), K(1) staged; Sᵀ(0) and its row max computed
-  load_k(0);
-  load_v(0);
-  store_k(0);
-  store_v(0);
-  if (T > 1) {
-    load_k(1);
-    store_k(1);
-  }
-#pragma unroll
-  for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(qf[s]));   // retire the Q loads before the loop
-  __syncthreads();
-  f32x16_t s_cur[2], s_nxt[2];
-  qk(0, s_cur);
-  rescale(rowmax(s_cur));
-
-  for (int t = 0; t + 1 < T; ++t) {
-    if (t + 2 < T) load_k(t + 2);
-    load_v(t + 1);
-    half8_t pf[2][2];
-    // ---- phase 1: 2*DS chunks of { 1 MFMA of Sᵀ(t+1) | 1 K-fragment read 8 MFMAs ahead | exp2 / sum /
-    //      pack of 32/(2*DS) values of P(t) }; __builtin_amdgcn_sched_barrier(0) pins the chunk order.
-    {
-      constexpr int NM = 2 * DS;                 // MFMAs (and chunks)
-      constexpr int PFD = NM < 8 ? NM : 8;       // K fragments in flight
-      constexpr int VPC = (32 + NM - 1) / NM;    // P values per chunk (D=128: 2)
-      const char* kb = smem + ((t + 1) & 1) * C::KBYTES;
-      half8_t kf[PFD];
-      auto kread = [&](int i) -> half8_t {
-        const int tt = i & 1, ks = i >> 1;
-        return *(const half8_t*)(kb + k_rd + tt * 32 * C::KSTRIDE + ks * 32);
-      };
-#pragma unroll
-      for (int i = 0; i < PFD; ++i) kf[i] = kread(i);
-      float ps[4] = {0.f, 0.f, 0.f, 0.f};
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        const int tt = i & 1, ks = i >> 1;
-        s_nxt[tt] = mfma32(kf[i % PFD], qf[ks], ks == 0 ? (f32x16_t)0.f : s_nxt[tt]);
-        if (i + PFD < NM) kf[i % PFD] = kread(i + PFD);
-#pragma unroll
-        for (int e = 0; e < VPC; ++e) {
-          const int v = i * VPC + e;             // 0..31 -> (tt, u, j)
-          if (v < 32) {
-            const int ptt = v >> 4, pu = (v >> 3) & 1, pj = v & 7;
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[ptt][8 * pu + pj], sl2, -m_run));
-            ps[pj & 3] += p;
-            pf[ptt][pu][pj] = (half_t)p;
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
-    }
-    // ---- phase 2: 4*DT chunks of { 1 MFMA of Oᵀ += Vᵀ(t)·Pᵀ(t) | 1 V fragment (2 transpose reads) 4 MFMAs
-    //      ahead | a slice of the row-max tree of Sᵀ(t+1) }
-    float mx;
-    {
-      constexpr int NM = 4 * DT;
-      constexpr int PFD = NM < 4 ? NM : 4;
-      const char* vb = smem + (t & 1) * VB;
-      half8_t vf[PFD];
-      auto vread = [&](int i) -> half8_t {
-        const int g = i / DT, dt = i % DT, tt = g >> 1, u = g & 1;
-        if constexpr (!VT) {
-          const char* p = vb + v_rd + (32 * tt + 16 * u) * C::VSTRIDE + dt * 64;
-          return cat4(lds_tr16(p), lds_tr16(p + 8 * C::VSTRIDE));
-        } else {
-          const char* p = vb + v_rd + dt * 32 * C::VT_STRIDE + (32 * tt + 16 * u) * 2;
-          return cat4(*(const half4_t*)p, *(const half4_t*)(p + 16));
-        }
-      };
-#pragma unroll
-      for (int i = 0; i < PFD; ++i) vf[i] = vread(i);
-      float mt[8];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        const int g = i / DT, dt = i % DT;
-        o[dt] = mfma32(vf[i % PFD], pf[g >> 1][g & 1], o[dt]);
-        if (i + PFD < NM) vf[i % PFD] = vread(i + PFD);
-        // the 8 leaves of the row-max tree of s_nxt, leaf c in chunk (c * NM) / 8
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-          if ((c * NM) / 8 == i)
-            mt[c] = fmaxf(fmaxf(s_nxt[0][c], s_nxt[0][c + 8]), fmaxf(s_nxt[1][c], s_nxt[1][c + 8]));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      mx = fmaxf(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3])),
-                 fmaxf(fmaxf(mt[4], mt[5]), fmaxf(mt[6], mt[7])));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-    }
-    rescale(mx);                         // after P·V(t): O, l at the old scale are complete
-    if (t + 2 < T) store_k(t & 1);       // K(t) was last read in iteration t-1
-    store_v((t + 1) & 1);                // V(t-1) was last read in iteration t-1
-    __syncthreads();
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) s_cur[tt] = s_nxt[tt];
-  }
-  {  // last tile: P(T-1), P·V(T-1)
-    half8_t pf[2][2];
-    softmax_p(s_cur, pf);
-    pv((T - 1) & 1, pf);
-  }
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
-  half_t* orow = Ob + (size_t)(q0 + l32) * D;
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      half4_t h;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) h[j] = (half_t)(o[dt][4 * rq + j] * inv);
-      *(half4_t*)(orow + 32 * dt + 8 * rq + 4 * hi) = h;
-    }
-  }
-}
+// (retired in round 2, git history: attn_fwd_pp_kernel — X/Y phases with the two waves of a SIMD one barrier apart —
+// and attn_fwd_swp_kernel — MFMAs of tile t+1 interleaved with the exp2 / pack VALU of tile t; both measured
+// 0.96-1.02 PFLOP/s at config 3, the same plateau as the lock-step kernel: DESIGN.md section 4.8.)
 
 // ------------------------------------------------------------------------------------------------
 // Large head dims (D = 256, 512): the FFPA-style fine-grained tiling of the reference's

@@ -1,7 +1,7 @@
-// probe.hip — tiny kernels that expose the hardware lane maps the production kernels rely on
+// probe_kernels.hip — tiny kernels that expose the hardware lane maps the production kernels rely on
 // (MFMA operand / accumulator layouts and the ds_read_b64_tr_b16 transpose). Tests only.
 #pragma once
-#include "lc_common.h"
+#include "../lc_common.h"
 
 namespace lc {
 

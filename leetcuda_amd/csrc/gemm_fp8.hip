@@ -322,33 +322,10 @@ __global__ __launch_bounds__(256) void gemm_fp8_w4_kernel(const uint8_t* __restr
   }
   LC_VMCNT(0);
 
-  // epilogue (as hgemm_w4): each wave stages 32 x 128 halves at a time, alpha applied in fp32
+  // epilogue shared with hgemm_w4 (alpha applied in fp32); a K = 64 MFMA is 16 passes: two extra drains
   w4_mfma_drain();
   w4_mfma_drain();
-  w4_mfma_drain();   // a K = 64 MFMA is 16 passes
-  __syncthreads();
-  char* stg = smem + wave * (32 * W4_EPI_STRIDE);
-  half_t* cw = C + (size_t)(m0 + wr * 128) * N + n0 + wc * 128;
-  static_for<4>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    static_for<16>([&](auto qc) {
-      constexpr int j = decltype(qc)::value >> 2, rq = decltype(qc)::value & 3;
-      half4_t h;
-      h[0] = (half_t)(w4_acc_read<16 * (4 * i + j) + 4 * rq + 0>() * alpha);
-      h[1] = (half_t)(w4_acc_read<16 * (4 * i + j) + 4 * rq + 1>() * alpha);
-      h[2] = (half_t)(w4_acc_read<16 * (4 * i + j) + 4 * rq + 2>() * alpha);
-      h[3] = (half_t)(w4_acc_read<16 * (4 * i + j) + 4 * rq + 3>() * alpha);
-      *(half4_t*)(stg + l32 * W4_EPI_STRIDE + (j * 32 + 8 * rq + 4 * hi) * 2) = h;
-    });
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = it * 4 + (lane >> 4);
-      const u32x4_t v = *(const u32x4_t*)(stg + row * W4_EPI_STRIDE + (lane & 15) * 16);
-      *(u32x4_t*)(cw + (size_t)(i * 32 + row) * N + (lane & 15) * 8) = v;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  });
+  w4_epilogue<true>(smem, C, N, m0, n0, wave, wr, wc, lane, alpha);
 }
 
 }  // namespace lc

@@ -8,18 +8,11 @@
 // v_mfma_f32_32x32x16_f16, swapped operands (accumulator = Cᵀ fragments).
 //
 // Wave (wr, wc) = (wave>>2, wave&3) owns C rows [128wr,+128) x cols [64wc,+64) of the tile as
-// 4 (mt) x 2 (nt) 32x32 accumulators. A K tile (64) is processed in 4 phases of 8 MFMAs = one 64x32
-// quadrant each:   P0: A-half0 x B-half0   P1: A-half0 x B-half1   P2: A-half1 x B-half1   P3: A-half1 x B-half0
-// fragment reads:  P0: A0 (8 b128) + B0 (4)   P1: B1 (4)   P2: A1 (8)   P3: none (B0 stays in registers).
-// "half h" of A = rows with ((row>>6)&1)==h, of B = cols with ((col>>5)&1)==h: 16 KiB = 16 DMA pieces,
-// 2 per wave, so each phase issues exactly 2 global_load_lds per wave:
-//       P0: B1(kt+1)   P1: A1(kt+1)   P2: B0(kt+2)   P3: A0(kt+2)        (tile t lives in ring slot t&1)
-// Hazards (j = global phase index, group-1 waves run one barrier behind group-0):
-//   RAW  a half is read in phase j only after every wave executed vmcnt(8) at the end of phase j-1 and a
-//        barrier: exactly 4 younger issue groups (8 loads) may still be in flight at each of those waits.
-//   WAR  a half last read in phase j is re-staged in phase >= j+2 (B0/A0: read P0, restaged P2/P3;
-//        B1: read P1, restaged next P0; A1: read P2, restaged next P1).
-// Tail: issues past the last K tile re-load tile KT-1 into a dead slot (keeps the vmcnt counts exact).
+// 4 (mt) x 2 (nt) 32x32 accumulators; the schedule itself (two phases of 16 MFMAs per K tile, hazards, DMA piece
+// order) is described in front of hgemm_pingpong2_kernel below.  "half h" of A = rows with ((row>>6)&1)==h
+// (16 KiB = 16 DMA pieces, 2 per wave); NN B: sub-image h = columns [128h, +128).
+// This 8-wave kernel is the independently scheduled CROSS-CHECK of the default 4-wave kernel (hgemm_w4.hip); tests
+// require the two to agree.  Its helpers (PPSrc/PPFrag, pp_barrier, LC_VMCNT) are shared with gemm_fp8.hip.
 #pragma once
 #include "hgemm_mfma256.hip"
 
@@ -39,7 +32,7 @@ struct PPSrc {
 
 template <bool B_KN>
 LC_DEVINL void pp_src_init(PPSrc<B_KN>& s, const half_t* A, const half_t* B, int m0, int n0, int N,
-                           int K, int wave, int lane, bool nn_full = false) {
+                           int K, int wave, int lane) {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -63,11 +56,9 @@ LC_DEVINL void pp_src_init(PPSrc<B_KN>& s, const half_t* A, const half_t* B, int
         const int pp = lane & 15;
         const int pair = (pp >> 1) ^ ((k & 3) << 1);
         const int nc = pair * 2 + (pp & 1);  // 16-B chunk index inside the sub-image row
-        // nn_full: sub-image h = the 128 CONTIGUOUS columns [128h, +128) -> every DMA lane group fetches whole
-        // 128-B lines (measured: 64-B source segments double the TA time of a DMA piece); otherwise
-        // sub-image h = the h-th 32-column half of every 64-column wave strip (needed by the 4-phase
-        // schedule, which stages and reads the two halves at different times).
-        const int n = nn_full ? 128 * h + nc * 8 : 64 * (nc >> 2) + 32 * h + (nc & 3) * 8;
+        // sub-image h = the 128 CONTIGUOUS columns [128h, +128) -> every DMA lane group fetches whole 128-B lines
+        // (measured: 64-B source segments double the TA time of a DMA piece)
+        const int n = 128 * h + nc * 8;
         s.b[h][i] = B + (size_t)k * N + n0 + n;
         s.b_lds[h][i] = TILE_BYTES + h * HALF_BYTES + q * 1024;
       }
@@ -83,7 +74,7 @@ struct PPFrag {
 };
 
 template <bool B_KN>
-LC_DEVINL void pp_frag_init(PPFrag<B_KN>& f, int wr, int wc, int lane, bool nn_full = false) {
+LC_DEVINL void pp_frag_init(PPFrag<B_KN>& f, int wr, int wc, int lane) {
   const int l32 = lane & 31, hi = lane >> 5;
   const int swz = (lane >> 1) & 7;
   f.a0 = (wr * 128 + l32) * 128 + ((hi ^ swz) * 16);
@@ -93,10 +84,7 @@ LC_DEVINL void pp_frag_init(PPFrag<B_KN>& f, int wr, int wc, int lane, bool nn_f
   } else {
     const int i = lane & 15, gi = (lane >> 4) & 1;
     const int k = 8 * hi + (i >> 2);
-    if (!nn_full) {
-      f.b0 = TILE_BYTES + k * 256 + (((2 * wc + gi) ^ ((i >> 2) << 1)) * 32) + (i & 3) * 8;
-      f.b1 = f.b0 + HALF_BYTES;
-    } else {   // columns 64wc + 32nh + 16gi.. live in sub-image wc>>1 at 32-B pair 4(wc&1) + 2nh + gi
+    {   // columns 64wc + 32nh + 16gi.. live in sub-image wc>>1 at 32-B pair 4(wc&1) + 2nh + gi
       const int base = TILE_BYTES + (wc >> 1) * HALF_BYTES + k * 256 + (i & 3) * 8;
       f.b0 = base + (((4 * (wc & 1) + gi) ^ ((i >> 2) << 1)) * 32);
       f.b1 = base + (((4 * (wc & 1) + 2 + gi) ^ ((i >> 2) << 1)) * 32);
@@ -147,16 +135,6 @@ LC_DEVINL void pp_b_nn_finish(half4_t (&raw)[8], half8_t (&bf)[4]) {
   for (int ks = 0; ks < 4; ++ks) bf[ks] = cat4(raw[2 * ks], raw[2 * ks + 1]);
 }
 
-LC_DEVINL void pp_mfma(f32x16_t (&acc)[4][2], int mh, int nh, const half8_t (&af)[2][4],
-                       const half8_t (&bf)[4]) {
-  __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-    for (int m = 0; m < 2; ++m) acc[mh * 2 + m][nh] = mfma32(bf[ks], af[m][ks], acc[mh * 2 + m][nh]);
-  __builtin_amdgcn_s_setprio(0);
-}
-
 LC_DEVINL void pp_barrier() {
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
@@ -195,100 +173,6 @@ LC_DEVINL void pp_epilogue(char* smem, f32x16_t (&acc)[4][2], half_t* C, int N, 
   }
 }
 
-template <bool B_KN>
-__global__ __launch_bounds__(512, 2) void hgemm_pingpong_kernel(const half_t* __restrict__ A,
-                                                                const half_t* __restrict__ B,
-                                                                half_t* __restrict__ C, int M, int N,
-                                                                int K, int tiles_m, int tiles_n,
-                                                                int panel_w) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = wave_id();
-  const int wr = wave >> 2, wc = wave & 3;
-
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const TileCoord tc = raster(id, tiles_m, tiles_n, panel_w);
-  const int m0 = tc.tm * BM, n0 = tc.tn * BN;
-
-  PPSrc<B_KN> src;
-  pp_src_init<B_KN>(src, A, B, m0, n0, N, K, wave, lane);
-  PPFrag<B_KN> fr;
-  pp_frag_init<B_KN>(fr, wr, wc, lane);
-
-  f32x16_t acc[4][2];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  const int KT = K / BK;
-  const size_t bstep = B_KN ? (size_t)BK * N : (size_t)BK;
-  // issue half `h` of operand A / B of K tile t (clamped) into ring slot t&1
-  auto issue_a = [&](int h, int t) {
-    const int te = t < KT ? t : KT - 1;
-    char* slot = smem + (t & 1) * SLOT_BYTES;
-    glds16(src.a[h][0] + (size_t)te * BK, slot + src.a_lds[h][0]);
-    glds16(src.a[h][1] + (size_t)te * BK, slot + src.a_lds[h][1]);
-  };
-  auto issue_b = [&](int h, int t) {
-    const int te = t < KT ? t : KT - 1;
-    char* slot = smem + (t & 1) * SLOT_BYTES;
-    glds16(src.b[h][0] + (size_t)te * bstep, slot + src.b_lds[h][0]);
-    glds16(src.b[h][1] + (size_t)te * bstep, slot + src.b_lds[h][1]);
-  };
-
-  // prologue: B0(0) A0(0) B1(0) A1(0) B0(1) A0(1); A0(0), B0(0) must have landed
-  issue_b(0, 0); issue_a(0, 0); issue_b(1, 0); issue_a(1, 0); issue_b(0, 1); issue_a(0, 1);
-  LC_VMCNT(8);
-  pp_barrier();
-  if (wr == 1) pp_barrier();  // group 1 runs one barrier behind group 0 (wave-uniform branch)
-
-  half8_t af[2][4], b0f[4], b1f[4];
-  for (int kt = 0; kt < KT; ++kt) {
-    const char* cur = smem + (kt & 1) * SLOT_BYTES;
-    // ---- phase 0
-    half4_t braw[8];
-    if constexpr (B_KN) pp_read_b_nn_issue<0>(cur, fr, braw); else pp_read_b<B_KN>(cur, fr, 0, b0f);
-    pp_read_a<B_KN>(cur, fr, 0, af);
-    if constexpr (B_KN) pp_b_nn_finish(braw, b0f);
-    issue_b(1, kt + 1);
-    LC_VMCNT(8);
-    pp_barrier();
-    pp_mfma(acc, 0, 0, af, b0f);
-    pp_barrier();
-    // ---- phase 1
-    if constexpr (B_KN) {
-      pp_read_b_nn_issue<1>(cur, fr, braw);
-      pp_b_nn_finish(braw, b1f);
-    } else {
-      pp_read_b<B_KN>(cur, fr, 1, b1f);
-    }
-    issue_a(1, kt + 1);
-    LC_VMCNT(8);
-    pp_barrier();
-    pp_mfma(acc, 0, 1, af, b1f);
-    pp_barrier();
-    // ---- phase 2
-    pp_read_a<B_KN>(cur, fr, 1, af);
-    issue_b(0, kt + 2);
-    pp_barrier();
-    pp_mfma(acc, 1, 1, af, b1f);
-    pp_barrier();
-    // ---- phase 3 (no fragment reads: A1 and B0 are in registers)
-    issue_a(0, kt + 2);
-    LC_VMCNT(8);
-    pp_barrier();
-    pp_mfma(acc, 1, 0, af, b0f);
-    pp_barrier();
-  }
-  if (wr == 0) pp_barrier();
-  LC_VMCNT(0);
-  pp_epilogue(smem, acc, C, N, m0, n0, wave, wr, wc, lane);
-}
-
-
 // ------------------------------------------------------------------------------------------------
 // Two-phase ping-pong (LC_HGEMM_MFMA256P2): 16 MFMAs per phase, 4 barriers per K tile, LDS-DMA issued
 // from INSIDE the MFMA clusters (between MFMAs, where the wave has spare issue slots) instead of from the
@@ -323,13 +207,9 @@ LC_DEVINL void pp2_mfma(f32x16_t (&acc)[4][2], int mh, const half8_t (&af)[2][4]
   __builtin_amdgcn_s_setprio(0);
 }
 
-// DMA_IN_LOAD = false: DMA pieces ride inside the MFMA clusters (3 slots of flight, but every issue can
-//                      hold the wave's next MFMA back);
-// DMA_IN_LOAD = true : the load sections issue them (A0,B0,B1 of tile T+1 in load A(T), A1(T+1) in load
-//                      B(T); 2 slots of flight; MFMA clusters are bare).  Same vmcnt counts in both forms:
-//                      issue order ... A0B(T) | A1(T) | A0B(T+1) | A1(T+1) ..., WAR: re-stage in load phase
-//                      j+2 of the last read j.
-template <bool B_KN, bool DMA_IN_LOAD, bool STAMPS = false>
+// (measured and dropped in round 1: issuing the DMA from the load sections instead — 2 barrier intervals of flight are
+// not enough, 1187 vs 1322 TFLOP/s — and the 4-phase / 8-barrier schedule, 1283)
+template <bool B_KN, bool STAMPS = false>
 __global__ __launch_bounds__(512, 2) void hgemm_pingpong2_kernel(const half_t* __restrict__ A,
                                                                  const half_t* __restrict__ B,
                                                                  half_t* __restrict__ C, int M, int N,
@@ -345,9 +225,9 @@ __global__ __launch_bounds__(512, 2) void hgemm_pingpong2_kernel(const half_t* _
   const int m0 = tc.tm * BM, n0 = tc.tn * BN;
 
   PPSrc<B_KN> src;
-  pp_src_init<B_KN>(src, A, B, m0, n0, N, K, wave, lane, true);
+  pp_src_init<B_KN>(src, A, B, m0, n0, N, K, wave, lane);
   PPFrag<B_KN> fr;
-  pp_frag_init<B_KN>(fr, wr, wc, lane, true);
+  pp_frag_init<B_KN>(fr, wr, wc, lane);
 
   f32x16_t acc[4][2];
 #pragma unroll
@@ -376,13 +256,9 @@ __global__ __launch_bounds__(512, 2) void hgemm_pingpong2_kernel(const half_t* _
   for (int g = 0; g < 6; ++g) issue_ab0(g, 0);
   piece(0, 1, 0, 0);
   piece(0, 1, 1, 0);
-  if constexpr (!DMA_IN_LOAD) {
 #pragma unroll
-    for (int g = 0; g < 6; ++g) issue_ab0(g, 1);
-    LC_VMCNT(8);
-  } else {
-    LC_VMCNT(2);
-  }
+  for (int g = 0; g < 6; ++g) issue_ab0(g, 1);
+  LC_VMCNT(8);
   pp_barrier();
   if (wr == 1) pp_barrier();
 
@@ -403,10 +279,6 @@ __global__ __launch_bounds__(512, 2) void hgemm_pingpong2_kernel(const half_t* _
     const char* cur = smem + (kt & 1) * SLOT_BYTES;
     STAMP(kt, 0);
     // ---- phase A
-    if constexpr (DMA_IN_LOAD) {
-#pragma unroll
-      for (int g = 0; g < 6; ++g) issue_ab0(g, kt + 1);
-    }
     half4_t braw0[8], braw1[8];
     if constexpr (B_KN) {
       pp_read_b_nn_issue<0>(cur, fr, braw0);
@@ -427,26 +299,16 @@ __global__ __launch_bounds__(512, 2) void hgemm_pingpong2_kernel(const half_t* _
     STAMP(kt, 1);
     pp_barrier();
     STAMP(kt, 2);
-    if constexpr (DMA_IN_LOAD)
-      pp2_mfma<B_KN, 0>(acc, 0, af, b0f, b1f, [](int) {});
-    else
-      pp2_mfma<B_KN, 2>(acc, 0, af, b0f, b1f, [&](int g) { piece(0, 1, g, kt + 1); });
+    pp2_mfma<B_KN, 2>(acc, 0, af, b0f, b1f, [&](int g) { piece(0, 1, g, kt + 1); });
     STAMP(kt, 3);
     pp_barrier();
     STAMP(kt, 4);
     // ---- phase B
-    if constexpr (DMA_IN_LOAD) {
-      piece(0, 1, 0, kt + 1);
-      piece(0, 1, 1, kt + 1);
-    }
     pp_read_a<B_KN>(cur, fr, 1, af);
     LC_VMCNT(2);
     pp_barrier();
     STAMP(kt, 6);
-    if constexpr (DMA_IN_LOAD)
-      pp2_mfma<B_KN, 0>(acc, 1, af, b0f, b1f, [](int) {});
-    else
-      pp2_mfma<B_KN, 6>(acc, 1, af, b0f, b1f, [&](int g) { issue_ab0(g, kt + 2); });
+    pp2_mfma<B_KN, 6>(acc, 1, af, b0f, b1f, [&](int g) { issue_ab0(g, kt + 2); });
     STAMP(kt, 7);
     pp_barrier();
   }

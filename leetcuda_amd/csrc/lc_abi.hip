@@ -6,7 +6,10 @@
 #include "../../include/lc_abi.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
+
+#include <new>
 
 #include <mutex>
 #include <utility>
@@ -18,7 +21,6 @@
 #include "hgemm_mfma128.hip"
 #include "hgemm_mfma256.hip"
 #include "hgemm_pingpong.hip"
-#include "probe.hip"
 
 using namespace lc;
 
@@ -32,7 +34,8 @@ namespace {
 
 // run-time tuning knobs (lc_tune_set): experiments and A/B benches, never required for correctness
 int g_tune_fp8_mx = 1;                       // fp8 GEMM: 1 = MX-scaled K=64 MFMA, 4-wave kernel; 2 = MX, 8-wave kernel; 0 = plain K=16 MFMA
-int g_tune_attn_nw = 0;                    // waves per attention workgroup: 0 = auto, 8 / 4 / 2
+int g_tune_attn_nw = 0;                    // attention kernel for D = 128: 0 = auto, 128 / 64 / 8 / 4 / 2 (lc_abi.h)
+int g_tune_attn_d512 = 0;                  // D = 512: 0 = auto (full-width workgroup), 1 = column-split kernel
 int g_tune_hgemm_auto = LC_HGEMM_MFMA256W4C;   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -162,26 +165,17 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   const int tiles_m = M / BM, tiles_n = N / BN;
   const int pw = panel_tiles(swizzle_stride, tiles_n, BN);
   const dim3 grid(tiles_m * tiles_n), block(512);
-  if (variant == LC_HGEMM_MFMA256W4 || variant == LC_HGEMM_MFMA256W4S || variant == LC_HGEMM_MFMA256W4B ||
-      variant == LC_HGEMM_MFMA256W4C)
+  if (variant == LC_HGEMM_MFMA256W4B || variant == LC_HGEMM_MFMA256W4C || variant == LC_HGEMM_MFMA256W4D)
     return launch_w4_family(A, B, C, M, N, K, variant, B_KN, tiles_m, tiles_n, pw, st);
   if (false) {
 #ifdef LC_DIAG
   } else if (variant == LC_HGEMM_MFMA256P2 && g_tune_hgemm_stamps) {
-    auto kern = hgemm_pingpong2_kernel<B_KN, false, true>;
-    if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
-    hipLaunchKernelGGL(kern, grid, block, HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
-#endif
-  } else if (variant == LC_HGEMM_MFMA256P3) {
     auto kern = hgemm_pingpong2_kernel<B_KN, true>;
     if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
     hipLaunchKernelGGL(kern, grid, block, HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
+#endif
   } else if (variant == LC_HGEMM_MFMA256P2) {
-    auto kern = hgemm_pingpong2_kernel<B_KN, false>;
-    if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
-    hipLaunchKernelGGL(kern, grid, block, HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
-  } else if (variant == LC_HGEMM_MFMA256P) {
-    auto kern = hgemm_pingpong_kernel<B_KN>;
+    auto kern = hgemm_pingpong2_kernel<B_KN>;
     if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
     hipLaunchKernelGGL(kern, grid, block, HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
   } else {
@@ -226,19 +220,6 @@ int launch_attn(const half_t* Q, const half_t* K, const half_t* V, half_t* O, in
   return check_launch();
 }
 
-template <int D, bool VT>
-int launch_attn_pp(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
-                   hipStream_t st) {
-  auto kern = attn_fwd_pp_kernel<D, VT>;
-  constexpr int lds = attn_lds_bytes<D, VT>();
-  if (int rc = set_dyn_lds(kern, lds)) return rc;
-  const int nqb = N / 256;
-  const dim3 grid((unsigned)((size_t)nqb * B * H)), block(512);
-  const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
-  hipLaunchKernelGGL(kern, grid, block, lds, st, Q, K, V, O, N, nqb, sl2);
-  return check_launch();
-}
-
 template <int D>
 int launch_attn_c4(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                    hipStream_t st) {
@@ -263,27 +244,27 @@ int launch_attn_c4(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   return check_launch();
 }
 
-template <int D, bool VT>
-int launch_attn_swp(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
-                    hipStream_t st) {
-  auto kern = attn_fwd_swp_kernel<D, VT>;
-  constexpr int lds = attn_lds_bytes<D, VT>();
-  if (int rc = set_dyn_lds(kern, lds)) return rc;
-  const int nqb = N / 256;
-  const dim3 grid((unsigned)((size_t)nqb * B * H)), block(512);
-  const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
-  hipLaunchKernelGGL(kern, grid, block, lds, st, Q, K, V, O, N, nqb, sl2);
-  return check_launch();
+// Which kernel serves a D <= 128 problem: 128 = 4 waves x 64 rows (attn_w4.hip), 64 = four-cluster kernel, 8 / 4 / 2 =
+// lock-step kernel with that many waves.  ONE function for the launcher and lc_attn_kernel_name().
+int choose_attn_nw(int D, bool vt, int N) {
+  const int want = g_tune_attn_nw;   // 0 = auto
+  if (D == 128 && !vt && N % 256 == 0) {
+    if (want == 128) return 128;
+    // default for D = 128: the four-cluster LDS-DMA kernel (measured 2-3 % ahead of the lock-step kernel at config 3)
+    if (want == 64 || (want == 0 && g_tune_attn_ablate == 0)) return 64;
+  }
+  if (N % 256 == 0 && (want == 0 || want >= 8)) return 8;
+  if (N % 128 == 0 && (want == 0 || want >= 4)) return 4;
+  return 2;
 }
 
 template <int D, bool VT>
 int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                    hipStream_t st) {
+  const int nw = choose_attn_nw(D, VT, N);
   if constexpr (D == 128 && !VT) {
-    // default for D = 128: the four-cluster LDS-DMA kernel (measured 2-3 % ahead of the lock-step kernel at config 3)
-    if (N % 256 == 0 && (g_tune_attn_nw == 64 || (g_tune_attn_nw == 0 && g_tune_attn_ablate == 0)))
-      return launch_attn_c4<D>(Q, K, V, O, B, H, N, st);
-    if (N % 256 == 0 && g_tune_attn_nw == 128) return launch_attn_w4_d128(Q, K, V, O, B, H, N, st);
+    if (nw == 64) return launch_attn_c4<D>(Q, K, V, O, B, H, N, st);
+    if (nw == 128) return launch_attn_w4_d128(Q, K, V, O, B, H, N, st);
   }
   if constexpr (D == 128 && !VT) {   // perf-diagnosis instantiations (lc_tune_set "attn_ablate")
     switch (g_tune_attn_ablate) {
@@ -304,11 +285,8 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
       default: break;
     }
   }
-  const int want = g_tune_attn_nw;  // 0 = auto
-  if (N % 256 == 0 && want == 32) return launch_attn_swp<D, VT>(Q, K, V, O, B, H, N, st);
-  if (N % 256 == 0 && want == 16) return launch_attn_pp<D, VT>(Q, K, V, O, B, H, N, st);
-  if (N % 256 == 0 && (want == 0 || want == 8)) return launch_attn<D, 8, VT>(Q, K, V, O, B, H, N, st);
-  if (N % 128 == 0 && (want == 0 || want >= 4)) return launch_attn<D, 4, VT>(Q, K, V, O, B, H, N, st);
+  if (nw == 8) return launch_attn<D, 8, VT>(Q, K, V, O, B, H, N, st);
+  if (nw == 4) return launch_attn<D, 4, VT>(Q, K, V, O, B, H, N, st);
   return launch_attn<D, 2, VT>(Q, K, V, O, B, H, N, st);
 }
 
@@ -348,40 +326,11 @@ int launch_attn_d(const half_t* Q, const half_t* K, const half_t* V, half_t* O, 
   }
 }
 
+}  // namespace
+
 // ------------------------------------------------------------------------------------------------
 // vendor comparator (hipBLASLt), resolved lazily with dlopen so the core library has no link-time
 // dependency on it.
-template <int F, int K>
-int probe_coissue_mode(int mode, unsigned long long* out, hipStream_t st) {
-  const int threads = mode == 1 ? 512 : 256;
-  if (mode == 0) hipLaunchKernelGGL((probe_coissue_kernel<F, K, 0>), dim3(1), dim3(threads), 0, st, out, 1.0f);
-  else if (mode == 1) return LC_ERR_ARG;   // (cross-wave mode removed: its per-instruction branches dominated the result)
-  else if (mode == 3) hipLaunchKernelGGL((probe_coissue_kernel<F, K, 3>), dim3(1), dim3(threads), 0, st, out, 1.0f);
-  else hipLaunchKernelGGL((probe_coissue_kernel<F, K, 2>), dim3(1), dim3(threads), 0, st, out, 1.0f);
-  return check_launch();
-}
-template <int F>
-int probe_coissue_k(int k, int mode, unsigned long long* out, hipStream_t st) {
-  switch (k) {
-    case 1: return probe_coissue_mode<F, 1>(mode, out, st);
-    case 2: return probe_coissue_mode<F, 2>(mode, out, st);
-    case 4: return probe_coissue_mode<F, 4>(mode, out, st);
-    case 8: return probe_coissue_mode<F, 8>(mode, out, st);
-    default: return LC_ERR_ARG;
-  }
-}
-template <int KIND, int QUEUED>
-int probe_war_delay(int delay, const half_t* a, const half_t* b, float* d, hipStream_t st) {
-#define LC_WAR_CASE(D) case D: hipLaunchKernelGGL((probe_mfma_war_kernel<D, KIND, QUEUED>), dim3(1), dim3(64), 0, st, a, b, d); break;
-  switch (delay) {
-    LC_WAR_CASE(0) LC_WAR_CASE(1) LC_WAR_CASE(2) LC_WAR_CASE(3) LC_WAR_CASE(4) LC_WAR_CASE(6) LC_WAR_CASE(8)
-    LC_WAR_CASE(11) LC_WAR_CASE(15)
-    default: return LC_ERR_ARG;
-  }
-#undef LC_WAR_CASE
-  return check_launch();
-}
-}  // namespace
 
 #include "vendor_gemm.inc"
 
@@ -402,11 +351,86 @@ const char* lc_status_string(int status) {
   }
 }
 
+const char* lc_build_info(int* is_diag) {
+#ifdef LC_DIAG
+  if (is_diag) *is_diag = 1;
+  return "gfx950 -O3 LC_DIAG=1 (diagnosis build: ablation / stamp kernels compiled in)";
+#else
+  if (is_diag) *is_diag = 0;
+  return "gfx950 -O3 LC_DIAG=0";
+#endif
+}
+
+namespace {
+bool is_w4_variant(int v) {
+  return v == LC_HGEMM_MFMA256W4B || v == LC_HGEMM_MFMA256W4C || v == LC_HGEMM_MFMA256W4D;
+}
+bool is_tile256_variant(int v) { return v == LC_HGEMM_MFMA256 || v == LC_HGEMM_MFMA256P2 || is_w4_variant(v); }
+bool is_hgemm_variant(int v) {
+  return v == LC_HGEMM_AUTO || v == LC_HGEMM_GENERIC || v == LC_HGEMM_MFMA128 || is_tile256_variant(v);
+}
+}  // namespace
+
+namespace {
+// LC_HGEMM_AUTO -> a concrete kernel family; tile checks of the explicit families.  ONE function for lc_hgemm_f16
+// and lc_hgemm_kernel_name().  Returns the variant or a negative lc_status.
+int resolve_hgemm_variant(int variant, int M, int N, int K, bool al) {
+  const bool tiles256 = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && al;
+  const bool tiles128 = (M % BM1 == 0) && (N % BN1 == 0) && (K % BK == 0) && al;
+  if (variant == LC_HGEMM_AUTO) {
+    // measured crossover on MI355X (TN, square): the 256-tile kernel wins once its grid has more
+    // than ~128 workgroups (n >= 3072); below that the 128-tile kernel fills the 256 CUs better
+    // (n = 2048: 715 vs 436 TFLOP/s).
+    const long wg256 = (long)(M / BM) * (N / BN);
+    if (tiles256 && wg256 > 128) return g_tune_hgemm_auto;
+    return tiles128 ? LC_HGEMM_MFMA128 : LC_HGEMM_GENERIC;
+  }
+  if (is_tile256_variant(variant) && !tiles256) return LC_ERR_SHAPE;
+  if (variant == LC_HGEMM_MFMA128 && !tiles128) return LC_ERR_SHAPE;
+  return variant;
+}
+}  // namespace
+
+int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf, int buflen) {
+  if (!buf || buflen < 8 || M <= 0 || N <= 0 || K <= 0 || !is_hgemm_variant(variant)) return LC_ERR_ARG;
+  if (layout != LC_LAYOUT_NN && layout != LC_LAYOUT_TN) return LC_ERR_ARG;
+  int v = resolve_hgemm_variant(variant, M, N, K, true);
+  if (v < 0) return v;
+  const char* nn = layout == LC_LAYOUT_NN ? "true" : "false";
+  if (is_w4_variant(v)) {
+    v = w4_effective_variant(v, layout == LC_LAYOUT_NN, N, K);
+    snprintf(buf, buflen, "hgemm_w4b_kernel<%s,%s,%s,0>", nn, v == LC_HGEMM_MFMA256W4B ? "false" : "true",
+             v == LC_HGEMM_MFMA256W4D ? "true" : "false");
+  } else if (v == LC_HGEMM_MFMA256P2) snprintf(buf, buflen, "hgemm_pingpong2_kernel<%s,false>", nn);
+  else if (v == LC_HGEMM_MFMA256) snprintf(buf, buflen, "hgemm_mfma256_kernel<%s>", nn);
+  else if (v == LC_HGEMM_MFMA128) snprintf(buf, buflen, "hgemm_mfma128_kernel<%s>", nn);
+  else snprintf(buf, buflen, "hgemm_generic_kernel<%s>", nn);
+  return LC_OK;
+}
+
+int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int buflen) {
+  if (!buf || buflen < 8 || N <= 0 || N % KVB != 0) return LC_ERR_ARG;
+  const char* vt = v_transposed ? "true" : "false";
+  if (D == 32 || D == 64 || D == 96 || D == 128) {
+    if (bf16) return LC_ERR_HEADDIM;
+    const int nw = choose_attn_nw(D, v_transposed != 0, N);
+    if (nw == 128) snprintf(buf, buflen, "attn_fwd_w4_kernel<%d,false>", D);
+    else if (nw == 64) snprintf(buf, buflen, "attn_fwd_c4_kernel<%d,0>", D);
+    else snprintf(buf, buflen, "attn_fwd_kernel<%d,%d,%s,0>", D, nw, vt);
+    return LC_OK;
+  }
+  if (D == 256 || D == 512 || (D == 1024 && !bf16)) {
+    snprintf(buf, buflen, "attn_fwd_bigd_kernel<%d,%d,%d,%s,%s>", D, D > 256 ? 256 : D, N % 128 == 0 ? 4 : 2, vt,
+             bf16 ? "true" : "false");
+    return LC_OK;
+  }
+  return LC_ERR_HEADDIM;
+}
+
 int lc_tune_set(const char* key, int value) {
   if (!key) return LC_ERR_ARG;
   if (strcmp(key, "attn_nw") == 0) {
-    if (value != 0 && value != 128 && value != 64 && value != 32 && value != 16 && value != 8 && value != 4 && value != 2)
-      return LC_ERR_ARG;
+    if (value != 0 && value != 128 && value != 64 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
     g_tune_attn_nw = value;
     return LC_OK;
   }
@@ -415,6 +439,17 @@ int lc_tune_set(const char* key, int value) {
     g_tune_fp8_mx = value;
     return LC_OK;
   }
+  if (strcmp(key, "attn_d512") == 0) {
+    if (value < 0 || value > 1) return LC_ERR_ARG;
+    g_tune_attn_d512 = value;
+    return LC_OK;
+  }
+  if (strcmp(key, "hgemm_auto") == 0) {
+    if (!is_tile256_variant(value)) return LC_ERR_ARG;
+    g_tune_hgemm_auto = value;
+    return LC_OK;
+  }
+#ifdef LC_DIAG   // diagnosis keys (include/lc_diag.h): results may be WRONG; a production library rejects them
   if (strcmp(key, "w4_abl") == 0) {
     g_tune_w4_abl = value;
     return LC_OK;
@@ -427,13 +462,7 @@ int lc_tune_set(const char* key, int value) {
     g_tune_attn_ablate = value;
     return LC_OK;
   }
-  if (strcmp(key, "hgemm_auto") == 0) {
-    if (value != LC_HGEMM_MFMA256 && value != LC_HGEMM_MFMA256P && value != LC_HGEMM_MFMA256P2 &&
-        value != LC_HGEMM_MFMA256P3 && value != LC_HGEMM_MFMA256W4 && value != LC_HGEMM_MFMA256W4S && value != LC_HGEMM_MFMA256W4B && value != LC_HGEMM_MFMA256W4C)
-      return LC_ERR_ARG;
-    g_tune_hgemm_auto = value;
-    return LC_OK;
-  }
+#endif
   return LC_ERR_ARG;
 }
 
@@ -449,38 +478,24 @@ int lc_device_check(int* num_cus) {
 
 int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int layout, int variant,
                  int stages, int swizzle_stride, void* stream) {
-  (void)stages;  // LDS ring depth is fixed per kernel family; accepted for signature parity
+  (void)stages;  // accepted and ignored: the LDS ring depth is fixed per kernel family (lc_abi.h)
   if (!A || !B || !C) return LC_ERR_ARG;
   if (layout != LC_LAYOUT_NN && layout != LC_LAYOUT_TN) return LC_ERR_ARG;
-  if (variant < LC_HGEMM_AUTO || variant > LC_HGEMM_MFMA256W4C) return LC_ERR_ARG;
+  if (!is_hgemm_variant(variant)) return LC_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0) return LC_ERR_SHAPE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const half_t* a = static_cast<const half_t*>(A);
   const half_t* b = static_cast<const half_t*>(B);
   half_t* c = static_cast<half_t*>(C);
   const bool al = aligned16(A) && aligned16(B) && aligned16(C);
-  const bool tiles256 = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && al;
-  const bool tiles128 = (M % BM1 == 0) && (N % BN1 == 0) && (K % BK == 0) && al;
-  if (variant == LC_HGEMM_AUTO) {
-    // measured crossover on MI355X (TN, square): the 256-tile ping-pong kernel wins once its grid has more
-    // than ~128 workgroups (n >= 3072); below that the 128-tile kernel fills the 256 CUs better
-    // (n = 2048: 715 vs 436 TFLOP/s).
-    const long wg256 = (long)(M / BM) * (N / BN);
-    if (tiles256 && wg256 > 128)
-      variant = g_tune_hgemm_auto;
-    else if (tiles128)
-      variant = LC_HGEMM_MFMA128;
-    else
-      variant = LC_HGEMM_GENERIC;
-  }
-  if (variant == LC_HGEMM_MFMA256 || variant == LC_HGEMM_MFMA256P || variant == LC_HGEMM_MFMA256P2 ||
-      variant == LC_HGEMM_MFMA256P3 || variant == LC_HGEMM_MFMA256W4 || variant == LC_HGEMM_MFMA256W4S || variant == LC_HGEMM_MFMA256W4B || variant == LC_HGEMM_MFMA256W4C) {
-    if (!tiles256) return LC_ERR_SHAPE;
+  variant = resolve_hgemm_variant(variant, M, N, K, al);
+  if (variant < 0) return variant;
+  if (int rc = launch_guard()) return rc;   // a sticky HIP error of an earlier call: report it, launch nothing
+  if (is_tile256_variant(variant)) {
     return layout == LC_LAYOUT_NN ? launch_mfma256<true>(a, b, c, M, N, K, variant, swizzle_stride, st)
                                   : launch_mfma256<false>(a, b, c, M, N, K, variant, swizzle_stride, st);
   }
   if (variant == LC_HGEMM_MFMA128) {
-    if (!tiles128) return LC_ERR_SHAPE;
     return layout == LC_LAYOUT_NN ? launch_mfma128<true>(a, b, c, M, N, K, swizzle_stride, st)
                                   : launch_mfma128<false>(a, b, c, M, N, K, swizzle_stride, st);
   }
@@ -493,6 +508,7 @@ int lc_gemm_fp8_e4m3(const void* A, const void* B, void* C, int M, int N, int K,
   if (!A || !B || !C) return LC_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0) return LC_ERR_SHAPE;
   if (M % BM || N % BN || K % 128 || !aligned16(A) || !aligned16(B) || !aligned16(C)) return LC_ERR_SHAPE;
+  if (int rc = launch_guard()) return rc;
   const int tiles_m = M / BM, tiles_n = N / BN;
   const int pw = panel_tiles(swizzle_stride, tiles_n, BN);
   return launch_gemm_fp8(static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), static_cast<half_t*>(C), M, N, K,
@@ -538,6 +554,7 @@ int lc_attn_fwd_f16(const void* Q, const void* K, const void* V, void* O, int B,
   if (N % KVB != 0) return LC_ERR_SHAPE;
   if ((size_t)B * H * (size_t)(N / 64) > 0x7fffffffull) return LC_ERR_SHAPE;  // 1-D grid of workgroups
   if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O)) return LC_ERR_SHAPE;
+  if (int rc = launch_guard()) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const half_t* q = static_cast<const half_t*>(Q);
   const half_t* k = static_cast<const half_t*>(K);
@@ -553,6 +570,7 @@ int lc_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, int B
   if (B <= 0 || H <= 0 || N <= 0 || D <= 0 || N % KVB != 0) return LC_ERR_SHAPE;
   if ((size_t)B * H * (size_t)(N / 64) * 4 > 0x7fffffffull) return LC_ERR_SHAPE;
   if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O)) return LC_ERR_SHAPE;
+  if (int rc = launch_guard()) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const half_t* q = static_cast<const half_t*>(Q);   // raw 16-bit lanes; the kernel flavour decodes bf16
   const half_t* k = static_cast<const half_t*>(K);
@@ -598,103 +616,88 @@ int lc_attn_call(const char* entry, const void* Q, const void* K, const void* V,
 }
 
 // ------------------------------------------------------------------------------------------------
+// measurement helpers: every HIP return code is checked (a faulting kernel must not turn into a plausible ms value)
+struct LcTimer {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t st = nullptr;
+};
+
+int lc_timer_start(void* stream, void** timer) {
+  if (!timer) return LC_ERR_ARG;
+  *timer = nullptr;
+  LcTimer* t = new (std::nothrow) LcTimer();
+  if (!t) return LC_ERR_LAUNCH;
+  t->st = static_cast<hipStream_t>(stream);
+  if (hipEventCreate(&t->e0) != hipSuccess) { delete t; return LC_ERR_LAUNCH; }
+  if (hipEventCreate(&t->e1) != hipSuccess) { (void)hipEventDestroy(t->e0); delete t; return LC_ERR_LAUNCH; }
+  if (hipEventRecord(t->e0, t->st) != hipSuccess) {
+    (void)hipEventDestroy(t->e0); (void)hipEventDestroy(t->e1); delete t;
+    return LC_ERR_LAUNCH;
+  }
+  *timer = t;
+  return LC_OK;
+}
+
+int lc_timer_stop(void* timer, float* elapsed_ms) {
+  LcTimer* t = static_cast<LcTimer*>(timer);
+  if (!t) return LC_ERR_ARG;
+  int rc = LC_OK;
+  float ms = 0.f;
+  if (hipEventRecord(t->e1, t->st) != hipSuccess) rc = LC_ERR_LAUNCH;
+  if (rc == LC_OK && hipEventSynchronize(t->e1) != hipSuccess) rc = LC_ERR_LAUNCH;   // execution faults surface here
+  if (rc == LC_OK && hipEventElapsedTime(&ms, t->e0, t->e1) != hipSuccess) rc = LC_ERR_LAUNCH;
+  (void)hipEventDestroy(t->e0);
+  (void)hipEventDestroy(t->e1);
+  delete t;
+  if (elapsed_ms) *elapsed_ms = ms;
+  return (rc == LC_OK && !elapsed_ms) ? LC_ERR_ARG : rc;
+}
+
 int lc_hgemm_time(const void* A, const void* B, void* C, int M, int N, int K, int layout, int variant,
                   int stages, int swizzle_stride, int warmup, int iters, void* stream,
                   float* ms_per_launch) {
   if (!ms_per_launch || iters <= 0 || warmup < 0) return LC_ERR_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
   for (int i = 0; i < warmup; ++i)
     if (int rc = lc_hgemm_f16(A, B, C, M, N, K, layout, variant, stages, swizzle_stride, stream)) return rc;
-  hipEvent_t e0, e1;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return LC_ERR_LAUNCH;
-  (void)hipEventRecord(e0, st);
+  void* t = nullptr;
+  if (int rc = lc_timer_start(stream, &t)) return rc;
   int rc = LC_OK;
   for (int i = 0; i < iters && rc == LC_OK; ++i)
     rc = lc_hgemm_f16(A, B, C, M, N, K, layout, variant, stages, swizzle_stride, stream);
-  (void)hipEventRecord(e1, st);
-  (void)hipEventSynchronize(e1);
   float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, e0, e1);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  const int rc2 = lc_timer_stop(t, &ms);
   *ms_per_launch = ms / iters;
-  return rc;
+  return rc != LC_OK ? rc : rc2;
 }
 
 int lc_attn_time(const void* Q, const void* K, const void* V, void* O, int B, int H, int N, int D,
                  int v_transposed, int family, int stages, int warmup, int iters, void* stream,
                  float* ms_per_launch) {
   if (!ms_per_launch || iters <= 0 || warmup < 0) return LC_ERR_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
   for (int i = 0; i < warmup; ++i)
     if (int rc = lc_attn_fwd_f16(Q, K, V, O, B, H, N, D, v_transposed, family, 0, stages, stream)) return rc;
-  hipEvent_t e0, e1;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return LC_ERR_LAUNCH;
-  (void)hipEventRecord(e0, st);
+  void* t = nullptr;
+  if (int rc = lc_timer_start(stream, &t)) return rc;
   int rc = LC_OK;
   for (int i = 0; i < iters && rc == LC_OK; ++i)
     rc = lc_attn_fwd_f16(Q, K, V, O, B, H, N, D, v_transposed, family, 0, stages, stream);
-  (void)hipEventRecord(e1, st);
-  (void)hipEventSynchronize(e1);
   float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, e0, e1);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  const int rc2 = lc_timer_stop(t, &ms);
   *ms_per_launch = ms / iters;
-  return rc;
+  return rc != LC_OK ? rc : rc2;
 }
 
-// ------------------------------------------------------------------------------------------------
-int lc_probe_mfma16(const void* a, const void* b, float* d, void* stream) {
-  if (!a || !b || !d) return LC_ERR_ARG;
-  hipLaunchKernelGGL(probe_mfma16_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const half_t*>(a), static_cast<const half_t*>(b), d);
-  return check_launch();
-}
-int lc_probe_mfma32(const void* a, const void* b, float* d, void* stream) {
-  if (!a || !b || !d) return LC_ERR_ARG;
-  hipLaunchKernelGGL(probe_mfma32_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const half_t*>(a), static_cast<const half_t*>(b), d);
-  return check_launch();
-}
-int lc_probe_coissue(int filler, int k, int mode, void* out_u64x16, void* stream) {
-  if (!out_u64x16 || mode < 0 || mode > 3) return LC_ERR_ARG;
-  unsigned long long* out = static_cast<unsigned long long*>(out_u64x16);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (filler) {
-    case 0: return probe_coissue_mode<0, 1>(mode == 2 ? 0 : mode, out, st);
-    case 1: return probe_coissue_k<1>(k, mode, out, st);
-    case 2: return probe_coissue_k<2>(k, mode, out, st);
-    case 3: return probe_coissue_k<3>(k, mode, out, st);
-    case 4: return probe_coissue_k<4>(k, mode, out, st);
-    case 5: return probe_coissue_k<5>(k, mode, out, st);
-    case 6: return probe_coissue_k<6>(k, mode, out, st);
-    case 7: return probe_coissue_k<7>(k, mode, out, st);
-    case 8: return probe_coissue_k<8>(k, mode, out, st);
-    default: return LC_ERR_ARG;
+__global__ void lc_clock_probe_kernel(unsigned long long* out) {
+  if (threadIdx.x == 0) {
+    out[0] = __builtin_readcyclecounter();        // s_memtime: shader cycles
+    out[1] = __builtin_amdgcn_s_memrealtime();    // constant 100 MHz
   }
 }
 
-int lc_probe_mfma_war(int delay, int kind, int queued, const void* a, const void* b, float* d, void* stream) {
-  const half_t* ah = static_cast<const half_t*>(a);
-  const half_t* bh = static_cast<const half_t*>(b);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (kind == 0 && queued == 0) return probe_war_delay<0, 0>(delay, ah, bh, d, st);
-  if (kind == 0 && queued == 1) return probe_war_delay<0, 1>(delay, ah, bh, d, st);
-  if (kind == 1 && queued == 0) return probe_war_delay<1, 0>(delay, ah, bh, d, st);
-  if (kind == 1 && queued == 1) return probe_war_delay<1, 1>(delay, ah, bh, d, st);
-  if (kind == 2 && queued == 0) return probe_war_delay<2, 0>(delay, ah, bh, d, st);
-  if (kind == 2 && queued == 1) return probe_war_delay<2, 1>(delay, ah, bh, d, st);
-  if (kind == 2 && queued == 2) return probe_war_delay<2, 2>(delay, ah, bh, d, st);
-  if (kind == 2 && queued == 4) return probe_war_delay<2, 4>(delay, ah, bh, d, st);
-  if (kind == 0 && queued == 4) return probe_war_delay<0, 4>(delay, ah, bh, d, st);
-  return LC_ERR_ARG;
-}
-
-int lc_probe_tr16(const void* src, void* dst, void* stream) {
-  if (!src || !dst) return LC_ERR_ARG;
-  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const uint16_t*>(src), static_cast<uint16_t*>(dst));
+int lc_clock_probe(void* out_u64x2, void* stream) {
+  if (!out_u64x2) return LC_ERR_ARG;
+  hipLaunchKernelGGL(lc_clock_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     static_cast<unsigned long long*>(out_u64x2));
   return check_launch();
 }
 

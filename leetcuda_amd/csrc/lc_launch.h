@@ -12,6 +12,10 @@
 
 namespace lc {
 
+// Launch status of the kernel just submitted.  hipGetLastError() also returns (and clears) a sticky error left by an
+// EARLIER, unrelated call of this thread; launchers call launch_guard() first so that such an error is reported as
+// what it is (LC_ERR_LAUNCH before our kernel is even submitted) instead of being blamed on the new launch.
+inline int launch_guard() { return hipPeekAtLastError() == hipSuccess ? LC_OK : LC_ERR_LAUNCH; }
 inline int check_launch() { return hipGetLastError() == hipSuccess ? LC_OK : LC_ERR_LAUNCH; }
 
 // The reference re-issues cudaFuncSetAttribute on every call (hgemm_mma_stage.cu:2284); here the attribute is
@@ -37,6 +41,7 @@ extern int g_tune_attn_ablate, g_tune_w4_abl, g_tune_hgemm_stamps;
 
 // launchers living in their own translation units
 // tu_w4.hip: LC_HGEMM_MFMA256W4 / W4S / W4B / W4C (M, N % 256 == 0, K % 64 == 0 checked by the caller)
+int w4_effective_variant(int variant, bool b_kn, int N, int K);   // W4C / W4D -> W4B when 32-bit DMA offsets could overflow
 int launch_w4_family(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant, bool b_kn,
                      int tiles_m, int tiles_n, int panel_w, hipStream_t st);
 // tu_attn_w4.hip: 4-wave x 64-row attention kernel, D = 128, N % 256 == 0

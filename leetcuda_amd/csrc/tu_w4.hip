@@ -1,57 +1,51 @@
-// tu_w4.hip — translation unit of the 4-wave HGEMM kernels (hgemm_w4.hip) — see lc_launch.h
+// tu_w4.hip — translation unit of the 4-wave HGEMM kernel (hgemm_w4.hip) — see lc_launch.h
 #include "lc_launch.h"
 #include "hgemm_w4.hip"
 
 namespace lc {
 namespace {
+template <bool B_KN, bool BUF, bool SPREAD, int DG>
+int launch_w4_one(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int tiles_m, int tiles_n, int pw,
+                  hipStream_t st) {
+  auto kern = hgemm_w4b_kernel<B_KN, BUF, SPREAD, DG>;
+  if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
+  return check_launch();
+}
+
 template <bool B_KN>
 int launch_w4_t(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant, int tiles_m,
                 int tiles_n, int pw, hipStream_t st) {
-  const dim3 grid(tiles_m * tiles_n);
-  // buffer-descriptor DMA addresses are 32-bit offsets from the wave's first row: fall back to the 64-bit global form
-  // when an offset could reach 2 GiB (NN: K tiles step through the whole of B)
-  if (variant == LC_HGEMM_MFMA256W4C) {
-    const size_t max_off = B_KN ? (size_t)K * N * 2 + (size_t)N * 64 : (size_t)K * 2 * 130;
-    if (max_off >= ((size_t)1 << 31)) variant = LC_HGEMM_MFMA256W4B;
-  }
+  variant = w4_effective_variant(variant, B_KN, N, K);
 #ifdef LC_DIAG
-  if (variant == LC_HGEMM_MFMA256W4C && g_tune_hgemm_stamps) {
-    auto kern = hgemm_w4b_kernel<B_KN, true, true>;
-    if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
-  } else
-#endif
-  if (variant == LC_HGEMM_MFMA256W4C) {
-    auto kern = hgemm_w4b_kernel<B_KN, true>;
-    if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
-  } else if (variant == LC_HGEMM_MFMA256W4B) {
-    auto kern = hgemm_w4b_kernel<B_KN>;
-    if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
-  } else if (variant == LC_HGEMM_MFMA256W4S) {
-    auto kern = hgemm_w4s_kernel<B_KN>;
-    if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(256), HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
-  } else {
-#define LC_W4_CASE(ABL)                                                                                   \
-  case ABL: {                                                                                             \
-    auto kern = hgemm_w4_kernel<B_KN, ABL>;                                                               \
-    if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;                                              \
-    hipLaunchKernelGGL(kern, grid, dim3(256), HGEMM256_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);  \
-  } break;
-    switch (g_tune_w4_abl) {
-      LC_W4_CASE(0)
-#ifdef LC_DIAG
-      LC_W4_CASE(1) LC_W4_CASE(2) LC_W4_CASE(3) LC_W4_CASE(4) LC_W4_CASE(7)
-#endif
+  if (variant == LC_HGEMM_MFMA256W4C && g_tune_hgemm_stamps)
+    return launch_w4_one<B_KN, true, false, 1>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+  if (variant == LC_HGEMM_MFMA256W4C && g_tune_w4_abl) {
+    switch (g_tune_w4_abl) {   // bits: 2 no DMA, 4 no wait + barrier, 8 no fragment reads
+      case 2: return launch_w4_one<B_KN, true, false, 2>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+      case 4: return launch_w4_one<B_KN, true, false, 4>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+      case 6: return launch_w4_one<B_KN, true, false, 6>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+      case 8: return launch_w4_one<B_KN, true, false, 8>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+      case 14: return launch_w4_one<B_KN, true, false, 14>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
       default: return LC_ERR_ARG;
     }
-#undef LC_W4_CASE
   }
-  return check_launch();
+#endif
+  if (variant == LC_HGEMM_MFMA256W4D) return launch_w4_one<B_KN, true, true, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+  if (variant == LC_HGEMM_MFMA256W4C) return launch_w4_one<B_KN, true, false, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+  return launch_w4_one<B_KN, false, false, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
 }
 }  // namespace
+
+// buffer-descriptor DMA addresses are 32-bit offsets from the wave's first row: fall back to the 64-bit global form
+// when an offset could reach 2 GiB (NN: K tiles step through the whole of B)
+int w4_effective_variant(int variant, bool b_kn, int N, int K) {
+  if (variant == LC_HGEMM_MFMA256W4C || variant == LC_HGEMM_MFMA256W4D) {
+    const size_t max_off = b_kn ? (size_t)K * N * 2 + (size_t)N * 64 : (size_t)K * 2 * 130;
+    if (max_off >= ((size_t)1 << 31)) return LC_HGEMM_MFMA256W4B;
+  }
+  return variant;
+}
 
 int launch_w4_family(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant, bool b_kn,
                      int tiles_m, int tiles_n, int panel_w, hipStream_t st) {

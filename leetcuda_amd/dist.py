@@ -2,8 +2,10 @@
 
 The hot paths shard into independent units (attention: (batch, head) problems; HGEMM: replicas), so the
 ONLY collectives are a barrier around the timed region and a gather of per-rank timings — there is no
-data-path collective (SURVEY.md §8e).  Launch: `python -m torch.distributed.run --nproc-per-node N ...`;
-RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from the environment."""
+data-path collective.  Launch: `python -m torch.distributed.run --nproc-per-node N ...`
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from the environment), or `spawn()` below — the
+torch.multiprocessing.spawn idiom of the reference's others/pytorch/distributed/test_dist_all.py:189-234 — which is
+what a bare `python bench.py --gpus N` uses."""
 from __future__ import annotations
 
 import os
@@ -75,6 +77,24 @@ def gather_row(w: World, values) -> torch.Tensor:
 
 def max_over_ranks(w: World, value: float) -> float:
     return float(gather_row(w, [value])[:, 0].max())
+
+
+def _spawn_entry(rank: int, fn, args, world: int, port: int):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    fn(*args)
+
+
+def spawn(fn, nprocs: int, args=()):
+    """Run `fn(*args)` in `nprocs` fresh processes (one per GPU), each with the environment torch.distributed.run
+    would have provided (rendezvous on 127.0.0.1, a free port).  `fn` must be a module-level function."""
+    import socket
+
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_spawn_entry, args=(fn, tuple(args), nprocs, port), nprocs=nprocs, join=True)
 
 
 def shutdown(w: World):

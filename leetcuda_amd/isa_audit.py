@@ -1,0 +1,178 @@
+"""Post-build ISA audit of the literal-AGPR / asm-load kernels.
+
+The 4-wave kernels keep state where hipcc cannot see it: accumulators (and, in the attention kernel, Q / K fragments)
+live in LITERAL AGPRs across separate asm statements, and `ds_read_b64_tr_b16` / `ds_read_b128` issued from asm
+statements return asynchronously although hipcc believes their "=v" outputs are written at `;;#ASMEND`.  Correctness
+therefore depends on properties of the EMITTED code that a ROCm or flag change could silently break.  This module
+re-derives them from the device assembly of every translation unit that contains such kernels
+(`hipcc -S --cuda-device-only`, same flags as the shipped objects) and `leetcuda_amd.build` fails the build when
+one does not hold:
+
+  R1  no compiler-emitted `v_accvgpr_*` (i.e. outside ;;#ASMSTART / ;;#ASMEND) touches an AGPR the kernel owns
+      (w4 GEMM / fp8 kernels: a0-a255; attention w4 kernels: the ranges named in their clobber lists)
+  R2  no scratch: `.private_segment_fixed_size` == 0 (a spilled tuple would be reloaded around asm statements
+      without the wait states the asm needs)
+  R3  no compiler instruction reads or writes the destination registers of an asm-issued LDS / global load between
+      the load and the next `s_waitcnt ... lgkmcnt(0)` / `vmcnt(0)` that retires it
+"""
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass, field
+from pathlib import Path
+
+# kernel-name regex -> AGPR ranges owned by the kernel's asm statements (inclusive)
+OWNED_AGPRS = [
+    (re.compile(r"hgemm_w4b_kernel|gemm_fp8_w4_kernel"), [(0, 255)]),
+    (re.compile(r"attn_fwd_w4_kernel"), [(0, 127), (192, 255)]),      # a[128:191] stay with hipcc (AGPR spills)
+    (re.compile(r"attn_fwd_w4k_kernel|attn_fwd_d512_kernel"), [(0, 255)]),
+]
+
+_REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
+_ASM_LOAD = re.compile(r"^\s*(ds_read\w*|ds_load\w*|global_load_(?!lds)\w+|buffer_load_\w+)\s+(.*)$")
+
+
+def _regs(text: str, kind: str) -> set[int]:
+    out: set[int] = set()
+    for m in _REG.finditer(text):
+        if m.group(1) == kind:
+            out.add(int(m.group(2)))
+        elif m.group(3) == kind:
+            out.update(range(int(m.group(4)), int(m.group(5)) + 1))
+    return out
+
+
+@dataclass
+class KernelReport:
+    name: str
+    scratch: int = 0
+    vgpr_count: int = 0
+    agpr_count: int = 0
+    violations: list[str] = field(default_factory=list)
+    mfma: int = 0
+    compiler_accvgpr: int = 0
+    asm_loads: int = 0
+
+
+def _owned(name: str):
+    for rx, ranges in OWNED_AGPRS:
+        if rx.search(name):
+            s: set[int] = set()
+            for lo, hi in ranges:
+                s.update(range(lo, hi + 1))
+            return s
+    return None
+
+
+def audit_asm(path: Path) -> list[KernelReport]:
+    lines = Path(path).read_text().splitlines()
+    reports: dict[str, KernelReport] = {}
+    cur: KernelReport | None = None
+    owned: set[int] | None = None
+    in_asm = False
+    pending: set[int] = set()     # VGPR destinations of asm loads not yet retired by a wait
+    for ln, raw in enumerate(lines, 1):
+        line = raw.split(";", 1)[0] if not raw.lstrip().startswith(";;#") else raw
+        s = line.strip()
+        m = re.match(r"\.type\s+(\S+),@function", s)
+        if m:
+            name = m.group(1)
+            cur = reports.setdefault(name, KernelReport(name))
+            owned = _owned(name)
+            in_asm = False
+            pending = set()
+            continue
+        if s.startswith(".Lfunc_end"):
+            cur = None
+            continue
+        m = re.match(r"\.amdhsa_kernel\s+(\S+)", s)
+        if m:
+            cur = reports.setdefault(m.group(1), KernelReport(m.group(1)))
+            owned = None
+            continue
+        if cur is not None and s.startswith(".amdhsa_private_segment_fixed_size"):
+            cur.scratch = int(s.split()[-1])
+            continue
+        if s.startswith(".end_amdhsa_kernel"):
+            cur = None
+            continue
+        if cur is None:
+            continue
+        if raw.lstrip().startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if raw.lstrip().startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not s or s.endswith(":") or s.startswith("."):
+            continue
+        if s.startswith("v_mfma"):
+            cur.mfma += 1
+        is_wait = s.startswith("s_waitcnt") and ("lgkmcnt(0)" in s or "vmcnt(0)" in s)
+        if is_wait:
+            # a counted wait retires everything older in program order; a plain lgkmcnt(0) retires LDS reads, a
+            # vmcnt(0) global ones — asm loads in these kernels are LDS reads, global asm loads are followed by
+            # vmcnt waits written next to them
+            pending.clear()
+            continue
+        if in_asm:
+            m = _ASM_LOAD.match(s)
+            if m and " lds" not in s and not s.rstrip().endswith("lds"):
+                dst = m.group(2).split(",")[0]
+                pending |= _regs(dst, "v")
+                cur.asm_loads += 1
+            continue
+        # ---- compiler-emitted instruction
+        if s.startswith("v_accvgpr_"):
+            cur.compiler_accvgpr += 1
+            if owned is not None:
+                hit = _regs(s, "a") & owned
+                if hit:
+                    cur.violations.append(f"R1 {path.name}:{ln}: compiler `{s}` touches asm-owned AGPR(s) {sorted(hit)[:4]}")
+        if pending:
+            hit = _regs(s, "v") & pending
+            if hit:
+                cur.violations.append(f"R3 {path.name}:{ln}: compiler `{s}` uses v{sorted(hit)[:4]} before the wait "
+                                      "that retires the asm load writing it")
+                pending -= hit     # report each register once
+    # metadata block: .name / .vgpr_count / .agpr_count
+    txt = "\n".join(lines)
+    for blk in re.split(r"\n  - \.agpr_count:", txt)[1:]:
+        nm = re.search(r"\.name:\s+(\S+)", blk)
+        if not nm or nm.group(1) not in reports:
+            continue
+        r = reports[nm.group(1)]
+        r.agpr_count = int(blk.strip().split()[0])
+        m = re.search(r"\.vgpr_count:\s+(\d+)", blk)
+        r.vgpr_count = int(m.group(1)) if m else 0
+        m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+        if m:
+            r.scratch = max(r.scratch, int(m.group(1)))
+    out = []
+    for r in reports.values():
+        if _owned(r.name) is None and r.asm_loads == 0:
+            continue      # ordinary compiler-scheduled kernel: nothing hidden from hipcc
+        if r.scratch != 0:
+            r.violations.append(f"R2 {path.name}: {r.name} uses {r.scratch} B of scratch")
+        out.append(r)
+    return out
+
+
+def audit_files(paths) -> tuple[list[KernelReport], list[str]]:
+    reps, bad = [], []
+    for p in paths:
+        for r in audit_asm(Path(p)):
+            reps.append(r)
+            bad.extend(r.violations)
+    return reps, bad
+
+
+if __name__ == "__main__":
+    import sys
+    reps, bad = audit_files(sys.argv[1:])
+    for r in reps:
+        print(f"{r.name}: vgpr {r.vgpr_count} agpr {r.agpr_count} scratch {r.scratch} mfma {r.mfma} "
+              f"compiler v_accvgpr {r.compiler_accvgpr} violations {len(r.violations)}")
+    for b in bad:
+        print("VIOLATION", b)
+    sys.exit(1 if bad else 0)

@@ -275,6 +275,14 @@ void lc_oracle_attn_exact_f32_bf16(const uint16_t* Q, const uint16_t* K, const u
   g_decode_bf16 = 0;
 }
 
+/* sampled query rows of a bf16 problem (full-size config-5 parity: (1,48,8192,512) is sampled, not swept) */
+void lc_oracle_attn_exact_f32_rows_bf16(const uint16_t* Qrows, const uint16_t* K, const uint16_t* V, float* O,
+                                        int BH, int Nq, int N, int D) {
+  g_decode_bf16 = 1;
+  attn_exact_impl(Qrows, K, V, O, BH, 1, Nq, N, D, 0, 1);
+  g_decode_bf16 = 0;
+}
+
 /* fp16-accumulated dot over `len` elements in steps of 16 (one mma.sync k16 step each). */
 static float dot_f16acc(const float* a, const float* b, int len, int bstride) {
   float acc = 0.f;

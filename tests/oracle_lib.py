@@ -36,6 +36,8 @@ class Oracle:
         lib.lc_oracle_num_threads.restype, lib.lc_oracle_num_threads.argtypes = _i, []
         lib.lc_oracle_attn_exact_f32_bf16.restype = None
         lib.lc_oracle_attn_exact_f32_bf16.argtypes = [_u16, _u16, _u16, _f32, _i, _i, _i, _i]
+        lib.lc_oracle_attn_exact_f32_rows_bf16.restype = None
+        lib.lc_oracle_attn_exact_f32_rows_bf16.argtypes = [_u16, _u16, _u16, _f32, _i, _i, _i, _i]
         lib.lc_e4m3_to_f32.restype, lib.lc_e4m3_to_f32.argtypes = C.c_float, [C.c_uint8]
         _u8 = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
         lib.lc_oracle_gemm_fp8_exact_f32.restype = None
@@ -91,6 +93,15 @@ class Oracle:
             return np.ascontiguousarray(x.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16))
         o = np.empty((B, H, N, D), np.float32)
         self.lib.lc_oracle_attn_exact_f32_bf16(u(q), u(k), u(v), o, B, H, N, D)
+        return o
+
+    def attn_rows_bf16(self, qrows, k, v, BH, Nq, N, D):
+        """torch.bfloat16 tensors: Nq sampled query rows per problem against all N keys -> fp32 exact."""
+        import torch
+        def u(x):
+            return np.ascontiguousarray(x.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16))
+        o = np.empty((BH, Nq, D), np.float32)
+        self.lib.lc_oracle_attn_exact_f32_rows_bf16(u(qrows), u(k), u(v), o, BH, Nq, N, D)
         return o
 
     def attn_rows(self, qrows, k, v, BH, Nq, N, D, vt=False):

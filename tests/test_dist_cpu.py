@@ -58,3 +58,30 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     assert sum(r[1] for r in rows) == 24 and rows[0][2] == 0 and rows[1][2] == 12   # units partitioned
     assert abs(res["max"] - 0.10) < 1e-9                                             # MAX over ranks
     assert min(r[3] for r in rows) >= 0.095        # barrier-bracketed: both ranks waited for the slow one
+
+
+def _spawned_worker(outdir):
+    """module-level (picklable) body of one self-spawned rank: the N > 1 plumbing of bench.py on gloo / CPU."""
+    import json
+    from leetcuda_amd import dist as lcd, host
+    w = lcd.init("gloo")
+    b, h, first = host.attn_shard(32, 32, w.size, w.rank)       # config 4 batch shard
+    lcd.barrier(w)
+    mx = lcd.max_over_ranks(w, 1.0 + w.rank)
+    rows = lcd.gather_row(w, [w.rank, b, h, first])
+    if w.rank == 0:
+        Path(outdir, "out.json").write_text(json.dumps({"size": w.size, "max": mx, "rows": rows.tolist()}))
+    lcd.shutdown(w)
+
+
+def test_self_spawn_two_ranks_gloo(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` without torch.distributed.run self-spawns its ranks through dist.spawn()
+    (torch.multiprocessing.spawn, rendezvous on 127.0.0.1): same partition and MAX-over-ranks as the torchrun path."""
+    import json
+    from leetcuda_amd import dist as lcd
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    lcd.spawn(_spawned_worker, 2, (str(tmp_path),))
+    res = json.loads((tmp_path / "out.json").read_text())
+    assert res["size"] == 2 and res["max"] == 2.0
+    assert res["rows"] == [[0.0, 16.0, 32.0, 0.0], [1.0, 16.0, 32.0, 512.0]]

@@ -1,0 +1,50 @@
+"""GPU tests of bench.py itself: the one-JSON-line contract at N = 1, and the self-spawned N = 2 launch
+(`python bench.py --gpus 2` with no torch.distributed.run) with both ranks sharing this box's single GPU over gloo."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _run(args, env_extra=None, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], env=env, capture_output=True, text=True,
+                       timeout=timeout, cwd=str(ROOT))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]          # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_quick_line():
+    out = _run(["--steps", "5", "--warmup", "2", "--quick"])
+    assert out["n_gpus"] == 1 and out["steps"] == 5 and out["unit"] == "TFLOP/s" and out["higher_is_better"] is True
+    assert out["metric"].startswith("achieved fp16 TFLOPS vs MI355X MFMA peak")
+    r = out["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 2500.0 and 0.2 < r["frac"] < 1.0
+    assert r["kernel"].startswith("hgemm_w4b_kernel<false,")
+    # kernel time <= step time (launch overhead on top), and the two agree within 15 %
+    assert r["kernel_ms"] <= out["ms_per_step"] * 1.02 and r["kernel_ms"] > 0.85 * out["ms_per_step"]
+    assert out["value"] == pytest.approx(2 * 8192 ** 3 / (out["ms_per_step"] * 1e-3) * 1e-12, rel=1e-6)
+    assert out["attention"]["roofline"]["kernel"].startswith("attn_fwd_")
+    assert "LC_DIAG=0" in out["library"]
+
+
+def test_bench_self_spawns_two_ranks_on_one_gpu_gloo():
+    """Round-1 verdict: `python bench.py --gpus 2` used to exit unless launched by torch.distributed.run."""
+    out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--quick", "--workload", "attn_cfg4"],
+               {"LC_DIST_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert "16x32 (batch,head) problems per rank" in out["config"]["workload"]      # 32 batches over 2 ranks
+    assert "gloo" in out["config"]["parallelism"]
+    # whole-job FLOPs / max-rank time: both ranks share one GPU here, so ~ the single-GPU rate, never above it x1.1
+    assert 200 < out["value"] < 2500

@@ -8,8 +8,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _lib():
+    """capi + liblc_diag.so (the probes of include/lc_diag.h live outside the drop-in library)."""
     from leetcuda_amd import capi
-    return capi, capi.load()
+    capi.load()
+    return capi, capi.load_diag()
 
 
 def test_device_is_gfx950():

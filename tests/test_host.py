@@ -99,23 +99,37 @@ def test_attn_shard_prefers_batch_axis():
         host.shard_bounds(4, 2, 2)
 
 
-def test_bench_traffic_keys_exist_in_committed_pmc_summary():
-    """bench.py looks the dominant kernels' HBM bytes up in profiles/latest_pmc.json (written by
-    tools/summarize_prof.py from the separate rocprofv3 --pmc passes): the keys it asks for must be there, otherwise
-    `roofline.traffic` silently degrades to null."""
+def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
+    """bench.py labels its roofline rows with the kernel name the DISPATCHER reports (lc_*_kernel_name) and looks the
+    fabric bytes of that kernel up in profiles/latest_pmc.json (tools/summarize_prof.py, separate rocprofv3 --pmc
+    passes).  The names must be in the form summarize_prof.py derives from the mangled symbols, and a key that is
+    present must be what bench.py reports; a profile that predates a kernel rename degrades to traffic = null."""
     import importlib.util
     import json
+    from leetcuda_amd import capi
     root = Path(__file__).resolve().parent.parent
     spec = importlib.util.spec_from_file_location("lc_bench", root / "bench.py")
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
+    spec2 = importlib.util.spec_from_file_location("lc_sumprof", root / "tools" / "summarize_prof.py")
+    sump = importlib.util.module_from_spec(spec2)
+    spec2.loader.exec_module(sump)
+    # dispatcher names == demangled symbol names of the kernels actually in the library
+    assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN) == "hgemm_w4b_kernel<false,true,false,0>"
+    assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_NN, capi.HGEMM_MFMA256P2) == "hgemm_pingpong2_kernel<true,false>"
+    assert capi.hgemm_kernel_name(1024, 1024, 1024, capi.LAYOUT_NN) == "hgemm_mfma128_kernel<true>"
+    assert capi.hgemm_kernel_name(1000, 1024, 1024, capi.LAYOUT_NN) == "hgemm_generic_kernel<true>"
+    assert capi.attn_kernel_name(4096, 128) == "attn_fwd_c4_kernel<128,0>"
+    assert capi.attn_kernel_name(192, 64, True) == "attn_fwd_kernel<64,2,true,0>"
+    assert capi.attn_kernel_name(8192, 512, False, True).startswith("attn_fwd_bigd_kernel<512,")
+    assert sump.short("_ZN2lc16hgemm_w4b_kernelILb0ELb1ELb0ELi0EEEvPKDF16_S2_PDF16_iiiiii") == \
+        "hgemm_w4b_kernel<false,true,false,0>"
+    assert sump.short("_ZN2lc18attn_fwd_c4_kernelILi128ELi0EEEvPKDF16_S2_S2_PDF16_iif") == "attn_fwd_c4_kernel<128,0>"
     pmc = json.loads((root / "profiles" / "latest_pmc.json").read_text())
-    for layout in ("tn", "nn"):
-        key = bench.pmc_key_hgemm("auto", layout)
-        assert key in pmc and pmc[key]["hbm_bytes_per_launch"] > 0, key
-        assert bench.pmc_traffic(key) == pmc[key]["hbm_bytes_per_launch"]
-    src = (root / "bench.py").read_text()
-    m = re.search(r'pmc_traffic\("(attn_[^"]+)"\)', src)
-    assert m and m.group(1) in pmc, m and m.group(1)
-    # algorithmic bytes of the 8192^3 HGEMM are 3 * 8192^2 * 2; fabric traffic is a small multiple of it, never less
-    assert pmc[bench.pmc_key_hgemm("auto", "tn")]["hbm_bytes_per_launch"] >= 3 * 8192 * 8192 * 2
+    for key in (capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN), capi.attn_kernel_name(4096, 128)):
+        if key in pmc:
+            assert bench.pmc_traffic(key) == pmc[key]["hbm_bytes_per_launch"] > 0
+            r = bench.roofline(key, 1.0e12, 4.0e8, 1.0)
+            assert r["traffic"] == pmc[key]["hbm_bytes_per_launch"] and "profiles/" in r["traffic_source"]
+        else:
+            assert bench.pmc_traffic(key) is None and bench.roofline(key, 1.0e12, 4.0e8, 1.0)["traffic_source"] is None

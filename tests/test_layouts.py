@@ -5,7 +5,7 @@ ds_read_b64_tr_b16, lane groups of one LDS cycle each:
     ds_read_b128        {0-3,12-15,20-27} {4-11,16-19,28-31} {32-35,44-47,52-59} {36-43,48-51,60-63}
     ds_read_b64_tr_b16  {0-31} {32-63}
 A group is conflict-free when its lanes touch pairwise different banks (or identical addresses).
-These are the formulas of hgemm_pingpong.hip / hgemm_w4.hip (st_2x8, 128-B rows; 64-B rows of the w4s variant) and of
+These are the formulas of hgemm_pingpong.hip / hgemm_w4.hip (st_2x8, 128-B rows) and of
 attn_fwd.hip / attn_w4.hip (K: chunk ^ (row & 15) on 256-B rows; V: 64-B unit ^ (row & 3) for the transpose reads)."""
 import itertools
 
@@ -43,17 +43,6 @@ def test_gemm_st2x8_swizzle_is_conflict_free_for_b128_fragment_reads():
             assert conflict_free(addrs, 16), (ks, grp)
     for r in range(16):   # a permutation of the 8 chunk slots in every row
         assert sorted(c ^ ((r >> 1) & 7) for c in range(8)) == list(range(8))
-
-
-def test_gemm_64_byte_row_swizzle_of_the_four_stage_ring():
-    # 64-B rows (hgemm_w4s): chunk c of row r at slot c ^ ((r >> 2) & 3)
-    for ks in range(2):
-        for grp in B128_GROUPS:
-            addrs = []
-            for lane in grp:
-                l32, hi = lane & 31, lane >> 5
-                addrs.append(l32 * 64 + (((2 * ks + hi) ^ ((l32 >> 2) & 3)) * 16))
-            assert conflict_free(addrs, 16), (ks, grp)
 
 
 def test_attention_k_tile_swizzle_256_byte_rows():

@@ -6,7 +6,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch  # noqa: E402
 from leetcuda_amd import capi  # noqa: E402
 
-lib = capi.load()
+lib = capi.load_diag()
 out = torch.zeros(16, dtype=torch.int64, device="cuda")
 names = {1: "v_fma_f32", 2: "v_exp_f32", 3: "v_pk_fma_f32", 4: "v_cvt_pk_f16_f32", 5: "ds_read_b128",
          6: "v_accvgpr_read", 7: "v_exp+dep v_add", 8: "ds_read_b64_tr_b16"}

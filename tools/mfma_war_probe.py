@@ -5,7 +5,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch  # noqa: E402
 from leetcuda_amd import capi  # noqa: E402
-lib = capi.load()
+lib = capi.load_diag()
 torch.manual_seed(0)
 a = torch.randn(32, 16, device="cuda").half(); b = torch.randn(32, 16, device="cuda").half()
 want = (b.float() @ a.float().t())   # d[row from first operand = a? see probe_mfma32: rows follow operand 1]

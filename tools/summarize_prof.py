@@ -25,10 +25,6 @@ def short(name: str) -> str:
         m2 = re.match(r"_ZN2lc\d+(\w+?_kernel)E", name)
         return m2.group(1) if m2 else name[:60]
     args = m.group(2).replace("Lb0E", "false,").replace("Lb1E", "true,")
-    if m.group(1) == "hgemm_pingpong2_kernel" and args.endswith("true,"):
-        return "hgemm_pingpong3_kernel<" + args.split(",")[0] + ">"   # <B_KN, DMA_IN_LOAD=true>
-    if m.group(1) == "hgemm_pingpong2_kernel":
-        return "hgemm_pingpong2_kernel<" + args.split(",")[0] + ">"
     args = re.sub(r"Li(\d+)E", r"\1,", args).rstrip(",")
     return f"{m.group(1)}<{args}>"
 
