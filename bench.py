@@ -107,9 +107,11 @@ def pmc_traffic(kernel: str):
         return None
 
 
-def roofline(kernel, flops, nbytes, ms_kernel):
+def roofline(kernel, flops, nbytes, ms_kernel, profiled_config=False):
+    """profiled_config: this launch is one of the two the committed --pmc passes were taken on (HGEMM 8192^3, attention
+    config 3); a per-launch byte count of another shape would be meaningless, so traffic stays null elsewhere."""
     ach = flops / (ms_kernel * 1e-3) * 1e-12
-    t = pmc_traffic(kernel)
+    t = pmc_traffic(kernel) if profiled_config else None
     return {"bound": "mfma", "achieved": ach, "peak": PEAK, "unit": "TFLOP/s", "frac": ach / PEAK,
             "kernel_ms": ms_kernel, "kernel": kernel, "algorithmic_flops_per_launch": flops,
             "algorithmic_bytes_per_launch": nbytes, "traffic": t,
@@ -163,7 +165,7 @@ def bench_hgemm(w, args):
         "workload": f"HGEMM M=N=K={n} fp16 {args.layout.upper()} (BASELINE config 2), randn inputs, "
                     f"variant={args.variant}, block-swizzle stride {stride}",
         "scaling": "weak",
-        "roofline": roofline(kname, flops, 3.0 * n * n * 2, ms_kernel),
+        "roofline": roofline(kname, flops, 3.0 * n * n * 2, ms_kernel, profiled_config=(n == 8192)),
     }
     if w.rank == 0 and w.size == 1 and not args.quick:
         # same-run comparator: hipBLASLt behind the reference's cuBLAS entry points (config 2: "rocprof vs rocBLAS")
@@ -241,7 +243,8 @@ def bench_attn(w, args, cfg4=False, steps=None, warmup=None, prewarm=PREWARM):
                     f"randn inputs, {b_loc}x{h_loc} (batch,head) problems per rank, entry {entry}",
         "scaling": "strong",
         "n_ranks": w.size,
-        "roofline": roofline(capi.attn_kernel_name(N, D), flops_local, 4.0 * b_loc * h_loc * N * D * 2, ms_kernel),
+        "roofline": roofline(capi.attn_kernel_name(N, D), flops_local, 4.0 * b_loc * h_loc * N * D * 2, ms_kernel,
+                             profiled_config=(not cfg4 and w.size == 1)),
     }
 
 
@@ -290,11 +293,39 @@ def _timed3(fn):
     return sorted(ts)[1], ts
 
 
+def _cpu_quota():
+    """cgroup CPU quota of this container in cores (None = unlimited): torch sees every host CPU, the scheduler may not."""
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        return None
+
+
+def _pick_threads():
+    """fp16 CPU matmul with torch's default thread count (half the logical CPUs) collapses on big hosts (round 1: 1.4 s
+    for 1024^3 on 128 threads): probe a few thread counts on 512^3 and keep the fastest; the count used is reported."""
+    default = torch.get_num_threads()
+    a = torch.randn(512, 512, dtype=torch.half)
+    probe = {}
+    for th in sorted({default, 64, 32, 16, 8}):
+        if th > default:
+            continue
+        torch.set_num_threads(th)
+        torch.matmul(a, a)
+        t0 = time.perf_counter()
+        torch.matmul(a, a)
+        probe[th] = time.perf_counter() - t0
+    best = min(probe, key=probe.get)
+    torch.set_num_threads(best)
+    return best, default, probe
+
+
 def cpu_baseline_hgemm(budget_s: float = 10.0):
     """torch.matmul on fp16 CPU tensors = the reference's `--torch` baseline callable (hgemm.py:1088), SURVEY §8(d):
     all host cores (thread count stated), 1 warm-up + 3 timed at 1024^3 (config 1's size) and at the largest cube of
     the 8192^3 problem whose 4 runs fit `budget_s`."""
-    threads = torch.get_num_threads()
+    threads, default_threads, probe = _pick_threads()
     torch.manual_seed(0)
     runs = {}
     n = 1024
@@ -314,6 +345,8 @@ def cpu_baseline_hgemm(budget_s: float = 10.0):
         runs[str(big)] = {"median_s": med2, "runs_s": ts2, "tflops": 2.0 * big ** 3 / med2 * 1e-12}
     head = runs[str(big)]
     out = {"value": head["tflops"], "unit": "TFLOP/s", "cores": threads, "host_cpus": os.cpu_count(),
+           "cpu_quota_cores": _cpu_quota(), "torch_default_threads": default_threads,
+           "thread_probe_512cubed_s": {str(k): v for k, v in probe.items()},
            "kind": "reference", "runs": runs,
            "sample": f"torch.matmul fp16 on CPU tensors, {threads} threads, 1 warm-up + 3 timed (median), M=N=K={big} "
                      f"(1/{(8192 // big) ** 3} of the 8192^3 work) and 1024^3; the reference bench's own torch "
@@ -339,21 +372,23 @@ def cpu_baseline_attn():
     """F.scaled_dot_product_attention and the unfused formula (flash_attn_mma.py:448-462) on fp16 CPU tensors:
     4 of the 128 (batch, head) problems of config 3, 1 warm-up + 3 timed."""
     import torch.nn.functional as F
-    threads = torch.get_num_threads()
+    threads = torch.get_num_threads()     # (cpu_baseline_hgemm ran first in the default line and set the best count)
     B, H, N, D = 1, 4, 4096, 128
     torch.manual_seed(0)
     q, k, v = (torch.randn(B, H, N, D, dtype=torch.half) for _ in range(3))
     fl = host.mha_matmul_flops(B, H, N, D)
     med, ts = _timed3(lambda: F.scaled_dot_product_attention(q, k, v))
 
+    q1, k1, v1 = q[:, :1], k[:, :1], v[:, :1]      # one head: the unfused fp16 formula is ~100x slower on CPU
+
     def unfused():   # flash_attn_mma.py:448-452
-        att = (q @ k.transpose(-2, -1)) * (1.0 / (D ** 0.5))
+        att = (q1 @ k1.transpose(-2, -1)) * (1.0 / (D ** 0.5))
         att = F.softmax(att, dim=-1)
-        return att @ v
+        return att @ v1
     med_u, ts_u = _timed3(unfused)
     return {"value": fl / med * 1e-12, "unit": "TFLOP/s", "cores": threads, "host_cpus": os.cpu_count(),
             "kind": "reference", "runs_s": ts,
-            "unfused": {"value": fl / med_u * 1e-12, "runs_s": ts_u},
+            "unfused": {"value": fl / H / med_u * 1e-12, "runs_s": ts_u, "sample": "one head (1/128 of config 3)"},
             "sample": f"F.scaled_dot_product_attention (and unfused_standard_attn) fp16 on CPU tensors, {threads} "
                       f"threads, 1 warm-up + 3 timed (median), B={B} H={H} S={N} D={D} = 1/32 of config 3; the "
                       f"reference bench's own baseline callables (flash_attn_mma.py:448-462)"}

@@ -92,7 +92,8 @@ def test_large_head_dims_tiling_qkv(oracle, D, N):
         _check(oracle, q, k, tv, o, vt=True)
     else:
         with pytest.raises(capi.LcError) as e:   # the reference dispatcher stops at 256 for this entry
-            capi.attn_call("flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv", q, k, v, o, 2)
+            capi.attn_call("flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv", q, k,
+                           v.transpose(-2, -1).contiguous(), o, 2)
         assert e.value.status == capi.LC_ERR_HEADDIM
 
 
