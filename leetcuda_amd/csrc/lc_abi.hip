@@ -249,11 +249,12 @@ int launch_attn_c4(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
 int choose_attn_nw(int D, bool vt, int N) {
   const int want = g_tune_attn_nw;   // 0 = auto
   if (D == 128 && !vt && N % 256 == 0) {
+    if (want == 256 || want == 260) return want;   // merged-phase 4-wave kernel (attn_w4m.hip), 260 = padded Q·Kᵀ MFMAs
     if (want == 128) return 128;
     // default for D = 128: the four-cluster LDS-DMA kernel (measured 2-3 % ahead of the lock-step kernel at config 3)
     if (want == 64 || (want == 0 && g_tune_attn_ablate == 0)) return 64;
   }
-  if (N % 256 == 0 && (want == 0 || want >= 8)) return 8;
+  if (N % 256 == 0 && (want == 0 || want >= 8)) return 8;   // (also what 64 / 128 / 256 fall back to for D < 128)
   if (N % 128 == 0 && (want == 0 || want >= 4)) return 4;
   return 2;
 }
@@ -265,6 +266,7 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   if constexpr (D == 128 && !VT) {
     if (nw == 64) return launch_attn_c4<D>(Q, K, V, O, B, H, N, st);
     if (nw == 128) return launch_attn_w4_d128(Q, K, V, O, B, H, N, st);
+    if (nw == 256 || nw == 260) return launch_attn_w4m_d128(Q, K, V, O, B, H, N, nw == 260, st);
   }
   if constexpr (D == 128 && !VT) {   // perf-diagnosis instantiations (lc_tune_set "attn_ablate")
     switch (g_tune_attn_ablate) {
@@ -414,7 +416,8 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
   if (D == 32 || D == 64 || D == 96 || D == 128) {
     if (bf16) return LC_ERR_HEADDIM;
     const int nw = choose_attn_nw(D, v_transposed != 0, N);
-    if (nw == 128) snprintf(buf, buflen, "attn_fwd_w4_kernel<%d,false>", D);
+    if (nw == 256 || nw == 260) snprintf(buf, buflen, "attn_fwd_w4m_kernel<%d,%d>", D, nw == 260 ? 4 : 0);
+    else if (nw == 128) snprintf(buf, buflen, "attn_fwd_w4_kernel<%d,false>", D);
     else if (nw == 64) snprintf(buf, buflen, "attn_fwd_c4_kernel<%d,0>", D);
     else snprintf(buf, buflen, "attn_fwd_kernel<%d,%d,%s,0>", D, nw, vt);
     return LC_OK;
@@ -430,7 +433,8 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
 int lc_tune_set(const char* key, int value) {
   if (!key) return LC_ERR_ARG;
   if (strcmp(key, "attn_nw") == 0) {
-    if (value != 0 && value != 128 && value != 64 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
+    if (value != 0 && value != 256 && value != 260 && value != 128 && value != 64 && value != 8 && value != 4 && value != 2)
+      return LC_ERR_ARG;
     g_tune_attn_nw = value;
     return LC_OK;
   }

@@ -47,6 +47,8 @@ int launch_w4_family(const half_t* A, const half_t* B, half_t* C, int M, int N, 
 // tu_attn_w4.hip: 4-wave x 64-row attention kernel, D = 128, N % 256 == 0
 int launch_attn_w4_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                         hipStream_t st);
+int launch_attn_w4m_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int pad,
+                         hipStream_t st);
 // tu_fp8.hip: fp8 e4m3 GEMM, mx = 1 (MX, 4 waves) / 2 (MX, 8 waves) / 0 (plain K = 16)
 int launch_gemm_fp8(const uint8_t* A, const uint8_t* B, half_t* C, int M, int N, int K, float alpha, int tiles_m,
                     int tiles_n, int panel_w, int mx, hipStream_t st);

@@ -3,6 +3,7 @@
 
 #include "lc_launch.h"
 #include "attn_w4.hip"
+#include "attn_w4m.hip"
 
 namespace lc {
 int launch_attn_w4_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
@@ -22,6 +23,25 @@ int launch_attn_w4_d128(const half_t* Q, const half_t* K, const half_t* V, half_
     auto kern = attn_fwd_w4_kernel<D>;
     if (int rc = set_dyn_lds(kern, AW4_LDS)) return rc;
     hipLaunchKernelGGL(kern, grid, block, AW4_LDS, st, Q, K, V, O, N, nqb, sl2);
+  }
+  return check_launch();
+}
+
+// merged-phase kernel (attn_w4m.hip); pad = wait states appended to the accumulating Q·Kᵀ MFMAs (0 or 4, A/B knob)
+int launch_attn_w4m_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int pad,
+                         hipStream_t st) {
+  constexpr int D = 128;
+  const int nqb = N / 256;
+  const dim3 grid((unsigned)((size_t)nqb * B * H)), block(256);
+  const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+  if (pad) {
+    auto kern = attn_fwd_w4m_kernel<D, 4>;
+    if (int rc = set_dyn_lds(kern, AM_LDS)) return rc;
+    hipLaunchKernelGGL(kern, grid, block, AM_LDS, st, Q, K, V, O, N, nqb, sl2);
+  } else {
+    auto kern = attn_fwd_w4m_kernel<D, 0>;
+    if (int rc = set_dyn_lds(kern, AM_LDS)) return rc;
+    hipLaunchKernelGGL(kern, grid, block, AM_LDS, st, Q, K, V, O, N, nqb, sl2);
   }
   return check_launch();
 }

@@ -48,11 +48,12 @@ def test_attn_vs_oracle(oracle, D, N):
     assert (o.float() - o2.float()).abs().max().item() < 1e-3
 
 
-@pytest.mark.parametrize("nw", [128, 64, 8, 4, 2])
+@pytest.mark.parametrize("nw", [256, 260, 128, 64, 8, 4, 2])
 @pytest.mark.parametrize("D", [128, 64, 96, 32])
 def test_workgroup_shapes_agree(oracle, nw, D):
-    """The same problem through the 4-wave x 64-row (128), four-cluster (64) and 8-, 4-, 2-wave lock-step kernels
-    (lc_tune_set "attn_nw"); D < 128 always runs the lock-step kernel."""
+    """The same problem through the merged-phase 4-wave kernel (256; 260 = its padded A/B twin), the round-1 4-wave x
+    64-row kernel (128), the four-cluster kernel (64) and the 8-, 4-, 2-wave lock-step kernels (lc_tune_set "attn_nw");
+    D < 128 always runs the lock-step kernel."""
     capi = _capi()
     B, H, N = 1, 3, 768
     torch.manual_seed(77 + D)
@@ -128,7 +129,7 @@ def test_golden_fixtures(oracle, golden):
         assert d.max() < tol.ATTN_MAX_ABS, d.max()
 
 
-@pytest.mark.parametrize("nw", [0, 128, 64, 8])
+@pytest.mark.parametrize("nw", [0, 256, 260, 128, 64, 8])
 def test_forced_rescale_spike(oracle, nw):
     """One K row matches one Q row so strongly that the running max jumps by >> 8 in the middle of the
     sequence (tile 5 of 8): every row's accumulator must be rescaled exactly once (rule 26)."""
@@ -256,3 +257,39 @@ def test_full_size_config3_properties(oracle):
     capi.attn_fwd(q, k, v1 + v2, o12)
     torch.cuda.synchronize()
     assert (o12.float() - o1.float() - o2.float()).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("nw", [256, 64])
+def test_scale_jumps_and_extreme_scores(oracle, nw):
+    """The merged-phase kernel treats the running max as a mere SCALE and only corrects it when a half-tile's row sums
+    get large (attn_w4m.hip).  Inputs that force that path in many places: (a) scores that grow steadily along the
+    sequence (every tile raises the max), (b) a huge uniform score level (s ~ 1000 in log2 units), (c) a first tile far
+    ABOVE everything else (later P underflow harmlessly), (d) maxima that jump by > 2^14 in the LAST half-tile."""
+    capi = _capi()
+    B, H, N, D = 1, 2, 1024, 128
+    torch.manual_seed(11)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    cases = {}
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    ramp = torch.linspace(0.0, 6.0, N, device="cuda").half()
+    cases["ramp"] = (q, (k + ramp[None, None, :, None] * q[:, :, :1].sign()).contiguous())      # growing scores
+    cases["level"] = (torch.full_like(q, 8.0), torch.full_like(q, 8.0))                       # s = 64*128/sqrt(128) ~ 724
+    k2 = k.clone()
+    k2[:, :, :32] = 4.0 * q[:, :, :32]                                                           # dominant first half-tile
+    cases["first"] = (q, k2)
+    k3 = k.clone()
+    k3[:, :, N - 7] = 3.0 * q[:, :, 100]
+    k3[:, :, N - 40] = 2.0 * q[:, :, 900]
+    cases["last"] = (q, k3)
+    capi.tune("attn_nw", nw)
+    try:
+        for name, (qq, kk) in cases.items():
+            o = torch.full_like(q, float("nan"))
+            capi.attn_fwd(qq, kk, v, o)
+            torch.cuda.synchronize()
+            truth = oracle.attn(qq, kk, v, B, H, N, D, mode="f32")
+            d = np.abs(o.float().cpu().numpy() - truth)
+            assert np.isfinite(d).all() and d.max() < 8e-3, (name, d.max())
+    finally:
+        capi.tune("attn_nw", 0)

@@ -129,7 +129,7 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     for key in (capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN), capi.attn_kernel_name(4096, 128)):
         if key in pmc:
             assert bench.pmc_traffic(key) == pmc[key]["hbm_bytes_per_launch"] > 0
-            r = bench.roofline(key, 1.0e12, 4.0e8, 1.0)
+            r = bench.roofline(key, 1.0e12, 4.0e8, 1.0, profiled_config=True)
             assert r["traffic"] == pmc[key]["hbm_bytes_per_launch"] and "profiles/" in r["traffic_source"]
         else:
-            assert bench.pmc_traffic(key) is None and bench.roofline(key, 1.0e12, 4.0e8, 1.0)["traffic_source"] is None
+            assert bench.pmc_traffic(key) is None and bench.roofline(key, 1.0e12, 4.0e8, 1.0, profiled_config=True)["traffic_source"] is None
