@@ -143,6 +143,17 @@ def build_diag(force: bool = False) -> Path:
     return out
 
 
+def build_cpp_bench(force: bool = False) -> Path:
+    """tools/cpp/hgemm_bench.bin: the torch-free C++ bench / error-check harness; links only the C-ABI."""
+    d = ROOT / "tools" / "cpp"
+    out = d / "hgemm_bench.bin"
+    abi = build_abi(False)
+    if not force and _newer(out, [d / "hgemm_bench.cpp", d / "Makefile", ROOT / "include" / "lc_abi.h", abi]):
+        return out
+    _run(["make", "-C", d, "-B"])
+    return out
+
+
 def build_oracle(force: bool = False) -> Path:
     """gcc -> oracle/liblc_oracle.so (CPU restatement of the reference algorithms; TEST INFRASTRUCTURE)."""
     out = ORACLE / ORACLE_NAME
@@ -190,6 +201,7 @@ def build_torch_ext(force: bool = False):
 def build_all(force: bool = False, torch_ext: bool = True):
     abi = build_abi(force)
     build_diag(force)
+    build_cpp_bench(force)
     orc = build_oracle(force)
     ext = build_torch_ext(force) if torch_ext else []
     return abi, orc, ext

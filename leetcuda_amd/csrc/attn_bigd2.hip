@@ -1,0 +1,298 @@
+// attn_bigd2.hip — FlashAttention-2 forward for LARGE head dims (D = 256, 512; fp16 and bf16): one workgroup owns ALL D
+// output columns of its 128 query rows (round 2; replaces the column-split attn_fwd_bigd_kernel for these shapes).
+//
+// Reference: the FFPA ancestor kernels/flash-attn/mma/basic/flash_attn_mma_tiling_qkv.cu:75-797 (fine-grained d tiling,
+// O(1) SRAM in D), entry flash_attn_mma_stages_split_q_tiling_qkv (:881-945).  BASELINE config 5a: (1,48,8192,512).
+//
+// Why round 1's kernel stopped at 281 TFLOP/s (11 %): it split D = 512 into two workgroups of 256 output columns that
+// BOTH recomputed the full-D Q·Kᵀ (1.5x the MFMA work), re-streamed the Q slices from global memory for every KV tile,
+// and ran 12 register-staged 8-MFMA stages per tile with a __syncthreads() each.  Here:
+//   * four wave64, one per SIMD with the whole 512-entry register file; a wave owns 32 query rows x all D columns:
+//       Oᵀ accumulators  a[0 : D/2)   literal AGPRs (256 registers at D = 512), written only by asm P·V MFMAs
+//       Q fragments      D/4 arch VGPRs (128 at D = 512), loaded ONCE — Q is never re-read
+//       Sᵀ               4 blocks (2 KV halves x even/odd k-step partial sums: no MFMA depends on the previous three)
+//     -> every MFMA issued is useful work (no recomputation), waves exchange nothing;
+//   * KV tile = 64 rows: K tile 64 x D and V tile 64 x D live in LDS once (2 x 64 KiB at D = 512, single-buffered) and
+//     are filled by LDS-DMA (buffer_load ... lds, one 1-KiB row per wave-instruction) in the shadow of the OTHER phase:
+//         phase QK(t):  D/16 x 2 MFMAs  Sᵀ = K(t)·Qᵀ       | DMA of V(t)   (V region free since P·V(t−1))
+//         softmax(t)    fp32, row sums from the unrounded P (tiling_qkv.cu keeps the same order)
+//         barrier       (K(t) dead for everybody, V(t) landed)
+//         phase PV(t):  D/32 x 4 MFMAs  Oᵀ += Vᵀ(t)·Pᵀ(t)   | DMA of K(t+1) (K region free since the barrier)
+//         barrier       (V(t) dead, K(t+1) landed)
+//     a DMA piece has >= 32 MFMAs (>= 1000 cycles) of flight; K/V bytes per MFMA are a third of round 1's;
+//   * swizzles (LDS-DMA writes lane-linearly, so they are applied to the per-lane SOURCE address): K 16-B chunk c of row r
+//     at slot c ^ (r & 15) (conflict-free ds_read_b128 on 1-KiB rows), V 64-B unit u of row r at unit u ^ (r & 3)
+//     (transpose-read half-waves on disjoint bank quarters) — the layouts of attn_fwd_c4_kernel on longer rows;
+//   * softmax: the running max is only a SCALE (attn_w4m.hip): the fast path exponentiates against the stale max and a
+//     rare wave-uniform slow path (row sums >= 2^14, non-finite, or the first tile) finds the true max and rescales O, l;
+//   * O leaves through LDS as whole rows with 16-B stores.
+// Roofline: MFMA-bound (4·B·H·N²·D FLOPs, 4·B·H·N·D·2 algorithmic bytes; AI = N/2 FLOP/B per... >> 300).
+#pragma once
+#include "attn_fwd.hip"
+#include "attn_w4m.hip"   // am_acc_* / am_drain / am_xhalf_* helpers
+
+namespace lc {
+
+template <int D>
+constexpr int bigd2_lds_bytes() {   // K tile + V tile; the epilogue's O staging (4 waves x 32 rows x (2D + 16) B) aliases them
+  return 2 * KVB * D * 2 > 4 * 32 * (2 * D + 16) ? 2 * KVB * D * 2 : 4 * 32 * (2 * D + 16);
+}
+
+// Oᵀ block a[R0:R0+15] += Vᵀ fragment x Pᵀ fragment (fp16 / bf16)
+template <int R0, bool BF16>
+LC_DEVINL void bd2_pv(half8_t v, half8_t p) {
+  if constexpr (BF16)
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%2:%3], %0, %1, a[%2:%3]" :: "v"(v), "v"(p), "n"(R0), "n"(R0 + 15) : LC_AGPR_ALL);
+  else
+    asm volatile("v_mfma_f32_32x32x16_f16 a[%2:%3], %0, %1, a[%2:%3]" :: "v"(v), "v"(p), "n"(R0), "n"(R0 + 15) : LC_AGPR_ALL);
+}
+// Sᵀ block (VGPRs) += K fragment x Q fragment.  As an asm statement with "v" operands: the builtin would let hipcc keep the
+// accumulators in AGPRs — a[0:63], on top of the literal Oᵀ accumulators (caught by leetcuda_amd/isa_audit.py rule R1).
+template <bool BF16>
+LC_DEVINL void bd2_qk(f32x16_t& s, half8_t k, half8_t q) {
+  if constexpr (BF16)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(k), "v"(q) : LC_AGPR_ALL);
+  else
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(s) : "v"(k), "v"(q) : LC_AGPR_ALL);
+}
+// four of them (d tiles 4dq .. 4dq+3, one P fragment) in ONE statement: hipcc pads a wait state at every asm boundary
+template <int R0, bool BF16>
+LC_DEVINL void bd2_pv4(half8_t v0, half8_t v1, half8_t v2, half8_t v3, half8_t p) {
+#define LC_BD2_PV4(OP)                                                                                               \
+  asm volatile(OP " a[%5:%6], %0, %4, a[%5:%6]\n\t" OP " a[%7:%8], %1, %4, a[%7:%8]\n\t" OP                         \
+               " a[%9:%10], %2, %4, a[%9:%10]\n\t" OP " a[%11:%12], %3, %4, a[%11:%12]"                              \
+               :: "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(p), "n"(R0), "n"(R0 + 15), "n"(R0 + 16), "n"(R0 + 31),      \
+                  "n"(R0 + 32), "n"(R0 + 47), "n"(R0 + 48), "n"(R0 + 63) : LC_AGPR_ALL)
+  if constexpr (BF16) LC_BD2_PV4("v_mfma_f32_32x32x16_bf16");
+  else LC_BD2_PV4("v_mfma_f32_32x32x16_f16");
+#undef LC_BD2_PV4
+}
+template <int OFF>
+LC_DEVINL half4_t bd2_tr(uint32_t addr) {   // asm transpose read (hipcc would guard the builtin with vmcnt(0) after LDS-DMA)
+  half4_t r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+
+template <int D, bool BF16>
+__global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
+    const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
+    half_t* __restrict__ O, int N, int nqb, float sl2) {
+  static_assert(D == 256 || D == 512, "bigd2: D = 256 or 512");
+  constexpr int ROWB = D * 2;              // bytes per K / V row
+  constexpr int TILE = KVB * ROWB;         // one K or V tile
+  constexpr int NKS = D / 16;              // k-steps of Q·Kᵀ
+  constexpr int NDT = D / 32;              // 32-column Oᵀ blocks
+  constexpr int CPR = ROWB / 16;           // 16-B chunks per row (64 at D = 512)
+  constexpr int PPR = ROWB / 1024;         // DMA pieces per row: 1 (D = 512); D = 256: one piece = 2 rows
+  constexpr int NPIECE = TILE / 1024 / 4;  // DMA pieces per wave and tile (16 at D = 512, 8 at D = 256)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  const int hi = lane >> 5, l32 = lane & 31;
+
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const size_t bh = id / nqb;
+  const int q0 = (id - (int)bh * nqb) * 128 + wave * 32;
+  const half_t* Qb = Q + bh * (size_t)N * D;
+  const char* Kb = (const char*)(K + bh * (size_t)N * D);
+  const char* Vb = (const char*)(V + bh * (size_t)N * D);
+  half_t* Ob = O + bh * (size_t)N * D;
+  const int T = N / KVB;
+  const uint32_t smem32 = lds_addr32(smem);
+  char* const ksm = smem;
+  char* const vsm = smem + TILE;
+
+  // ---- LDS-DMA.  D = 512: piece = one 1-KiB row; this wave stages rows wave + 4i.  D = 256: piece = two 512-B rows
+  // 2p, 2p+1 with p = wave + 4i (lane>>5 selects the row).  Lane chunk slot cs holds source chunk cs ^ key(row).
+  const buf_rsrc_t rk = make_rsrc(Kb), rv = make_rsrc(Vb);
+  unsigned k_off[4], v_off;
+  {
+    const int cs = lane & (CPR - 1), rsub = PPR ? 0 : (lane >> 5);
+    // row = (wave + 4i) [* 2 + rsub at D = 256]; row & 15 takes 4 values over i -> 4 lane-offset registers
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = PPR ? (wave + 4 * j) : (2 * (wave + 4 * j) + rsub);
+      k_off[j] = (unsigned)(rsub * ROWB + ((cs ^ (row & 15)) * 16));
+    }
+    const int rowv = PPR ? wave : (2 * wave + rsub);      // (row & 3) does not depend on i
+    v_off = (unsigned)(rsub * ROWB + ((cs ^ ((rowv & 3) << 2)) * 16));
+  }
+  auto issue_k = [&](int i, int t) {   // piece i of tile t (clamped) -> K region
+    const int te = t < T ? t : T - 1;
+    const int p = wave + 4 * i;
+    blds16(rk, k_off[i & 3], (unsigned)te * TILE + (unsigned)p * 1024u, ksm + p * 1024);
+  };
+  auto issue_v = [&](int i, int t) {
+    const int te = t < T ? t : T - 1;
+    const int p = wave + 4 * i;
+    blds16(rv, v_off, (unsigned)te * TILE + (unsigned)p * 1024u, vsm + p * 1024);
+  };
+#pragma unroll
+  for (int i = 0; i < NPIECE; ++i) issue_k(i, 0);
+
+  // ---- Q fragments -> registers (once): lane holds Q[q0 + l32][16 ks + 8 hi .. +8]
+  half8_t qf[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const half8_t*)(Qb + (size_t)(q0 + l32) * D + 16 * ks + 8 * hi);
+  static_for<D / 2>([&](auto r) { am_acc_zero<decltype(r)::value>(); });
+
+  // ---- fragment read addresses
+  const char* kx[8];   // K: row l32 (+32 tt), chunk (2ks + hi): low 4 bits XOR (row & 15); + (ks >> 3) * 256 as immediate
+#pragma unroll
+  for (int k8 = 0; k8 < 8; ++k8) kx[k8] = ksm + l32 * ROWB + (((2 * k8 + hi) ^ (l32 & 15)) * 16);
+  const int vi = lane & 15, vgi = (lane >> 4) & 1;
+  uint32_t vx[4];   // Vᵀ: kv row 4hi + (vi>>2) (+16g, +8), 64-B unit dt: low 2 bits XOR (row & 3); + (dt >> 2) * 256 immediate
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+    vx[b] = smem32 + (uint32_t)(TILE + (4 * hi + (vi >> 2)) * ROWB + 32 * vgi + 8 * (vi & 3) + ((b ^ (vi >> 2)) << 6));
+
+  float m_run = -INFINITY, l_run = 0.f;
+  half8_t pf[4];   // P fragments, k-step g = 16 kv rows
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  raw_barrier();   // K(0) landed
+
+  for (int t = 0; t < T; ++t) {
+    // =========================== phase QK(t): Sᵀ = K(t)·Qᵀ, V(t) DMA in its shadow
+    f32x16_t s[2][2];   // [tt][k-step parity]
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[tt][par][r] = 0.f;
+    // K fragments: plain LDS loads (hipcc counts their lgkmcnt), software-pipelined by hand TWO k-steps ahead through a
+    // ring of three register pairs — behind opaque asm MFMAs hipcc would otherwise load and wait in the same k-step
+    {
+      half8_t kfr[3][2];
+      auto ldk = [&](auto kc, auto rc) {
+        constexpr int ks = decltype(kc)::value, r = decltype(rc)::value;
+        kfr[r][0] = *(const half8_t*)(kx[ks & 7] + (ks >> 3) * 256);
+        kfr[r][1] = *(const half8_t*)(kx[ks & 7] + (ks >> 3) * 256 + 32 * ROWB);
+      };
+      ldk(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      ldk(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+      static_for<NKS>([&](auto kc) {
+        constexpr int ks = decltype(kc)::value;
+        if constexpr (ks + 2 < NKS) ldk(std::integral_constant<int, ks + 2>{}, std::integral_constant<int, (ks + 2) % 3>{});
+        if constexpr ((ks & 1) == 0 && (ks >> 1) < NPIECE) issue_v(ks >> 1, t);        // one V piece per 4 MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        bd2_qk<BF16>(s[0][ks & 1], kfr[ks % 3][0], qf[ks]);
+        bd2_qk<BF16>(s[1][ks & 1], kfr[ks % 3][1], qf[ks]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    am_drain();   // asm MFMAs: hipcc does not know their latency; their results are read by VALU next
+    // =========================== softmax(t)
+    float e[2][16];
+    {
+      float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          e[tt][r] = (s[tt][0][r] + s[tt][1][r]) * sl2;
+          const float p = __builtin_amdgcn_exp2f(e[tt][r] - m_run);
+          if (r & 1) ps1 += p; else ps0 += p;
+          pf[2 * tt + (r >> 3)][r & 7] = cvt16<BF16>(p);     // (r is a compile-time index after unrolling)
+        }
+      float psum = ps0 + ps1;
+      if (!__all(psum < 16384.0f) || t == 0) {        // overflow guard / first tile: establish the true max
+        float mx = e[0][0];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, e[tt][r]);
+        mx = am_xhalf_max(mx);
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
+        m_run = m_new;
+        l_run *= alpha;
+        am_drain();    // the P·V MFMAs of the previous tile have written Oᵀ
+        static_for<D / 2>([&](auto rc) { am_acc_scale<decltype(rc)::value>(alpha); });
+        psum = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(e[tt][r] - m_run);
+            psum += p;
+            pf[2 * tt + (r >> 3)][r & 7] = cvt16<BF16>(p);
+          }
+      }
+      l_run += psum;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own V(t) pieces landed, own K reads retired
+    raw_barrier();                                                // K(t) is dead, V(t) complete
+
+    // =========================== phase PV(t): Oᵀ += Vᵀ(t)·Pᵀ(t), K(t+1) DMA in its shadow
+    {
+      // step = (g, dq): k-step g = 16 kv rows, dq = quad of 32-column d tiles (dt = 4dq + j); the 8 transpose reads of
+      // step st+1 are issued before the 4 MFMAs of step st (>= 128 cycles of cover) into the other buffer.
+      // address: vx[dt & 3] + (dt >> 2) * 256 = vx[j] + dq * 256, + g * 16 rows (+ 8 rows for the second half)
+      half4_t vlo[2][4], vhi[2][4];
+      constexpr int NQ = NDT / 4, NST = 4 * NQ;
+      auto rd = [&](auto stc, auto bufc) {
+        constexpr int st = decltype(stc)::value, buf = decltype(bufc)::value, g = st / NQ, dq = st % NQ;
+        static_for<4>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          vlo[buf][j] = bd2_tr<dq * 256 + g * 16 * ROWB>(vx[j]);
+          vhi[buf][j] = bd2_tr<dq * 256 + g * 16 * ROWB + 8 * ROWB>(vx[j]);
+        });
+      };
+      using B0 = std::integral_constant<int, 0>;
+      using B1 = std::integral_constant<int, 1>;
+      rd(std::integral_constant<int, 0>{}, B0{});
+      static_for<NST>([&](auto stc) {
+        constexpr int st = decltype(stc)::value, cb = st & 1, g = st / NQ, dq = st % NQ;
+        // retire the reads of this step's buffer (issued one step ago; nothing younger is outstanding)
+        if constexpr (cb == 0)
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[0][0]), "+v"(vhi[0][0]), "+v"(vlo[0][1]), "+v"(vhi[0][1]),
+                       "+v"(vlo[0][2]), "+v"(vhi[0][2]), "+v"(vlo[0][3]), "+v"(vhi[0][3]));
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[1][0]), "+v"(vhi[1][0]), "+v"(vlo[1][1]), "+v"(vhi[1][1]),
+                       "+v"(vlo[1][2]), "+v"(vhi[1][2]), "+v"(vlo[1][3]), "+v"(vhi[1][3]));
+        if constexpr (st + 1 < NST) {
+          if constexpr (cb == 0) rd(std::integral_constant<int, st + 1>{}, B1{});
+          else rd(std::integral_constant<int, st + 1>{}, B0{});
+        }
+        if constexpr (st < NPIECE) issue_k(st, t + 1);      // one K piece per 4 MFMAs
+        bd2_pv4<64 * dq, BF16>(cat4(vlo[cb][0], vhi[cb][0]), cat4(vlo[cb][1], vhi[cb][1]), cat4(vlo[cb][2], vhi[cb][2]),
+                               cat4(vlo[cb][3], vhi[cb][3]), pf[g]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own K(t+1) pieces landed, own V reads retired
+    raw_barrier();                                                // V(t) is dead, K(t+1) complete
+  }
+
+  // ---- epilogue: O = Oᵀ / l through LDS (whole rows, 16-B stores).  Lane holds O[q = l32][d = 32dt + 8rq + 4hi + (0..3)]
+  // in a[16dt + 4rq ..]; every wave owns a private 32 x (ROWB + 16) B staging area (the KV tiles are dead).
+  constexpr int ESTR = ROWB + 16;
+  am_drain();
+  const float inv = 1.0f / am_xhalf_sum(l_run);
+  char* stg = smem + wave * (32 * ESTR);
+  static_for<NDT * 4>([&](auto ec) {
+    constexpr int dt = decltype(ec)::value >> 2, rq = decltype(ec)::value & 3;
+    constexpr int base = 16 * dt + 4 * rq;
+    half4_t h;
+    h[0] = cvt16<BF16>(am_acc_read<base + 0>() * inv);
+    h[1] = cvt16<BF16>(am_acc_read<base + 1>() * inv);
+    h[2] = cvt16<BF16>(am_acc_read<base + 2>() * inv);
+    h[3] = cvt16<BF16>(am_acc_read<base + 3>() * inv);
+    *(half4_t*)(stg + l32 * ESTR + (32 * dt + 8 * rq + 4 * hi) * 2) = h;
+  });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  half_t* ow = Ob + (size_t)q0 * D;
+  constexpr int LPR = ROWB / 16;             // lanes per row
+  constexpr int RPI = 64 / LPR;              // rows per wave-instruction (1 at D = 512, 2 at D = 256)
+#pragma unroll
+  for (int it = 0; it < 32 / RPI; ++it) {
+    const int row = it * RPI + lane / LPR, c = lane % LPR;
+    const u32x4_t v = *(const u32x4_t*)(stg + row * ESTR + c * 16);
+    *(u32x4_t*)(ow + (size_t)row * D + c * 8) = v;
+  }
+}
+
+}  // namespace lc

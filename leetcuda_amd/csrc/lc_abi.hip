@@ -306,9 +306,17 @@ int launch_attn_bigd(const half_t* Q, const half_t* K, const half_t* V, half_t* 
   return check_launch();
 }
 
+// D = 256 / 512 with V as [B,H,N,D] and N % 128 == 0: the full-width kernel (attn_bigd2.hip) unless lc_tune_set
+// "attn_d512" = 1 asks for round 1's column-split kernel (kept as the independently written cross-check; it also
+// serves D = 1024, V-transposed inputs and N % 128 != 0).
+bool use_bigd2(int D, bool vt, int N) {
+  return (D == 256 || D == 512) && !vt && N % 128 == 0 && g_tune_attn_d512 == 0;
+}
+
 template <int D, bool VT>
 int launch_attn_bigd_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                         hipStream_t st) {
+  if (use_bigd2(D, VT, N)) return launch_attn_bigd2(Q, K, V, O, B, H, N, D, false, st);
   if (N % 128 == 0) return launch_attn_bigd<D, 4, VT>(Q, K, V, O, B, H, N, st);
   return launch_attn_bigd<D, 2, VT>(Q, K, V, O, B, H, N, st);
 }
@@ -420,6 +428,10 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
     else if (nw == 128) snprintf(buf, buflen, "attn_fwd_w4_kernel<%d,false>", D);
     else if (nw == 64) snprintf(buf, buflen, "attn_fwd_c4_kernel<%d,0>", D);
     else snprintf(buf, buflen, "attn_fwd_kernel<%d,%d,%s,0>", D, nw, vt);
+    return LC_OK;
+  }
+  if (use_bigd2(D, v_transposed != 0, N)) {
+    snprintf(buf, buflen, "attn_fwd_bigd2_kernel<%d,%s>", D, bf16 ? "true" : "false");
     return LC_OK;
   }
   if (D == 256 || D == 512 || (D == 1024 && !bf16)) {
@@ -580,6 +592,7 @@ int lc_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, int B
   const half_t* k = static_cast<const half_t*>(K);
   const half_t* v = static_cast<const half_t*>(V);
   half_t* o = static_cast<half_t*>(O);
+  if (use_bigd2(D, false, N)) return launch_attn_bigd2(q, k, v, o, B, H, N, D, true, st);
   const bool w4 = N % 128 == 0;
   switch (D) {
     case 256:

@@ -25,7 +25,7 @@ from pathlib import Path
 OWNED_AGPRS = [
     (re.compile(r"hgemm_w4b_kernel|gemm_fp8_w4_kernel"), [(0, 255)]),
     (re.compile(r"attn_fwd_w4_kernel"), [(0, 127), (192, 255)]),      # a[128:191] stay with hipcc (AGPR spills)
-    (re.compile(r"attn_fwd_w4m_kernel|attn_fwd_d512_kernel"), [(0, 255)]),
+    (re.compile(r"attn_fwd_w4m_kernel|attn_fwd_bigd2_kernel"), [(0, 255)]),
 ]
 
 _REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")

@@ -61,7 +61,8 @@ def test_isa_audit_report_is_clean(built):
     import json
     rep = json.loads((built["abi"].parent / "obj" / "isa_audit.json").read_text())
     names = " ".join(r["kernel"] for r in rep)
-    for k in ("hgemm_w4b_kernel", "gemm_fp8_w4_kernel", "attn_fwd_w4", "hgemm_pingpong2_kernel", "attn_fwd_c4_kernel"):
+    for k in ("hgemm_w4b_kernel", "gemm_fp8_w4_kernel", "attn_fwd_w4m_kernel", "attn_fwd_bigd2_kernel",
+              "hgemm_pingpong2_kernel", "attn_fwd_c4_kernel"):
         assert k in names, k
     assert all(r["scratch"] == 0 and not r["violations"] for r in rep)
     w4 = [r for r in rep if "hgemm_w4b_kernel" in r["kernel"]]
@@ -185,3 +186,18 @@ def test_torch_modules_error_conventions(torch_mods, capfd):
         flash_attn_lib.flash_attn_mma_stages_split_q(q.float(), q, q, q, 2)
     with pytest.raises(RuntimeError, match="no CPU path"):
         flash_attn_lib.flash_attn_cute(q, q, q, q)
+
+
+def test_cpp_bench_harness_builds_and_fails_loudly_without_gpu(built):
+    """tools/cpp/hgemm_bench.bin: torch-free, links only libleetcuda_amd.so; without an MI355X it must
+    stop at lc_device_check with a non-zero exit code, never fall back to anything."""
+    from leetcuda_amd import build
+    exe = build.build_cpp_bench()
+    assert exe.exists()
+    ldd = subprocess.run(["ldd", str(exe)], capture_output=True, text=True).stdout
+    assert "libleetcuda_amd.so" in ldd and "libtorch" not in ldd and "libc10" not in ldd
+    p = subprocess.run([str(exe), "--help"], capture_output=True, text=True)
+    assert p.returncode == 0 and "--layout nn|tn" in p.stdout
+    if not torch.cuda.is_available():
+        p = subprocess.run([str(exe), "--mnk", "256", "256", "256"], capture_output=True, text=True)
+        assert p.returncode == 4 and "no gfx950 device" in p.stderr

@@ -293,3 +293,42 @@ def test_scale_jumps_and_extreme_scores(oracle, nw):
             assert np.isfinite(d).all() and d.max() < 8e-3, (name, d.max())
     finally:
         capi.tune("attn_nw", 0)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("D", [256, 512])
+def test_full_width_large_head_dim_kernel(oracle, D, dtype):
+    """attn_fwd_bigd2_kernel (one workgroup owns all D columns; N % 128 == 0) against the oracle, against round 1's
+    independently written column-split kernel (lc_tune_set "attn_d512" = 1), and on inputs that force its rescale
+    path (the running max is only a scale there): a spike row late in the sequence and a dominant first tile."""
+    capi = _capi()
+    B, H, N = 1, 3, 1024
+    bf = dtype == "bf16"
+    tdt = torch.bfloat16 if bf else torch.half
+    torch.manual_seed(D + (7 if bf else 0))
+    q = torch.randn(B, H, N, D, device="cuda").to(tdt)
+    k = torch.randn(B, H, N, D, device="cuda").to(tdt)
+    v = torch.randn(B, H, N, D, device="cuda").to(tdt)
+    k2 = k.clone()
+    k2[:, :, 700] = 1.5 * q[:, :, 33]            # score ~ 1.5*D/sqrt(D): far above everything before it
+    k2[:, :, :64] = 0.5 * q[:, :, :64]           # dominant first tile for the first 64 query rows
+    tol_max = 1.6e-2 if bf else 4e-3
+    run = (lambda a, b, c, o: capi.attn_fwd_bf16(a, b, c, o)) if bf else \
+        (lambda a, b, c, o: capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", a, b, c, o, 2))
+    for kk in (k, k2):
+        outs = []
+        for knob in (0, 1):
+            capi.tune("attn_d512", knob)
+            try:
+                o = torch.full_like(q, float("nan"))
+                run(q, kk, v, o)
+                torch.cuda.synchronize()
+            finally:
+                capi.tune("attn_d512", 0)
+            outs.append(o.float().cpu().numpy())
+        truth = oracle.attn_bf16(q, kk, v, B, H, N, D) if bf else oracle.attn(q, kk, v, B, H, N, D, mode="f32")
+        for o in outs:
+            d = np.abs(o - truth)
+            assert np.isfinite(d).all() and d.max() < tol_max, d.max()
+        assert np.abs(outs[0] - outs[1]).max() < tol_max
+    assert capi.attn_kernel_name(N, D, False, bf).startswith("attn_fwd_bigd2_kernel")

@@ -121,7 +121,8 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     assert capi.hgemm_kernel_name(1000, 1024, 1024, capi.LAYOUT_NN) == "hgemm_generic_kernel<true>"
     assert capi.attn_kernel_name(4096, 128) == "attn_fwd_c4_kernel<128,0>"
     assert capi.attn_kernel_name(192, 64, True) == "attn_fwd_kernel<64,2,true,0>"
-    assert capi.attn_kernel_name(8192, 512, False, True).startswith("attn_fwd_bigd_kernel<512,")
+    assert capi.attn_kernel_name(8192, 512, False, True) == "attn_fwd_bigd2_kernel<512,true>"
+    assert capi.attn_kernel_name(192, 512, False, False).startswith("attn_fwd_bigd_kernel<512,")     # N % 128 != 0
     assert sump.short("_ZN2lc16hgemm_w4b_kernelILb0ELb1ELb0ELi0EEEvPKDF16_S2_PDF16_iiiiii") == \
         "hgemm_w4b_kernel<false,true,false,0>"
     assert sump.short("_ZN2lc18attn_fwd_c4_kernelILi128ELi0EEEvPKDF16_S2_S2_PDF16_iif") == "attn_fwd_c4_kernel<128,0>"
