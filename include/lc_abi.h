@@ -61,7 +61,8 @@ typedef enum lc_hgemm_variant {
   LC_HGEMM_MFMA128 = 6,    /* 128x128x64 tile, 4 wave64: M, N multiples of 128 (the reference's own tile)               */
   LC_HGEMM_MFMA256W4B = 9, /* 256x256x64 tile, FOUR wave64 with 128x128 wave tiles, A ring of 2 + B ring of 3 K tiles   */
   LC_HGEMM_MFMA256W4C = 10, /* W4B with buffer_load ... lds (descriptor + scalar offset) DMA: the AUTO kernel            */
-  LC_HGEMM_MFMA256W4D = 11  /* W4C with the A pieces spread over two k-steps (one DMA piece per 4 MFMAs everywhere)      */
+  LC_HGEMM_MFMA256W4D = 11, /* W4C with the A pieces spread over two k-steps (one DMA piece per 4 MFMAs everywhere)      */
+  LC_HGEMM_MFMA256W4E = 12  /* W4D with the DMA issue of odd / even waves staggered by one MFMA pair                     */
 } lc_hgemm_variant;
 
 /* FlashAttention-2 forward families (resource policies of kernels/flash-attn/mma/basic/ .cu files). */
@@ -85,8 +86,9 @@ int lc_device_check(int* num_cus);
 const char* lc_build_info(int* is_diag);
 
 /* Run-time selection knobs for A-B benches (not part of the reference surface; correctness never depends on them):
- *   "attn_nw"      attention kernel for D = 128: 0 = auto, 128 = 4 waves x 64 query rows (one wave per SIMD, literal
- *                  AGPRs; N % 256 == 0), 64 = 8-wave four-cluster kernel (N % 256 == 0),
+ *   "attn_nw"      attention kernel for D = 128: 0 = auto (= 256 when N % 256 == 0), 256 = merged-phase kernel, 4 waves x 64
+ *                  query rows, one wave per SIMD (attn_w4m.hip; 260 = its A/B twin with padded Q.K^T MFMAs),
+ *                  64 = 8-wave four-cluster kernel (N % 256 == 0),
  *                  8 / 4 / 2 = lock-step kernel with that many waves (any N % (32 x waves) == 0, every D <= 128)
  *   "hgemm_auto"   kernel LC_HGEMM_AUTO launches on large 256-tileable shapes (a 256-tile lc_hgemm_variant value)
  *   "fp8_mx"       fp8 GEMM: 1 = MX-scaled K = 64 MFMA, 4-wave kernel (default); 2 = MX, 8-wave kernel; 0 = plain K = 16

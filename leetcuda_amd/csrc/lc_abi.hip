@@ -244,17 +244,17 @@ int launch_attn_c4(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   return check_launch();
 }
 
-// Which kernel serves a D <= 128 problem: 128 = 4 waves x 64 rows (attn_w4.hip), 64 = four-cluster kernel, 8 / 4 / 2 =
-// lock-step kernel with that many waves.  ONE function for the launcher and lc_attn_kernel_name().
+// Which kernel serves a D <= 128 problem: 256 = merged-phase 4-wave x 64-row kernel (attn_w4m.hip; 260 = its padded A/B
+// twin), 64 = 8-wave four-cluster kernel, 8 / 4 / 2 = lock-step kernel with that many waves.  ONE function for the
+// launcher and lc_attn_kernel_name().  Default for D = 128, N % 256 == 0: the merged-phase kernel (measured at config 3 /
+// config 4's shard on one box: 1216-1233 / 1265 TFLOP/s against 945-1037 / 1062 for the four-cluster kernel).
 int choose_attn_nw(int D, bool vt, int N) {
   const int want = g_tune_attn_nw;   // 0 = auto
   if (D == 128 && !vt && N % 256 == 0) {
-    if (want == 256 || want == 260) return want;   // merged-phase 4-wave kernel (attn_w4m.hip), 260 = padded Q·Kᵀ MFMAs
-    if (want == 128) return 128;
-    // default for D = 128: the four-cluster LDS-DMA kernel (measured 2-3 % ahead of the lock-step kernel at config 3)
-    if (want == 64 || (want == 0 && g_tune_attn_ablate == 0)) return 64;
+    if (want == 0 && g_tune_attn_ablate == 0) return 256;
+    if (want == 256 || want == 260 || want == 64) return want;
   }
-  if (N % 256 == 0 && (want == 0 || want >= 8)) return 8;   // (also what 64 / 128 / 256 fall back to for D < 128)
+  if (N % 256 == 0 && (want == 0 || want >= 8)) return 8;   // (also what 64 / 256 fall back to for D < 128)
   if (N % 128 == 0 && (want == 0 || want >= 4)) return 4;
   return 2;
 }
@@ -265,7 +265,6 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   const int nw = choose_attn_nw(D, VT, N);
   if constexpr (D == 128 && !VT) {
     if (nw == 64) return launch_attn_c4<D>(Q, K, V, O, B, H, N, st);
-    if (nw == 128) return launch_attn_w4_d128(Q, K, V, O, B, H, N, st);
     if (nw == 256 || nw == 260) return launch_attn_w4m_d128(Q, K, V, O, B, H, N, nw == 260, st);
   }
   if constexpr (D == 128 && !VT) {   // perf-diagnosis instantiations (lc_tune_set "attn_ablate")
@@ -373,7 +372,7 @@ const char* lc_build_info(int* is_diag) {
 
 namespace {
 bool is_w4_variant(int v) {
-  return v == LC_HGEMM_MFMA256W4B || v == LC_HGEMM_MFMA256W4C || v == LC_HGEMM_MFMA256W4D;
+  return v == LC_HGEMM_MFMA256W4B || v == LC_HGEMM_MFMA256W4C || v == LC_HGEMM_MFMA256W4D || v == LC_HGEMM_MFMA256W4E;
 }
 bool is_tile256_variant(int v) { return v == LC_HGEMM_MFMA256 || v == LC_HGEMM_MFMA256P2 || is_w4_variant(v); }
 bool is_hgemm_variant(int v) {
@@ -409,8 +408,8 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
   const char* nn = layout == LC_LAYOUT_NN ? "true" : "false";
   if (is_w4_variant(v)) {
     v = w4_effective_variant(v, layout == LC_LAYOUT_NN, N, K);
-    snprintf(buf, buflen, "hgemm_w4b_kernel<%s,%s,%s,0>", nn, v == LC_HGEMM_MFMA256W4B ? "false" : "true",
-             v == LC_HGEMM_MFMA256W4D ? "true" : "false");
+    snprintf(buf, buflen, "hgemm_w4b_kernel<%s,%s,%s,0,%s>", nn, v == LC_HGEMM_MFMA256W4B ? "false" : "true",
+             (v == LC_HGEMM_MFMA256W4D || v == LC_HGEMM_MFMA256W4E) ? "true" : "false", v == LC_HGEMM_MFMA256W4E ? "true" : "false");
   } else if (v == LC_HGEMM_MFMA256P2) snprintf(buf, buflen, "hgemm_pingpong2_kernel<%s,false>", nn);
   else if (v == LC_HGEMM_MFMA256) snprintf(buf, buflen, "hgemm_mfma256_kernel<%s>", nn);
   else if (v == LC_HGEMM_MFMA128) snprintf(buf, buflen, "hgemm_mfma128_kernel<%s>", nn);
@@ -425,7 +424,6 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
     if (bf16) return LC_ERR_HEADDIM;
     const int nw = choose_attn_nw(D, v_transposed != 0, N);
     if (nw == 256 || nw == 260) snprintf(buf, buflen, "attn_fwd_w4m_kernel<%d,%d>", D, nw == 260 ? 4 : 0);
-    else if (nw == 128) snprintf(buf, buflen, "attn_fwd_w4_kernel<%d,false>", D);
     else if (nw == 64) snprintf(buf, buflen, "attn_fwd_c4_kernel<%d,0>", D);
     else snprintf(buf, buflen, "attn_fwd_kernel<%d,%d,%s,0>", D, nw, vt);
     return LC_OK;
@@ -445,8 +443,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
 int lc_tune_set(const char* key, int value) {
   if (!key) return LC_ERR_ARG;
   if (strcmp(key, "attn_nw") == 0) {
-    if (value != 0 && value != 256 && value != 260 && value != 128 && value != 64 && value != 8 && value != 4 && value != 2)
-      return LC_ERR_ARG;
+    if (value != 0 && value != 256 && value != 260 && value != 64 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
     g_tune_attn_nw = value;
     return LC_OK;
   }

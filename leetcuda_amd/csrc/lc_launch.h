@@ -44,9 +44,7 @@ extern int g_tune_attn_ablate, g_tune_w4_abl, g_tune_hgemm_stamps;
 int w4_effective_variant(int variant, bool b_kn, int N, int K);   // W4C / W4D -> W4B when 32-bit DMA offsets could overflow
 int launch_w4_family(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant, bool b_kn,
                      int tiles_m, int tiles_n, int panel_w, hipStream_t st);
-// tu_attn_w4.hip: 4-wave x 64-row attention kernel, D = 128, N % 256 == 0
-int launch_attn_w4_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
-                        hipStream_t st);
+// tu_attn_w4.hip: 4-wave x 64-row merged-phase attention kernel, D = 128, N % 256 == 0; pad = A/B knob (0 / 4 wait states)
 int launch_attn_w4m_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int pad,
                          hipStream_t st);
 // tu_attn_big.hip: full-width large-head-dim kernel, D in {256, 512}, N % 128 == 0, V as [B,H,N,D]; fp16 or bf16

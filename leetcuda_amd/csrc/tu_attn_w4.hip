@@ -1,32 +1,10 @@
-// tu_attn_w4.hip — translation unit of the 4-wave x 64-row attention kernel (attn_w4.hip) — see lc_launch.h
+// tu_attn_w4.hip — translation unit of the 4-wave x 64-row merged-phase attention kernel (attn_w4m.hip) — see lc_launch.h
 #include <math.h>
 
 #include "lc_launch.h"
-#include "attn_w4.hip"
 #include "attn_w4m.hip"
 
 namespace lc {
-int launch_attn_w4_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
-                        hipStream_t st) {
-  constexpr int D = 128;
-  const int nqb = N / 256;
-  const dim3 grid((unsigned)((size_t)nqb * B * H)), block(256);
-  const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
-#ifdef LC_DIAG
-  if (g_tune_attn_ablate == 32) {
-    auto kern = attn_fwd_w4_kernel<D, true>;
-    if (int rc = set_dyn_lds(kern, AW4_LDS)) return rc;
-    hipLaunchKernelGGL(kern, grid, block, AW4_LDS, st, Q, K, V, O, N, nqb, sl2);
-  } else
-#endif
-  {
-    auto kern = attn_fwd_w4_kernel<D>;
-    if (int rc = set_dyn_lds(kern, AW4_LDS)) return rc;
-    hipLaunchKernelGGL(kern, grid, block, AW4_LDS, st, Q, K, V, O, N, nqb, sl2);
-  }
-  return check_launch();
-}
-
 // merged-phase kernel (attn_w4m.hip); pad = wait states appended to the accumulating Q·Kᵀ MFMAs (0 or 4, A/B knob)
 int launch_attn_w4m_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int pad,
                          hipStream_t st) {

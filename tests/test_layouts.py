@@ -6,7 +6,7 @@ ds_read_b64_tr_b16, lane groups of one LDS cycle each:
     ds_read_b64_tr_b16  {0-31} {32-63}
 A group is conflict-free when its lanes touch pairwise different banks (or identical addresses).
 These are the formulas of hgemm_pingpong.hip / hgemm_w4.hip (st_2x8, 128-B rows) and of
-attn_fwd.hip / attn_w4.hip (K: chunk ^ (row & 15) on 256-B rows; V: 64-B unit ^ (row & 3) for the transpose reads)."""
+attn_fwd.hip / attn_w4m.hip / attn_bigd2.hip (K: chunk ^ (row & 15) on 256-B rows; V: 64-B unit ^ (row & 3) for the transpose reads)."""
 import itertools
 
 B128_GROUPS = [

@@ -22,20 +22,32 @@ if a.what in ("all", "hgemm"):
     B = torch.randn(n, n, dtype=torch.half, device="cuda")
     C = torch.zeros(n, n, dtype=torch.half, device="cuda")
     Bt = host.as_col_major(B)
-    for var in (capi.HGEMM_MFMA256W4C, capi.HGEMM_MFMA256P2, capi.HGEMM_MFMA256W4, capi.HGEMM_MFMA256):
+    for var in (capi.HGEMM_MFMA256W4C, capi.HGEMM_MFMA256W4E, capi.HGEMM_MFMA256P2, capi.HGEMM_MFMA256):
         for lay, bb in ((capi.LAYOUT_TN, Bt), (capi.LAYOUT_NN, B)):
             for _ in range(a.iters):
                 capi.hgemm(A, bb, C, layout=lay, variant=var, swizzle_stride=2048)
     torch.cuda.synchronize()
 if a.what in ("all", "attn"):
     q, k, v, o, tv = host.get_qkvo(4, 32, 4096, 128, seed=0)
-    for nw in (0, 8, 128):     # default (four-cluster LDS-DMA), lock-step, 4-wave x 64-row
+    for nw in (0, 64, 8):     # default (merged-phase 4-wave), four-cluster LDS-DMA, lock-step
         capi.tune("attn_nw", nw)
         for _ in range(a.iters):
             capi.attn_fwd(q, k, v, o)
     capi.tune("attn_nw", 0)
     torch.cuda.synchronize()
     del q, k, v, o, tv
+    # config 5a: FFPA shape, fp16 through the tiling-QKV entry and bf16 (full-width kernel attn_bigd2.hip)
+    q = torch.randn(1, 48, 8192, 512, device="cuda").half()
+    k = torch.randn(1, 48, 8192, 512, device="cuda").half()
+    v = torch.randn(1, 48, 8192, 512, device="cuda").half()
+    o = torch.zeros_like(q)
+    for _ in range(max(1, a.iters // 2)):
+        capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, o, 2)
+    qb, kb, vb, ob = q.bfloat16(), k.bfloat16(), v.bfloat16(), o.bfloat16()
+    for _ in range(max(1, a.iters // 2)):
+        capi.attn_fwd_bf16(qb, kb, vb, ob)
+    torch.cuda.synchronize()
+    del q, k, v, o, qb, kb, vb, ob
     n = 8192   # config-5 extension: fp8 e4m3 GEMM
     a8 = torch.randn(n, n, device="cuda").to(torch.float8_e4m3fn)
     b8 = torch.randn(n, n, device="cuda").to(torch.float8_e4m3fn)

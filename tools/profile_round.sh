@@ -2,7 +2,7 @@
 # rocprofv3 evidence for profiles/: kernel-trace stats of bench.py ITSELF + separate PMC passes of the hot kernels
 TAG=${1:-r02p}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 set +e
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o stats -- python bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err; echo "stats rc=$?" | tee -a $OUT/steps.log
+timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o stats -- python bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err; echo "stats rc=$?" | tee -a $OUT/steps.log
 timeout 300 python bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
 pmc() { local name=$1; shift; timeout 400 rocprofv3 --pmc "$@" -d $OUT/pmc_$name -o pmc -- python tools/prof_kernels.py --iters 2 > $OUT/pmc_$name.log 2>&1; echo "pmc $name rc=$?" | tee -a $OUT/steps.log; }
 pmc fetch FETCH_SIZE
