@@ -21,9 +21,6 @@
 //     SPREAD = false: all 8 A pieces in step 3 (the step behind the barrier);
 //     SPREAD = true : 4 in step 3 and 4 in step 0 of the next tile (one DMA piece per 4 MFMAs in EVERY step; the
 //                     counted wait is unchanged because the 8 B pieces are still the youngest at the wait).
-//     STAG (with SPREAD): waves 0, 2 issue their piece behind the EVEN MFMA pair of a step, waves 1, 3 behind the odd one:
-//                     after the barrier the four waves run in lock-step, so un-staggered they hit the CU's single
-//                     texture-address path in the same cycle and the last one waits past its MFMA cover.
 //   * BUF: the DMA pieces are buffer_load ... lds (descriptor from a readfirstlane'd pointer + scalar offset + one
 //     32-bit lane offset) instead of global_load_lds with a 64-bit address per lane.
 //   * NN B image: two sub-images of 128 CONTIGUOUS columns ([64 k][256 B] each, 32-B pairs XOR-ed by (k&3)<<1,
@@ -171,7 +168,7 @@ LC_DEVINL void w4_epilogue(char* smem, half_t* C, int N, int m0, int n0, int wav
 //       tiles 32..35 (lc_tune_set "hgemm_stamps", tools/hgemm_w4c_stamps.py)
 //   2 = no DMA after the prologue, 4 = no per-tile wait + barrier, 8 = no fragment reads in the loop (2|4|8 = MFMA
 //       issue only: the ceiling of the matrix pipe at the sustained clock; lc_tune_set "w4_abl", tools/w4_ablate.py)
-template <bool B_KN, bool BUF, bool SPREAD, int DG = 0, bool STAG = false>
+template <bool B_KN, bool BUF, bool SPREAD, int DG = 0>
 __global__ __launch_bounds__(256) void hgemm_w4b_kernel(const half_t* __restrict__ A,
                                                        const half_t* __restrict__ B,
                                                        half_t* __restrict__ C, int M, int N, int K,
@@ -263,10 +260,9 @@ __global__ __launch_bounds__(256) void hgemm_w4b_kernel(const half_t* __restrict
 
   // one k-step: 16 MFMAs from fragment buffer cb; chunks 0..3 carry the 8 fragment reads of the next step into
   // buffer cb^1; DMA: NP pieces g0.. of tile t2 into wslot, one per 8/NP chunks (NP = 0, 4 or 8)
-  auto step = [&](auto parc, auto cbc, const char* rsa, const char* rsb, int rks, auto npc, int g0, int t2, char* wslot) {
+  auto step = [&](auto cbc, const char* rsa, const char* rsb, int rks, auto npc, int g0, int t2, char* wslot) {
     constexpr int cb = decltype(cbc)::value;
     constexpr int NP = decltype(npc)::value;
-    constexpr int PAR = decltype(parc)::value;   // which MFMA pair of a 2-pair group carries the DMA piece (NP = 4)
     if constexpr (B_KN) {   // the asm reads of this buffer were issued >= 8 MFMAs ago
       lds_tr16_wait8(braw[cb]);
 #pragma unroll
@@ -292,7 +288,7 @@ __global__ __launch_bounds__(256) void hgemm_w4b_kernel(const half_t* __restrict
       }
       if constexpr (!NO_DMA) {
         if constexpr (NP == 8) piece(g0 + c, t2, wslot);
-        if constexpr (NP == 4 && (c & 1) == PAR) piece(g0 + (c >> 1), t2, wslot);
+        if constexpr (NP == 4 && (c & 1) == 1) piece(g0 + (c >> 1), t2, wslot);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -313,50 +309,36 @@ __global__ __launch_bounds__(256) void hgemm_w4b_kernel(const half_t* __restrict
       }
     }
   };
-  auto mainloop = [&](auto parc) {
-    int b0 = 0, b1 = 1, b2 = 2;   // B slot indices of tiles kt, kt+1, kt+2 (rotating, kt % 3)
-    for (int kt = 0; kt < KT; ++kt) {
-      const char* ca = a_slot(kt);
-      const char* cbs = b_slot(b0);
-      STAMP(kt, 0);
-      if constexpr (SPREAD)   // the second half of A(kt+1): its slot has been dead since the barrier of tile kt-1
-        step(parc, I0{}, ca, cbs, 1, P4{}, 4, kt + 1, a_slot(kt + 1));
-      else
-        step(parc, I0{}, ca, cbs, 1, P0{}, 0, 0, nullptr);
-      STAMP(kt, 1);
-      step(parc, I1{}, ca, cbs, 2, P4{}, 8, kt + 2, b_slot(b2));
-      STAMP(kt, 2);
-      step(parc, I0{}, ca, cbs, 3, P4{}, 12, kt + 2, b_slot(b2));
-      STAMP(kt, 3);
-      // every read of tile kt is issued; A(kt+1), B(kt+1) must have landed (the 8 B pieces of tile kt+2 stay in flight)
-      if constexpr (!NO_BAR) {
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        STAMP(kt, 4);
-        pp_barrier();
-      }
-      STAMP(kt, 5);
-      if constexpr (SPREAD)
-        step(parc, I1{}, a_slot(kt + 1), b_slot(b1), 0, P4{}, 0, kt + 2, a_slot(kt));
-      else
-        step(parc, I1{}, a_slot(kt + 1), b_slot(b1), 0, P8{}, 0, kt + 2, a_slot(kt));
-      STAMP(kt, 6);
-      const int t = b0;
-      b0 = b1;
-      b1 = b2;
-      b2 = t;
+  int b0 = 0, b1 = 1, b2 = 2;   // B slot indices of tiles kt, kt+1, kt+2 (rotating, kt % 3)
+  for (int kt = 0; kt < KT; ++kt) {
+    const char* ca = a_slot(kt);
+    const char* cbs = b_slot(b0);
+    STAMP(kt, 0);
+    if constexpr (SPREAD)   // the second half of A(kt+1): its slot has been dead since the barrier of tile kt-1
+      step(I0{}, ca, cbs, 1, P4{}, 4, kt + 1, a_slot(kt + 1));
+    else
+      step(I0{}, ca, cbs, 1, P0{}, 0, 0, nullptr);
+    STAMP(kt, 1);
+    step(I1{}, ca, cbs, 2, P4{}, 8, kt + 2, b_slot(b2));
+    STAMP(kt, 2);
+    step(I0{}, ca, cbs, 3, P4{}, 12, kt + 2, b_slot(b2));
+    STAMP(kt, 3);
+    // every read of tile kt is issued; A(kt+1), B(kt+1) must have landed (the 8 B pieces of tile kt+2 stay in flight)
+    if constexpr (!NO_BAR) {
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      STAMP(kt, 4);
+      pp_barrier();
     }
-    if constexpr (B_KN && STAG) {
-      lds_tr16_wait8(braw[0]);
-      lds_tr16_wait8(braw[1]);
-    }
-  };
-  if constexpr (STAG) {
-    // two copies of the K loop: retire the asm transpose reads in flight BEFORE control flow splits (and again inside
-    // each copy, below) — at a branch / join hipcc may copy their destination registers (isa_audit.py rule R3)
-    if constexpr (B_KN) lds_tr16_wait8(braw[0]);
-    if (wave & 1) mainloop(I1{}); else mainloop(I0{});
-  } else {
-    mainloop(I1{});
+    STAMP(kt, 5);
+    if constexpr (SPREAD)
+      step(I1{}, a_slot(kt + 1), b_slot(b1), 0, P4{}, 0, kt + 2, a_slot(kt));
+    else
+      step(I1{}, a_slot(kt + 1), b_slot(b1), 0, P8{}, 0, kt + 2, a_slot(kt));
+    STAMP(kt, 6);
+    const int t = b0;
+    b0 = b1;
+    b1 = b2;
+    b2 = t;
   }
   LC_VMCNT(0);
   if constexpr (B_KN) {

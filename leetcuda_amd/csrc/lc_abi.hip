@@ -372,7 +372,7 @@ const char* lc_build_info(int* is_diag) {
 
 namespace {
 bool is_w4_variant(int v) {
-  return v == LC_HGEMM_MFMA256W4B || v == LC_HGEMM_MFMA256W4C || v == LC_HGEMM_MFMA256W4D || v == LC_HGEMM_MFMA256W4E;
+  return v == LC_HGEMM_MFMA256W4B || v == LC_HGEMM_MFMA256W4C || v == LC_HGEMM_MFMA256W4D;
 }
 bool is_tile256_variant(int v) { return v == LC_HGEMM_MFMA256 || v == LC_HGEMM_MFMA256P2 || is_w4_variant(v); }
 bool is_hgemm_variant(int v) {
@@ -408,8 +408,8 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
   const char* nn = layout == LC_LAYOUT_NN ? "true" : "false";
   if (is_w4_variant(v)) {
     v = w4_effective_variant(v, layout == LC_LAYOUT_NN, N, K);
-    snprintf(buf, buflen, "hgemm_w4b_kernel<%s,%s,%s,0,%s>", nn, v == LC_HGEMM_MFMA256W4B ? "false" : "true",
-             (v == LC_HGEMM_MFMA256W4D || v == LC_HGEMM_MFMA256W4E) ? "true" : "false", v == LC_HGEMM_MFMA256W4E ? "true" : "false");
+    snprintf(buf, buflen, "hgemm_w4b_kernel<%s,%s,%s,0>", nn, v == LC_HGEMM_MFMA256W4B ? "false" : "true",
+             v == LC_HGEMM_MFMA256W4D ? "true" : "false");
   } else if (v == LC_HGEMM_MFMA256P2) snprintf(buf, buflen, "hgemm_pingpong2_kernel<%s,false>", nn);
   else if (v == LC_HGEMM_MFMA256) snprintf(buf, buflen, "hgemm_mfma256_kernel<%s>", nn);
   else if (v == LC_HGEMM_MFMA128) snprintf(buf, buflen, "hgemm_mfma128_kernel<%s>", nn);

@@ -115,7 +115,7 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     sump = importlib.util.module_from_spec(spec2)
     spec2.loader.exec_module(sump)
     # dispatcher names == demangled symbol names of the kernels actually in the library
-    assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN) == "hgemm_w4b_kernel<false,true,false,0,false>"
+    assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN) == "hgemm_w4b_kernel<false,true,false,0>"
     assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_NN, capi.HGEMM_MFMA256P2) == "hgemm_pingpong2_kernel<true,false>"
     assert capi.hgemm_kernel_name(1024, 1024, 1024, capi.LAYOUT_NN) == "hgemm_mfma128_kernel<true>"
     assert capi.hgemm_kernel_name(1000, 1024, 1024, capi.LAYOUT_NN) == "hgemm_generic_kernel<true>"
@@ -124,8 +124,8 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     assert capi.attn_kernel_name(192, 64, True) == "attn_fwd_kernel<64,2,true,0>"
     assert capi.attn_kernel_name(8192, 512, False, True) == "attn_fwd_bigd2_kernel<512,true>"
     assert capi.attn_kernel_name(192, 512, False, False).startswith("attn_fwd_bigd_kernel<512,")     # N % 128 != 0
-    assert sump.short("_ZN2lc16hgemm_w4b_kernelILb0ELb1ELb0ELi0ELb0EEEvPKDF16_S2_PDF16_iiiiii") == \
-        "hgemm_w4b_kernel<false,true,false,0,false>"
+    assert sump.short("_ZN2lc16hgemm_w4b_kernelILb0ELb1ELb0ELi0EEEvPKDF16_S2_PDF16_iiiiii") == \
+        "hgemm_w4b_kernel<false,true,false,0>"
     assert sump.short("_ZN2lc18attn_fwd_c4_kernelILi128ELi0EEEvPKDF16_S2_S2_PDF16_iif") == "attn_fwd_c4_kernel<128,0>"
     pmc = json.loads((root / "profiles" / "latest_pmc.json").read_text())
     for key in (capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN), capi.attn_kernel_name(4096, 128)):

@@ -22,7 +22,7 @@ if a.what in ("all", "hgemm"):
     B = torch.randn(n, n, dtype=torch.half, device="cuda")
     C = torch.zeros(n, n, dtype=torch.half, device="cuda")
     Bt = host.as_col_major(B)
-    for var in (capi.HGEMM_MFMA256W4C, capi.HGEMM_MFMA256W4E, capi.HGEMM_MFMA256P2, capi.HGEMM_MFMA256):
+    for var in (capi.HGEMM_MFMA256W4C, capi.HGEMM_MFMA256P2, capi.HGEMM_MFMA256):
         for lay, bb in ((capi.LAYOUT_TN, Bt), (capi.LAYOUT_NN, B)):
             for _ in range(a.iters):
                 capi.hgemm(A, bb, C, layout=lay, variant=var, swizzle_stride=2048)
