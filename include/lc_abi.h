@@ -61,7 +61,9 @@ typedef enum lc_hgemm_variant {
   LC_HGEMM_MFMA128 = 6,    /* 128x128x64 tile, 4 wave64: M, N multiples of 128 (the reference's own tile)               */
   LC_HGEMM_MFMA256W4B = 9, /* 256x256x64 tile, FOUR wave64 with 128x128 wave tiles, A ring of 2 + B ring of 3 K tiles   */
   LC_HGEMM_MFMA256W4C = 10, /* W4B with buffer_load ... lds (descriptor + scalar offset) DMA: the AUTO kernel            */
-  LC_HGEMM_MFMA256W4D = 11  /* W4C with the A pieces spread over two k-steps (one DMA piece per 4 MFMAs everywhere)      */
+  LC_HGEMM_MFMA256W4D = 11, /* W4C with the A pieces spread over two k-steps (one DMA piece per 4 MFMAs everywhere)      */
+  LC_HGEMM_MFMA256W4X = 12  /* W4C's ring / DMA schedule with v_mfma_f32_16x16x32_f16 (8 x 8 blocks of 16 x 16 per wave): fewer  */
+                            /* joules per FLOP at the board power cap (hgemm_w4x.hip); NN shapes run W4C                    */
 } lc_hgemm_variant;
 
 /* FlashAttention-2 forward families (resource policies of kernels/flash-attn/mma/basic/ .cu files). */

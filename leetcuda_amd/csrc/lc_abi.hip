@@ -151,6 +151,10 @@ const AttnEntry* find_attn(const char* name) {
 
 // ------------------------------------------------------------------------------------------------
 // HGEMM launchers
+bool is_w4_variant(int v) {
+  return v == LC_HGEMM_MFMA256W4B || v == LC_HGEMM_MFMA256W4C || v == LC_HGEMM_MFMA256W4D || v == LC_HGEMM_MFMA256W4X;
+}
+
 int panel_tiles(int swizzle_stride, int tiles_n, int tile_n) {
   if (swizzle_stride <= 1) return tiles_n;  // no thread-block swizzle: plain N-major raster
   int w = swizzle_stride / tile_n;
@@ -165,7 +169,7 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   const int tiles_m = M / BM, tiles_n = N / BN;
   const int pw = panel_tiles(swizzle_stride, tiles_n, BN);
   const dim3 grid(tiles_m * tiles_n), block(512);
-  if (variant == LC_HGEMM_MFMA256W4B || variant == LC_HGEMM_MFMA256W4C || variant == LC_HGEMM_MFMA256W4D)
+  if (is_w4_variant(variant))
     return launch_w4_family(A, B, C, M, N, K, variant, B_KN, tiles_m, tiles_n, pw, st);
   if (false) {
 #ifdef LC_DIAG
@@ -371,9 +375,6 @@ const char* lc_build_info(int* is_diag) {
 }
 
 namespace {
-bool is_w4_variant(int v) {
-  return v == LC_HGEMM_MFMA256W4B || v == LC_HGEMM_MFMA256W4C || v == LC_HGEMM_MFMA256W4D;
-}
 bool is_tile256_variant(int v) { return v == LC_HGEMM_MFMA256 || v == LC_HGEMM_MFMA256P2 || is_w4_variant(v); }
 bool is_hgemm_variant(int v) {
   return v == LC_HGEMM_AUTO || v == LC_HGEMM_GENERIC || v == LC_HGEMM_MFMA128 || is_tile256_variant(v);
@@ -408,7 +409,8 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
   const char* nn = layout == LC_LAYOUT_NN ? "true" : "false";
   if (is_w4_variant(v)) {
     v = w4_effective_variant(v, layout == LC_LAYOUT_NN, N, K);
-    snprintf(buf, buflen, "hgemm_w4b_kernel<%s,%s,%s,0>", nn, v == LC_HGEMM_MFMA256W4B ? "false" : "true",
+    if (v == LC_HGEMM_MFMA256W4X) snprintf(buf, buflen, "hgemm_w4x_kernel<%s>", nn);
+    else snprintf(buf, buflen, "hgemm_w4b_kernel<%s,%s,%s,0>", nn, v == LC_HGEMM_MFMA256W4B ? "false" : "true",
              v == LC_HGEMM_MFMA256W4D ? "true" : "false");
   } else if (v == LC_HGEMM_MFMA256P2) snprintf(buf, buflen, "hgemm_pingpong2_kernel<%s,false>", nn);
   else if (v == LC_HGEMM_MFMA256) snprintf(buf, buflen, "hgemm_mfma256_kernel<%s>", nn);

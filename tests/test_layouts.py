@@ -45,6 +45,21 @@ def test_gemm_st2x8_swizzle_is_conflict_free_for_b128_fragment_reads():
         assert sorted(c ^ ((r >> 1) & 7) for c in range(8)) == list(range(8))
 
 
+def test_gemm_st2x8_swizzle_is_conflict_free_for_16x16x32_fragment_reads():
+    # hgemm_w4x.hip: the SAME image (128-B rows, chunk c of row r at slot c ^ ((r >> 1) & 7)) read for v_mfma_f32_16x16x32:
+    # lane -> row 16 i + (l & 15), chunk 4 ks + (l >> 4)
+    for ks, i in itertools.product(range(2), range(8)):
+        for grp in B128_GROUPS:
+            addrs = []
+            for lane in grp:
+                row, kg = 16 * i + (lane & 15), lane >> 4
+                addrs.append(row * 128 + (((4 * ks + kg) ^ ((row >> 1) & 7)) * 16))
+            assert conflict_free(addrs, 16), (ks, i, grp)
+            # the kernel's address form: (l >> 1) & 7 == (row >> 1) & 7 for row = 16 i + (l & 15)
+            for lane in grp:
+                assert ((lane >> 1) & 7) == (((16 * i + (lane & 15)) >> 1) & 7)
+
+
 def test_attention_k_tile_swizzle_256_byte_rows():
     # K tile [64 kv][256 B]: chunk c of row r at slot c ^ (r & 15); fragment lane -> row tt*32 + l32, chunk 2ks + hi
     for ks, tt in itertools.product(range(8), range(2)):

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Back-to-back launches of one hot kernel for a few seconds per spec (the workload of tools/power_watch.sh; join the
+sampler log with tools/power_join.py).  usage: sustain.py [--seconds S] spec...
+   spec = hgemm | vendor | attn | attn8k | d512, optionally :zero (zero-filled inputs), :uniform, :var=auto|w4c|w4x|pingpong2, :abl=N (hgemm only:
+          lc_tune_set "w4_abl", LC_DIAG library — ablated kernels compute WRONG results), :nw=N (attention kernel choice)"""
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+
+from leetcuda_amd import capi, host  # noqa: E402
+
+args = sys.argv[1:]
+secs = 2.5
+if args and args[0] == "--seconds":
+    secs = float(args[1])
+    args = args[2:]
+capi.load()
+vendor_ready = False
+VAR = {"auto": capi.HGEMM_AUTO, "w4c": capi.HGEMM_MFMA256W4C, "w4x": capi.HGEMM_MFMA256W4X, "pingpong2": capi.HGEMM_MFMA256P2}
+
+
+def fill(t, opts):
+    if "zero" in opts:
+        t.zero_()
+    elif "uniform" in opts:
+        t.uniform_(-1, 1)
+    return t
+
+
+for spec in args:
+    what, *opts = spec.split(":")
+    abl = next((int(o[4:]) for o in opts if o.startswith("abl=")), 0)
+    nw = next((int(o[3:]) for o in opts if o.startswith("nw=")), 0)
+    var = next((o[4:] for o in opts if o.startswith("var=")), "auto")
+    if what in ("hgemm", "vendor"):
+        n = 8192
+        a = fill(torch.randn(n, n, dtype=torch.half, device="cuda"), opts)
+        b = fill(host.as_col_major(torch.randn(n, n, dtype=torch.half, device="cuda")), opts)
+        c = torch.empty(n, n, dtype=torch.half, device="cuda")
+        flops = 2.0 * n ** 3
+        if what == "vendor":
+            if not vendor_ready:
+                capi.vendor_init()
+                vendor_ready = True
+            step = lambda: capi.hgemm_vendor(a, b, c, layout=capi.LAYOUT_TN)  # noqa: E731
+        else:
+            if abl:
+                capi.tune("w4_abl", abl)
+                var = "w4c"
+            step = lambda: capi.hgemm(a, b, c, layout=capi.LAYOUT_TN, variant=VAR[var], swizzle_stride=2048)  # noqa: E731
+    elif what in ("attn", "attn8k"):
+        B, H, N, D = (4, 32, 4096, 128) if what == "attn" else (4, 32, 8192, 128)
+        q, k, v, o, _ = host.get_qkvo(B, H, N, D, seed=0)
+        for t in (q, k, v):
+            fill(t, opts)
+        capi.tune("attn_nw", nw)
+        step = lambda: capi.attn_fwd(q, k, v, o)  # noqa: E731
+        flops = host.mha_matmul_flops(B, H, N, D)
+    elif what == "d512":
+        q = fill(torch.randn(1, 48, 8192, 512, device="cuda").half(), opts)
+        k = fill(torch.randn(1, 48, 8192, 512, device="cuda").half(), opts)
+        v = fill(torch.randn(1, 48, 8192, 512, device="cuda").half(), opts)
+        o = torch.zeros_like(q)
+        step = lambda: capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, o, 2)  # noqa: E731
+        flops = host.mha_matmul_flops(1, 48, 8192, 512)
+    else:
+        raise SystemExit(f"unknown spec {spec}")
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t_start = time.time()
+    n_l = 0
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    while time.time() - t_start < secs:
+        for _ in range(100):
+            step()
+        n_l += 100
+        torch.cuda.synchronize()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    print(f"RUN {spec:24s} {flops * n_l / ms * 1e-9:7.1f} TFLOP/s(-equivalent)  t0={t_start:.3f} t1={time.time():.3f}", flush=True)
+    if abl:
+        capi.tune("w4_abl", 0)
+    if nw:
+        capi.tune("attn_nw", 0)
