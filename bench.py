@@ -80,7 +80,7 @@ def parse(argv=None):
 
 
 VARIANT = {"auto": capi.HGEMM_AUTO, "mfma256": capi.HGEMM_MFMA256, "pingpong2": capi.HGEMM_MFMA256P2,
-           "w4b": capi.HGEMM_MFMA256W4B, "w4c": capi.HGEMM_MFMA256W4C, "w4d": capi.HGEMM_MFMA256W4D, "w4x": capi.HGEMM_MFMA256W4X,
+           "w4b": capi.HGEMM_MFMA256W4B, "w4c": capi.HGEMM_MFMA256W4C, "w4d": capi.HGEMM_MFMA256W4D, "w4x": capi.HGEMM_MFMA256W4X, "w4y": capi.HGEMM_MFMA256W4Y,
            "mfma128": capi.HGEMM_MFMA128, "generic": capi.HGEMM_GENERIC}
 
 
@@ -196,7 +196,7 @@ def bench_hgemm(w, args):
     if args.sweep and w.rank == 0:
         for lname, l2 in (("tn", capi.LAYOUT_TN), ("nn", capi.LAYOUT_NN)):
             b2 = host.as_col_major(b) if l2 == capi.LAYOUT_TN else b
-            for vn in ("mfma256", "pingpong2", "w4b", "w4c", "w4d", "w4x"):
+            for vn in ("mfma256", "pingpong2", "w4b", "w4c", "w4d", "w4x", "w4y"):
                 for st in (1, 1024, 2048):
                     ms = capi.hgemm_time(a, b2, c, l2, VARIANT[vn], 2, st, warmup=2, iters=20)
                     print(f"[sweep] hgemm {lname} {vn:9s} stride {st:5d}: {ms:.4f} ms  "

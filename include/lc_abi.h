@@ -62,6 +62,7 @@ typedef enum lc_hgemm_variant {
   LC_HGEMM_MFMA256W4B = 9, /* 256x256x64 tile, FOUR wave64 with 128x128 wave tiles, A ring of 2 + B ring of 3 K tiles   */
   LC_HGEMM_MFMA256W4C = 10, /* W4B with buffer_load ... lds (descriptor + scalar offset) DMA: the AUTO kernel            */
   LC_HGEMM_MFMA256W4D = 11, /* W4C with the A pieces spread over two k-steps (one DMA piece per 4 MFMAs everywhere)      */
+  LC_HGEMM_MFMA256W4Y = 13, /* W4X with the K loop as one hand-ordered instruction stream (hgemm_w4y.hip, generated loop body)  */
   LC_HGEMM_MFMA256W4X = 12  /* W4C's ring / DMA schedule with v_mfma_f32_16x16x32_f16 (8 x 8 blocks of 16 x 16 per wave): fewer  */
                             /* joules per FLOP at the board power cap (hgemm_w4x.hip); NN shapes run W4C                    */
 } lc_hgemm_variant;
@@ -91,6 +92,7 @@ const char* lc_build_info(int* is_diag);
  *                  query rows, one wave per SIMD (attn_w4m.hip; 260 = its A/B twin with padded Q.K^T MFMAs),
  *                  64 = 8-wave four-cluster kernel (N % 256 == 0),
  *                  8 / 4 / 2 = lock-step kernel with that many waves (any N % (32 x waves) == 0, every D <= 128)
+ *   "w4y_sched"    schedule 0..2 of LC_HGEMM_MFMA256W4Y's generated loop body (tools/gen_hgemm_w4y.py; same bits, A/B knob)
  *   "hgemm_auto"   kernel LC_HGEMM_AUTO launches on large 256-tileable shapes (a 256-tile lc_hgemm_variant value)
  *   "fp8_mx"       fp8 GEMM: 1 = MX-scaled K = 64 MFMA, 4-wave kernel (default); 2 = MX, 8-wave kernel; 0 = plain K = 16
  *   "attn_d512"    D = 512 kernel: 0 = auto (one workgroup owns all 512 output columns), 1 = round-1 column-split kernel

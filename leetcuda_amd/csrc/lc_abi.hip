@@ -27,6 +27,7 @@ using namespace lc;
 namespace lc {
 int g_tune_attn_ablate = 0;      // attention ablation / stamp builds (diagnosis only, LC_DIAG)
 int g_tune_w4_abl = 0;           // hgemm_w4 ablation bits (diagnosis only, LC_DIAG)
+int g_tune_w4y_sched = 1;        // hgemm_w4y_kernel loop schedule 0..2 (lc_tune_set "w4y_sched")
 int g_tune_hgemm_stamps = 0;     // GEMM cycle-stamp builds (diagnosis only, LC_DIAG)
 }  // namespace lc
 
@@ -36,7 +37,7 @@ namespace {
 int g_tune_fp8_mx = 1;                       // fp8 GEMM: 1 = MX-scaled K=64 MFMA, 4-wave kernel; 2 = MX, 8-wave kernel; 0 = plain K=16 MFMA
 int g_tune_attn_nw = 0;                    // attention kernel for D = 128: 0 = auto, 128 / 64 / 8 / 4 / 2 (lc_abi.h)
 int g_tune_attn_d512 = 0;                  // D = 512: 0 = auto (full-width workgroup), 1 = column-split kernel
-int g_tune_hgemm_auto = LC_HGEMM_MFMA256W4C;   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
+int g_tune_hgemm_auto = LC_HGEMM_MFMA256W4Y;   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -152,7 +153,8 @@ const AttnEntry* find_attn(const char* name) {
 // ------------------------------------------------------------------------------------------------
 // HGEMM launchers
 bool is_w4_variant(int v) {
-  return v == LC_HGEMM_MFMA256W4B || v == LC_HGEMM_MFMA256W4C || v == LC_HGEMM_MFMA256W4D || v == LC_HGEMM_MFMA256W4X;
+  return v == LC_HGEMM_MFMA256W4B || v == LC_HGEMM_MFMA256W4C || v == LC_HGEMM_MFMA256W4D || v == LC_HGEMM_MFMA256W4X ||
+         v == LC_HGEMM_MFMA256W4Y;
 }
 
 int panel_tiles(int swizzle_stride, int tiles_n, int tile_n) {
@@ -410,6 +412,7 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
   if (is_w4_variant(v)) {
     v = w4_effective_variant(v, layout == LC_LAYOUT_NN, N, K);
     if (v == LC_HGEMM_MFMA256W4X) snprintf(buf, buflen, "hgemm_w4x_kernel<%s>", nn);
+    else if (v == LC_HGEMM_MFMA256W4Y) snprintf(buf, buflen, "hgemm_w4y_kernel<%s,%d>", nn, g_tune_w4y_sched);
     else snprintf(buf, buflen, "hgemm_w4b_kernel<%s,%s,%s,0>", nn, v == LC_HGEMM_MFMA256W4B ? "false" : "true",
              v == LC_HGEMM_MFMA256W4D ? "true" : "false");
   } else if (v == LC_HGEMM_MFMA256P2) snprintf(buf, buflen, "hgemm_pingpong2_kernel<%s,false>", nn);
@@ -457,6 +460,11 @@ int lc_tune_set(const char* key, int value) {
   if (strcmp(key, "attn_d512") == 0) {
     if (value < 0 || value > 1) return LC_ERR_ARG;
     g_tune_attn_d512 = value;
+    return LC_OK;
+  }
+  if (strcmp(key, "w4y_sched") == 0) {
+    if (value < 0 || value > 2) return LC_ERR_ARG;
+    g_tune_w4y_sched = value;
     return LC_OK;
   }
   if (strcmp(key, "hgemm_auto") == 0) {

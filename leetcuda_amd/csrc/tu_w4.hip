@@ -1,6 +1,6 @@
 // tu_w4.hip — translation unit of the 4-wave HGEMM kernel (hgemm_w4.hip) — see lc_launch.h
 #include "lc_launch.h"
-#include "hgemm_w4x.hip"
+#include "hgemm_w4y.hip"
 
 namespace lc {
 namespace {
@@ -13,10 +13,13 @@ int launch_w4_one(const half_t* A, const half_t* B, half_t* C, int M, int N, int
   return check_launch();
 }
 
-template <bool B_KN>
+template <bool B_KN, int Y>   // Y: -1 = hgemm_w4x_kernel, 0.. = hgemm_w4y_kernel<.., Y>
 int launch_w4x_one(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int tiles_m, int tiles_n, int pw,
                    hipStream_t st) {
-  auto kern = hgemm_w4x_kernel<B_KN>;
+  auto kern = [] {
+    if constexpr (Y < 0) return hgemm_w4x_kernel<B_KN>;
+    else return hgemm_w4y_kernel<B_KN, Y>;
+  }();
   if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
   return check_launch();
@@ -41,10 +44,16 @@ int launch_w4_t(const half_t* A, const half_t* B, half_t* C, int M, int N, int K
   }
 #endif
   if constexpr (!B_KN) {
-    if (variant == LC_HGEMM_MFMA256W4X) return launch_w4x_one<B_KN>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+    if (variant == LC_HGEMM_MFMA256W4X) return launch_w4x_one<B_KN, -1>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+    if (variant == LC_HGEMM_MFMA256W4Y) {
+      if (g_tune_w4y_sched == 0) return launch_w4x_one<B_KN, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+      if (g_tune_w4y_sched == 1) return launch_w4x_one<B_KN, 1>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+      return launch_w4x_one<B_KN, 2>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+    }
   }
   if (variant == LC_HGEMM_MFMA256W4D) return launch_w4_one<B_KN, true, true, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
-  if (variant == LC_HGEMM_MFMA256W4C || variant == LC_HGEMM_MFMA256W4X) return launch_w4_one<B_KN, true, false, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+  if (variant == LC_HGEMM_MFMA256W4C || variant == LC_HGEMM_MFMA256W4X || variant == LC_HGEMM_MFMA256W4Y)
+    return launch_w4_one<B_KN, true, false, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
   return launch_w4_one<B_KN, false, false, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
 }
 }  // namespace
@@ -52,8 +61,9 @@ int launch_w4_t(const half_t* A, const half_t* B, half_t* C, int M, int N, int K
 // buffer-descriptor DMA addresses are 32-bit offsets from the wave's first row: fall back to the 64-bit global form
 // when an offset could reach 2 GiB (NN: K tiles step through the whole of B)
 int w4_effective_variant(int variant, bool b_kn, int N, int K) {
-  if (variant == LC_HGEMM_MFMA256W4X && b_kn) variant = LC_HGEMM_MFMA256W4C;   // NN: the 32x32x16 kernel (for now)
-  if (variant == LC_HGEMM_MFMA256W4C || variant == LC_HGEMM_MFMA256W4D || variant == LC_HGEMM_MFMA256W4X) {
+  if ((variant == LC_HGEMM_MFMA256W4X || variant == LC_HGEMM_MFMA256W4Y) && b_kn) variant = LC_HGEMM_MFMA256W4C;   // NN: the 32x32x16 kernel (for now)
+  if (variant == LC_HGEMM_MFMA256W4C || variant == LC_HGEMM_MFMA256W4D || variant == LC_HGEMM_MFMA256W4X ||
+      variant == LC_HGEMM_MFMA256W4Y) {
     const size_t max_off = b_kn ? (size_t)K * N * 2 + (size_t)N * 64 : (size_t)K * 2 * 130;
     if (max_off >= ((size_t)1 << 31)) return LC_HGEMM_MFMA256W4B;
   }

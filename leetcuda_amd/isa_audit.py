@@ -23,7 +23,7 @@ from pathlib import Path
 
 # kernel-name regex -> AGPR ranges owned by the kernel's asm statements (inclusive)
 OWNED_AGPRS = [
-    (re.compile(r"hgemm_w4b_kernel|hgemm_w4x_kernel|gemm_fp8_w4_kernel"), [(0, 255)]),
+    (re.compile(r"hgemm_w4b_kernel|hgemm_w4x_kernel|hgemm_w4y_kernel|gemm_fp8_w4_kernel"), [(0, 255)]),
     (re.compile(r"attn_fwd_w4_kernel"), [(0, 127), (192, 255)]),      # a[128:191] stay with hipcc (AGPR spills)
     (re.compile(r"attn_fwd_w4m_kernel|attn_fwd_bigd2_kernel"), [(0, 255)]),
 ]

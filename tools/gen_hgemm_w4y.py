@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Emit leetcuda_amd/csrc/hgemm_w4y_loop.inc: the whole K loop of hgemm_w4y_kernel (hgemm_w4y.hip) as ONE asm statement.
+
+Why a generator: with one wave per SIMD and 16-cycle MFMAs (v_mfma_f32_16x16x32_f16) every instruction hipcc adds between
+two MFMAs (an s_nop at each asm-statement boundary, its own s_waitcnt placement, SALU address arithmetic per DMA piece)
+opens a bubble in the matrix pipe — hgemm_w4x_kernel (the same algorithm as C++ + small asm statements) measures 77 %
+MFMA-busy where a hand-ordered stream of the same work reaches > 90 %.  This script writes the stream by hand-rule:
+
+  per K tile (64) and wave: 128 MFMAs = 2 k-steps x (8 A fragments x 8 B fragments), accumulators a[0:255];
+  fragments fully double-buffered per k-step in LITERAL VGPRs: A(ks, i) = v[128 + 64 ks + 4 i ..], B(ks, j) = v[160 + 64 ks + 4 j ..];
+  k-step 0 carries: 16 ds_read_b128 of (tile t, k-step 1)           (one per 2 MFMAs, first half)
+                    8 LDS-DMA pieces B(t+2) -> B ring slot t+2       (one per 4 MFMAs, second half)
+  k-step 1 starts with  s_waitcnt vmcnt(8) lgkmcnt(0) | MFMA | s_barrier   (tile t fully read, tile t+1 landed)
+           carries: 16 ds_read_b128 of (tile t+1, k-step 0), 8 LDS-DMA pieces A(t+2) -> A ring slot t (dead now),
+                    the ring rotation, the next iteration's source offset / read addresses
+                    and the loop counter (the loop top is one s_waitcnt).
+  A DMA piece = s_add m0 / s_add soffset behind one MFMA, buffer_load_dwordx4 ... offen lds behind the next (an M0 write
+  needs one wait state before the LDS-DMA that uses it).
+Ring, swizzles, piece order and the vmcnt(8) count are those of hgemm_w4b_kernel (hgemm_w4.hip).
+
+usage: tools/gen_hgemm_w4y.py [--check]     (--check: exit 1 if the committed .inc differs from what would be generated)"""
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+NSCHED = 3
+
+
+def out_path(sched):
+    return ROOT / "leetcuda_amd" / "csrc" / f"hgemm_w4y_loop{sched}.inc"
+
+VA, VB = "v124", "v125"          # fragment read addresses (slot base + lane part)
+FRAG0 = 128                      # first literal fragment VGPR
+VCLOB = list(range(124, 256))    # literal VGPRs owned by the statement
+
+
+def fa(ks, i):
+    b = FRAG0 + 64 * ks + 4 * i
+    return f"v[{b}:{b + 3}]"
+
+
+def fb(ks, j):
+    b = FRAG0 + 32 + 64 * ks + 4 * j
+    return f"v[{b}:{b + 3}]"
+
+
+def acc(i, j):
+    b = 4 * (8 * i + j)
+    return f"a[{b}:{b + 3}]"
+
+
+def mfma(ks, i, j):
+    # SrcA = B fragment, SrcB = A fragment: lane holds C[m = 16 i + (l & 15)][n = 16 j + 4 (l >> 4) + r]
+    return f"v_mfma_f32_16x16x32_f16 {acc(i, j)}, {fb(ks, j)}, {fa(ks, i)}, {acc(i, j)}"
+
+
+def gen(sched):
+    L = []
+    e = L.append
+    # ---- init
+    e("s_mov_b32 %[t], 0")
+    e("s_mov_b32 %[acur], %[a0]")
+    e("s_add_u32 %[anxt], %[a0], 0x8000")
+    e("s_add_u32 %[b0], %[a0], 0x10000")
+    e("s_add_u32 %[b1], %[a0], 0x18000")
+    e("s_add_u32 %[b2], %[a0], 0x20000")
+    e(f"v_add_u32_e32 {VA}, %[acur], %[ar0]")
+    e(f"v_add_u32_e32 {VB}, %[b0], %[br0]")
+    for i in range(8):
+        e(f"ds_read_b128 {fa(0, i)}, {VA} offset:{i * 2048}")
+    for j in range(8):
+        e(f"ds_read_b128 {fb(0, j)}, {VB} offset:{j * 2048}")
+    # source offset of tile min(t + 2, KT - 1) and the read addresses of (t, k-step 1): computed here for t = 0 and in
+    # the tail of every iteration for the next one, so the loop top is the wait alone
+    e("s_sub_u32 %[swp], %[kt], 1")
+    e("s_min_u32 %[swp], %[swp], 2")
+    e("s_lshl_b32 %[t2off], %[swp], 7")
+    e(f"v_add_u32_e32 {VA}, %[acur], %[ar1]")
+    e(f"v_add_u32_e32 {VB}, %[b0], %[br1]")
+    e(".Lw4y_loop_%=:")
+    e("s_waitcnt lgkmcnt(0)")
+    fill = {}   # MFMA index -> instructions issued right behind it
+
+    def after(m, *ins):
+        fill.setdefault(m, []).extend(ins)
+
+    # k-step 0: reads of (t, ks 1), B pieces of tile t + 2
+    for r in range(16):
+        after(2 * r, f"ds_read_b128 {fa(1, r)}, {VA} offset:{r * 2048}" if r < 8
+              else f"ds_read_b128 {fb(1, r - 8)}, {VB} offset:{(r - 8) * 2048}")
+    after(31, "s_add_u32 %[tmp], %[b2], %[wv]")
+    for p in range(8):
+        after(32 + 4 * p, f"s_add_u32 m0, %[tmp], {p * 1024}",
+              "s_mov_b32 %[soff], %[t2off]" if p == 0 else "s_add_u32 %[soff], %[soff], %[blk]")
+        after(33 + 4 * p, f"buffer_load_dwordx4 %[ao{p & 1}], %[rb], %[soff] offen lds")
+    # k-step 1: addresses and reads of (t + 1, ks 0), A pieces of tile t + 2, ring rotation, loop counter.
+    #   sched 0: reads first (66..96), A pieces late (97..126)
+    #   sched 1: A pieces first, right behind the barrier (their data is needed one tile later, at the next barrier:
+    #            late pieces leave < 1100 MFMA cycles of latency cover), reads interleaved with them
+    #   sched 2: sched 1 with the wait + barrier 8 MFMAs into the k-step (skew between the waves is absorbed by
+    #            MFMAs whose operands are already in registers)
+    bar = 72 if sched == 2 else 64
+    after(bar, "s_barrier", f"v_add_u32_e32 {VA}, %[anxt], %[ar0]", "s_add_u32 %[tmp], %[acur], %[wv]")
+    after(bar + 1, f"v_add_u32_e32 {VB}, %[b1], %[br0]")
+    if sched == 0:
+        rd = [66 + 2 * r for r in range(16)]
+        dma = [97 + 4 * g for g in range(8)]
+    else:
+        dma = [bar + 2 + 4 * g for g in range(8)]
+        rd = [bar + 4 + 4 * (r >> 1) + (r & 1) for r in range(16)]
+    for r, m in enumerate(rd):
+        after(m, f"ds_read_b128 {fa(0, r)}, {VA} offset:{r * 2048}" if r < 8
+              else f"ds_read_b128 {fb(0, r - 8)}, {VB} offset:{(r - 8) * 2048}")
+    for g, m in enumerate(dma):
+        after(m, f"s_add_u32 m0, %[tmp], {g * 1024}",
+              "s_mov_b32 %[soff], %[t2off]" if g == 0 else "s_add_u32 %[soff], %[soff], %[blk]")
+        after(m + 1, f"buffer_load_dwordx4 %[ao{g & 1}], %[ra], %[soff] offen lds")
+    # ring rotation, then the next iteration's t2off = 128 min(t + 3, KT - 1) and its k-step-1 read addresses: in the
+    # empty gaps behind the last read / the first A piece (acur, b*, t2off, VA, VB are dead from there on)
+    rot = ["s_mov_b32 %[swp], %[b0]", "s_mov_b32 %[b0], %[b1]", "s_mov_b32 %[b1], %[b2]", "s_mov_b32 %[b2], %[swp]",
+           "s_mov_b32 %[swp], %[acur]", "s_mov_b32 %[acur], %[anxt]", "s_mov_b32 %[anxt], %[swp]",
+           "s_add_u32 %[swp], %[t], 3", "s_sub_u32 %[t2off], %[kt], 1", "s_min_u32 %[swp], %[swp], %[t2off]",
+           "s_lshl_b32 %[t2off], %[swp], 7", f"v_add_u32_e32 {VA}, %[acur], %[ar1]", f"v_add_u32_e32 {VB}, %[b0], %[br1]"]
+    first = max(max(rd), dma[0] + 1) + 1
+    slots = [m for m in range(first, 126) if m not in fill]
+    assert len(slots) >= len(rot), (sched, len(slots))
+    for ins, m in zip(rot, slots):
+        after(m, ins)
+    after(126, "s_add_u32 %[t], %[t], 1", "s_cmp_lt_u32 %[t], %[kt]")
+    wait_at = bar
+    for m in range(128):
+        ks, i, j = m >> 6, (m >> 3) & 7, m & 7
+        if m == 64:
+            e("s_waitcnt lgkmcnt(0)" if wait_at != 64 else "s_waitcnt vmcnt(8) lgkmcnt(0)")
+        if m == wait_at and wait_at != 64:
+            e("s_waitcnt vmcnt(8)")
+        e(mfma(ks, i, j))
+        for ins in fill.get(m, []):
+            e(ins)
+    e("s_cbranch_scc1 .Lw4y_loop_%=")
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    return L
+
+
+def render(sched):
+    lines = gen(sched)
+    body = "\n".join(f'    "{ln}\\n\\t"' for ln in lines)
+    vclob = ", ".join(f'"v{r}"' for r in VCLOB)
+    n_mfma = sum(ln.startswith("v_mfma") for ln in lines)
+    head = (f"// GENERATED by tools/gen_hgemm_w4y.py (schedule {sched}) — do not edit ({len(lines)} instructions, {n_mfma} MFMAs per K tile).\n"
+            "// Operands (hgemm_w4y.hip): kt, a0 (LDS address of A ring slot 0), wv (wave * 8192), blk (bytes between 8-row\n"
+            "// blocks), ra / rb (buffer descriptors, u32x4 SGPR tuples), ao0 / ao1 (DMA lane offsets), ar0 / ar1 / br0 / br1\n"
+            "// (fragment read lane offsets of k-step 0 / 1).\n")
+    return (head + "asm volatile(\n" + body + "\n"
+            "    : [t] \"=&s\"(w4y_t), [acur] \"=&s\"(w4y_acur), [anxt] \"=&s\"(w4y_anxt), [b0] \"=&s\"(w4y_b0), [b1] \"=&s\"(w4y_b1),\n"
+            "      [b2] \"=&s\"(w4y_b2), [soff] \"=&s\"(w4y_soff), [t2off] \"=&s\"(w4y_t2off), [tmp] \"=&s\"(w4y_tmp), [swp] \"=&s\"(w4y_swp)\n"
+            "    : [kt] \"s\"(KT), [a0] \"s\"(w4y_a0), [wv] \"s\"(w4y_wv), [blk] \"s\"(w4y_blk), [ra] \"s\"(w4y_ra), [rb] \"s\"(w4y_rb),\n"
+            "      [ao0] \"v\"(w4y_ao0), [ao1] \"v\"(w4y_ao1), [ar0] \"v\"(fr.a_ad[0]), [ar1] \"v\"(fr.a_ad[1]), [br0] \"v\"(fr.b_ad[0]),\n"
+            "      [br1] \"v\"(fr.b_ad[1])\n"
+            f"    : \"memory\", \"scc\", {vclob}, LC_AGPR_ALL);\n")
+
+
+def main():
+    rc = 0
+    for sched in range(NSCHED):
+        text, out = render(sched), out_path(sched)
+        if "--check" in sys.argv:
+            if not out.exists() or out.read_text() != text:
+                print(f"{out} is stale: run tools/gen_hgemm_w4y.py", file=sys.stderr)
+                rc = 1
+        else:
+            out.write_text(text)
+            print(f"wrote {out} ({len(text.splitlines())} lines)")
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -22,10 +22,14 @@ if a.what in ("all", "hgemm"):
     B = torch.randn(n, n, dtype=torch.half, device="cuda")
     C = torch.zeros(n, n, dtype=torch.half, device="cuda")
     Bt = host.as_col_major(B)
-    for var in (capi.HGEMM_MFMA256W4C, capi.HGEMM_MFMA256P2, capi.HGEMM_MFMA256):
+    for var in (capi.HGEMM_MFMA256W4Y, capi.HGEMM_MFMA256W4X, capi.HGEMM_MFMA256W4C, capi.HGEMM_MFMA256P2, capi.HGEMM_MFMA256):
         for lay, bb in ((capi.LAYOUT_TN, Bt), (capi.LAYOUT_NN, B)):
             for _ in range(a.iters):
                 capi.hgemm(A, bb, C, layout=lay, variant=var, swizzle_stride=2048)
+    capi.vendor_init()   # hipBLASLt on the same inputs: its kernels show up under their own (Cijk_...) names
+    for lay, bb in ((capi.LAYOUT_TN, Bt), (capi.LAYOUT_NN, B)):
+        for _ in range(a.iters):
+            capi.hgemm_vendor(A, bb, C, layout=lay)
     torch.cuda.synchronize()
 if a.what in ("all", "attn"):
     q, k, v, o, tv = host.get_qkvo(4, 32, 4096, 128, seed=0)

@@ -19,7 +19,7 @@ if args and args[0] == "--seconds":
     args = args[2:]
 capi.load()
 vendor_ready = False
-VAR = {"auto": capi.HGEMM_AUTO, "w4c": capi.HGEMM_MFMA256W4C, "w4x": capi.HGEMM_MFMA256W4X, "pingpong2": capi.HGEMM_MFMA256P2}
+VAR = {"auto": capi.HGEMM_AUTO, "w4c": capi.HGEMM_MFMA256W4C, "w4x": capi.HGEMM_MFMA256W4X, "w4y": capi.HGEMM_MFMA256W4Y, "pingpong2": capi.HGEMM_MFMA256P2}
 
 
 def fill(t, opts):
@@ -35,6 +35,7 @@ for spec in args:
     abl = next((int(o[4:]) for o in opts if o.startswith("abl=")), 0)
     nw = next((int(o[3:]) for o in opts if o.startswith("nw=")), 0)
     var = next((o[4:] for o in opts if o.startswith("var=")), "auto")
+    capi.tune("w4y_sched", next((int(o[6:]) for o in opts if o.startswith("sched=")), 1))
     if what in ("hgemm", "vendor"):
         n = 8192
         a = fill(torch.randn(n, n, dtype=torch.half, device="cuda"), opts)
