@@ -412,7 +412,7 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
   if (is_w4_variant(v)) {
     v = w4_effective_variant(v, layout == LC_LAYOUT_NN, N, K);
     if (v == LC_HGEMM_MFMA256W4X) snprintf(buf, buflen, "hgemm_w4x_kernel<%s>", nn);
-    else if (v == LC_HGEMM_MFMA256W4Y) snprintf(buf, buflen, "hgemm_w4y_kernel<%s,%d>", nn, g_tune_w4y_sched);
+    else if (v == LC_HGEMM_MFMA256W4Y) snprintf(buf, buflen, "hgemm_w4y_kernel<%s,%d>", nn, layout == LC_LAYOUT_NN ? 1 : g_tune_w4y_sched);
     else snprintf(buf, buflen, "hgemm_w4b_kernel<%s,%s,%s,0>", nn, v == LC_HGEMM_MFMA256W4B ? "false" : "true",
              v == LC_HGEMM_MFMA256W4D ? "true" : "false");
   } else if (v == LC_HGEMM_MFMA256P2) snprintf(buf, buflen, "hgemm_pingpong2_kernel<%s,false>", nn);

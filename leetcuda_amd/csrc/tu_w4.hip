@@ -50,6 +50,8 @@ int launch_w4_t(const half_t* A, const half_t* B, half_t* C, int M, int N, int K
       if (g_tune_w4y_sched == 1) return launch_w4x_one<B_KN, 1>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
       return launch_w4x_one<B_KN, 2>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
     }
+  } else {
+    if (variant == LC_HGEMM_MFMA256W4Y) return launch_w4x_one<B_KN, 1>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);   // one NN schedule
   }
   if (variant == LC_HGEMM_MFMA256W4D) return launch_w4_one<B_KN, true, true, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
   if (variant == LC_HGEMM_MFMA256W4C || variant == LC_HGEMM_MFMA256W4X || variant == LC_HGEMM_MFMA256W4Y)
@@ -61,7 +63,7 @@ int launch_w4_t(const half_t* A, const half_t* B, half_t* C, int M, int N, int K
 // buffer-descriptor DMA addresses are 32-bit offsets from the wave's first row: fall back to the 64-bit global form
 // when an offset could reach 2 GiB (NN: K tiles step through the whole of B)
 int w4_effective_variant(int variant, bool b_kn, int N, int K) {
-  if ((variant == LC_HGEMM_MFMA256W4X || variant == LC_HGEMM_MFMA256W4Y) && b_kn) variant = LC_HGEMM_MFMA256W4C;   // NN: the 32x32x16 kernel (for now)
+  if (variant == LC_HGEMM_MFMA256W4X && b_kn) variant = LC_HGEMM_MFMA256W4C;   // the compiler-scheduled 16x16x32 kernel is TN only
   if (variant == LC_HGEMM_MFMA256W4C || variant == LC_HGEMM_MFMA256W4D || variant == LC_HGEMM_MFMA256W4X ||
       variant == LC_HGEMM_MFMA256W4Y) {
     const size_t max_off = b_kn ? (size_t)K * N * 2 + (size_t)N * 64 : (size_t)K * 2 * 130;

@@ -116,7 +116,7 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     spec2.loader.exec_module(sump)
     # dispatcher names == demangled symbol names of the kernels actually in the library
     assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN) == "hgemm_w4y_kernel<false,1>"
-    assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_NN) == "hgemm_w4b_kernel<true,true,false,0>"
+    assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_NN) == "hgemm_w4y_kernel<true,1>"
     assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_NN, capi.HGEMM_MFMA256P2) == "hgemm_pingpong2_kernel<true,false>"
     assert capi.hgemm_kernel_name(1024, 1024, 1024, capi.LAYOUT_NN) == "hgemm_mfma128_kernel<true>"
     assert capi.hgemm_kernel_name(1000, 1024, 1024, capi.LAYOUT_NN) == "hgemm_generic_kernel<true>"

@@ -102,6 +102,31 @@ def test_nn_b_image_pair_swizzle_for_transpose_reads():
         assert sorted(p ^ ((k & 3) << 1) for p in range(8)) == list(range(8))
 
 
+def test_nn_b_image_key_for_16x16x32_transpose_reads():
+    # hgemm_w4y.hip NN: 32-B pair P of row k at pair slot P ^ key(k), key(k) = ((k & 3) << 1) | ((k >> 3) & 1); a B fragment
+    # read: lane i of 16-lane group g supplies k row 32 ks + 8 g + 4 x + (i >> 2), 8 bytes at column 4 (i & 3) of pair j
+    def key(k):
+        return ((k & 3) << 1) | ((k >> 3) & 1)
+    for j, ks, x in itertools.product(range(8), range(2), range(2)):
+        for grp in TR_GROUPS:
+            addrs = []
+            for lane in grp:
+                i, g = lane & 15, lane >> 4
+                k = 32 * ks + 8 * g + 4 * x + (i >> 2)
+                assert key(k) == (((i >> 2) << 1) | (g & 1))          # the kernel's lane-constant form
+                addrs.append(k * 256 + (j ^ key(k)) * 32 + (i & 3) * 8)
+            assert conflict_free(addrs, 8), (j, ks, x)
+        # (the 32x32x16 kernel's key (k & 3) << 1 alone would put rows k and k + 8 of a 32-lane group on the same banks)
+        bad = [(32 * ks + 8 * (lane >> 4) + 4 * x + ((lane & 15) >> 2)) * 256 + (j ^ (((lane & 15) >> 2) << 1)) * 32
+               + (lane & 3) * 8 for lane in TR_GROUPS[0]]
+        assert not conflict_free(bad, 8)
+    for k in range(64):   # a permutation of the 8 pair slots in every row; DMA side: (k >> 3) & 1 == (p2 >> 1) & 1, k = 4 (4 w + p2) + r
+        assert sorted(p ^ key(k) for p in range(8)) == list(range(8))
+    for w, p2, r in itertools.product(range(4), range(4), range(4)):
+        k = 4 * (4 * w + p2) + r
+        assert key(k) == ((r << 1) | ((p2 >> 1) & 1))
+
+
 def test_dma_source_permutation_is_the_inverse_of_the_read_mapping():
     # LDS-DMA writes lane-linearly: the lane that fills slot s of row r must FETCH logical chunk s ^ key(r); reading
     # logical chunk c then finds it at slot c ^ key(r) (XOR is an involution) — for every key used above

@@ -142,6 +142,119 @@ def gen(sched):
     return L
 
 
+def gen_nn():
+    """NN (B stored [K][N]): the B image is two sub-images of 128 contiguous columns, [64 k][256 B] each, 32-B column pairs
+    XOR-ed by key(k) = ((k & 3) << 1) | ((k >> 3) & 1); a B fragment (16 columns x 32 k) is two ds_read_b64_tr_b16 (4 k
+    rows each) per lane group.  Per k-step: 8 A reads + 16 transpose reads.  Literal VGPRs: v108..v115 = B read lane
+    offsets per column pair j (without the slot base), v116..v123 = the same + the base of the B slot of the tile being
+    read, v124 = A read address."""
+    L = []
+    e = L.append
+    BJ0, BJ = 108, 116
+
+    def rd_a(ks, i):
+        return f"ds_read_b128 {fa(ks, i)}, {VA} offset:{i * 2048}"
+
+    def rd_b(ks, j, x):
+        b = FRAG0 + 32 + 64 * ks + 4 * j + 2 * x
+        return f"ds_read_b64_tr_b16 v[{b}:{b + 1}], v{BJ + j} offset:{ks * 8192 + x * 1024}"
+
+    def reads(ks):
+        return [rd_a(ks, i) for i in range(8)] + [rd_b(ks, j, x) for j in range(8) for x in range(2)]
+
+    e("s_mov_b32 %[t], 0")
+    e("s_mov_b32 %[acur], %[a0]")
+    e("s_add_u32 %[anxt], %[a0], 0x8000")
+    e("s_add_u32 %[b0], %[a0], 0x10000")
+    e("s_add_u32 %[b1], %[a0], 0x18000")
+    e("s_add_u32 %[b2], %[a0], 0x20000")
+    for j in range(8):
+        e(f"v_xor_b32_e32 v{BJ0 + j}, {j}, %[key]")
+    for j in range(8):
+        e(f"v_lshl_add_u32 v{BJ0 + j}, v{BJ0 + j}, 5, %[bk]")
+    for j in range(8):
+        e(f"v_add_u32_e32 v{BJ + j}, %[b0], v{BJ0 + j}")
+    e(f"v_add_u32_e32 {VA}, %[acur], %[ar0]")
+    for ins in reads(0):
+        e(ins)
+    e("s_sub_u32 %[swp], %[kt], 1")
+    e("s_min_u32 %[swp], %[swp], 2")
+    e("s_lshl_b32 %[t2off], %[swp], 7")
+    e("s_mul_i32 %[t2offb], %[swp], %[bkt]")
+    e(f"v_add_u32_e32 {VA}, %[acur], %[ar1]")
+    e(".Lw4y_loop_%=:")
+    e("s_waitcnt lgkmcnt(0)")
+    fill = {}
+
+    def after(m, *ins):
+        fill.setdefault(m, []).extend(ins)
+
+    # k-step 0: the 24 reads of (t, ks 1) two per three MFMAs, then the B pieces of tile t + 2 (sub-image h = p >> 2,
+    # piece 4 wave + (p & 3))
+    slots0 = [m for m in range(36) if m % 3 != 2]
+    for ins, m in zip(reads(1), slots0):
+        after(m, ins)
+    after(36, "s_add_u32 %[tmp], %[b2], %[wvb]")
+    for p in range(8):
+        h, p2 = p >> 2, p & 3
+        soff = ("s_mov_b32 %[soff], %[t2offb]" if p == 0 else "s_add_u32 %[soff], %[t2offb], 256" if p == 4
+                else "s_add_u32 %[soff], %[soff], %[bq]")
+        after(37 + 3 * p, f"s_add_u32 m0, %[tmp], {h * 16384 + p2 * 1024}", soff)
+        after(38 + 3 * p, f"buffer_load_dwordx4 %[bo{(p2 >> 1) & 1}], %[rb], %[soff] offen lds")
+    # k-step 1: barrier, addresses of tile t + 1, A pieces of tile t + 2 right behind the barrier, reads of (t + 1, ks 0)
+    bar = 64
+    after(bar, "s_barrier", f"v_add_u32_e32 {VA}, %[anxt], %[ar0]", "s_add_u32 %[tmp], %[acur], %[wv]")
+    for j in range(8):
+        after(bar + 1 + (j >> 1), f"v_add_u32_e32 v{BJ + j}, %[b1], v{BJ0 + j}")
+    dma = [bar + 2 + 4 * g for g in range(8)]
+    for g, m in enumerate(dma):
+        after(m, f"s_add_u32 m0, %[tmp], {g * 1024}",
+              "s_mov_b32 %[soff], %[t2off]" if g == 0 else "s_add_u32 %[soff], %[soff], %[blk]")
+        after(m + 1, f"buffer_load_dwordx4 %[ao{g & 1}], %[ra], %[soff] offen lds")
+    slots1 = [m for m in range(bar + 5, 126) if m not in [d + 1 for d in dma]][:24]
+    for ins, m in zip(reads(0), slots1):
+        after(m, ins)
+    rot = ["s_mov_b32 %[swp], %[b0]", "s_mov_b32 %[b0], %[b1]", "s_mov_b32 %[b1], %[b2]", "s_mov_b32 %[b2], %[swp]",
+           "s_mov_b32 %[swp], %[acur]", "s_mov_b32 %[acur], %[anxt]", "s_mov_b32 %[anxt], %[swp]",
+           "s_add_u32 %[swp], %[t], 3", "s_sub_u32 %[t2off], %[kt], 1", "s_min_u32 %[swp], %[swp], %[t2off]",
+           "s_lshl_b32 %[t2off], %[swp], 7", "s_mul_i32 %[t2offb], %[swp], %[bkt]", f"v_add_u32_e32 {VA}, %[acur], %[ar1]"]
+    first = max(slots1) + 1
+    slots = [m for m in range(first, 126) if m not in fill]
+    assert len(slots) >= len(rot), len(slots)
+    for ins, m in zip(rot, slots):
+        after(m, ins)
+    after(126, "s_add_u32 %[t], %[t], 1", "s_cmp_lt_u32 %[t], %[kt]")
+    for m in range(128):
+        ks, i, j = m >> 6, (m >> 3) & 7, m & 7
+        if m == 64:
+            e("s_waitcnt vmcnt(8) lgkmcnt(0)")
+        e(mfma(ks, i, j))
+        for ins in fill.get(m, []):
+            e(ins)
+    e("s_cbranch_scc1 .Lw4y_loop_%=")
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    return L
+
+
+def render_nn():
+    lines = gen_nn()
+    body = "\n".join(f'    "{ln}\\n\\t"' for ln in lines)
+    vclob = ", ".join(f'"v{r}"' for r in range(108, 256))
+    n_mfma = sum(ln.startswith("v_mfma") for ln in lines)
+    head = (f"// GENERATED by tools/gen_hgemm_w4y.py (NN) — do not edit ({len(lines)} instructions, {n_mfma} MFMAs per K tile).\n"
+            "// Operands (hgemm_w4y.hip): as the TN statement + wvb (wave * 4096), bq (bytes between 4-row B pieces), bkt (bytes\n"
+            "// per B K tile), bo0 / bo1 (B DMA lane offsets), bk / key (B transpose-read lane offset and swizzle key).\n")
+    return (head + "asm volatile(\n" + body + "\n"
+            "    : [t] \"=&s\"(w4y_t), [acur] \"=&s\"(w4y_acur), [anxt] \"=&s\"(w4y_anxt), [b0] \"=&s\"(w4y_b0), [b1] \"=&s\"(w4y_b1),\n"
+            "      [b2] \"=&s\"(w4y_b2), [soff] \"=&s\"(w4y_soff), [t2off] \"=&s\"(w4y_t2off), [t2offb] \"=&s\"(w4y_t2offb),\n"
+            "      [tmp] \"=&s\"(w4y_tmp), [swp] \"=&s\"(w4y_swp)\n"
+            "    : [kt] \"s\"(KT), [a0] \"s\"(w4y_a0), [wv] \"s\"(w4y_wv), [wvb] \"s\"(w4y_wvb), [blk] \"s\"(w4y_blk), [bq] \"s\"(w4y_bq),\n"
+            "      [bkt] \"s\"(w4y_bkt), [ra] \"s\"(w4y_ra), [rb] \"s\"(w4y_rb), [ao0] \"v\"(w4y_ao0), [ao1] \"v\"(w4y_ao1),\n"
+            "      [bo0] \"v\"(w4y_bo0), [bo1] \"v\"(w4y_bo1), [ar0] \"v\"(fr.a_ad[0]), [ar1] \"v\"(fr.a_ad[1]), [bk] \"v\"(w4y_bk),\n"
+            "      [key] \"v\"(w4y_key)\n"
+            f"    : \"memory\", \"scc\", {vclob}, LC_AGPR_ALL);\n")
+
+
 def render(sched):
     lines = gen(sched)
     body = "\n".join(f'    "{ln}\\n\\t"' for ln in lines)
@@ -162,8 +275,9 @@ def render(sched):
 
 def main():
     rc = 0
-    for sched in range(NSCHED):
-        text, out = render(sched), out_path(sched)
+    todo = [(render(sched), out_path(sched)) for sched in range(NSCHED)]
+    todo.append((render_nn(), ROOT / "leetcuda_amd" / "csrc" / "hgemm_w4y_loop_nn.inc"))
+    for text, out in todo:
         if "--check" in sys.argv:
             if not out.exists() or out.read_text() != text:
                 print(f"{out} is stale: run tools/gen_hgemm_w4y.py", file=sys.stderr)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Back-to-back launches of one hot kernel for a few seconds per spec (the workload of tools/power_watch.sh; join the
 sampler log with tools/power_join.py).  usage: sustain.py [--seconds S] spec...
-   spec = hgemm | vendor | attn | attn8k | d512, optionally :zero (zero-filled inputs), :uniform, :var=auto|w4c|w4x|pingpong2, :abl=N (hgemm only:
+   spec = hgemm | vendor | attn | attn8k | d512, optionally :nn (B stored [K][N]), :zero (zero-filled inputs), :uniform, :var=auto|w4c|w4x|pingpong2, :abl=N (hgemm only:
           lc_tune_set "w4_abl", LC_DIAG library — ablated kernels compute WRONG results), :nw=N (attention kernel choice)"""
 import sys
 import time
@@ -39,19 +39,22 @@ for spec in args:
     if what in ("hgemm", "vendor"):
         n = 8192
         a = fill(torch.randn(n, n, dtype=torch.half, device="cuda"), opts)
-        b = fill(host.as_col_major(torch.randn(n, n, dtype=torch.half, device="cuda")), opts)
+        lay = capi.LAYOUT_NN if "nn" in opts else capi.LAYOUT_TN
+        b = fill(torch.randn(n, n, dtype=torch.half, device="cuda"), opts)
+        if lay == capi.LAYOUT_TN:
+            b = host.as_col_major(b)
         c = torch.empty(n, n, dtype=torch.half, device="cuda")
         flops = 2.0 * n ** 3
         if what == "vendor":
             if not vendor_ready:
                 capi.vendor_init()
                 vendor_ready = True
-            step = lambda: capi.hgemm_vendor(a, b, c, layout=capi.LAYOUT_TN)  # noqa: E731
+            step = lambda: capi.hgemm_vendor(a, b, c, layout=lay)  # noqa: E731
         else:
             if abl:
                 capi.tune("w4_abl", abl)
                 var = "w4c"
-            step = lambda: capi.hgemm(a, b, c, layout=capi.LAYOUT_TN, variant=VAR[var], swizzle_stride=2048)  # noqa: E731
+            step = lambda: capi.hgemm(a, b, c, layout=lay, variant=VAR[var], swizzle_stride=2048)  # noqa: E731
     elif what in ("attn", "attn8k"):
         B, H, N, D = (4, 32, 4096, 128) if what == "attn" else (4, 32, 8192, 128)
         q, k, v, o, _ = host.get_qkvo(B, H, N, D, seed=0)
