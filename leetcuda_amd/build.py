@@ -79,7 +79,12 @@ def build_abi(force: bool = False, audit: bool = True) -> Path:
     srcs = sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.inc"))
     srcs.append(ROOT / "include" / "lc_abi.h")
     srcs.append(PKG / "isa_audit.py")
+    srcs.append(ROOT / "tools" / "gen_hgemm_w4y.py")
     flags = _flags()
+    # the generated K loops (hgemm_w4y_loop*.inc) must be what tools/gen_hgemm_w4y.py emits today
+    gen = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_hgemm_w4y.py"), "--check"], capture_output=True, text=True)
+    if gen.returncode != 0:
+        raise RuntimeError("generated sources are stale: " + gen.stderr.strip())
     if not force and _newer(out, srcs) and _stamp_ok(stamp, flags):
         return out
     # translation units (lc_abi.hip + the compile-heavy literal-AGPR kernels in tu_*.hip), compiled in parallel; each

@@ -1,5 +1,6 @@
 // hgemm_w4.hip — fp16 GEMM for gfx950, 256x256x64 tile, FOUR wave64 (2 x 2), wave tile 128 x 128: the kernel
-// LC_HGEMM_AUTO launches for large 256-tileable shapes (LC_HGEMM_MFMA256W4B / W4C / W4D).
+// 32x32x16-MFMA baseline of the 4-wave family (LC_HGEMM_MFMA256W4B / W4C; LC_HGEMM_AUTO until round 2's 16x16x32 kernels
+// hgemm_w4x.hip / hgemm_w4y.hip, which keep this file's ring, DMA and swizzles).
 //
 // Same contract, LDS images and swizzles as hgemm_pingpong.hip (reference: kernels/hgemm/mma/basic/
 // hgemm_mma_stage.cu:644-1052 NN, kernels/hgemm/mma/swizzle/hgemm_mma_stage_tn_swizzle_x4.cu:207 TN).
@@ -18,9 +19,8 @@
 //     piece is issued less than 1500 MFMA cycles before it is needed, and the wait in front of the barrier is a
 //     counted vmcnt(8) (the 8 B pieces of tile t+2 stay in flight across it):
 //       issue order  ... | B(t+1): steps 1-2 of t-1 | A(t+1) | B(t+2): steps 1-2 of t | A(t+2) ...
-//     SPREAD = false: all 8 A pieces in step 3 (the step behind the barrier);
-//     SPREAD = true : 4 in step 3 and 4 in step 0 of the next tile (one DMA piece per 4 MFMAs in EVERY step; the
-//                     counted wait is unchanged because the 8 B pieces are still the youngest at the wait).
+//     All 8 A pieces ride in step 3 (the step behind the barrier); spreading them over steps 3 / 0 (round 2's W4D)
+//     or staggering the waves' issue (W4E) measured neutral / slower and is retired (git history).
 //   * BUF: the DMA pieces are buffer_load ... lds (descriptor from a readfirstlane'd pointer + scalar offset + one
 //     32-bit lane offset) instead of global_load_lds with a 64-bit address per lane.
 //   * NN B image: two sub-images of 128 CONTIGUOUS columns ([64 k][256 B] each, 32-B pairs XOR-ed by (k&3)<<1,
@@ -168,7 +168,7 @@ LC_DEVINL void w4_epilogue(char* smem, half_t* C, int N, int m0, int n0, int wav
 //       tiles 32..35 (lc_tune_set "hgemm_stamps", tools/hgemm_w4c_stamps.py)
 //   2 = no DMA after the prologue, 4 = no per-tile wait + barrier, 8 = no fragment reads in the loop (2|4|8 = MFMA
 //       issue only: the ceiling of the matrix pipe at the sustained clock; lc_tune_set "w4_abl", tools/w4_ablate.py)
-template <bool B_KN, bool BUF, bool SPREAD, int DG = 0>
+template <bool B_KN, bool BUF, int DG = 0>
 __global__ __launch_bounds__(256) void hgemm_w4b_kernel(const half_t* __restrict__ A,
                                                        const half_t* __restrict__ B,
                                                        half_t* __restrict__ C, int M, int N, int K,
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void hgemm_w4b_kernel(const half_t* __restrict
 
   static_for<256>([&](auto r) { w4_acc_zero<decltype(r)::value>(); });   // accumulator (i, j) = a[16(4i+j) ..]
 
-  // prologue: B(0) A(0) B(1) A(1) [SPREAD: only the first 4 pieces of A(1)]; tile 0 landed, step-0 fragments of tile 0
+  // prologue: B(0) A(0) B(1) A(1); tile 0 landed, step-0 fragments of tile 0
   // in registers
 #pragma unroll
   for (int g = 8; g < 16; ++g) piece(g, 0, b_slot(0));
@@ -242,8 +242,8 @@ __global__ __launch_bounds__(256) void hgemm_w4b_kernel(const half_t* __restrict
 #pragma unroll
   for (int g = 8; g < 16; ++g) piece(g, 1, b_slot(1));
 #pragma unroll
-  for (int g = 0; g < (SPREAD ? 4 : 8); ++g) piece(g, 1, a_slot(1));
-  if constexpr (SPREAD) LC_VMCNT(12); else LC_VMCNT(16);
+  for (int g = 0; g < 8; ++g) piece(g, 1, a_slot(1));
+  LC_VMCNT(16);
   pp_barrier();
 
   half8_t af[2][4], bf[2][4];
@@ -314,10 +314,7 @@ __global__ __launch_bounds__(256) void hgemm_w4b_kernel(const half_t* __restrict
     const char* ca = a_slot(kt);
     const char* cbs = b_slot(b0);
     STAMP(kt, 0);
-    if constexpr (SPREAD)   // the second half of A(kt+1): its slot has been dead since the barrier of tile kt-1
-      step(I0{}, ca, cbs, 1, P4{}, 4, kt + 1, a_slot(kt + 1));
-    else
-      step(I0{}, ca, cbs, 1, P0{}, 0, 0, nullptr);
+    step(I0{}, ca, cbs, 1, P0{}, 0, 0, nullptr);
     STAMP(kt, 1);
     step(I1{}, ca, cbs, 2, P4{}, 8, kt + 2, b_slot(b2));
     STAMP(kt, 2);
@@ -330,10 +327,7 @@ __global__ __launch_bounds__(256) void hgemm_w4b_kernel(const half_t* __restrict
       pp_barrier();
     }
     STAMP(kt, 5);
-    if constexpr (SPREAD)
-      step(I1{}, a_slot(kt + 1), b_slot(b1), 0, P4{}, 0, kt + 2, a_slot(kt));
-    else
-      step(I1{}, a_slot(kt + 1), b_slot(b1), 0, P8{}, 0, kt + 2, a_slot(kt));
+    step(I1{}, a_slot(kt + 1), b_slot(b1), 0, P8{}, 0, kt + 2, a_slot(kt));
     STAMP(kt, 6);
     const int t = b0;
     b0 = b1;

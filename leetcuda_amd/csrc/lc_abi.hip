@@ -153,7 +153,7 @@ const AttnEntry* find_attn(const char* name) {
 // ------------------------------------------------------------------------------------------------
 // HGEMM launchers
 bool is_w4_variant(int v) {
-  return v == LC_HGEMM_MFMA256W4B || v == LC_HGEMM_MFMA256W4C || v == LC_HGEMM_MFMA256W4D || v == LC_HGEMM_MFMA256W4X ||
+  return v == LC_HGEMM_MFMA256W4B || v == LC_HGEMM_MFMA256W4C || v == LC_HGEMM_MFMA256W4X ||
          v == LC_HGEMM_MFMA256W4Y;
 }
 
@@ -413,8 +413,7 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
     v = w4_effective_variant(v, layout == LC_LAYOUT_NN, N, K);
     if (v == LC_HGEMM_MFMA256W4X) snprintf(buf, buflen, "hgemm_w4x_kernel<%s>", nn);
     else if (v == LC_HGEMM_MFMA256W4Y) snprintf(buf, buflen, "hgemm_w4y_kernel<%s,%d>", nn, layout == LC_LAYOUT_NN ? 1 : g_tune_w4y_sched);
-    else snprintf(buf, buflen, "hgemm_w4b_kernel<%s,%s,%s,0>", nn, v == LC_HGEMM_MFMA256W4B ? "false" : "true",
-             v == LC_HGEMM_MFMA256W4D ? "true" : "false");
+    else snprintf(buf, buflen, "hgemm_w4b_kernel<%s,%s,0>", nn, v == LC_HGEMM_MFMA256W4B ? "false" : "true");
   } else if (v == LC_HGEMM_MFMA256P2) snprintf(buf, buflen, "hgemm_pingpong2_kernel<%s,false>", nn);
   else if (v == LC_HGEMM_MFMA256) snprintf(buf, buflen, "hgemm_mfma256_kernel<%s>", nn);
   else if (v == LC_HGEMM_MFMA128) snprintf(buf, buflen, "hgemm_mfma128_kernel<%s>", nn);

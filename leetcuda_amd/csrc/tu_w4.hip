@@ -4,10 +4,10 @@
 
 namespace lc {
 namespace {
-template <bool B_KN, bool BUF, bool SPREAD, int DG>
+template <bool B_KN, bool BUF, int DG>
 int launch_w4_one(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int tiles_m, int tiles_n, int pw,
                   hipStream_t st) {
-  auto kern = hgemm_w4b_kernel<B_KN, BUF, SPREAD, DG>;
+  auto kern = hgemm_w4b_kernel<B_KN, BUF, DG>;
   if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
   return check_launch();
@@ -31,14 +31,14 @@ int launch_w4_t(const half_t* A, const half_t* B, half_t* C, int M, int N, int K
   variant = w4_effective_variant(variant, B_KN, N, K);
 #ifdef LC_DIAG
   if (variant == LC_HGEMM_MFMA256W4C && g_tune_hgemm_stamps)
-    return launch_w4_one<B_KN, true, false, 1>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+    return launch_w4_one<B_KN, true, 1>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
   if (variant == LC_HGEMM_MFMA256W4C && g_tune_w4_abl) {
     switch (g_tune_w4_abl) {   // bits: 2 no DMA, 4 no wait + barrier, 8 no fragment reads
-      case 2: return launch_w4_one<B_KN, true, false, 2>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
-      case 4: return launch_w4_one<B_KN, true, false, 4>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
-      case 6: return launch_w4_one<B_KN, true, false, 6>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
-      case 8: return launch_w4_one<B_KN, true, false, 8>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
-      case 14: return launch_w4_one<B_KN, true, false, 14>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+      case 2: return launch_w4_one<B_KN, true, 2>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+      case 4: return launch_w4_one<B_KN, true, 4>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+      case 6: return launch_w4_one<B_KN, true, 6>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+      case 8: return launch_w4_one<B_KN, true, 8>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+      case 14: return launch_w4_one<B_KN, true, 14>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
       default: return LC_ERR_ARG;
     }
   }
@@ -53,10 +53,9 @@ int launch_w4_t(const half_t* A, const half_t* B, half_t* C, int M, int N, int K
   } else {
     if (variant == LC_HGEMM_MFMA256W4Y) return launch_w4x_one<B_KN, 1>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);   // one NN schedule
   }
-  if (variant == LC_HGEMM_MFMA256W4D) return launch_w4_one<B_KN, true, true, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
   if (variant == LC_HGEMM_MFMA256W4C || variant == LC_HGEMM_MFMA256W4X || variant == LC_HGEMM_MFMA256W4Y)
-    return launch_w4_one<B_KN, true, false, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
-  return launch_w4_one<B_KN, false, false, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+    return launch_w4_one<B_KN, true, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+  return launch_w4_one<B_KN, false, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
 }
 }  // namespace
 
@@ -64,7 +63,7 @@ int launch_w4_t(const half_t* A, const half_t* B, half_t* C, int M, int N, int K
 // when an offset could reach 2 GiB (NN: K tiles step through the whole of B)
 int w4_effective_variant(int variant, bool b_kn, int N, int K) {
   if (variant == LC_HGEMM_MFMA256W4X && b_kn) variant = LC_HGEMM_MFMA256W4C;   // the compiler-scheduled 16x16x32 kernel is TN only
-  if (variant == LC_HGEMM_MFMA256W4C || variant == LC_HGEMM_MFMA256W4D || variant == LC_HGEMM_MFMA256W4X ||
+  if (variant == LC_HGEMM_MFMA256W4C || variant == LC_HGEMM_MFMA256W4X ||
       variant == LC_HGEMM_MFMA256W4Y) {
     const size_t max_off = b_kn ? (size_t)K * N * 2 + (size_t)N * 64 : (size_t)K * 2 * 130;
     if (max_off >= ((size_t)1 << 31)) return LC_HGEMM_MFMA256W4B;

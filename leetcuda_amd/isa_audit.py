@@ -12,6 +12,8 @@ one does not hold:
       (w4 GEMM / fp8 kernels: a0-a255; attention w4 kernels: the ranges named in their clobber lists)
   R2  no scratch: `.private_segment_fixed_size` == 0 (a spilled tuple would be reloaded around asm statements
       without the wait states the asm needs)
+  R4  kernels whose asm owns LITERAL arch VGPRs across statements or loop iterations (hgemm_w4y_kernel: v108..v255 hold the
+      fragments and read addresses of the generated K loop): no compiler-emitted instruction names one of them
   R3  no compiler instruction reads or writes the destination registers of an asm-issued LDS / global load between
       the load and the next `s_waitcnt ... lgkmcnt(0)` / `vmcnt(0)` that retires it
 """
@@ -26,6 +28,11 @@ OWNED_AGPRS = [
     (re.compile(r"hgemm_w4b_kernel|hgemm_w4x_kernel|hgemm_w4y_kernel|gemm_fp8_w4_kernel"), [(0, 255)]),
     (re.compile(r"attn_fwd_w4_kernel"), [(0, 127), (192, 255)]),      # a[128:191] stay with hipcc (AGPR spills)
     (re.compile(r"attn_fwd_w4m_kernel|attn_fwd_bigd2_kernel"), [(0, 255)]),
+]
+
+# kernel-name regex -> literal arch VGPR range owned by the kernel's asm (inclusive)
+OWNED_VGPRS = [
+    (re.compile(r"hgemm_w4y_kernel"), (108, 255)),
 ]
 
 _REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
@@ -69,6 +76,7 @@ def audit_asm(path: Path) -> list[KernelReport]:
     reports: dict[str, KernelReport] = {}
     cur: KernelReport | None = None
     owned: set[int] | None = None
+    owned_v: set[int] = set()
     in_asm = False
     pending: set[int] = set()     # VGPR destinations of asm loads not yet retired by a wait
     for ln, raw in enumerate(lines, 1):
@@ -79,6 +87,10 @@ def audit_asm(path: Path) -> list[KernelReport]:
             name = m.group(1)
             cur = reports.setdefault(name, KernelReport(name))
             owned = _owned(name)
+            owned_v = set()
+            for rx, (lo, hi) in OWNED_VGPRS:
+                if rx.search(name):
+                    owned_v = set(range(lo, hi + 1))
             in_asm = False
             pending = set()
             continue
@@ -123,6 +135,10 @@ def audit_asm(path: Path) -> list[KernelReport]:
                 cur.asm_loads += 1
             continue
         # ---- compiler-emitted instruction
+        if owned_v:
+            hit = _regs(s, "v") & owned_v
+            if hit:
+                cur.violations.append(f"R4 {path.name}:{ln}: compiler `{s}` names asm-owned VGPR(s) v{sorted(hit)[:4]}")
         if s.startswith("v_accvgpr_"):
             cur.compiler_accvgpr += 1
             if owned is not None:

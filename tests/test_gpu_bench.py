@@ -31,7 +31,7 @@ def test_bench_single_gpu_quick_line():
     assert out["metric"].startswith("achieved fp16 TFLOPS vs MI355X MFMA peak")
     r = out["roofline"]
     assert r["bound"] == "mfma" and r["peak"] == 2500.0 and 0.2 < r["frac"] < 1.0
-    assert r["kernel"].startswith("hgemm_w4b_kernel<false,")
+    assert r["kernel"].startswith("hgemm_w4y_kernel<false,")
     # kernel time <= step time (launch overhead on top), and the two agree within 15 %
     assert r["kernel_ms"] <= out["ms_per_step"] * 1.02 and r["kernel_ms"] > 0.85 * out["ms_per_step"]
     assert out["value"] == pytest.approx(2 * 8192 ** 3 / (out["ms_per_step"] * 1e-3) * 1e-12, rel=1e-6)

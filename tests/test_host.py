@@ -99,6 +99,38 @@ def test_attn_shard_prefers_batch_axis():
         host.shard_bounds(4, 2, 2)
 
 
+def test_generated_hgemm_loops_are_current_and_well_formed():
+    """hgemm_w4y's K loops are generated (tools/gen_hgemm_w4y.py): the committed .inc files must equal the generator's
+    output, and every schedule must hold the invariants the hand-ordering relies on."""
+    import importlib.util
+    import re
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("lc_gen_w4y", root / "tools" / "gen_hgemm_w4y.py")
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    for sched in range(gen.NSCHED):
+        assert gen.out_path(sched).read_text() == gen.render(sched)
+    assert (root / "leetcuda_amd" / "csrc" / "hgemm_w4y_loop_nn.inc").read_text() == gen.render_nn()
+    for lines in [gen.gen(s) for s in range(gen.NSCHED)] + [gen.gen_nn()]:
+        body = lines[lines.index(".Lw4y_loop_%=:"):]
+        mf = [l for l in body if l.startswith("v_mfma")]
+        blocks = [l.split(",")[0] for l in mf]
+        assert len(mf) == 128 and len(set(blocks)) == 64 and blocks[:64] == blocks[64:]   # 64 blocks x 2 k-steps
+        assert sum(l.startswith("buffer_load_dwordx4") for l in body) == 16 and body.count("s_barrier") == 1
+        # an M0 write is never directly followed by the LDS-DMA that uses it (one wait state needed), and the loop counter's
+        # s_cmp is followed only by MFMAs (nothing that writes SCC) up to the branch
+        for a, b in zip(body, body[1:]):
+            assert not (a.startswith("s_add_u32 m0") and b.startswith("buffer_load"))
+        tail = body[[i for i, l in enumerate(body) if l.startswith("s_cmp_lt_u32")][-1] + 1:]
+        assert tail[-2].startswith("s_cbranch_scc1") and all(l.startswith("v_mfma") for l in tail[:-2])
+        # the counted wait: 8 pieces (B of tile t+2) are issued between the barrier's wait and the previous one
+        w = [i for i, l in enumerate(body) if "vmcnt(8)" in l][0]
+        assert sum(l.startswith("buffer_load") for l in body[:w]) == 8
+        # fragment registers: every ds_read destination is read by an MFMA of the OTHER k-step buffer only after a wait
+        dst = [int(re.search(r"v\[(\d+):", l).group(1)) for l in body if l.startswith("ds_read")]
+        assert min(dst) >= 128 and max(dst) <= 254
+
+
 def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     """bench.py labels its roofline rows with the kernel name the DISPATCHER reports (lc_*_kernel_name) and looks the
     fabric bytes of that kernel up in profiles/latest_pmc.json (tools/summarize_prof.py, separate rocprofv3 --pmc
@@ -125,8 +157,8 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     assert capi.attn_kernel_name(192, 64, True) == "attn_fwd_kernel<64,2,true,0>"
     assert capi.attn_kernel_name(8192, 512, False, True) == "attn_fwd_bigd2_kernel<512,true>"
     assert capi.attn_kernel_name(192, 512, False, False).startswith("attn_fwd_bigd_kernel<512,")     # N % 128 != 0
-    assert sump.short("_ZN2lc16hgemm_w4b_kernelILb0ELb1ELb0ELi0EEEvPKDF16_S2_PDF16_iiiiii") == \
-        "hgemm_w4b_kernel<false,true,false,0>"
+    assert sump.short("_ZN2lc16hgemm_w4b_kernelILb0ELb1ELi0EEEvPKDF16_S2_PDF16_iiiiii") == \
+        "hgemm_w4b_kernel<false,true,0>"
     assert sump.short("_ZN2lc18attn_fwd_c4_kernelILi128ELi0EEEvPKDF16_S2_S2_PDF16_iif") == "attn_fwd_c4_kernel<128,0>"
     pmc = json.loads((root / "profiles" / "latest_pmc.json").read_text())
     for key in (capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN), capi.attn_kernel_name(4096, 128)):

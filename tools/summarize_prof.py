@@ -20,6 +20,9 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def short(name: str) -> str:
+    v = re.match(r"(Custom_)?Cijk_(\w+?)_(HHS|HSS|BBS)\w*?_(MT\d+x\d+x\d+)_(MI\d+x\d+x\d+)", name)
+    if v:   # hipBLASLt (the comparator): operand layout, macro tile, MFMA shape
+        return f"hipblaslt:{'Custom_' if v.group(1) else ''}Cijk_{v.group(2)}_{v.group(4)}_{v.group(5)}"
     m = re.match(r"_ZN2lc\d+(\w+?_kernel)I(.*?)EEv", name)
     if not m:
         m2 = re.match(r"_ZN2lc\d+(\w+?_kernel)E", name)
@@ -38,7 +41,7 @@ def main(tag: str):
     if db:
         cur = sqlite3.connect(db).cursor()
         rows = cur.execute("select name, duration, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, grid_x, "
-                           "workgroup_x from kernels where name like '_ZN2lc%'").fetchall()
+                           "workgroup_x from kernels where name like '_ZN2lc%' or name like '%Cijk_%'").fetchall()
         agg = defaultdict(list)
         meta = {}
         for name, dur, vg, ag, sg, lds, gx, wx in rows:
@@ -64,7 +67,7 @@ def main(tag: str):
             continue
         cur = sqlite3.connect(db).cursor()
         rows = cur.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
-                           "where kernel_name like '_ZN2lc%' group by kernel_name, counter_name").fetchall()
+                           "where kernel_name like '_ZN2lc%' or kernel_name like '%Cijk_%' group by kernel_name, counter_name").fetchall()
         for name, cname, val, cnt in rows:
             pmc[short(name)][cname] = val
     for k, c in pmc.items():
