@@ -55,7 +55,9 @@ from leetcuda_amd import capi, host  # noqa: E402
 from leetcuda_amd import dist as lcd  # noqa: E402
 
 PEAK = host.MI355X_FP16_DENSE_PEAK_TFLOPS
-PREWARM = 10  # untimed launches before the W warm-up steps (DVFS settles; documented in DESIGN.md §6)
+PREWARM = 10  # minimum untimed launches before the W warm-up steps
+PREWARM_SECONDS = 0.4   # ... and at least this long: both paths run at the board power cap, whose clock takes a few hundred
+                        # milliseconds of load to settle; never part of W or K
 PMC_FILE = "profiles/latest_pmc.json"
 
 
@@ -86,8 +88,13 @@ VARIANT = {"auto": capi.HGEMM_AUTO, "mfma256": capi.HGEMM_MFMA256, "pingpong2": 
 
 def timed_region(w, step, steps, warmup, prewarm=PREWARM):
     """W untimed + exactly K timed steps, barrier+sync on both sides; returns local seconds."""
-    for _ in range(prewarm):   # setup: clocks / code objects / allocator, not part of W or K
-        step()
+    t_pre = time.perf_counter()
+    n_pre = 0
+    while n_pre < prewarm or (prewarm >= PREWARM and time.perf_counter() - t_pre < PREWARM_SECONDS):
+        step()                 # setup: clocks / code objects / allocator, not part of W or K
+        n_pre += 1
+        if n_pre % 16 == 0:
+            torch.cuda.synchronize()   # (bounds the launch queue; the wall clock above then tracks GPU time)
     for _ in range(warmup):
         step()
     lcd.barrier(w)
