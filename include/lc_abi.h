@@ -89,7 +89,8 @@ int lc_device_check(int* num_cus);
 const char* lc_build_info(int* is_diag);
 
 /* Run-time selection knobs for A-B benches (not part of the reference surface; correctness never depends on them):
- *   "attn_nw"      attention kernel for D = 128: 0 = auto (= 256 when N % 256 == 0), 256 = merged-phase kernel, 4 waves x 64
+ *   "attn_nw"      attention kernel for D = 128: 0 = auto (= 512 when N % 256 == 0), 512 = merged-phase kernel with 16x16x32
+ *                  MFMAs (attn_w4n.hip), 256 = the same with 32x32x16 MFMAs, 4 waves x 64
  *                  query rows, one wave per SIMD (attn_w4m.hip; 260 = its A/B twin with padded Q.K^T MFMAs),
  *                  64 = 8-wave four-cluster kernel (N % 256 == 0),
  *                  8 / 4 / 2 = lock-step kernel with that many waves (any N % (32 x waves) == 0, every D <= 128)

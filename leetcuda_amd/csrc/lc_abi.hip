@@ -250,15 +250,16 @@ int launch_attn_c4(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   return check_launch();
 }
 
-// Which kernel serves a D <= 128 problem: 256 = merged-phase 4-wave x 64-row kernel (attn_w4m.hip; 260 = its padded A/B
-// twin), 64 = 8-wave four-cluster kernel, 8 / 4 / 2 = lock-step kernel with that many waves.  ONE function for the
-// launcher and lc_attn_kernel_name().  Default for D = 128, N % 256 == 0: the merged-phase kernel (measured at config 3 /
-// config 4's shard on one box: 1216-1233 / 1265 TFLOP/s against 945-1037 / 1062 for the four-cluster kernel).
+// Which kernel serves a D <= 128 problem: 512 = merged-phase 4-wave x 64-row kernel with 16x16x32 MFMAs (attn_w4n.hip),
+// 256 = the same with 32x32x16 MFMAs (attn_w4m.hip; 260 = its padded A/B twin), 64 = 8-wave four-cluster kernel, 8 / 4 / 2 =
+// lock-step kernel with that many waves.  ONE function for the launcher and lc_attn_kernel_name().  Default for D = 128,
+// N % 256 == 0: 512 (sustained, one box, config 3 / config 4's shard: 1235 / 1311 TFLOP/s at 2.08 GHz against 1220 / 1260 at
+// 1.80 GHz for 256 — both at the 1400 W cap — and 1030 / 1080 for the four-cluster kernel).
 int choose_attn_nw(int D, bool vt, int N) {
   const int want = g_tune_attn_nw;   // 0 = auto
   if (D == 128 && !vt && N % 256 == 0) {
-    if (want == 0 && g_tune_attn_ablate == 0) return 256;
-    if (want == 256 || want == 260 || want == 64) return want;
+    if (want == 0 && g_tune_attn_ablate == 0) return 512;
+    if (want == 256 || want == 260 || want == 512 || want == 64) return want;
   }
   if (N % 256 == 0 && (want == 0 || want >= 8)) return 8;   // (also what 64 / 256 fall back to for D < 128)
   if (N % 128 == 0 && (want == 0 || want >= 4)) return 4;
@@ -272,6 +273,7 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   if constexpr (D == 128 && !VT) {
     if (nw == 64) return launch_attn_c4<D>(Q, K, V, O, B, H, N, st);
     if (nw == 256 || nw == 260) return launch_attn_w4m_d128(Q, K, V, O, B, H, N, nw == 260, st);
+    if (nw == 512) return launch_attn_w4n_d128(Q, K, V, O, B, H, N, st);
   }
   if constexpr (D == 128 && !VT) {   // perf-diagnosis instantiations (lc_tune_set "attn_ablate")
     switch (g_tune_attn_ablate) {
@@ -428,6 +430,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
     if (bf16) return LC_ERR_HEADDIM;
     const int nw = choose_attn_nw(D, v_transposed != 0, N);
     if (nw == 256 || nw == 260) snprintf(buf, buflen, "attn_fwd_w4m_kernel<%d,%d>", D, nw == 260 ? 4 : 0);
+    else if (nw == 512) snprintf(buf, buflen, "attn_fwd_w4n_kernel<%d>", D);
     else if (nw == 64) snprintf(buf, buflen, "attn_fwd_c4_kernel<%d,0>", D);
     else snprintf(buf, buflen, "attn_fwd_kernel<%d,%d,%s,0>", D, nw, vt);
     return LC_OK;
@@ -447,7 +450,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
 int lc_tune_set(const char* key, int value) {
   if (!key) return LC_ERR_ARG;
   if (strcmp(key, "attn_nw") == 0) {
-    if (value != 0 && value != 256 && value != 260 && value != 64 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
+    if (value != 0 && value != 256 && value != 260 && value != 512 && value != 64 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
     g_tune_attn_nw = value;
     return LC_OK;
   }

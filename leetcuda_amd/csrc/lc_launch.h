@@ -48,6 +48,8 @@ int launch_w4_family(const half_t* A, const half_t* B, half_t* C, int M, int N, 
 // tu_attn_w4.hip: 4-wave x 64-row merged-phase attention kernel, D = 128, N % 256 == 0; pad = A/B knob (0 / 4 wait states)
 int launch_attn_w4m_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int pad,
                          hipStream_t st);
+// attn_w4n.hip: the same kernel with v_mfma_f32_16x16x32_f16
+int launch_attn_w4n_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, hipStream_t st);
 // tu_attn_big.hip: full-width large-head-dim kernel, D in {256, 512}, N % 128 == 0, V as [B,H,N,D]; fp16 or bf16
 int launch_attn_bigd2(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, bool bf16,
                       hipStream_t st);

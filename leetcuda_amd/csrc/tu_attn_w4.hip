@@ -2,7 +2,7 @@
 #include <math.h>
 
 #include "lc_launch.h"
-#include "attn_w4m.hip"
+#include "attn_w4n.hip"
 
 namespace lc {
 // merged-phase kernel (attn_w4m.hip); pad = wait states appended to the accumulating Q·Kᵀ MFMAs (0 or 4, A/B knob)
@@ -21,6 +21,16 @@ int launch_attn_w4m_d128(const half_t* Q, const half_t* K, const half_t* V, half
     if (int rc = set_dyn_lds(kern, AM_LDS)) return rc;
     hipLaunchKernelGGL(kern, grid, block, AM_LDS, st, Q, K, V, O, N, nqb, sl2);
   }
+  return check_launch();
+}
+int launch_attn_w4n_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, hipStream_t st) {
+  constexpr int D = 128;
+  const int nqb = N / 256;
+  const dim3 grid((unsigned)((size_t)nqb * B * H)), block(256);
+  const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+  auto kern = attn_fwd_w4n_kernel<D>;
+  if (int rc = set_dyn_lds(kern, AM_LDS)) return rc;
+  hipLaunchKernelGGL(kern, grid, block, AM_LDS, st, Q, K, V, O, N, nqb, sl2);
   return check_launch();
 }
 }  // namespace lc

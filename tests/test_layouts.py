@@ -102,6 +102,46 @@ def test_nn_b_image_pair_swizzle_for_transpose_reads():
         assert sorted(p ^ ((k & 3) << 1) for p in range(8)) == list(range(8))
 
 
+def test_attention_tiles_for_16x16x32_fragments():
+    # attn_w4n.hip.  K tile (unchanged image: chunk c of row r at slot c ^ (r & 15), 256-B rows): fragment lane -> row
+    # 16 kvb + (l & 15), chunk 4 ds + (l >> 4)
+    for ds, kvb in itertools.product(range(4), range(4)):
+        for grp in B128_GROUPS:
+            addrs = [(16 * kvb + (l & 15)) * 256 + (((4 * ds + (l >> 4)) ^ (l & 15)) * 16) for l in grp]
+            assert conflict_free(addrs, 16), (ds, kvb)
+    # V tile: 32-B pair p of row r at pair slot p ^ key(r), key(r) = ((r & 3) << 1) | ((r >> 2) & 1); a transpose read: lane i
+    # of 16-lane group g supplies row 32 H + 16 x + 4 g + (i >> 2), 8 bytes at column 4 (i & 3) of pair db
+    def key(r):
+        return ((r & 3) << 1) | ((r >> 2) & 1)
+    for db, hh, x in itertools.product(range(8), range(2), range(2)):
+        for grp in TR_GROUPS:
+            addrs = []
+            for lane in grp:
+                i, g = lane & 15, lane >> 4
+                r = 32 * hh + 16 * x + 4 * g + (i >> 2)
+                assert key(r) == (((i >> 2) << 1) | (g & 1))
+                a = r * 256 + (db ^ key(r)) * 32 + (i & 3) * 8
+                # the kernel's address form: pair 2u at (2u ^ key) * 32, pair 2u + 1 at +32 (g even) / -32 (g odd)
+                u = db >> 1
+                a2 = r * 256 + ((2 * u) ^ key(r)) * 32 + (i & 3) * 8 + ((db & 1) * (-32 if (g & 1) else 32))
+                assert a == a2
+                addrs.append(a)
+            assert conflict_free(addrs, 8), (db, hh, x)
+        # (attn_w4m's 64-B-unit swizzle u ^ (r & 3) is 2-way conflicted for this read pattern)
+        bad = []
+        for lane in TR_GROUPS[0]:
+            i, g = lane & 15, lane >> 4
+            r = 32 * hh + 16 * x + 4 * g + (i >> 2)
+            bad.append(r * 256 + ((db >> 1) ^ (r & 3)) * 64 + (db & 1) * 32 + (i & 3) * 8)
+        assert not conflict_free(bad, 8)
+    # DMA side: the lane filling 16-B slot cs of row r = 4 p + r4 fetches logical chunk ((cs >> 1) ^ key(r)) * 2 + (cs & 1)
+    for p, r4, cs in itertools.product(range(16), range(4), range(16)):
+        r = 4 * p + r4
+        assert key(r) == ((r4 << 1) | (p & 1))
+        chunk = (((cs >> 1) ^ key(r)) << 1) | (cs & 1)
+        assert ((chunk >> 1) ^ key(r)) == (cs >> 1) and (chunk & 1) == (cs & 1)     # reading pair P finds it at slot P ^ key
+
+
 def test_nn_b_image_key_for_16x16x32_transpose_reads():
     # hgemm_w4y.hip NN: 32-B pair P of row k at pair slot P ^ key(k), key(k) = ((k & 3) << 1) | ((k >> 3) & 1); a B fragment
     # read: lane i of 16-lane group g supplies k row 32 ks + 8 g + 4 x + (i >> 2), 8 bytes at column 4 (i & 3) of pair j
