@@ -64,8 +64,21 @@ typedef enum lc_hgemm_variant {
   LC_HGEMM_MFMA256W4C = 10, /* W4B with buffer_load ... lds (descriptor + scalar offset) DMA: the 32x32x16 baseline         */
   LC_HGEMM_MFMA256W4X = 12, /* W4C's ring / DMA schedule with v_mfma_f32_16x16x32_f16 (8 x 8 blocks of 16 x 16 per wave):   */
                             /* fewer joules per FLOP at the board power cap (hgemm_w4x.hip, compiler-scheduled; TN only)   */
-  LC_HGEMM_MFMA256W4Y = 13  /* W4X with the K loop as one generated, hand-ordered instruction stream (hgemm_w4y.hip; TN and  */
+  LC_HGEMM_MFMA256W4Y = 13, /* W4X with the K loop as one generated, hand-ordered instruction stream (hgemm_w4y.hip; TN and  */
                             /* NN): what LC_HGEMM_AUTO launches for large 256-tileable shapes                              */
+  /* the reference's "CUDA-core" ladder as vector-ALU kernels (hgemm_valu.hip; NN only; v_dot2c_f32_f16, fp32 accumulate);
+   * shapes a rung does not tile (and TN) run LC_HGEMM_GENERIC */
+  LC_HGEMM_VALU_NAIVE = 20,                  /* one thread per C element, operands from global memory                       */
+  LC_HGEMM_VALU_SLICED_K = 21,               /* 32x32x32 LDS tile, one C element per thread                                 */
+  LC_HGEMM_VALU_T8X8_X4 = 22,                /* 128x128 tile, 8x8 per thread, BK = 8, 8-byte global loads                   */
+  LC_HGEMM_VALU_T8X8_X4_PACK = 23,           /* + vector LDS stores                                                         */
+  LC_HGEMM_VALU_T8X8_X4_BCF = 24,            /* + bank-conflict-free LDS layout / thread tile                               */
+  LC_HGEMM_VALU_T8X8_X4_PACK_BCF = 25,
+  LC_HGEMM_VALU_T8X8_X8_PACK_BCF = 26,       /* 16-byte global loads                                                        */
+  LC_HGEMM_VALU_T8X8_X8_PACK_BCF_DBUF = 27,  /* + double-buffered LDS                                                       */
+  LC_HGEMM_VALU_T8X8_K16 = 28,               /* BK = 16                                                                     */
+  LC_HGEMM_VALU_T8X8_K32 = 29,               /* BK = 32                                                                     */
+  LC_HGEMM_VALU_T16X8_K32 = 30               /* 256x128 tile, 16x8 per thread                                               */
 } lc_hgemm_variant;
 
 /* FlashAttention-2 forward families (resource policies of kernels/flash-attn/mma/basic/ .cu files). */

@@ -14,6 +14,7 @@ LC_OK, LC_ERR_ARG, LC_ERR_SHAPE, LC_ERR_HEADDIM, LC_ERR_LAUNCH, LC_ERR_VENDOR, L
 LAYOUT_NN, LAYOUT_TN = 0, 1
 # lc_hgemm_variant (values 2, 5, 7, 8 were retired round-1 experiments: LC_ERR_ARG)
 HGEMM_AUTO, HGEMM_MFMA256, HGEMM_GENERIC, HGEMM_MFMA256P2, HGEMM_MFMA128 = 0, 1, 3, 4, 6
+HGEMM_VALU_NAIVE, HGEMM_VALU_SLICED_K, HGEMM_VALU_T8X8_X4, HGEMM_VALU_T16X8_K32 = 20, 21, 22, 30   # the VALU ladder: 20..30
 HGEMM_MFMA256W4B, HGEMM_MFMA256W4C, HGEMM_MFMA256W4X, HGEMM_MFMA256W4Y = 9, 10, 12, 13
 ATTN_SPLIT_Q, ATTN_SHARED_QKV, ATTN_SHARED_KV, ATTN_TILING_QK, ATTN_TILING_QKV, ATTN_SPLIT_KV = range(6)
 

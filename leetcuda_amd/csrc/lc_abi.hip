@@ -54,33 +54,33 @@ struct HgemmEntry {
 #define TN LC_LAYOUT_TN
 // kernels/hgemm/pybind/hgemm.cc:126-181, in the reference's registration order.
 const HgemmEntry kHgemmEntries[] = {
-    {"hgemm_naive_f16", NN, 3, LC_HGEMM_GENERIC},
-    {"hgemm_sliced_k_f16", NN, 3, LC_HGEMM_GENERIC},
-    {"hgemm_t_8x8_sliced_k_f16x4", NN, 3, LC_HGEMM_GENERIC},
-    {"hgemm_t_8x8_sliced_k_f16x4_pack", NN, 3, LC_HGEMM_GENERIC},
-    {"hgemm_t_8x8_sliced_k_f16x4_bcf", NN, 3, LC_HGEMM_GENERIC},
-    {"hgemm_t_8x8_sliced_k_f16x4_pack_bcf", NN, 3, LC_HGEMM_GENERIC},
-    {"hgemm_t_8x8_sliced_k_f16x8_pack_bcf", NN, 3, LC_HGEMM_GENERIC},
-    {"hgemm_t_8x8_sliced_k_f16x8_pack_bcf_dbuf", NN, 3, LC_HGEMM_GENERIC},
-    {"hgemm_t_8x8_sliced_k16_f16x8_pack_dbuf", NN, 3, LC_HGEMM_GENERIC},
-    {"hgemm_t_8x8_sliced_k16_f16x8_pack_dbuf_async", NN, 3, LC_HGEMM_GENERIC},
-    {"hgemm_t_8x8_sliced_k32_f16x8_pack_dbuf", NN, 3, LC_HGEMM_GENERIC},
-    {"hgemm_t_8x8_sliced_k32_f16x8_pack_dbuf_async", NN, 3, LC_HGEMM_GENERIC},
-    {"hgemm_t_16x8_sliced_k32_f16x8_pack_dbuf", NN, 3, LC_HGEMM_GENERIC},
-    {"hgemm_t_16x8_sliced_k32_f16x8_pack_dbuf_async", NN, 3, LC_HGEMM_GENERIC},
+    {"hgemm_naive_f16", NN, 3, LC_HGEMM_VALU_NAIVE},
+    {"hgemm_sliced_k_f16", NN, 3, LC_HGEMM_VALU_SLICED_K},
+    {"hgemm_t_8x8_sliced_k_f16x4", NN, 3, LC_HGEMM_VALU_T8X8_X4},
+    {"hgemm_t_8x8_sliced_k_f16x4_pack", NN, 3, LC_HGEMM_VALU_T8X8_X4_PACK},
+    {"hgemm_t_8x8_sliced_k_f16x4_bcf", NN, 3, LC_HGEMM_VALU_T8X8_X4_BCF},
+    {"hgemm_t_8x8_sliced_k_f16x4_pack_bcf", NN, 3, LC_HGEMM_VALU_T8X8_X4_PACK_BCF},
+    {"hgemm_t_8x8_sliced_k_f16x8_pack_bcf", NN, 3, LC_HGEMM_VALU_T8X8_X8_PACK_BCF},
+    {"hgemm_t_8x8_sliced_k_f16x8_pack_bcf_dbuf", NN, 3, LC_HGEMM_VALU_T8X8_X8_PACK_BCF_DBUF},
+    {"hgemm_t_8x8_sliced_k16_f16x8_pack_dbuf", NN, 3, LC_HGEMM_VALU_T8X8_K16},
+    {"hgemm_t_8x8_sliced_k16_f16x8_pack_dbuf_async", NN, 3, LC_HGEMM_VALU_T8X8_K16},
+    {"hgemm_t_8x8_sliced_k32_f16x8_pack_dbuf", NN, 3, LC_HGEMM_VALU_T8X8_K32},
+    {"hgemm_t_8x8_sliced_k32_f16x8_pack_dbuf_async", NN, 3, LC_HGEMM_VALU_T8X8_K32},
+    {"hgemm_t_16x8_sliced_k32_f16x8_pack_dbuf", NN, 3, LC_HGEMM_VALU_T16X8_K32},
+    {"hgemm_t_16x8_sliced_k32_f16x8_pack_dbuf_async", NN, 3, LC_HGEMM_VALU_T16X8_K32},
     {"init_cublas_handle", NN, 0, -2},
     {"destroy_cublas_handle", NN, 0, -3},
     {"hgemm_cublas_tensor_op_nn", NN, 3, -1},
     {"hgemm_cublas_tensor_op_tn", TN, 3, -1},
     {"hgemm_wmma_m16n16k16_naive", NN, 3, LC_HGEMM_GENERIC},
     {"hgemm_wmma_m16n16k16_mma4x2", NN, 3, LC_HGEMM_GENERIC},
-    {"hgemm_wmma_m16n16k16_mma4x2_warp2x4", NN, 3, LC_HGEMM_MFMA256},
-    {"hgemm_wmma_m16n16k16_mma4x2_warp2x4_dbuf_async", NN, 3, LC_HGEMM_MFMA256},
-    {"hgemm_wmma_m32n8k16_mma2x4_warp2x4_dbuf_async", NN, 3, LC_HGEMM_MFMA256},
+    {"hgemm_wmma_m16n16k16_mma4x2_warp2x4", NN, 3, LC_HGEMM_MFMA128},
+    {"hgemm_wmma_m16n16k16_mma4x2_warp2x4_dbuf_async", NN, 3, LC_HGEMM_MFMA128},
+    {"hgemm_wmma_m32n8k16_mma2x4_warp2x4_dbuf_async", NN, 3, LC_HGEMM_MFMA128},
     {"hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages", NN, 6, LC_HGEMM_MFMA256},
     {"hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages_dsmem", NN, 6, LC_HGEMM_MFMA256},
-    {"hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem", NN, 6, LC_HGEMM_AUTO},
-    {"hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", NN, 6, LC_HGEMM_AUTO},
+    {"hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem", NN, 6, LC_HGEMM_MFMA256P2},
+    {"hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", NN, 6, LC_HGEMM_MFMA256P2},
     {"hgemm_mma_m16n8k16_naive", NN, 3, LC_HGEMM_GENERIC},
     {"hgemm_mma_m16n8k16_mma2x4_warp4x4", NN, 3, LC_HGEMM_MFMA256},
     {"hgemm_mma_m16n8k16_mma2x4_warp4x4_stages", NN, 6, LC_HGEMM_MFMA256},
@@ -380,8 +380,9 @@ const char* lc_build_info(int* is_diag) {
 
 namespace {
 bool is_tile256_variant(int v) { return v == LC_HGEMM_MFMA256 || v == LC_HGEMM_MFMA256P2 || is_w4_variant(v); }
+bool is_valu_variant(int v) { return v >= LC_HGEMM_VALU_NAIVE && v <= LC_HGEMM_VALU_T16X8_K32; }
 bool is_hgemm_variant(int v) {
-  return v == LC_HGEMM_AUTO || v == LC_HGEMM_GENERIC || v == LC_HGEMM_MFMA128 || is_tile256_variant(v);
+  return v == LC_HGEMM_AUTO || v == LC_HGEMM_GENERIC || v == LC_HGEMM_MFMA128 || is_tile256_variant(v) || is_valu_variant(v);
 }
 }  // namespace
 
@@ -399,6 +400,12 @@ int resolve_hgemm_variant(int variant, int M, int N, int K, bool al) {
     if (tiles256 && wg256 > 128) return g_tune_hgemm_auto;
     return tiles128 ? LC_HGEMM_MFMA128 : LC_HGEMM_GENERIC;
   }
+  if (is_valu_variant(variant)) {   // a rung of the vector-ALU ladder: its own tile, else the edge kernel (never an error)
+    int tm, tn, tk;
+    valu_rung_tile(variant, &tm, &tn, &tk);
+    const bool ok = (M % tm == 0) && (N % tn == 0) && (K % tk == 0) && (variant == LC_HGEMM_VALU_NAIVE || (al && K % 8 == 0));
+    return ok ? variant : LC_HGEMM_GENERIC;
+  }
   if (is_tile256_variant(variant) && !tiles256) return LC_ERR_SHAPE;
   if (variant == LC_HGEMM_MFMA128 && !tiles128) return LC_ERR_SHAPE;
   return variant;
@@ -410,7 +417,12 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
   if (layout != LC_LAYOUT_NN && layout != LC_LAYOUT_TN) return LC_ERR_ARG;
   int v = resolve_hgemm_variant(variant, M, N, K, true);
   if (v < 0) return v;
+  if (is_valu_variant(v) && layout != LC_LAYOUT_NN) v = LC_HGEMM_GENERIC;   // the ladder is NN only
   const char* nn = layout == LC_LAYOUT_NN ? "true" : "false";
+  if (is_valu_variant(v)) {
+    snprintf(buf, buflen, "%s", valu_rung_kernel_name(v));
+    return LC_OK;
+  }
   if (is_w4_variant(v)) {
     v = w4_effective_variant(v, layout == LC_LAYOUT_NN, N, K);
     if (v == LC_HGEMM_MFMA256W4X) snprintf(buf, buflen, "hgemm_w4x_kernel<%s>", nn);
@@ -516,6 +528,10 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   variant = resolve_hgemm_variant(variant, M, N, K, al);
   if (variant < 0) return variant;
   if (int rc = launch_guard()) return rc;   // a sticky HIP error of an earlier call: report it, launch nothing
+  if (is_valu_variant(variant)) {
+    if (layout == LC_LAYOUT_NN) return launch_valu_rung(a, b, c, M, N, K, variant, st);
+    variant = LC_HGEMM_GENERIC;   // the ladder is NN only
+  }
   if (is_tile256_variant(variant)) {
     return layout == LC_LAYOUT_NN ? launch_mfma256<true>(a, b, c, M, N, K, variant, swizzle_stride, st)
                                   : launch_mfma256<false>(a, b, c, M, N, K, variant, swizzle_stride, st);
@@ -564,7 +580,9 @@ int lc_hgemm_call(const char* entry, const void* A, const void* B, void* C, int 
   // legal shapes (multiples of 128 / K of 32, hgemm_mma_stage.cu:650,675), so fall back per shape.
   const bool tiles256 = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && aligned16(A) &&
                         aligned16(B) && aligned16(C);
-  if (variant != LC_HGEMM_GENERIC && !tiles256) variant = LC_HGEMM_AUTO;   // 128-tile kernel or generic
+  const bool tiles128 = (M % BM1 == 0) && (N % BN1 == 0) && (K % BK == 0) && aligned16(A) && aligned16(B) && aligned16(C);
+  if (is_tile256_variant(variant) && !tiles256) variant = LC_HGEMM_AUTO;   // 128-tile kernel or generic
+  if (variant == LC_HGEMM_MFMA128 && !tiles128) variant = LC_HGEMM_GENERIC;
   const int stride = (e->nargs == 6 && swizzle) ? swizzle_stride : 1;
   return lc_hgemm_f16(A, B, C, M, N, K, e->layout, variant, e->nargs == 6 ? stages : 2, stride, stream);
 }

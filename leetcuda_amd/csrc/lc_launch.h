@@ -46,6 +46,10 @@ int w4_effective_variant(int variant, bool b_kn, int N, int K);   // W4C / W4X /
 int launch_w4_family(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant, bool b_kn,
                      int tiles_m, int tiles_n, int panel_w, hipStream_t st);
 // tu_attn_w4.hip: 4-wave x 64-row merged-phase attention kernel, D = 128, N % 256 == 0; pad = A/B knob (0 / 4 wait states)
+// tu_valu.hip: the vector-ALU ladder (hgemm_valu.hip), rung = LC_HGEMM_VALU_*
+int launch_valu_rung(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int rung, hipStream_t st);
+void valu_rung_tile(int rung, int* tm, int* tn, int* tk);
+const char* valu_rung_kernel_name(int rung);
 int launch_attn_w4m_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int pad,
                          hipStream_t st);
 // attn_w4n.hip: the same kernel with v_mfma_f32_16x16x32_f16

@@ -106,7 +106,7 @@ def test_status_strings_and_argument_errors(built):
     assert lib.lc_hgemm_f16(None, None, None, 256, 256, 256, 0, 0, 2, 1, None) == capi.LC_ERR_ARG
     one = C.c_void_p(16)
     assert lib.lc_hgemm_f16(one, one, one, 256, 256, 256, 7, 0, 2, 1, None) == capi.LC_ERR_ARG
-    for retired in (2, 5, 7, 8, 11, 14):       # round-1 experiment variants / out of range
+    for retired in (2, 5, 7, 8, 11, 14, 19, 31):       # round-1 experiment variants / out of range
         assert lib.lc_hgemm_f16(one, one, one, 256, 256, 256, 0, retired, 2, 1, None) == capi.LC_ERR_ARG
     assert lib.lc_hgemm_f16(one, one, one, 0, 256, 256, 0, 0, 2, 1, None) == capi.LC_ERR_SHAPE
     assert lib.lc_hgemm_f16(one, one, one, 128, 256, 256, 0, capi.HGEMM_MFMA256, 2, 1, None) == capi.LC_ERR_SHAPE

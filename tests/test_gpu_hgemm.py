@@ -158,6 +158,36 @@ def test_every_reference_entry_name_computes_the_gemm(oracle):
         capi.hgemm_call("destroy_cublas_handle", a, b, a)
 
 
+@pytest.mark.parametrize("rung", list(range(20, 31)))
+def test_vector_alu_ladder_rungs(oracle, rung):
+    """f2: the reference's CUDA-core ladder (naive/hgemm.cu) as real vector-ALU kernels (hgemm_valu.hip): every rung against
+    the oracle on a shape all of them tile (incl. the 256-row t_16x8 rung), the dispatcher reporting the rung's own kernel,
+    and the documented fall-backs (TN, shapes a rung does not tile -> the edge kernel; the naive rung takes ANY shape)."""
+    capi = _capi()
+    M, N, K = 512, 384, 320
+    torch.manual_seed(rung)
+    a = torch.randn(M, K, dtype=torch.half, device="cuda")
+    b = torch.randn(K, N, dtype=torch.half, device="cuda")
+    c = torch.zeros(M, N, dtype=torch.half, device="cuda")
+    name = capi.hgemm_kernel_name(M, N, K, capi.LAYOUT_NN, rung)
+    assert name.startswith("hgemm_valu_"), name
+    capi.hgemm(a, b, c, layout=capi.LAYOUT_NN, variant=rung)
+    torch.cuda.synchronize()
+    ok, mx, _ = tol.hgemm_close(c.float().cpu().numpy(), oracle.hgemm(a, b, M, N, K, 0, "f32"), K)
+    assert ok, (rung, mx)
+    assert capi.hgemm_kernel_name(M, N, K, capi.LAYOUT_TN, rung) == "hgemm_generic_kernel<false>"
+    M2, N2, K2 = 100, 72, 50          # tiles nothing
+    a2 = torch.randn(M2, K2, dtype=torch.half, device="cuda")
+    b2 = torch.randn(K2, N2, dtype=torch.half, device="cuda")
+    c2 = torch.zeros(M2, N2, dtype=torch.half, device="cuda")
+    want = "hgemm_valu_naive_kernel" if rung == 20 else "hgemm_generic_kernel<true>"
+    assert capi.hgemm_kernel_name(M2, N2, K2, capi.LAYOUT_NN, rung) == want
+    capi.hgemm(a2, b2, c2, layout=capi.LAYOUT_NN, variant=rung)
+    torch.cuda.synchronize()
+    ok, mx, _ = tol.hgemm_close(c2.float().cpu().numpy(), oracle.hgemm(a2, b2, M2, N2, K2, 0, "f32"), K2)
+    assert ok, (rung, mx)
+
+
 def test_torch_extension_module_drop_in(oracle):
     """The reference's call convention end to end: import toy_hgemm; f(a, b, c, stages, swizzle, stride)."""
     import sys
