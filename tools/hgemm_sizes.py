@@ -9,8 +9,26 @@ from leetcuda_amd import capi, host  # noqa: E402
 capi.load()
 capi.vendor_init()
 sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1024, 2048, 3072, 4096, 6144, 8192]
-V = {"mfma128": capi.HGEMM_MFMA128, "mfma256": capi.HGEMM_MFMA256, "pingpong2": capi.HGEMM_MFMA256P2,
-     "w4c": capi.HGEMM_MFMA256W4C, "auto": capi.HGEMM_AUTO}
+V = {"mfma128": capi.HGEMM_MFMA128, "pingpong2": capi.HGEMM_MFMA256P2, "w4c": capi.HGEMM_MFMA256W4C,
+     "w4y": capi.HGEMM_MFMA256W4Y, "auto": capi.HGEMM_AUTO}
+
+
+def rate(step, fl, seconds=0.3):
+    """>= `seconds` of back-to-back launches (both sides run at the power cap from ~4096^3 on: short bursts mislead)"""
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(10):
+        step()
+    t1.record(); torch.cuda.synchronize()
+    n = max(10, int(seconds / (t0.elapsed_time(t1) / 10 * 1e-3)))
+    t0.record()
+    for _ in range(n):
+        step()
+    t1.record(); torch.cuda.synchronize()
+    return fl / (t0.elapsed_time(t1) / n) * 1e-9
 for n in sizes:
     a = torch.randn(n, n, dtype=torch.half, device="cuda")
     b = torch.randn(n, n, dtype=torch.half, device="cuda")
@@ -23,16 +41,7 @@ for n in sizes:
         for name, var in V.items():
             if name != "mfma128" and name != "auto" and n % 256:
                 continue
-            ms = min(capi.hgemm_time(a, b2, c, lay, var, 2, st, warmup=3, iters=20) for _ in range(2))
-            row.append(f"{name} {fl / ms * 1e-9:7.1f}")
-        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
-        for _ in range(3):
-            capi.hgemm_vendor(a, b2, c, lay)
-        t0.record()
-        for _ in range(20):
-            capi.hgemm_vendor(a, b2, c, lay)
-        t1.record(); torch.cuda.synchronize()
-        ms = t0.elapsed_time(t1) / 20
-        row.append(f"hipBLASLt {fl / ms * 1e-9:7.1f}")
+            row.append(f"{name} {rate(lambda: capi.hgemm(a, b2, c, layout=lay, variant=var, swizzle_stride=st), fl):7.1f}")
+        row.append(f"hipBLASLt {rate(lambda: capi.hgemm_vendor(a, b2, c, lay), fl):7.1f}")
         print(f"n={n:5d} {lname}: " + " | ".join(row), flush=True)
 capi.vendor_destroy()
