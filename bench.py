@@ -29,7 +29,7 @@ per-rank timings.  W warm-up steps, then EXACTLY K timed steps between barrier +
 sides; time = MAX over ranks; rank 0 prints ONE JSON line.
 
 "roofline": achieved = algorithmic FLOPs per launch / average launch duration from HIP events recorded on the launch
-stream (lc_hgemm_time / lc_attn_time / lc_timer_*); peak = 2500 TFLOP/s dense fp16 MFMA; "kernel" comes from the
+stream around the SAME K timed launches (lc_timer_*: inside the wall-clock bracket, so kernel time <= step time); peak = 2500 TFLOP/s dense fp16 MFMA; "kernel" comes from the
 dispatcher itself (lc_*_kernel_name); "traffic" = fabric bytes per launch from the COMMITTED rocprofv3 --pmc passes
 ("traffic_source" names the file: it is not a same-run counter).
 "cpu_baseline": the reference benches' own CPU-capable baseline callables (torch.matmul, hgemm.py:1088;
@@ -99,9 +99,11 @@ def timed_region(w, step, steps, warmup, prewarm=PREWARM):
         step()
     lcd.barrier(w)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    with capi.Timer() as tm:        # HIP events on the launch stream around the SAME K launches: the roofline's kernel time
+        for _ in range(steps):
+            step()
     lcd.barrier(w)
+    timed_region.event_ms = tm.ms   # (events are recorded inside the wall-clock bracket: kernel time <= step time)
     return time.perf_counter() - t0
 
 
@@ -122,6 +124,8 @@ def roofline(kernel, flops, nbytes, ms_kernel, profiled_config=False):
     return {"bound": "mfma", "achieved": ach, "peak": PEAK, "unit": "TFLOP/s", "frac": ach / PEAK,
             "kernel_ms": ms_kernel, "kernel": kernel, "algorithmic_flops_per_launch": flops,
             "algorithmic_bytes_per_launch": nbytes, "traffic": t,
+            "power_cap_note": "both paths run at the 1400 W board cap on random data; an MFMA-only v_mfma_f32_16x16x32_f16 stream "
+                              "sustains 1854 TFLOP/s there, 32x32x16 1625 (profiles/r2_power_probe.log, DESIGN.md 4.10)",
             "traffic_source": (PMC_FILE + " (committed rocprofv3 --pmc passes, not a same-run counter)") if t else None}
 
 
@@ -163,8 +167,7 @@ def bench_hgemm(w, args):
     secs = timed_region(w, step, args.steps, args.warmup)
     secs = lcd.max_over_ranks(w, secs)
     flops = 2.0 * n * n * n
-    ms_kernel = capi.hgemm_time(a, bb, c, lay, var, 2, stride, warmup=2, iters=max(10, args.steps))
-    ms_kernel = lcd.max_over_ranks(w, ms_kernel)
+    ms_kernel = lcd.max_over_ranks(w, timed_region.event_ms / args.steps)
     kname = capi.hgemm_kernel_name(n, n, n, lay, var)
     res = {
         "value": w.size * flops * args.steps / secs * 1e-12,
@@ -236,8 +239,7 @@ def bench_attn(w, args, cfg4=False, steps=None, warmup=None, prewarm=PREWARM):
     secs = lcd.max_over_ranks(w, secs)
     flops_total = host.mha_matmul_flops(B, H, N, D)               # whole job, all ranks
     flops_local = host.mha_matmul_flops(b_loc, h_loc, N, D)
-    ms_kernel = capi.attn_time(q, k, v, o, False, fam, 2, warmup=1, iters=max(3, steps))
-    ms_kernel = lcd.max_over_ranks(w, ms_kernel)
+    ms_kernel = lcd.max_over_ranks(w, timed_region.event_ms / steps)
     return {
         "value": flops_total * steps / secs * 1e-12,
         "ms_per_step": secs / steps * 1e3,
@@ -274,10 +276,7 @@ def bench_attn_d512(w, args, steps=3):
         else:
             step = lambda: capi.attn_fwd_bf16(q, k, v, o)  # noqa: E731
         secs = lcd.max_over_ranks(w, timed_region(w, step, steps, 1, prewarm=2))
-        with capi.Timer() as tm:
-            for _ in range(steps):
-                step()
-        ms_kernel = lcd.max_over_ranks(w, tm.ms / steps)
+        ms_kernel = lcd.max_over_ranks(w, timed_region.event_ms / steps)
         out[name] = {"value": flops_total * steps / secs * 1e-12, "ms_per_step": secs / steps * 1e3, "steps": steps,
                      "roofline": roofline(capi.attn_kernel_name(N, D, False, dt == torch.bfloat16), flops_local,
                                           4.0 * B * h_loc * N * D * 2, ms_kernel)}
