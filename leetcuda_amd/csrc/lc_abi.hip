@@ -477,7 +477,11 @@ int lc_tune_set(const char* key, int value) {
     return LC_OK;
   }
   if (strcmp(key, "w4y_sched") == 0) {
+#ifdef LC_DIAG
+    if (value < 0 || value > 5) return LC_ERR_ARG;   // 3..5: ablations (results WRONG)
+#else
     if (value < 0 || value > 2) return LC_ERR_ARG;
+#endif
     g_tune_w4y_sched = value;
     return LC_OK;
   }

@@ -48,6 +48,11 @@ int launch_w4_t(const half_t* A, const half_t* B, half_t* C, int M, int N, int K
     if (variant == LC_HGEMM_MFMA256W4Y) {
       if (g_tune_w4y_sched == 0) return launch_w4x_one<B_KN, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
       if (g_tune_w4y_sched == 1) return launch_w4x_one<B_KN, 1>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+#ifdef LC_DIAG
+      if (g_tune_w4y_sched == 3) return launch_w4x_one<B_KN, 3>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+      if (g_tune_w4y_sched == 4) return launch_w4x_one<B_KN, 4>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+      if (g_tune_w4y_sched == 5) return launch_w4x_one<B_KN, 5>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+#endif
       return launch_w4x_one<B_KN, 2>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
     }
   } else {

@@ -111,8 +111,10 @@ def test_generated_hgemm_loops_are_current_and_well_formed():
     for sched in range(gen.NSCHED):
         assert gen.out_path(sched).read_text() == gen.render(sched)
     assert (root / "leetcuda_amd" / "csrc" / "hgemm_w4y_loop_nn.inc").read_text() == gen.render_nn()
-    for lines in [gen.gen(s) for s in range(gen.NSCHED)] + [gen.gen_nn()]:
-        body = lines[lines.index(".Lw4y_loop_%=:"):]
+    bodies = [gen.gen_body(s) for s in range(3)]
+    nn = gen.gen_nn()
+    bodies.append(nn[nn.index(".Lw4y_loop_%=:"):-1])
+    for body in bodies:
         mf = [l for l in body if l.startswith("v_mfma")]
         blocks = [l.split(",")[0] for l in mf]
         assert len(mf) == 128 and len(set(blocks)) == 64 and blocks[:64] == blocks[64:]   # 64 blocks x 2 k-steps
@@ -122,13 +124,16 @@ def test_generated_hgemm_loops_are_current_and_well_formed():
         for a, b in zip(body, body[1:]):
             assert not (a.startswith("s_add_u32 m0") and b.startswith("buffer_load"))
         tail = body[[i for i, l in enumerate(body) if l.startswith("s_cmp_lt_u32")][-1] + 1:]
-        assert tail[-2].startswith("s_cbranch_scc1") and all(l.startswith("v_mfma") for l in tail[:-2])
-        # the counted wait: 8 pieces (B of tile t+2) are issued between the barrier's wait and the previous one
+        assert tail[-1].startswith("s_cbranch_scc1") and all(l.startswith("v_mfma") for l in tail[:-1])
+        # the counted wait: 8 pieces (B of tile t+2) are issued between the loop top and the barrier's wait, 8 (A) behind it
         w = [i for i, l in enumerate(body) if "vmcnt(8)" in l][0]
         assert sum(l.startswith("buffer_load") for l in body[:w]) == 8
-        # fragment registers: every ds_read destination is read by an MFMA of the OTHER k-step buffer only after a wait
+        assert body.index("s_barrier") > w
+        # fragment registers stay inside the statement's literal range
         dst = [int(re.search(r"v\[(\d+):", l).group(1)) for l in body if l.startswith("ds_read")]
         assert min(dst) >= 128 and max(dst) <= 254
+        # every ds_read of a k-step's fragments is issued before the wait that precedes their first MFMA
+        assert all(not l.startswith("ds_read") for l in body[w - 2:w])
 
 
 def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):

@@ -24,6 +24,8 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 NSCHED = 3
+NDIAG = 3   # LC_DIAG-only ablations of schedule 1 (results are WRONG): 3 = no DMA in the loop, 4 = DMA issued but never waited
+            # for, 5 = no fragment reads (profiles/r2_w4y_ablation.log)
 
 
 def out_path(sched):
@@ -54,10 +56,9 @@ def mfma(ks, i, j):
     return f"v_mfma_f32_16x16x32_f16 {acc(i, j)}, {fb(ks, j)}, {fa(ks, i)}, {acc(i, j)}"
 
 
-def gen(sched):
+def gen_init():
     L = []
     e = L.append
-    # ---- init
     e("s_mov_b32 %[t], 0")
     e("s_mov_b32 %[acur], %[a0]")
     e("s_add_u32 %[anxt], %[a0], 0x8000")
@@ -77,7 +78,17 @@ def gen(sched):
     e("s_lshl_b32 %[t2off], %[swp], 7")
     e(f"v_add_u32_e32 {VA}, %[acur], %[ar1]")
     e(f"v_add_u32_e32 {VB}, %[b0], %[br1]")
-    e(".Lw4y_loop_%=:")
+    return L
+
+
+def gen_body(sched):
+    """One K-tile iteration, from the loop label to the backward branch.  (Tried and removed: one copy of the body per wave
+    with the DMA pieces shifted by the wave's index, so that the four lock-stepped waves of a CU do not hand their pieces to
+    the texture-address path in the same gap — no effect, profiles/r2_w4y_ablation.log.)"""
+    L = []
+    e = L.append
+    lab = ".Lw4y_loop_%="
+    e(lab + ":")
     e("s_waitcnt lgkmcnt(0)")
     fill = {}   # MFMA index -> instructions issued right behind it
 
@@ -88,11 +99,13 @@ def gen(sched):
     for r in range(16):
         after(2 * r, f"ds_read_b128 {fa(1, r)}, {VA} offset:{r * 2048}" if r < 8
               else f"ds_read_b128 {fb(1, r - 8)}, {VB} offset:{(r - 8) * 2048}")
-    after(31, "s_add_u32 %[tmp], %[b2], %[wv]")
+    d0 = 32
+    after(d0 - 1, "s_add_u32 %[tmp], %[b2], %[wv]")
     for p in range(8):
-        after(32 + 4 * p, f"s_add_u32 m0, %[tmp], {p * 1024}",
+        after(d0 + 4 * p, f"s_add_u32 m0, %[tmp], {p * 1024}",
               "s_mov_b32 %[soff], %[t2off]" if p == 0 else "s_add_u32 %[soff], %[soff], %[blk]")
-        after(33 + 4 * p, f"buffer_load_dwordx4 %[ao{p & 1}], %[rb], %[soff] offen lds")
+        after(d0 + 1 + 4 * p, f"buffer_load_dwordx4 %[ao{p & 1}], %[rb], %[soff] offen lds")
+    assert d0 + 1 + 4 * 7 < 64
     # k-step 1: addresses and reads of (t + 1, ks 0), A pieces of tile t + 2, ring rotation, loop counter.
     #   sched 0: reads first (66..96), A pieces late (97..126)
     #   sched 1: A pieces first, right behind the barrier (their data is needed one tile later, at the next barrier:
@@ -127,18 +140,32 @@ def gen(sched):
     for ins, m in zip(rot, slots):
         after(m, ins)
     after(126, "s_add_u32 %[t], %[t], 1", "s_cmp_lt_u32 %[t], %[kt]")
-    wait_at = bar
     for m in range(128):
         ks, i, j = m >> 6, (m >> 3) & 7, m & 7
         if m == 64:
-            e("s_waitcnt lgkmcnt(0)" if wait_at != 64 else "s_waitcnt vmcnt(8) lgkmcnt(0)")
-        if m == wait_at and wait_at != 64:
+            e("s_waitcnt lgkmcnt(0)" if bar != 64 else "s_waitcnt vmcnt(8) lgkmcnt(0)")
+        if m == bar and bar != 64:
             e("s_waitcnt vmcnt(8)")
         e(mfma(ks, i, j))
         for ins in fill.get(m, []):
             e(ins)
-    e("s_cbranch_scc1 .Lw4y_loop_%=")
-    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    e(f"s_cbranch_scc1 {lab}")
+    return L
+
+
+def gen(sched):
+    ablate = sched - NSCHED + 1 if sched >= NSCHED else 0   # 1 no DMA, 2 no vmcnt wait, 3 no reads
+    base = 1 if ablate else sched
+    L = gen_init()
+    L += gen_body(base)
+    L.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    if ablate == 1:
+        L = [ln for ln in L if not ln.startswith("buffer_load")]
+    if ablate in (1, 2):
+        L = [ln.replace("s_waitcnt vmcnt(8) lgkmcnt(0)", "s_waitcnt lgkmcnt(0)") for ln in L]
+    if ablate == 3:
+        keep_until = next(i for i, ln in enumerate(L) if ln.startswith(".Lw4y_loop"))
+        L = L[:keep_until] + [ln for ln in L[keep_until:] if not ln.startswith("ds_read")]
     return L
 
 
@@ -267,7 +294,8 @@ def render(sched):
     return (head + "asm volatile(\n" + body + "\n"
             "    : [t] \"=&s\"(w4y_t), [acur] \"=&s\"(w4y_acur), [anxt] \"=&s\"(w4y_anxt), [b0] \"=&s\"(w4y_b0), [b1] \"=&s\"(w4y_b1),\n"
             "      [b2] \"=&s\"(w4y_b2), [soff] \"=&s\"(w4y_soff), [t2off] \"=&s\"(w4y_t2off), [tmp] \"=&s\"(w4y_tmp), [swp] \"=&s\"(w4y_swp)\n"
-            "    : [kt] \"s\"(KT), [a0] \"s\"(w4y_a0), [wv] \"s\"(w4y_wv), [blk] \"s\"(w4y_blk), [ra] \"s\"(w4y_ra), [rb] \"s\"(w4y_rb),\n"
+            "    : [kt] \"s\"(KT), [a0] \"s\"(w4y_a0), [wv] \"s\"(w4y_wv), [blk] \"s\"(w4y_blk), [ra] \"s\"(w4y_ra),\n"
+            "      [rb] \"s\"(w4y_rb),\n"
             "      [ao0] \"v\"(w4y_ao0), [ao1] \"v\"(w4y_ao1), [ar0] \"v\"(fr.a_ad[0]), [ar1] \"v\"(fr.a_ad[1]), [br0] \"v\"(fr.b_ad[0]),\n"
             "      [br1] \"v\"(fr.b_ad[1])\n"
             f"    : \"memory\", \"scc\", {vclob}, LC_AGPR_ALL);\n")
@@ -275,7 +303,7 @@ def render(sched):
 
 def main():
     rc = 0
-    todo = [(render(sched), out_path(sched)) for sched in range(NSCHED)]
+    todo = [(render(sched), out_path(sched)) for sched in range(NSCHED + NDIAG)]
     todo.append((render_nn(), ROOT / "leetcuda_amd" / "csrc" / "hgemm_w4y_loop_nn.inc"))
     for text, out in todo:
         if "--check" in sys.argv:
