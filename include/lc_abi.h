@@ -105,7 +105,6 @@ const char* lc_build_info(int* is_diag);
  *   "attn_nw"      attention kernel for D = 128: 0 = auto (= 512 when N % 256 == 0), 512 = merged-phase kernel with 16x16x32
  *                  MFMAs (attn_w4n.hip), 256 = the same with 32x32x16 MFMAs, 4 waves x 64
  *                  query rows, one wave per SIMD (attn_w4m.hip; 260 = its A/B twin with padded Q.K^T MFMAs),
- *                  64 = 8-wave four-cluster kernel (N % 256 == 0),
  *                  8 / 4 / 2 = lock-step kernel with that many waves (any N % (32 x waves) == 0, every D <= 128)
  *   "w4y_sched"    schedule 0..2 of LC_HGEMM_MFMA256W4Y's generated loop body (tools/gen_hgemm_w4y.py; same bits, A/B knob)
  *   "hgemm_auto"   kernel LC_HGEMM_AUTO launches on large 256-tileable shapes (a 256-tile lc_hgemm_variant value)

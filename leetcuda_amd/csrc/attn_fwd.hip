@@ -320,271 +320,9 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Four-cluster role-split variant (8 waves, D = 128, N % 256 == 0): per KV tile every wave runs four
-// barrier-separated segments
-//     L1: K fragments LDS -> registers (16 ds_read_b128) + LDS-DMA issue of K/V(t+1)
-//     C1: Sᵀ = K·Qᵀ, 16 MFMAs on registers only
-//     SM: V fragments LDS -> registers (32 ds_read_b64_tr_b16, issued first) + online softmax (VALU)
-//     C2: Oᵀ += Vᵀ·Pᵀ, 16 MFMAs on registers only
-// and the two waves that share a SIMD (w and w+4) run ONE segment apart, so on every SIMD an MFMA segment
-// always faces a load / VALU segment:  (L1 | C2') (C1 | L1') (SM | C1') (C2 | SM').  K and V fragments
-// time-share one 64-register block.  K/V tiles are staged with LDS-DMA (no staging registers, no ds_write):
-// unpadded 256-B rows, K chunk c of row r at chunk slot c ^ (r & 15) (conflict-free ds_read_b128), V 64-B unit
-// u of row r at unit u ^ (r & 3) (the 4 rows of a transpose-read half-wave land on disjoint bank quarters);
-// LDS-DMA writes lane-linearly, so both permutations are applied to the per-lane SOURCE address.
-// Hazards (g = global segment index; group 1 runs one barrier behind group 0):
-//   WAR  tile t+1 is DMA-ed into the slot of tile t-1 from segment 4t (group 0) / 4t+1 (group 1); the last reads
-//        of tile t-1 are group 1's V reads in its SM(t-1) = segment 4t-1, completed (lgkmcnt(0)) before the barrier.
-//   RAW  every wave waits vmcnt(0) for its own pieces before the barrier that ends segment 4t+3 (group 0: end of
-//        C2(t); group 1: end of SM(t)); the first read of tile t+1 is group 0's L1(t+1) = segment 4t+4.
-// ABL (diagnosis, results WRONG unless 0 or 32): 1 = no v_exp, 2 = no softmax math at all (P = fp16(S)),
-// 4 = s_setprio 1 around the MFMA clusters, 8 = plain instead of packed fp32 softmax math, 16 = DMA pieces issued
-// from inside the MFMA clusters instead of from L1, 32 = cycle stamps into Q (results stay right for 4, 8, 16, 32).
-// Measured at config 3 (same box): default 1.09-1.13 ms; 4: +0..5 %; 8: +2 %; 16: +7 %.
-template <int D, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void attn_fwd_c4_kernel(
-    const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
-    half_t* __restrict__ O, int N, int nqb, float sl2) {
-  static_assert(D == 128, "c4 kernel: D = 128 only");
-  constexpr int DT = D / 32, DS = D / 16;
-  constexpr int TILE = KVB * D * 2;      // 16 KiB
-  constexpr int SLOT = 2 * TILE;         // K + V
-  constexpr bool STAMPS = (ABL & 32) != 0;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = wave_id();
-  const int grp = wave >> 2;
-  const int hi = lane >> 5, l32 = lane & 31;
-
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const size_t bh = id / nqb;
-  const int q0 = (id - (int)bh * nqb) * 256 + wave * 32;
-  const half_t* Qb = Q + bh * (size_t)N * D;
-  const char* Kb = (const char*)(K + bh * (size_t)N * D);
-  const char* Vb = (const char*)(V + bh * (size_t)N * D);
-  half_t* Ob = O + bh * (size_t)N * D;
-
-  half8_t qf[DS];
-#pragma unroll
-  for (int s = 0; s < DS; ++s) qf[s] = *(const half8_t*)(Qb + (size_t)(q0 + l32) * D + 16 * s + 8 * hi);
-
-  // ---- LDS-DMA sources: piece p = 4 rows x 256 B; this wave stages pieces wave and wave + 8 of K and of V.
-  // lane -> row (lane>>4) of the piece, 16-B slot cs = lane & 15.
-  const int r4 = lane >> 4, cs = lane & 15;
-  const unsigned k_off = (unsigned)(r4 * 256 + ((cs ^ (4 * (wave & 3) + r4)) * 16));   // (row & 15) = 4(p&3) + r4
-  const unsigned v_off = (unsigned)(r4 * 256 + ((cs ^ (r4 << 2)) * 16));               // (row & 3) = r4
-  // piece i = 0..3 of this wave for tile t: K pieces wave, wave+8, then V pieces wave, wave+8
-  // buffer_load..lds: descriptor per (b,h) + scalar offset + one 32-bit lane offset (no 64-bit lane address per piece)
-  const buf_rsrc_t rk = make_rsrc(Kb), rv = make_rsrc(Vb);
-  auto issue_piece = [&](int i, int t, char* slot) {
-    const unsigned tb = (unsigned)t * TILE;
-    const int p = wave + 8 * (i & 1);
-    if (i < 2)
-      blds16(rk, k_off, tb + (unsigned)p * 1024, slot + p * 1024);
-    else
-      blds16(rv, v_off, tb + (unsigned)p * 1024, slot + TILE + p * 1024);
-  };
-  auto issue_tile = [&](int t, char* slot) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) issue_piece(i, t, slot);
-  };
-
-  // ---- fragment read offsets
-  // K: row tt*32 + l32, logical chunk 2ks + hi  ->  slot (2ks) ^ (hi ^ (l32 & 15))
-  const int k_rd = l32 * 256 + ((hi ^ (l32 & 15)) * 16);          // ^ (ks*32), + tt*8192
-  // V (tr16): lane supplies row (32tt + 16u + 8x + 4hi + (i>>2)), bytes dt*64 + 32gi + 8(i&3), unit ^ (row & 3)
-  const int vi = lane & 15, vgi = (lane >> 4) & 1;
-  const int v_rd = TILE + (4 * hi + (vi >> 2)) * 256 + 32 * vgi + 8 * (vi & 3);   // + (32tt+16u+8x)*256 + ((dt ^ (vi>>2)) << 6)
-  const int v_sw = vi >> 2;
-
-  f32x16_t o[DT];
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  unsigned long long* stamp = reinterpret_cast<unsigned long long*>(const_cast<half_t*>(Q));
-  const bool stamping = STAMPS && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0;
-  auto STAMP = [&](int t, int k) {
-    if constexpr (STAMPS) {
-      if (t >= 16 && t < 20) {
-        const unsigned long long c = __builtin_readcyclecounter();
-        if (stamping) stamp[((wave >> 2) * 4 + (t - 16)) * 8 + k] = c;
-      }
-    }
-  };
-
-  const int T = N / KVB;
-  issue_tile(0, smem);
-#pragma unroll
-  for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(qf[s]));   // retire the Q loads before the loop
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  // DMA placement (inside MFMA clusters, one piece per 4 MFMAs): group 0 issues tile t+1 in C1(t) (segment 4t+1),
-  // group 1 issues tile t+2 in C2(t) (segment 4t+4); group 1's tile 1 goes out here.
-  if ((ABL & 16) && grp == 1 && T > 1) issue_tile(1, smem + SLOT);
-  raw_barrier();
-  if (grp == 1) raw_barrier();   // group 1 runs one segment behind
-
-  for (int t = 0; t < T; ++t) {
-    char* cur = smem + (t & 1) * SLOT;
-    char* nxt = smem + ((t & 1) ^ 1) * SLOT;
-    const bool more = t + 1 < T;
-    half8_t fr[16];   // K fragments in L1/C1, V fragments in SM/C2
-    // =========================== L1 ===========================
-    STAMP(t, 0);
-#pragma unroll
-    for (int idx = 0; idx < 2 * DS; ++idx) {
-      const int tt = idx & 1, ks = idx >> 1;
-      fr[idx] = *(const half8_t*)(cur + ((k_rd ^ (ks * 32)) + tt * 8192));
-    }
-    if (!(ABL & 16) && more) issue_tile(t + 1, nxt);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    STAMP(t, 1);
-    raw_barrier();
-    // =========================== C1 ===========================
-    STAMP(t, 2);
-    f32x16_t s[2];
-    if constexpr (ABL & 4) __builtin_amdgcn_s_setprio(1);
-    const bool dma_c1 = (ABL & 16) && grp == 0 && more;
-#pragma unroll
-    for (int idx = 0; idx < 2 * DS; ++idx) {
-      const int tt = idx & 1, ks = idx >> 1;
-      s[tt] = mfma32(fr[idx], qf[ks], ks == 0 ? (f32x16_t)0.f : s[tt]);
-      if ((idx & 3) == 3) {
-        if (dma_c1) issue_piece(idx >> 2, t + 1, nxt);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if constexpr (ABL & 4) __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    STAMP(t, 3);
-    raw_barrier();
-    // =========================== SM ===========================
-    STAMP(t, 4);
-    // asm transpose reads (lc_common.h lds_tr16_asm): the builtin form is guarded by s_waitcnt vmcnt(0) after an LDS-DMA
-    half4_t vlo[16], vhi[16];
-    {
-      uint32_t va[DT];
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) va[dt] = lds_addr32(cur + v_rd + ((dt ^ v_sw) << 6));
-      static_for<16>([&](auto ic) {
-        constexpr int i = decltype(ic)::value, g = i >> 2, dt = i & 3;
-        constexpr int ro = (32 * (g >> 1) + 16 * (g & 1)) * 256;
-        vlo[i] = lds_tr16_asm<ro>(va[dt]);
-        vhi[i] = lds_tr16_asm<ro + 8 * 256>(va[dt]);
-      });
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    half8_t pf[2][2];
-    if constexpr (ABL & 2) {
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) pf[tt][u][j] = (half_t)s[tt][8 * u + j];
-    } else {
-    float mt[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) mt[r] = fmaxf(fmaxf(s[0][r], s[0][r + 8]), fmaxf(s[1][r], s[1][r + 8]));
-    float mx = fmaxf(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3])),
-                     fmaxf(fmaxf(mt[4], mt[5]), fmaxf(mt[6], mt[7])));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_cand = fmaxf(m_run, mx * sl2);
-    if (!__all(m_cand - m_run <= RESCALE_THR)) {   // PV(t-1) is complete: O, l are all at the old scale
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);
-      m_run = m_cand;
-      l_run *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-    }
-    if constexpr (!(ABL & 8)) {
-      f32x2_t ps2[2] = {f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}};
-      const f32x2_t sl2v = {sl2, sl2}, nm = {-m_run, -m_run};
-  #pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-  #pragma unroll
-        for (int u = 0; u < 2; ++u)
-  #pragma unroll
-          for (int j = 0; j < 8; j += 2) {
-            const f32x2_t sv = {s[tt][8 * u + j], s[tt][8 * u + j + 1]};
-            const f32x2_t e = __builtin_elementwise_fma(sv, sl2v, nm);
-            f32x2_t pr;
-            pr[0] = (ABL & 1) ? e[0] : __builtin_amdgcn_exp2f(e[0]);
-            pr[1] = (ABL & 1) ? e[1] : __builtin_amdgcn_exp2f(e[1]);
-            ps2[(j >> 1) & 1] += pr;
-            pf[tt][u][j] = (half_t)pr[0];
-            pf[tt][u][j + 1] = (half_t)pr[1];
-          }
-      {
-        const f32x2_t t2 = ps2[0] + ps2[1];
-        l_run += t2[0] + t2[1];
-      }
-    } else {   // plain (unpacked) fp32 VALU: packed f32 ops are expensive beside a partner's MFMA stream
-      float ps[4] = {0.f, 0.f, 0.f, 0.f};
-      const float nmr = -m_run;
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float e = __builtin_fmaf(s[tt][8 * u + j], sl2, nmr);
-            const float pr = (ABL & 1) ? e : __builtin_amdgcn_exp2f(e);
-            ps[j & 3] += pr;
-            pf[tt][u][j] = (half_t)pr;
-          }
-      l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
-    }
-    }
-    if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_tr16_wait16(vlo);
-    lds_tr16_wait16(vhi);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) fr[i] = cat4(vlo[i], vhi[i]);
-    STAMP(t, 5);
-    raw_barrier();
-    // =========================== C2 ===========================
-    STAMP(t, 6);
-    if constexpr (ABL & 4) __builtin_amdgcn_s_setprio(1);
-    const bool dma_c2 = (ABL & 16) && grp == 1 && t + 2 < T;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[dt] = mfma32(fr[g * DT + dt], pf[g >> 1][g & 1], o[dt]);
-      if (dma_c2) issue_piece(g, t + 2, cur);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (ABL & 4) __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP(t, 7);
-    raw_barrier();
-  }
-  if (grp == 0) raw_barrier();
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
-  half_t* orow = Ob + (size_t)(q0 + l32) * D;
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      half4_t h;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) h[j] = (half_t)(o[dt][4 * rq + j] * inv);
-      *(half4_t*)(orow + 32 * dt + 8 * rq + 4 * hi) = h;
-    }
-  }
-}
-
-// (retired in round 2, git history: attn_fwd_pp_kernel — X/Y phases with the two waves of a SIMD one barrier apart —
-// and attn_fwd_swp_kernel — MFMAs of tile t+1 interleaved with the exp2 / pack VALU of tile t; both measured
-// 0.96-1.02 PFLOP/s at config 3, the same plateau as the lock-step kernel: DESIGN.md section 4.8.)
+// (The round-1 four-cluster role-split kernel, attn_fwd_c4_kernel — 8 waves, K/V by LDS-DMA, 0.95-1.04 PFLOP/s at config 3 —
+// was retired at the end of round 2: attn_w4m.hip / attn_w4n.hip keep its K-tile swizzle (16-B chunk c of row r at slot
+// c ^ (r & 15) on unpadded 256-B rows) and its LDS-DMA staging; git history has the kernel.)
 
 // ------------------------------------------------------------------------------------------------
 // Large head dims (D = 256, 512): the FFPA-style fine-grained tiling of the reference's

@@ -29,7 +29,7 @@
 // ≈ 3.7 instructions per MFMA gap (budget of one wave per SIMD: 5, MI355X_MICROARCH.md "Per-instruction cycle constants").
 // Register plan (literal AGPRs): a[0:127] Oᵀ(qb, dt) = a[16(4qb+dt)..]; a[128:191] two K fragment buffers
 // (half-tile n uses buffer n & 1, fragment ks at +4ks); a[192:255] Q~ fragments Q(qb, ks) = a[192 + 4(8qb+ks)..].
-// LDS: ring of 4 KV tiles of 64 rows (K 16 KiB + V 16 KiB, unpadded 256-B rows, swizzles of attn_fwd_c4_kernel) filled by
+// LDS: ring of 4 KV tiles of 64 rows (K 16 KiB + V 16 KiB, unpadded 256-B rows; K: 16-B chunk c of row r at slot c ^ (r & 15), V: 64-B unit u of row r at unit u ^ (r & 3)) filled by
 // LDS-DMA; ONE barrier per 64-row tile.  Tile t+2 is staged during phase 2t (its slot held tile t−2, last read in phase
 // 2t−2), every wave waits for its own pieces before the barrier that opens tile t+1's period, where K(t+2) is first read.
 #pragma once
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4m_kernel(
   });
   static_for<128>([&](auto r) { am_acc_zero<decltype(r)::value>(); });
 
-  // ---- fragment read offsets inside a ring slot (see attn_fwd_c4_kernel for the swizzles)
+  // ---- fragment read offsets inside a ring slot (swizzles: file header)
   uint32_t kx[8];   // K: row l32 (+32 per half-tile: immediate), 16-B chunk (2ks + hi) ^ (row & 15)
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) kx[ks] = (uint32_t)((l32 * 256 + ((hi ^ (l32 & 15)) * 16)) ^ (ks * 32));

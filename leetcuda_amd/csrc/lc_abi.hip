@@ -226,42 +226,18 @@ int launch_attn(const half_t* Q, const half_t* K, const half_t* V, half_t* O, in
   return check_launch();
 }
 
-template <int D>
-int launch_attn_c4(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
-                   hipStream_t st) {
-  constexpr int lds = 4 * KVB * D * 2;   // 2 slots x (K + V), unpadded
-  const int nqb = N / 256;
-  const dim3 grid((unsigned)((size_t)nqb * B * H)), block(512);
-  const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
-#define LC_C4_CASE(ABL)                                                         \
-  case ABL: {                                                                   \
-    auto kern = attn_fwd_c4_kernel<D, ABL>;                                     \
-    if (int rc = set_dyn_lds(kern, lds)) return rc;                             \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, Q, K, V, O, N, nqb, sl2);    \
-  } break;
-  switch (g_tune_attn_ablate) {
-    LC_C4_CASE(0)
-#ifdef LC_DIAG
-    LC_C4_CASE(32) LC_C4_CASE(4) LC_C4_CASE(8) LC_C4_CASE(16)
-#endif
-    default: return LC_ERR_ARG;
-  }
-#undef LC_C4_CASE
-  return check_launch();
-}
-
 // Which kernel serves a D <= 128 problem: 512 = merged-phase 4-wave x 64-row kernel with 16x16x32 MFMAs (attn_w4n.hip),
-// 256 = the same with 32x32x16 MFMAs (attn_w4m.hip; 260 = its padded A/B twin), 64 = 8-wave four-cluster kernel, 8 / 4 / 2 =
-// lock-step kernel with that many waves.  ONE function for the launcher and lc_attn_kernel_name().  Default for D = 128,
+// 256 = the same with 32x32x16 MFMAs (attn_w4m.hip; 260 = its padded A/B twin), 8 / 4 / 2 = lock-step kernel with that many
+// waves (the 8-wave four-cluster kernel, 64, was retired at the end of round 2).  ONE function for the launcher and lc_attn_kernel_name().  Default for D = 128,
 // N % 256 == 0: 512 (sustained, one box, config 3 / config 4's shard: 1235 / 1311 TFLOP/s at 2.08 GHz against 1220 / 1260 at
-// 1.80 GHz for 256 — both at the 1400 W cap — and 1030 / 1080 for the four-cluster kernel).
+// 1.80 GHz for 256 — both at the 1400 W cap — and 1000-1030 / 1040-1080 for the 8-wave kernels).
 int choose_attn_nw(int D, bool vt, int N) {
   const int want = g_tune_attn_nw;   // 0 = auto
   if (D == 128 && !vt && N % 256 == 0) {
     if (want == 0 && g_tune_attn_ablate == 0) return 512;
-    if (want == 256 || want == 260 || want == 512 || want == 64) return want;
+    if (want == 256 || want == 260 || want == 512) return want;
   }
-  if (N % 256 == 0 && (want == 0 || want >= 8)) return 8;   // (also what 64 / 256 fall back to for D < 128)
+  if (N % 256 == 0 && (want == 0 || want >= 8)) return 8;   // (also what 256 / 512 fall back to for D < 128)
   if (N % 128 == 0 && (want == 0 || want >= 4)) return 4;
   return 2;
 }
@@ -271,7 +247,6 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
                    hipStream_t st) {
   const int nw = choose_attn_nw(D, VT, N);
   if constexpr (D == 128 && !VT) {
-    if (nw == 64) return launch_attn_c4<D>(Q, K, V, O, B, H, N, st);
     if (nw == 256 || nw == 260) return launch_attn_w4m_d128(Q, K, V, O, B, H, N, nw == 260, st);
     if (nw == 512) return launch_attn_w4n_d128(Q, K, V, O, B, H, N, st);
   }
@@ -443,7 +418,6 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
     const int nw = choose_attn_nw(D, v_transposed != 0, N);
     if (nw == 256 || nw == 260) snprintf(buf, buflen, "attn_fwd_w4m_kernel<%d,%d>", D, nw == 260 ? 4 : 0);
     else if (nw == 512) snprintf(buf, buflen, "attn_fwd_w4n_kernel<%d>", D);
-    else if (nw == 64) snprintf(buf, buflen, "attn_fwd_c4_kernel<%d,0>", D);
     else snprintf(buf, buflen, "attn_fwd_kernel<%d,%d,%s,0>", D, nw, vt);
     return LC_OK;
   }
@@ -462,7 +436,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
 int lc_tune_set(const char* key, int value) {
   if (!key) return LC_ERR_ARG;
   if (strcmp(key, "attn_nw") == 0) {
-    if (value != 0 && value != 256 && value != 260 && value != 512 && value != 64 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
+    if (value != 0 && value != 256 && value != 260 && value != 512 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
     g_tune_attn_nw = value;
     return LC_OK;
   }

@@ -164,7 +164,7 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     assert capi.attn_kernel_name(192, 512, False, False).startswith("attn_fwd_bigd_kernel<512,")     # N % 128 != 0
     assert sump.short("_ZN2lc16hgemm_w4b_kernelILb0ELb1ELi0EEEvPKDF16_S2_PDF16_iiiiii") == \
         "hgemm_w4b_kernel<false,true,0>"
-    assert sump.short("_ZN2lc18attn_fwd_c4_kernelILi128ELi0EEEvPKDF16_S2_S2_PDF16_iif") == "attn_fwd_c4_kernel<128,0>"
+    assert sump.short("_ZN2lc19attn_fwd_w4n_kernelILi128EEEvPKDF16_S2_S2_PDF16_iif") == "attn_fwd_w4n_kernel<128>"
     pmc = json.loads((root / "profiles" / "latest_pmc.json").read_text())
     for key in (capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN), capi.attn_kernel_name(4096, 128)):
         if key in pmc:

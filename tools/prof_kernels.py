@@ -33,7 +33,7 @@ if a.what in ("all", "hgemm"):
     torch.cuda.synchronize()
 if a.what in ("all", "attn"):
     q, k, v, o, tv = host.get_qkvo(4, 32, 4096, 128, seed=0)
-    for nw in (0, 256, 64, 8):     # default (merged-phase 16x16x32), merged-phase 32x32x16, four-cluster LDS-DMA, lock-step
+    for nw in (0, 256, 8):     # default (merged-phase 16x16x32), merged-phase 32x32x16, lock-step
         capi.tune("attn_nw", nw)
         for _ in range(a.iters):
             capi.attn_fwd(q, k, v, o)
