@@ -12,6 +12,9 @@
  *      "attn_ablate"   attention ablation / stamp instantiations (tools/attn_ablate.py, tools/attn_*_stamps.py)
  *      "w4_abl"        4-wave HGEMM: 2 = no DMA after the prologue, 4 = no per-tile wait + barrier, 8 = no fragment
  *                      reads, 14 = MFMA issue only (tools/w4_ablate.py)
+ *    An LC_DIAG library also exports `int lc_diag_attn_slowpath(unsigned out4[4], int reset)`: how often attn_fwd_w4n_kernel's
+ *    overflow slow path ran since the last reset { executions, sum of half-tile indices, with a non-finite row sum, in half-tiles
+ *    0..3 } (it never runs on N(0,1) inputs: tools/attn_determinism.py).
  *      "hgemm_stamps"  s_memtime stamps of one wave at the k-step boundaries (tools/hgemm_w4c_stamps.py)
  */
 #ifndef LC_DIAG_H_
@@ -33,6 +36,10 @@ int lc_probe_coissue(int filler, int k, int mode, void* out_u64x16, void* stream
  * overwritten by VALU `delay`+1 wait states after the MFMA (kind 0 v_mov, 1 v_exp_f32; queued: behind another MFMA). */
 int lc_probe_mfma_war(int delay, int kind, int queued, const void* a32x16, const void* b32x16, float* d32x32,
                       void* stream);
+
+/* leave `pattern` in every arch VGPR (what & 1), AGPR (what & 2) and LDS dword (what & 4) of the chip: a following kernel
+ * that reads state it did not initialise inherits it (tools/attn_determinism.py) */
+int lc_diag_pollute(unsigned pattern, int what, void* stream);
 
 #ifdef __cplusplus
 }

@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4m_kernel(
   phase(I1{}, F_MID1{}, 0, sB, sA, pB, pA);
   for (int t = 1; t + 1 < T; ++t) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own pieces of tile t+1 landed; own LDS reads retired
-    raw_barrier();
+      raw_barrier();
     set_tile_addrs(t);
     phase(I0{}, F_MID{}, t, sA, sB, pA, pB);
     phase(I1{}, F_MID1{}, t, sB, sA, pB, pA);
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4m_kernel(
   {
     const int t = T - 1;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    raw_barrier();
+      raw_barrier();
     set_tile_addrs(t);
     phase(I0{}, F_LAST0{}, t, sA, sB, pA, pB);
     phase(I1{}, F_LAST1{}, t, sB, sA, pB, pA);

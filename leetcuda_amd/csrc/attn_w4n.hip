@@ -30,6 +30,12 @@
 
 namespace lc {
 
+#ifdef LC_DIAG
+// diagnosis: how often (and where) the overflow slow path runs — [0] executions, [1] sum of half-tile indices j, [2] how many
+// of them saw a non-finite row sum, [3] executions in half-tiles j < 4 (lc_diag_attn_slowpath in lc_abi.hip)
+__device__ unsigned int g_an_slowpath[4];
+#endif
+
 constexpr int AN_O = 0, AN_K = 128, AN_Q = 192;
 
 // one MFMA slot = ONE asm statement (see am_slot): KIND 0 Sᵀ block = K frag x Q~ frag + C; 1 accumulate; 2 Oᵀ block +=
@@ -299,6 +305,17 @@ __global__ __launch_bounds__(256) void attn_fwd_w4n_kernel(
     for (int qb = 0; qb < 4; ++qb) ok = ok && (ps[qb][0] + ps[qb][1] < AM_PSUM_LIMIT);
     if (!__all(ok)) {                                          // (NaN / inf compare false: they take this path too)
       am_drain();                                              // every MFMA of this phase has written its result
+#ifdef LC_DIAG
+      if (lane == 0) {
+        bool fin = true;
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) fin = fin && __builtin_isfinite(ps[qb][0] + ps[qb][1]);
+        atomicAdd(&g_an_slowpath[0], 1u);
+        atomicAdd(&g_an_slowpath[1], (unsigned)(2 * t + H));
+        if (!fin) atomicAdd(&g_an_slowpath[2], 1u);
+        if (2 * t + H < 4) atomicAdd(&g_an_slowpath[3], 1u);
+      }
+#endif
       static_for<4>([&](auto qc) {
         constexpr int qb = decltype(qc)::value;
         float mx = sr[0][qb][0];
@@ -346,7 +363,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4n_kernel(
   phase(I1{}, F_MID1{}, 0, sB, sA, pB, pA);
   for (int t = 1; t + 1 < T; ++t) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own pieces of tile t+1 landed; own LDS reads retired
-    raw_barrier();
+      raw_barrier();
     set_tile_addrs(t);
     phase(I0{}, F_MID{}, t, sA, sB, pA, pB);
     phase(I1{}, F_MID1{}, t, sB, sA, pB, pA);
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4n_kernel(
   {
     const int t = T - 1;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    raw_barrier();
+      raw_barrier();
     set_tile_addrs(t);
     phase(I0{}, F_LAST0{}, t, sA, sB, pA, pB);
     phase(I1{}, F_LAST1{}, t, sB, sA, pB, pA);

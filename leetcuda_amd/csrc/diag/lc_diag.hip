@@ -98,3 +98,16 @@ int lc_probe_mfma_war(int delay, int kind, int queued, const void* a, const void
 }
 
 }  // extern "C"
+
+int lc_diag_pollute(unsigned pattern, int what, void* stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pollute_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess)
+      return ERR_LAUNCH;
+    attr_set = true;
+  }
+  // 8 workgroups per CU, one resident at a time (160 KiB of LDS, 512 registers): every SIMD's file and every LDS is visited
+  hipLaunchKernelGGL(pollute_kernel, dim3(2048), dim3(256), 163840, static_cast<hipStream_t>(stream), pattern, what, nullptr);
+  return check_launch();
+}
+

@@ -165,4 +165,25 @@ __global__ void probe_mfma_war_kernel(const half_t* a, const half_t* b, float* d
   for (int r = 0; r < 16; ++r) d[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l32] = c[r] + 0.f * c0[r];
 }
 
+// Leave a chosen bit pattern in EVERY register and LDS byte a later kernel could inherit: a kernel whose results depend on
+// state it did not initialise shows it as run-to-run differences that follow the pattern (tools/attn_determinism.py).
+// what bit 0: arch VGPRs v0..v255, bit 1: AGPRs a0..a255, bit 2: LDS (160 KiB).  The register writes sit at the very end
+// of the kernel (nothing of hipcc's is live any more); the clobbers make hipcc allocate the full 512-entry file.
+template <int R>
+LC_DEVINL void pollute_v(uint32_t x) { asm volatile("v_mov_b32 v[%0], %1" :: "n"(R), "s"(x)); }
+template <int R>
+LC_DEVINL void pollute_a(uint32_t x) { asm volatile("v_accvgpr_write_b32 a[%0], %1" :: "n"(R), "s"(x) : LC_AGPR_ALL); }
+__global__ __launch_bounds__(256) void pollute_kernel(uint32_t pattern, int what, uint32_t* sink) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t pol_lds[];
+  const uint32_t x = __builtin_amdgcn_readfirstlane(pattern);
+  if (what & 4) {
+    for (int i = threadIdx.x; i < 163840 / 4; i += 256) pol_lds[i] = x;
+    __syncthreads();
+    if (sink && pol_lds[threadIdx.x] == 0x12345679u) sink[0] = 1;   // (keeps the stores)
+  }
+  asm volatile("" ::: "v255", LC_AGPR_ALL);
+  if (what & 2) static_for<256>([&](auto r) { pollute_a<decltype(r)::value>(x); });
+  if (what & 1) static_for<256>([&](auto r) { pollute_v<decltype(r)::value>(x); });
+}
+
 }  // namespace lc
