@@ -12,9 +12,6 @@
  *      "attn_ablate"   attention ablation / stamp instantiations (tools/attn_ablate.py, tools/attn_*_stamps.py)
  *      "w4_abl"        4-wave HGEMM: 2 = no DMA after the prologue, 4 = no per-tile wait + barrier, 8 = no fragment
  *                      reads, 14 = MFMA issue only (tools/w4_ablate.py)
- *    An LC_DIAG library also exports `int lc_diag_attn_slowpath(unsigned out4[4], int reset)`: how often attn_fwd_w4n_kernel's
- *    overflow slow path ran since the last reset { executions, sum of half-tile indices, with a non-finite row sum, in half-tiles
- *    0..3 } (it never runs on N(0,1) inputs: tools/attn_determinism.py).
  *      "hgemm_stamps"  s_memtime stamps of one wave at the k-step boundaries (tools/hgemm_w4c_stamps.py)
  */
 #ifndef LC_DIAG_H_

@@ -45,6 +45,7 @@ SYMBOLS = {
     "lc_attn_time": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _fp]),
     "lc_hgemm_kernel_name": (_i, [_i, _i, _i, _i, _i, _cp, _i]),
     "lc_attn_kernel_name": (_i, [_i, _i, _i, _i, _cp, _i]),
+    "lc_attn_slowpath_stats": (_i, [C.POINTER(C.c_uint), _i]),
     "lc_timer_start": (_i, [_vp, C.POINTER(_vp)]),
     "lc_timer_stop": (_i, [_vp, _fp]),
     "lc_clock_probe": (_i, [_vp, _vp]),
@@ -340,6 +341,14 @@ def hgemm_kernel_name(M, N, K, layout=LAYOUT_NN, variant=HGEMM_AUTO) -> str:
     buf = C.create_string_buffer(128)
     check(load().lc_hgemm_kernel_name(M, N, K, layout, variant, buf, 128), "lc_hgemm_kernel_name")
     return buf.value.decode()
+
+
+def attn_slowpath_stats(reset=True):
+    """[executions, sum of half-tile indices, non-finite, last offending row sum (float)] of attn_w4n's overflow slow path."""
+    import struct
+    out = (C.c_uint * 4)()
+    check(load().lc_attn_slowpath_stats(out, int(reset)), "lc_attn_slowpath_stats")
+    return [out[0], out[1], out[2], struct.unpack("f", struct.pack("I", out[3]))[0]]
 
 
 def attn_kernel_name(N, D, v_transposed=False, bf16=False) -> str:

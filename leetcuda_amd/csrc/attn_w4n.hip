@@ -30,11 +30,10 @@
 
 namespace lc {
 
-#ifdef LC_DIAG
-// diagnosis: how often (and where) the overflow slow path runs — [0] executions, [1] sum of half-tile indices j, [2] how many
-// of them saw a non-finite row sum, [3] executions in half-tiles j < 4 (lc_diag_attn_slowpath in lc_abi.hip)
+// introspection (lc_attn_slowpath_stats): how often the overflow slow path ran — [0] executions, [1] sum of half-tile indices
+// j, [2] how many of them saw a non-finite row sum, [3] bit pattern of the last offending row sum.  One atomic per execution
+// of a path that N(0,1) inputs never take.
 __device__ unsigned int g_an_slowpath[4];
-#endif
 
 constexpr int AN_O = 0, AN_K = 128, AN_Q = 192;
 
@@ -305,17 +304,23 @@ __global__ __launch_bounds__(256) void attn_fwd_w4n_kernel(
     for (int qb = 0; qb < 4; ++qb) ok = ok && (ps[qb][0] + ps[qb][1] < AM_PSUM_LIMIT);
     if (!__all(ok)) {                                          // (NaN / inf compare false: they take this path too)
       am_drain();                                              // every MFMA of this phase has written its result
-#ifdef LC_DIAG
-      if (lane == 0) {
+      {
+        float worst = 0.f;
         bool fin = true;
 #pragma unroll
-        for (int qb = 0; qb < 4; ++qb) fin = fin && __builtin_isfinite(ps[qb][0] + ps[qb][1]);
-        atomicAdd(&g_an_slowpath[0], 1u);
-        atomicAdd(&g_an_slowpath[1], (unsigned)(2 * t + H));
-        if (!fin) atomicAdd(&g_an_slowpath[2], 1u);
-        if (2 * t + H < 4) atomicAdd(&g_an_slowpath[3], 1u);
+        for (int qb = 0; qb < 4; ++qb) {
+          const float x = ps[qb][0] + ps[qb][1];
+          fin = fin && __builtin_isfinite(x);
+          if (!(x < AM_PSUM_LIMIT)) worst = x;
+        }
+        const unsigned long long culprit = __ballot(!ok);
+        if (lane == (int)__builtin_ctzll(culprit | (1ull << 63))) {
+          atomicAdd(&g_an_slowpath[0], 1u);
+          atomicAdd(&g_an_slowpath[1], (unsigned)(2 * t + H));
+          if (!fin) atomicAdd(&g_an_slowpath[2], 1u);
+          g_an_slowpath[3] = __builtin_bit_cast(unsigned, worst);
+        }
       }
-#endif
       static_for<4>([&](auto qc) {
         constexpr int qb = decltype(qc)::value;
         float mx = sr[0][qb][0];

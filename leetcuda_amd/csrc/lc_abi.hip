@@ -725,7 +725,5 @@ int lc_clock_probe(void* out_u64x2, void* stream) {
 
 }  // extern "C"
 
-#ifdef LC_DIAG
-extern "C" int lc_diag_attn_slowpath(unsigned* out4, int reset) { return lc::diag_attn_slowpath(out4, reset); }
-#endif
+extern "C" int lc_attn_slowpath_stats(unsigned* out4, int reset) { return lc::diag_attn_slowpath(out4, reset); }
 

@@ -52,9 +52,7 @@ void valu_rung_tile(int rung, int* tm, int* tn, int* tk);
 const char* valu_rung_kernel_name(int rung);
 int launch_attn_w4m_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int pad,
                          hipStream_t st);
-#ifdef LC_DIAG
 int diag_attn_slowpath(unsigned* out4, int reset);   // attn_w4n slow-path counters (host copy; resets when asked)
-#endif
 // attn_w4n.hip: the same kernel with v_mfma_f32_16x16x32_f16
 int launch_attn_w4n_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, hipStream_t st);
 // tu_attn_big.hip: full-width large-head-dim kernel, D in {256, 512}, N % 128 == 0, V as [B,H,N,D]; fp16 or bf16

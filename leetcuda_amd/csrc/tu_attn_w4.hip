@@ -33,7 +33,6 @@ int launch_attn_w4n_d128(const half_t* Q, const half_t* K, const half_t* V, half
   hipLaunchKernelGGL(kern, grid, block, AM_LDS, st, Q, K, V, O, N, nqb, sl2);
   return check_launch();
 }
-#ifdef LC_DIAG
 int diag_attn_slowpath(unsigned* out4, int reset) {
   if (out4 && hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_an_slowpath), 16) != hipSuccess) return LC_ERR_LAUNCH;
   if (reset) {
@@ -42,5 +41,4 @@ int diag_attn_slowpath(unsigned* out4, int reset) {
   }
   return LC_OK;
 }
-#endif
 }  // namespace lc
