@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
         __builtin_amdgcn_sched_barrier(0);
       });
     }
-    am_drain();   // asm MFMAs: hipcc does not know their latency; their results are read by VALU next
+    am_drain(s[0][0], s[0][1], s[1][0], s[1][1]);   // asm MFMAs: hipcc does not know their latency; VALU reads S next
     // =========================== softmax(t)
     float e[2][16];
     {

@@ -68,6 +68,22 @@ LC_DEVINL void am_acc_scale(float alpha) {   // a[R] *= alpha (slow path; MFMAs 
                : "=&v"(tmp) : "v"(alpha), "n"(R) : LC_AGPR_ALL);
 }
 LC_DEVINL void am_drain() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
+// Drain in front of COMPILER-scheduled reads of MFMA results held in VGPRs: the registers must be operands.  A bare
+// asm volatile is ordered against other volatile asm only — hipcc hoisted the v_max of the prologue's Sᵀ blocks above the
+// wait states, right behind the MFMA that writes them (no interlock: the VALU read the accumulator one k-step short when
+// issue was back to back and the full sum after an instruction-fetch stall -> a different but valid m, i.e. results that
+// differed in the last bit between a cold and a warm launch).
+LC_DEVINL void am_drain(f32x16_t& a, f32x16_t& b) {
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(a), "+v"(b)::"memory");
+}
+LC_DEVINL void am_drain(f32x16_t& a, f32x16_t& b, f32x16_t& c, f32x16_t& d) {
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+LC_DEVINL void am_drain(f32x4_t (&s)[2][4]) {
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+               : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[0][3]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(s[1][2]), "+v"(s[1][3])
+               :: "memory");
+}
 LC_DEVINL void am_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // K fragment: 16 bytes per lane straight into an AGPR quad
 template <int AREG, int OFF>
@@ -266,7 +282,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4m_kernel(
     if constexpr (ks == 0) am_qk_zero<AM_K + 4 * ks, AM_Q + 4 * (8 * qb + ks)>(sA[qb]);
     else am_qk<AM_K + 4 * ks, AM_Q + 4 * (8 * qb + ks)>(sA[qb]);
   });
-  am_drain();
+  am_drain(sA[0], sA[1]);
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     float mx = sA[qb][0];
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4m_kernel(
     // ---------------- overflow guard: m is only a scale; redo this half-tile with the true max when P got large
     const float t0 = ps[0][0] + ps[0][1], t1 = ps[1][0] + ps[1][1];
     if (!__all(t0 < AM_PSUM_LIMIT && t1 < AM_PSUM_LIMIT)) {     // (NaN / inf compare false: they take this path too)
-      am_drain();                                              // every MFMA of this phase has written its result
+      am_drain(sw[0], sw[1]);                                  // every MFMA of this phase has written its result
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         float mx = sr[qb][0];

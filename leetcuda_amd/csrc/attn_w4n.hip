@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4n_kernel(
     if constexpr (ds == 0) an_qk_zero<AN_K + 4 * (4 * kvb + ds), AN_Q + 4 * (4 * qb + ds)>(sA[kvb][qb]);
     else an_qk<AN_K + 4 * (4 * kvb + ds), AN_Q + 4 * (4 * qb + ds)>(sA[kvb][qb]);
   });
-  am_drain();
+  am_drain(sA);
 #pragma unroll
   for (int qb = 0; qb < 4; ++qb) {
     float mx = sA[0][qb][0];
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4n_kernel(
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) ok = ok && (ps[qb][0] + ps[qb][1] < AM_PSUM_LIMIT);
     if (!__all(ok)) {                                          // (NaN / inf compare false: they take this path too)
-      am_drain();                                              // every MFMA of this phase has written its result
+      am_drain(sw);                                            // every MFMA of this phase has written its result
       {
         float worst = 0.f;
         bool fin = true;

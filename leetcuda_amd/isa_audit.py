@@ -16,6 +16,11 @@ one does not hold:
       fragments and read addresses of the generated K loop): no compiler-emitted instruction names one of them
   R3  no compiler instruction reads or writes the destination registers of an asm-issued LDS / global load between
       the load and the next `s_waitcnt ... lgkmcnt(0)` / `vmcnt(0)` that retires it
+  R5  no non-MFMA instruction names an arch VGPR written by an asm-issued MFMA before the MFMA's result latency has
+      passed (MFMA_STATES wait states, counted conservatively: s_nop N = N + 1, an MFMA = 4, anything else = 1).  hipcc
+      does not know that the statement is an MFMA and inserts no wait states; the hardware does not interlock; a bare
+      `asm volatile("s_nop ...")` is no fence for compiler-scheduled VALU code (the round-2 attention kernels read Sᵀ one
+      k-step short that way — only when issue was back to back, so results depended on instruction-cache state)
 """
 from __future__ import annotations
 
@@ -34,6 +39,8 @@ OWNED_AGPRS = [
 OWNED_VGPRS = [
     (re.compile(r"hgemm_w4y_kernel"), (108, 255)),
 ]
+
+MFMA_STATES = {"16x16": 12, "32x32": 20, "4x4": 8}   # result latency budget per MFMA shape family (wait states)
 
 _REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
 _ASM_LOAD = re.compile(r"^\s*(ds_read\w*|ds_load\w*|global_load_(?!lds)\w+|buffer_load_\w+)\s+(.*)$")
@@ -79,6 +86,7 @@ def audit_asm(path: Path) -> list[KernelReport]:
     owned_v: set[int] = set()
     in_asm = False
     pending: set[int] = set()     # VGPR destinations of asm loads not yet retired by a wait
+    mfma_busy: dict[int, int] = {}   # arch VGPR written by an asm MFMA -> wait states until its result is readable
     for ln, raw in enumerate(lines, 1):
         line = raw.split(";", 1)[0] if not raw.lstrip().startswith(";;#") else raw
         s = line.strip()
@@ -93,6 +101,7 @@ def audit_asm(path: Path) -> list[KernelReport]:
                     owned_v = set(range(lo, hi + 1))
             in_asm = False
             pending = set()
+            mfma_busy = {}
             continue
         if s.startswith(".Lfunc_end"):
             cur = None
@@ -118,8 +127,25 @@ def audit_asm(path: Path) -> list[KernelReport]:
             continue
         if not s or s.endswith(":") or s.startswith("."):
             continue
+        # ---- R5: result latency of asm-issued MFMAs that write arch VGPRs
+        if mfma_busy:
+            if not s.startswith("v_mfma") and not s.startswith("s_"):
+                hit = _regs(s, "v") & mfma_busy.keys()
+                if hit:
+                    cur.violations.append(f"R5 {path.name}:{ln}: `{s}` names v{sorted(hit)[:4]} "
+                                          f"{max(mfma_busy[h] for h in hit)} wait states before the asm MFMA result is there")
+                    for h in hit:
+                        del mfma_busy[h]
+            m = re.match(r"s_nop\s+(\d+)", s)
+            adv = int(m.group(1)) + 1 if m else (4 if s.startswith("v_mfma") else 1)
+            mfma_busy = {r: n - adv for r, n in mfma_busy.items() if n - adv > 0}
         if s.startswith("v_mfma"):
             cur.mfma += 1
+            if in_asm:
+                dst = s.split(None, 1)[1].split(",")[0]
+                need = next((v for k, v in MFMA_STATES.items() if k in s.split()[0]), 20)
+                for r in _regs(dst, "v"):
+                    mfma_busy[r] = need
         is_wait = s.startswith("s_waitcnt") and ("lgkmcnt(0)" in s or "vmcnt(0)" in s)
         if is_wait:
             # a counted wait retires everything older in program order; a plain lgkmcnt(0) retires LDS reads, a

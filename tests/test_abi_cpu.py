@@ -97,6 +97,25 @@ _ZN2lc16hgemm_w4b_kernelILb0EEEvv:
     assert kinds == ["R1", "R2", "R3"], bad            # v5 after the wait is fine; v4 before it is not
 
 
+def test_isa_audit_detects_early_read_of_asm_mfma_result(tmp_path):
+    """Rule R5 (the round-2 reproducibility bug): hipcc scheduled `v_max` reads of the Sᵀ blocks directly
+    behind the asm MFMA that writes them because the drain was a bare asm volatile.  A bare s_nop drain AFTER the read does
+    not help; enough wait states BEFORE it do; MFMA -> MFMA accumulation chains are the hardware's business."""
+    from leetcuda_amd import isa_audit
+    head = "\t.type\t_ZN2lc19attn_fwd_w4n_kernelILi128EEEvv,@function\n_ZN2lc19attn_fwd_w4n_kernelILi128EEEvv:\n"
+    tail = ".Lfunc_end0:\n"
+    mfma = ("\t;;#ASMSTART\n\tv_mfma_f32_16x16x32_f16 v[2:5], a[0:3], a[4:7], v[2:5]\n\t;;#ASMEND\n"
+            "\t;;#ASMSTART\n\tv_mfma_f32_16x16x32_f16 v[2:5], a[8:11], a[12:15], v[2:5]\n\t;;#ASMEND\n")
+    early = head + mfma + "\ts_nop 0\n\tv_max_f32_e32 v1, v2, v3\n\t;;#ASMSTART\n\ts_nop 15\n\ts_nop 15\n\t;;#ASMEND\n" + tail
+    late = head + mfma + "\t;;#ASMSTART\n\ts_nop 15\n\ts_nop 15\n\t;;#ASMEND\n\tv_max_f32_e32 v1, v2, v3\n" + tail
+    (tmp_path / "early.s").write_text(early)
+    (tmp_path / "late.s").write_text(late)
+    _, bad = isa_audit.audit_files([tmp_path / "early.s"])
+    assert len(bad) == 1 and bad[0].startswith("R5") and "v_max_f32_e32 v1, v2, v3" in bad[0], bad
+    _, bad = isa_audit.audit_files([tmp_path / "late.s"])
+    assert bad == [], bad
+
+
 def test_status_strings_and_argument_errors(built):
     from leetcuda_amd import capi
     lib = capi.load()

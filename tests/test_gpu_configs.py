@@ -26,14 +26,10 @@ def _capi():
 
 
 def _same_up_to_rounding(a, b):
-    """Two launches of the merged-phase / full-width kernels on the SAME inputs.  Known issue (DESIGN.md §4.11,
-    tools/attn_determinism.py): on some boxes / some launches a few per cent of the 64-row wave groups come out with different
-    LAST BITS (both outcomes within 1 ulp of the fp64 oracle, i.e. equally accurate; never more than that; most runs are
-    bit-identical).  Root cause not found in round 2, so the tests bound the effect instead of asserting bit equality:
-    no element further apart than 2 fp16 ulps of its magnitude (floor 2^-6), and at least 95 % of the elements identical."""
-    d = (a.float() - b.float()).abs()
-    ulp = torch.clamp(torch.maximum(a.float().abs(), b.float().abs()), min=2.0 ** -6) * 2.0 ** -10
-    return bool((d <= 2.0 * ulp).all()) and float((a == b).float().mean()) >= 0.95
+    """Two launches on the SAME inputs must be BIT-identical.  (For most of round 2 they were not always: a drain fence
+    that hipcc could schedule VALU reads across made the softmax reference max depend on instruction-cache state —
+    DESIGN.md §4.11, ISA-audit rule R5.  The name is kept from the time the test could only bound the effect.)"""
+    return torch.equal(a, b)
 
 
 def _sampled_rows_check(oracle, q, k, v, o, heads, rows, max_abs, bf16=False):
@@ -84,8 +80,7 @@ def test_config4_per_rank_shard_shape(oracle):
 
 def test_config4_full_problem_and_shard_equality(oracle):
     """Full config 4 on one GPU (8 GiB of tensors) + what every rank of a W-way batch shard computes:
-    the shard outputs must equal the corresponding slice of the whole-problem output (bit for bit on most runs; see
-    _same_up_to_rounding for the bound the test enforces)
+    the shard outputs must equal the corresponding slice of the whole-problem output bit for bit
     (independent (batch, head) units, no exchange — SURVEY.md §8e), W in {2, 4, 8}."""
     capi = _capi()
     from leetcuda_amd import host

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Run-to-run reproducibility of the attention kernels (DESIGN.md §4.11 "known issue").
+"""Run-to-run reproducibility of the attention kernels (the round-2 drain-fence bug and how it was found).
+  attn_determinism.py cold               the experiment that located it: launches after idle / after other kernels / after a
+                                         one-workgroup launch of the same kernel, w4n + w4m + D=512 — all must be bit-identical
   attn_determinism.py classes [nw ...]   equality classes of 12 launches per shape (fresh tensors per shape)
   attn_determinism.py pollute [nw ...]   a polluter kernel (liblc_diag.so: lc_diag_pollute) leaves a bit pattern in every
                                          VGPR / AGPR / LDS byte before each launch: outputs must not follow the pattern"""
@@ -26,7 +28,41 @@ def classes(outs):
     return groups
 
 
-if mode == "classes":
+if mode == "cold":
+    import time
+
+    def mk(*shape, dt=torch.half):
+        return torch.randn(*shape, device="cuda").to(dt)
+
+    def run(fn, q, k, v):
+        o = torch.full_like(q, float("nan"))
+        fn(q, k, v, o)
+        torch.cuda.synchronize()
+        return o
+
+    torch.manual_seed(4)
+    a, b, c = mk(8192, 8192), mk(8192, 8192), torch.empty(8192, 8192, dtype=torch.half, device="cuda")
+    for name, nw, shape, dt in (("w4n", 0, (4, 32, 8192, 128), torch.half), ("w4m", 256, (4, 32, 8192, 128), torch.half),
+                                ("bigd2 fp16", 0, (1, 48, 8192, 512), torch.half),
+                                ("bigd2 bf16", 0, (1, 48, 8192, 512), torch.bfloat16)):
+        capi.tune("attn_nw", nw)
+        fn = capi.attn_fwd_bf16 if dt == torch.bfloat16 else capi.attn_fwd
+        q, k, v = mk(*shape, dt=dt), mk(*shape, dt=dt), mk(*shape, dt=dt)
+        first = run(fn, q, k, v)                       # first launch of the process / after the previous kernel family
+        res = {"second": torch.equal(run(fn, q, k, v), first)}
+        time.sleep(3.0)
+        res["after 3 s idle"] = torch.equal(run(fn, q, k, v), first)
+        time.sleep(3.0)
+        for _ in range(300):
+            capi.hgemm(a, b, c, layout=capi.LAYOUT_NN)
+        res["after idle + 300 GEMMs"] = torch.equal(run(fn, q, k, v), first)
+        time.sleep(3.0)
+        q2, k2, v2 = (t[:1, :2].contiguous() for t in (q, k, v))
+        run(fn, q2, k2, v2)
+        res["after idle + tiny launch"] = torch.equal(run(fn, q, k, v), first)
+        print(f"{name:10s} {capi.attn_kernel_name(shape[2], shape[3]):34s} equal to the first launch: {res}", flush=True)
+        del q, k, v, first
+elif mode == "classes":
     for shape in ((1, 1, 256, 128), (1, 1, 8192, 128), (1, 8, 8192, 128), (4, 32, 4096, 128), (4, 32, 8192, 128)):
         B, H, N, D = shape
         for nw in nws:
