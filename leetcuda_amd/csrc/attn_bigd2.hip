@@ -33,9 +33,15 @@
 
 namespace lc {
 
+// D = 512 runs at the 256-VGPR limit (Oᵀ fills the 256 AGPRs): the Q fragments of the last BD2_PARK k-steps live in the
+// 32 KiB of LDS that the two 64-KiB tiles leave free (8 KiB per wave, lane-private 16-B slots) and come back through a
+// three-deep register ring during the Q·Kᵀ phase — 32 VGPRs that the P·V + softmax phase needs.
 template <int D>
-constexpr int bigd2_lds_bytes() {   // K tile + V tile; the epilogue's O staging (4 waves x 32 rows x (2D + 16) B) aliases them
-  return 2 * KVB * D * 2 > 4 * 32 * (2 * D + 16) ? 2 * KVB * D * 2 : 4 * 32 * (2 * D + 16);
+constexpr int bigd2_park_ks() { return D == 512 ? 8 : 0; }
+template <int D>
+constexpr int bigd2_lds_bytes() {   // K tile + V tile (+ parked Q); the epilogue's O staging (4 waves x 32 rows x (2D + 16) B) aliases them
+  constexpr int tiles = 2 * KVB * D * 2 + 4 * bigd2_park_ks<D>() * 1024, stage = 4 * 32 * (2 * D + 16);
+  return tiles > stage ? tiles : stage;
 }
 
 // Oᵀ block a[R0:R0+15] += Vᵀ fragment x Pᵀ fragment (fp16 / bf16)
@@ -48,12 +54,16 @@ LC_DEVINL void bd2_pv(half8_t v, half8_t p) {
 }
 // Sᵀ block (VGPRs) += K fragment x Q fragment.  As an asm statement with "v" operands: the builtin would let hipcc keep the
 // accumulators in AGPRs — a[0:63], on top of the literal Oᵀ accumulators (caught by leetcuda_amd/isa_audit.py rule R1).
-template <bool BF16>
+// FIRST: the first MFMA of a chain — hipcc has just zeroed (or copied) the accumulator with VALU moves, and a VALU write needs
+// two wait states before an MFMA may read the register; hipcc pads that for its own MFMAs only (isa_audit.py rule R6).
+template <bool BF16, bool FIRST = false>
 LC_DEVINL void bd2_qk(f32x16_t& s, half8_t k, half8_t q) {
-  if constexpr (BF16)
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(k), "v"(q) : LC_AGPR_ALL);
-  else
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(s) : "v"(k), "v"(q) : LC_AGPR_ALL);
+#define LC_BD2_QK(OP)                                                                                         \
+  if constexpr (FIRST) asm volatile("s_nop 1\n\t" OP " %0, %1, %2, %0" : "+v"(s) : "v"(k), "v"(q) : LC_AGPR_ALL); \
+  else asm volatile(OP " %0, %1, %2, %0" : "+v"(s) : "v"(k), "v"(q) : LC_AGPR_ALL)
+  if constexpr (BF16) { LC_BD2_QK("v_mfma_f32_32x32x16_bf16"); }
+  else { LC_BD2_QK("v_mfma_f32_32x32x16_f16"); }
+#undef LC_BD2_QK
 }
 // four of them (d tiles 4dq .. 4dq+3, one P fragment) in ONE statement: hipcc pads a wait state at every asm boundary
 template <int R0, bool BF16>
@@ -66,6 +76,51 @@ LC_DEVINL void bd2_pv4(half8_t v0, half8_t v1, half8_t v2, half8_t v3, half8_t p
   if constexpr (BF16) LC_BD2_PV4("v_mfma_f32_32x32x16_bf16");
   else LC_BD2_PV4("v_mfma_f32_32x32x16_f16");
 #undef LC_BD2_PV4
+}
+// P·V step with the Vᵀ fragments in FOUR FIXED register quads v[240:255] (physical-register constraints): the statement
+// waits for fragment j (counted lgkmcnt: LDS returns in order), issues its MFMA and — RD — at once the two transpose reads of
+// the NEXT step's fragment j into the same quad (the MFMA has read its operands long before the LDS data lands), so every
+// read has a full step (>= 128 matrix-core cycles) of flight and no second register set is needed.
+// Entry: 8 reads outstanding, in fragment order (bd2_rd0 or the previous step).  !RD: last step, waits 6 / 4 / 2 / 0.
+// The leading s_nop 1: hipcc packs the P fragment with v_cvt_pk right in front of the statement that consumes it, and a
+// VALU write needs two wait states before an MFMA reads the register (rule R6 of the ISA audit).
+template <int R0, bool BF16, bool RD, int OFF, int HOFF>
+LC_DEVINL void bd2_pv4_fix(half8_t& f0, half8_t& f1, half8_t& f2, half8_t& f3, half8_t p, const uint32_t (&vx)[4]) {
+#define LC_BD2_RD2(Q, A) "ds_read_b64_tr_b16 v[" #Q ":" #Q "+1], " A " offset:%17\n\tds_read_b64_tr_b16 v[" #Q "+2:" #Q "+3], " A " offset:%18\n\t"
+#define LC_BD2_STEP(OP, W0, W1, W2, W3, R0_, R1_, R2_, R3_)                                                            \
+  asm volatile("s_nop 1\n\ts_waitcnt lgkmcnt(" #W0 ")\n\t" OP " a[%9:%10], v[240:243], %4, a[%9:%10]\n\t" R0_                          \
+               "s_waitcnt lgkmcnt(" #W1 ")\n\t" OP " a[%11:%12], v[244:247], %4, a[%11:%12]\n\t" R1_                        \
+               "s_waitcnt lgkmcnt(" #W2 ")\n\t" OP " a[%13:%14], v[248:251], %4, a[%13:%14]\n\t" R2_                        \
+               "s_waitcnt lgkmcnt(" #W3 ")\n\t" OP " a[%15:%16], v[252:255], %4, a[%15:%16]\n\t" R3_                        \
+               : "+{v[240:243]}"(f0), "+{v[244:247]}"(f1), "+{v[248:251]}"(f2), "+{v[252:255]}"(f3)                        \
+               : "v"(p), "v"(vx[0]), "v"(vx[1]), "v"(vx[2]), "v"(vx[3]), "n"(R0), "n"(R0 + 15), "n"(R0 + 16), "n"(R0 + 31),  \
+                 "n"(R0 + 32), "n"(R0 + 47), "n"(R0 + 48), "n"(R0 + 63), "n"(OFF), "n"(OFF + HOFF)                         \
+               : LC_AGPR_ALL)
+#define LC_BD2_RDS(OP)                                                                                                 \
+  LC_BD2_STEP(OP, 6, 6, 6, 6, "ds_read_b64_tr_b16 v[240:241], %5 offset:%17\n\tds_read_b64_tr_b16 v[242:243], %5 offset:%18\n\t", \
+              "ds_read_b64_tr_b16 v[244:245], %6 offset:%17\n\tds_read_b64_tr_b16 v[246:247], %6 offset:%18\n\t",             \
+              "ds_read_b64_tr_b16 v[248:249], %7 offset:%17\n\tds_read_b64_tr_b16 v[250:251], %7 offset:%18\n\t",             \
+              "ds_read_b64_tr_b16 v[252:253], %8 offset:%17\n\tds_read_b64_tr_b16 v[254:255], %8 offset:%18")
+  if constexpr (RD) {
+    if constexpr (BF16) LC_BD2_RDS("v_mfma_f32_32x32x16_bf16");
+    else LC_BD2_RDS("v_mfma_f32_32x32x16_f16");
+  } else {
+    if constexpr (BF16) LC_BD2_STEP("v_mfma_f32_32x32x16_bf16", 6, 4, 2, 0, "", "", "", "");
+    else LC_BD2_STEP("v_mfma_f32_32x32x16_f16", 6, 4, 2, 0, "", "", "", "");
+  }
+#undef LC_BD2_RDS
+#undef LC_BD2_STEP
+#undef LC_BD2_RD2
+}
+// step 0's fragments: eight transpose reads, in fragment order, into the fixed quads
+template <int HOFF>
+LC_DEVINL void bd2_rd0(half8_t& f0, half8_t& f1, half8_t& f2, half8_t& f3, const uint32_t (&vx)[4]) {
+  asm volatile("ds_read_b64_tr_b16 v[240:241], %4\n\tds_read_b64_tr_b16 v[242:243], %4 offset:%8\n\t"
+               "ds_read_b64_tr_b16 v[244:245], %5\n\tds_read_b64_tr_b16 v[246:247], %5 offset:%8\n\t"
+               "ds_read_b64_tr_b16 v[248:249], %6\n\tds_read_b64_tr_b16 v[250:251], %6 offset:%8\n\t"
+               "ds_read_b64_tr_b16 v[252:253], %7\n\tds_read_b64_tr_b16 v[254:255], %7 offset:%8"
+               : "={v[240:243]}"(f0), "={v[244:247]}"(f1), "={v[248:251]}"(f2), "={v[252:255]}"(f3)
+               : "v"(vx[0]), "v"(vx[1]), "v"(vx[2]), "v"(vx[3]), "n"(HOFF));
 }
 template <int OFF>
 LC_DEVINL half4_t bd2_tr(uint32_t addr) {   // asm transpose read (hipcc would guard the builtin with vmcnt(0) after LDS-DMA)
@@ -91,9 +146,12 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
   const int wave = wave_id();
   const int hi = lane >> 5, l32 = lane & 31;
 
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const size_t bh = id / nqb;
-  const int q0 = (id - (int)bh * nqb) * 128 + wave * 32;
+  // (wave-uniform values pinned to SGPRs: as per-lane 64-bit values the head offset and the O pointer would be the first
+  // things hipcc spills across the loop — the kernel runs at the 256-VGPR limit — and the ISA audit allows no scratch)
+  const int id = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x));
+  const int bhi = __builtin_amdgcn_readfirstlane(id / nqb);
+  const size_t bh = (size_t)bhi;
+  const int q0 = __builtin_amdgcn_readfirstlane((id - bhi * nqb) * 128 + wave * 32);
   const half_t* Qb = Q + bh * (size_t)N * D;
   const char* Kb = (const char*)(K + bh * (size_t)N * D);
   const char* Vb = (const char*)(V + bh * (size_t)N * D);
@@ -132,9 +190,14 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
   for (int i = 0; i < NPIECE; ++i) issue_k(i, 0);
 
   // ---- Q fragments -> registers (once): lane holds Q[q0 + l32][16 ks + 8 hi .. +8]
-  half8_t qf[NKS];
+  constexpr int PARK = bigd2_park_ks<D>(), NRES = NKS - PARK;   // k-steps whose Q fragment is parked in LDS / resident
+  half8_t qf[NRES];
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const half8_t*)(Qb + (size_t)(q0 + l32) * D + 16 * ks + 8 * hi);
+  for (int ks = 0; ks < NRES; ++ks) qf[ks] = *(const half8_t*)(Qb + (size_t)(q0 + l32) * D + 16 * ks + 8 * hi);
+  char* const qpark = smem + 2 * TILE + wave * (PARK * 1024) + lane * 16;   // + 1024 per parked k-step
+#pragma unroll
+  for (int i = 0; i < PARK; ++i)
+    *(half8_t*)(qpark + i * 1024) = *(const half8_t*)(Qb + (size_t)(q0 + l32) * D + 16 * (NRES + i) + 8 * hi);
   static_for<D / 2>([&](auto r) { am_acc_zero<decltype(r)::value>(); });
 
   // ---- fragment read addresses
@@ -148,124 +211,143 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
     vx[b] = smem32 + (uint32_t)(TILE + (4 * hi + (vi >> 2)) * ROWB + 32 * vgi + 8 * (vi & 3) + ((b ^ (vi >> 2)) << 6));
 
   float m_run = -INFINITY, l_run = 0.f;
-  half8_t pf[4];   // P fragments, k-step g = 16 kv rows
+  half8_t pfa[4], pfb[4];   // P fragments (k-step g = 16 kv rows) of the even / odd tiles
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   raw_barrier();   // K(0) landed
 
-  for (int t = 0; t < T; ++t) {
-    // =========================== phase QK(t): Sᵀ = K(t)·Qᵀ, V(t) DMA in its shadow
-    f32x16_t s[2][2];   // [tt][k-step parity]
+  // ---- P·V step st of the tile whose P fragments are `pf`: retire this step's transpose reads, issue the next step's,
+  // then the four MFMAs (one statement).  step = (g, dq): k-step g = 16 kv rows, dq = quad of 32-column d tiles (dt = 4dq + j);
+  // address: vx[dt & 3] + (dt >> 2) * 256 = vx[j] + dq * 256, + g * 16 rows (+ 8 rows for the second half)
+  // The Vᵀ fragments of a step live in ONE register set, the fixed quads v[240:255] (bd2_pv4_fix): a second set would not
+  // fit beside Sᵀ, Q and two P sets.
+  half8_t vf0, vf1, vf2, vf3;
+  constexpr int NQ = NDT / 4, NST = 4 * NQ;
+  auto rd0 = [&]() { bd2_rd0<8 * ROWB>(vf0, vf1, vf2, vf3, vx); };
+  auto pv_step = [&](auto stc, half8_t (&pf)[4]) {
+    constexpr int st = decltype(stc)::value, g = st / NQ, dq = st % NQ;
+    constexpr int g1 = (st + 1) / NQ, dq1 = (st + 1) % NQ;
+    bd2_pv4_fix<64 * dq, BF16, (st + 1 < NST), dq1 * 256 + g1 * 16 * ROWB, 8 * ROWB>(vf0, vf1, vf2, vf3, pf[g], vx);
+  };
+
+  // ---- one tile period.  Phase A: Sᵀ(t) = K(t)·Qᵀ with the DMA of V(t−1) in its shadow; barrier; phase B: P·V(t−1) with
+  // softmax(t) as compiler-scheduled filler between its MFMA statements (2 score elements per step) and the DMA of K(t+1);
+  // barrier.  The softmax is off the MFMA critical path that way (it was a serial ~20 % of the tile period).
+  // pn = P(t) (written), po = P(t−1) (read).  HAS_PV = false: tile 0.
+  auto tile = [&](auto pvc, int t, half8_t (&pn)[4], half8_t (&po)[4]) {
+    constexpr bool HAS_PV = decltype(pvc)::value;
+    f32x16_t s[2];   // [tt]: two independent accumulation chains (an MFMA depends on the one before the previous)
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int par = 0; par < 2; ++par)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[tt][par][r] = 0.f;
+      for (int r = 0; r < 16; ++r) s[tt][r] = 0.f;
     // K fragments: plain LDS loads (hipcc counts their lgkmcnt), software-pipelined by hand TWO k-steps ahead through a
     // ring of three register pairs — behind opaque asm MFMAs hipcc would otherwise load and wait in the same k-step
     {
-      half8_t kfr[3][2];
+      half8_t kfr[3][2], qfr[3];
       auto ldk = [&](auto kc, auto rc) {
         constexpr int ks = decltype(kc)::value, r = decltype(rc)::value;
         kfr[r][0] = *(const half8_t*)(kx[ks & 7] + (ks >> 3) * 256);
         kfr[r][1] = *(const half8_t*)(kx[ks & 7] + (ks >> 3) * 256 + 32 * ROWB);
+        if constexpr (ks >= NRES) qfr[r] = *(const half8_t*)(qpark + (ks - NRES) * 1024);
       };
       ldk(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
       ldk(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
       static_for<NKS>([&](auto kc) {
         constexpr int ks = decltype(kc)::value;
         if constexpr (ks + 2 < NKS) ldk(std::integral_constant<int, ks + 2>{}, std::integral_constant<int, (ks + 2) % 3>{});
-        if constexpr ((ks & 1) == 0 && (ks >> 1) < NPIECE) issue_v(ks >> 1, t);        // one V piece per 4 MFMAs
+        // V(t−1): two pieces per k-step, all of them in the first quarter of the phase — the tiles are single-buffered, so
+        // the phase ends with vmcnt(0) + barrier and a piece issued late exposes its whole L2 / HBM latency there
+        if constexpr (HAS_PV && 2 * ks < NPIECE) {
+          issue_v(2 * ks, t - 1);
+          issue_v(2 * ks + 1, t - 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        bd2_qk<BF16>(s[0][ks & 1], kfr[ks % 3][0], qf[ks]);
-        bd2_qk<BF16>(s[1][ks & 1], kfr[ks % 3][1], qf[ks]);
+        if constexpr (ks < NRES) {
+          bd2_qk<BF16, ks == 0>(s[0], kfr[ks % 3][0], qf[ks]);
+          bd2_qk<BF16, ks == 0>(s[1], kfr[ks % 3][1], qf[ks]);
+        } else {
+          bd2_qk<BF16>(s[0], kfr[ks % 3][0], qfr[ks % 3]);
+          bd2_qk<BF16>(s[1], kfr[ks % 3][1], qfr[ks % 3]);
+        }
         __builtin_amdgcn_sched_barrier(0);
       });
     }
-    am_drain(s[0][0], s[0][1], s[1][0], s[1][1]);   // asm MFMAs: hipcc does not know their latency; VALU reads S next
-    // =========================== softmax(t)
-    float e[2][16];
-    {
-      float ps0 = 0.f, ps1 = 0.f;
+    am_drain(s[0], s[1]);   // asm MFMAs: hipcc does not know their latency; VALU reads S next
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own V(t−1) pieces landed, own K reads retired
+    raw_barrier();                                                // K(t) is dead, V(t−1) complete
+
+    // =========================== phase B
+    float ps0 = 0.f, ps1 = 0.f;
+    const float nm = -m_run;
+    if constexpr (HAS_PV) rd0();
+    static_for<NST>([&](auto stc) {
+      constexpr int st = decltype(stc)::value;
+      if constexpr (4 * st < NPIECE) {                    // K(t+1): four pieces per step, front-loaded like V's
+        issue_k(4 * st, t + 1);
+        issue_k(4 * st + 1, t + 1);
+        issue_k(4 * st + 2, t + 1);
+        issue_k(4 * st + 3, t + 1);
+      }
+      if constexpr (HAS_PV) pv_step(stc, po);
+      __builtin_amdgcn_sched_barrier(0);
+      // softmax(t) of score elements 32 st / NST .. : row sums from the unrounded P (tiling_qkv.cu keeps the same order)
+      static_for<32 / NST>([&](auto jc) {
+        constexpr int e = st * (32 / NST) + decltype(jc)::value, tt = e >> 4, r = e & 15;
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[tt][r], sl2, nm));
+        if constexpr ((r & 1) != 0) ps1 += p; else ps0 += p;
+        pn[2 * tt + (r >> 3)][r & 7] = cvt16<BF16>(p);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    float psum = ps0 + ps1;
+    if (!__all(psum < 16384.0f) || !HAS_PV) {        // overflow guard / first tile: establish the true max
+      float mx = s[0][0];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[tt][r]);
+      mx = am_xhalf_max(mx * sl2);                   // (sl2 > 0)
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
+      m_run = m_new;
+      l_run *= alpha;
+      am_drain();    // the P·V MFMAs of this phase have written Oᵀ
+      static_for<D / 2>([&](auto rc) { am_acc_scale<decltype(rc)::value>(alpha); });
+      psum = 0.f;
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          e[tt][r] = (s[tt][0][r] + s[tt][1][r]) * sl2;
-          const float p = __builtin_amdgcn_exp2f(e[tt][r] - m_run);
-          if (r & 1) ps1 += p; else ps0 += p;
-          pf[2 * tt + (r >> 3)][r & 7] = cvt16<BF16>(p);     // (r is a compile-time index after unrolling)
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[tt][r], sl2, -m_run));
+          psum += p;
+          pn[2 * tt + (r >> 3)][r & 7] = cvt16<BF16>(p);
         }
-      float psum = ps0 + ps1;
-      if (!__all(psum < 16384.0f) || t == 0) {        // overflow guard / first tile: establish the true max
-        float mx = e[0][0];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, e[tt][r]);
-        mx = am_xhalf_max(mx);
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
-        m_run = m_new;
-        l_run *= alpha;
-        am_drain();    // the P·V MFMAs of the previous tile have written Oᵀ
-        static_for<D / 2>([&](auto rc) { am_acc_scale<decltype(rc)::value>(alpha); });
-        psum = 0.f;
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float p = __builtin_amdgcn_exp2f(e[tt][r] - m_run);
-            psum += p;
-            pf[2 * tt + (r >> 3)][r & 7] = cvt16<BF16>(p);
-          }
-      }
-      l_run += psum;
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own V(t) pieces landed, own K reads retired
-    raw_barrier();                                                // K(t) is dead, V(t) complete
-
-    // =========================== phase PV(t): Oᵀ += Vᵀ(t)·Pᵀ(t), K(t+1) DMA in its shadow
-    {
-      // step = (g, dq): k-step g = 16 kv rows, dq = quad of 32-column d tiles (dt = 4dq + j); the 8 transpose reads of
-      // step st+1 are issued before the 4 MFMAs of step st (>= 128 cycles of cover) into the other buffer.
-      // address: vx[dt & 3] + (dt >> 2) * 256 = vx[j] + dq * 256, + g * 16 rows (+ 8 rows for the second half)
-      half4_t vlo[2][4], vhi[2][4];
-      constexpr int NQ = NDT / 4, NST = 4 * NQ;
-      auto rd = [&](auto stc, auto bufc) {
-        constexpr int st = decltype(stc)::value, buf = decltype(bufc)::value, g = st / NQ, dq = st % NQ;
-        static_for<4>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          vlo[buf][j] = bd2_tr<dq * 256 + g * 16 * ROWB>(vx[j]);
-          vhi[buf][j] = bd2_tr<dq * 256 + g * 16 * ROWB + 8 * ROWB>(vx[j]);
-        });
-      };
-      using B0 = std::integral_constant<int, 0>;
-      using B1 = std::integral_constant<int, 1>;
-      rd(std::integral_constant<int, 0>{}, B0{});
-      static_for<NST>([&](auto stc) {
-        constexpr int st = decltype(stc)::value, cb = st & 1, g = st / NQ, dq = st % NQ;
-        // retire the reads of this step's buffer (issued one step ago; nothing younger is outstanding)
-        if constexpr (cb == 0)
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[0][0]), "+v"(vhi[0][0]), "+v"(vlo[0][1]), "+v"(vhi[0][1]),
-                       "+v"(vlo[0][2]), "+v"(vhi[0][2]), "+v"(vlo[0][3]), "+v"(vhi[0][3]));
-        else
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[1][0]), "+v"(vhi[1][0]), "+v"(vlo[1][1]), "+v"(vhi[1][1]),
-                       "+v"(vlo[1][2]), "+v"(vhi[1][2]), "+v"(vlo[1][3]), "+v"(vhi[1][3]));
-        if constexpr (st + 1 < NST) {
-          if constexpr (cb == 0) rd(std::integral_constant<int, st + 1>{}, B1{});
-          else rd(std::integral_constant<int, st + 1>{}, B0{});
-        }
-        if constexpr (st < NPIECE) issue_k(st, t + 1);      // one K piece per 4 MFMAs
-        bd2_pv4<64 * dq, BF16>(cat4(vlo[cb][0], vhi[cb][0]), cat4(vlo[cb][1], vhi[cb][1]), cat4(vlo[cb][2], vhi[cb][2]),
-                               cat4(vlo[cb][3], vhi[cb][3]), pf[g]);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    }
+    l_run += psum;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own K(t+1) pieces landed, own V reads retired
-    raw_barrier();                                                // V(t) is dead, K(t+1) complete
+    raw_barrier();                                                // V(t−1) is dead, K(t+1) complete
+  };
+  using HAS = std::integral_constant<bool, true>;
+  using HASNOT = std::integral_constant<bool, false>;
+  tile(HASNOT{}, 0, pfa, pfb);
+  tile(HAS{}, 1, pfb, pfa);
+  for (int t = 2; t < T; t += 2) {      // T = N / 64 is even (N % 128 == 0)
+    tile(HAS{}, t, pfa, pfb);
+    tile(HAS{}, t + 1, pfb, pfa);
   }
+  // ---- tail: V(T−1) -> LDS, Oᵀ += Vᵀ(T−1)·Pᵀ(T−1)   (P of the last, odd tile = pfb)
+#pragma unroll
+  for (int i = 0; i < NPIECE; ++i) issue_v(i, T - 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  raw_barrier();
+  rd0();
+  static_for<NST>([&](auto stc) {
+    pv_step(stc, pfb);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  raw_barrier();   // every wave is done with V(T−1): the epilogue's staging aliases the tiles
 
   // ---- epilogue: O = Oᵀ / l through LDS (whole rows, 16-B stores).  Lane holds O[q = l32][d = 32dt + 8rq + 4hi + (0..3)]
   // in a[16dt + 4rq ..]; every wave owns a private 32 x (ROWB + 16) B staging area (the KV tiles are dead).
@@ -273,6 +355,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
   am_drain();
   const float inv = 1.0f / am_xhalf_sum(l_run);
   char* stg = smem + wave * (32 * ESTR);
+  // the lane id again, from mbcnt: keeping `lane` / `l32` / `hi` alive across the loop costs the registers hipcc would spill
+  const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int l32e = lane_e & 31, hie = lane_e >> 5;
   static_for<NDT * 4>([&](auto ec) {
     constexpr int dt = decltype(ec)::value >> 2, rq = decltype(ec)::value & 3;
     constexpr int base = 16 * dt + 4 * rq;
@@ -281,7 +366,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
     h[1] = cvt16<BF16>(am_acc_read<base + 1>() * inv);
     h[2] = cvt16<BF16>(am_acc_read<base + 2>() * inv);
     h[3] = cvt16<BF16>(am_acc_read<base + 3>() * inv);
-    *(half4_t*)(stg + l32 * ESTR + (32 * dt + 8 * rq + 4 * hi) * 2) = h;
+    *(half4_t*)(stg + l32e * ESTR + (32 * dt + 8 * rq + 4 * hie) * 2) = h;
   });
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   half_t* ow = Ob + (size_t)q0 * D;
@@ -289,7 +374,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
   constexpr int RPI = 64 / LPR;              // rows per wave-instruction (1 at D = 512, 2 at D = 256)
 #pragma unroll
   for (int it = 0; it < 32 / RPI; ++it) {
-    const int row = it * RPI + lane / LPR, c = lane % LPR;
+    const int row = it * RPI + lane_e / LPR, c = lane_e % LPR;
     const u32x4_t v = *(const u32x4_t*)(stg + row * ESTR + c * 16);
     *(u32x4_t*)(ow + (size_t)row * D + c * 8) = v;
   }

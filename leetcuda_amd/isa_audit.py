@@ -21,6 +21,10 @@ one does not hold:
       does not know that the statement is an MFMA and inserts no wait states; the hardware does not interlock; a bare
       `asm volatile("s_nop ...")` is no fence for compiler-scheduled VALU code (the round-2 attention kernels read Sᵀ one
       k-step short that way — only when issue was back to back, so results depended on instruction-cache state)
+  R6  no asm-issued MFMA reads an arch VGPR that a VALU instruction wrote fewer than VALU_TO_MFMA_STATES wait states
+      earlier (hipcc pads this for its own MFMAs — LLVM's "legacy VALU write VGPR -> MFMA read" rule — but not in front of
+      an asm statement: a v_cvt_pk of the P fragment scheduled right in front of the statement that consumes it made
+      the pipelined D = 512 kernel read a half-written operand)
 """
 from __future__ import annotations
 
@@ -40,6 +44,7 @@ OWNED_VGPRS = [
     (re.compile(r"hgemm_w4y_kernel"), (108, 255)),
 ]
 
+VALU_TO_MFMA_STATES = 2
 MFMA_STATES = {"16x16": 12, "32x32": 20, "4x4": 8}   # result latency budget per MFMA shape family (wait states)
 
 _REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
@@ -87,6 +92,7 @@ def audit_asm(path: Path) -> list[KernelReport]:
     in_asm = False
     pending: set[int] = set()     # VGPR destinations of asm loads not yet retired by a wait
     mfma_busy: dict[int, int] = {}   # arch VGPR written by an asm MFMA -> wait states until its result is readable
+    valu_fresh: dict[int, int] = {}  # arch VGPR written by a VALU instruction -> wait states until an MFMA may read it
     for ln, raw in enumerate(lines, 1):
         line = raw.split(";", 1)[0] if not raw.lstrip().startswith(";;#") else raw
         s = line.strip()
@@ -102,6 +108,7 @@ def audit_asm(path: Path) -> list[KernelReport]:
             in_asm = False
             pending = set()
             mfma_busy = {}
+            valu_fresh = {}
             continue
         if s.startswith(".Lfunc_end"):
             cur = None
@@ -127,6 +134,21 @@ def audit_asm(path: Path) -> list[KernelReport]:
             continue
         if not s or s.endswith(":") or s.startswith("."):
             continue
+        # ---- R6: VALU write -> asm MFMA read
+        if s.startswith("v_mfma"):
+            if in_asm and valu_fresh:
+                hit = _regs(s.split(None, 1)[1], "v") & valu_fresh.keys()
+                if hit:
+                    cur.violations.append(f"R6 {path.name}:{ln}: asm `{s}` reads v{sorted(hit)[:4]} "
+                                          f"{max(valu_fresh[h] for h in hit)} wait states too early after a VALU write")
+            valu_fresh = {}
+        else:
+            m6 = re.match(r"s_nop\s+(\d+)", s)
+            adv6 = int(m6.group(1)) + 1 if m6 else 1
+            valu_fresh = {r: n - adv6 for r, n in valu_fresh.items() if n - adv6 > 0}
+            if s.startswith("v_") and not s.startswith(("v_cmp", "v_cmpx")):
+                for r in _regs(s.split(None, 1)[1].split(",")[0], "v"):
+                    valu_fresh[r] = VALU_TO_MFMA_STATES
         # ---- R5: result latency of asm-issued MFMAs that write arch VGPRs
         if mfma_busy:
             if not s.startswith("v_mfma") and not s.startswith("s_"):

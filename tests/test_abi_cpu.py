@@ -116,6 +116,24 @@ def test_isa_audit_detects_early_read_of_asm_mfma_result(tmp_path):
     assert bad == [], bad
 
 
+def test_isa_audit_detects_valu_write_in_front_of_asm_mfma(tmp_path):
+    """Rule R6: hipcc pads two wait states between a VALU write and an MFMA that reads the register only for its OWN
+    MFMAs; a v_cvt_pk of the P fragment scheduled in front of the asm statement that consumes it must be caught."""
+    from leetcuda_amd import isa_audit
+    head = "\t.type\t_ZN2lc21attn_fwd_bigd2_kernelILi512ELb0EEEvv,@function\n_ZN2lc21attn_fwd_bigd2_kernelILi512ELb0EEEvv:\n"
+    tail = ".Lfunc_end0:\n"
+    mfma = "\t;;#ASMSTART\n{pad}\tv_mfma_f32_32x32x16_f16 a[0:15], v[240:243], v[112:115], a[0:15]\n\t;;#ASMEND\n"
+    bad_s = head + "\tv_cvt_pk_f16_f32 v112, v112, v126\n" + mfma.format(pad="\ts_waitcnt lgkmcnt(6)\n") + tail
+    good_s = head + "\tv_cvt_pk_f16_f32 v112, v112, v126\n" + mfma.format(pad="\ts_nop 1\n\ts_waitcnt lgkmcnt(6)\n") + tail
+    other = head + "\tv_cvt_pk_f16_f32 v116, v116, v126\n" + mfma.format(pad="") + tail
+    for name, text in (("bad.s", bad_s), ("good.s", good_s), ("other.s", other)):
+        (tmp_path / name).write_text(text)
+    _, bad = isa_audit.audit_files([tmp_path / "bad.s"])
+    assert len(bad) == 1 and bad[0].startswith("R6") and "v[112]" in bad[0], bad
+    assert isa_audit.audit_files([tmp_path / "good.s"])[1] == []
+    assert isa_audit.audit_files([tmp_path / "other.s"])[1] == []
+
+
 def test_status_strings_and_argument_errors(built):
     from leetcuda_amd import capi
     lib = capi.load()
