@@ -176,3 +176,46 @@ def test_dma_source_permutation_is_the_inverse_of_the_read_mapping():
             image = {s: s ^ key(r) for s in range(width)}          # slot -> logical chunk stored there
             for c in range(width):
                 assert image[c ^ key(r)] == c
+
+
+def test_bigd2_tiles_on_long_rows():
+    """attn_bigd2.hip (D = 256 / 512: 512-B / 1-KiB rows).  K: 16-B chunk c of row r at slot (c & ~15) | ((c ^ r) & 15);
+    fragment lane -> row tt*32 + l32, chunk 2 ks + hi.  V: 64-B unit u of row r at unit u ^ (r & 3) inside its 256-B group;
+    transpose read of step (g, dq), d tile j: lane -> kv row 16 g + 8 x + 4 hi + (i >> 2), 32-column tile dt = 4 dq + j.
+    Parked Q: lane-private 16-B slots, 1 KiB per k-step."""
+    for D in (256, 512):
+        rowb = 2 * D
+        for ks, tt in itertools.product(range(D // 16), range(2)):
+            for grp in B128_GROUPS:
+                addrs = []
+                for lane in grp:
+                    l32, hi = lane & 31, lane >> 5
+                    row = tt * 32 + l32
+                    # the kernel's form: kx[ks & 7] + (ks >> 3) * 256, kx = l32 * ROWB + (((2 k8 + hi) ^ (l32 & 15)) * 16)
+                    addrs.append(row * rowb + (((2 * (ks & 7) + hi) ^ (l32 & 15)) * 16) + (ks >> 3) * 256)
+                    c = 2 * ks + hi                      # == the layout's definition
+                    assert addrs[-1] == row * rowb + ((c & ~15) | ((c ^ row) & 15)) * 16
+                assert conflict_free(addrs, 16), (D, ks, tt, grp)
+        ndt = D // 32
+        for g, x, dt in itertools.product(range(4), range(2), range(ndt)):
+            for grp in TR_GROUPS:
+                addrs = []
+                for lane in grp:
+                    i, gi, hi = lane & 15, (lane >> 4) & 1, lane >> 5
+                    # kernel: vx[j] + dq * 256 + g * 16 * ROWB (+ 8 * ROWB), vx[j] = (4 hi + (i >> 2)) * ROWB + 32 gi + 8 (i & 3)
+                    #         + ((j ^ (i >> 2)) << 6)
+                    j, dq = dt & 3, dt >> 2
+                    a = (4 * hi + (i >> 2)) * rowb + 32 * gi + 8 * (i & 3) + ((j ^ (i >> 2)) << 6) + dq * 256 \
+                        + g * 16 * rowb + x * 8 * rowb
+                    row = 16 * g + 8 * x + 4 * hi + (i >> 2)
+                    unit = (dt & ~3) | ((dt ^ row) & 3)
+                    assert a == row * rowb + unit * 64 + 32 * gi + 8 * (i & 3)
+                    addrs.append(a)
+                assert conflict_free(addrs, 8), (D, g, x, dt)
+        # LDS-DMA source side: lane slot cs of a 1-KiB piece receives source chunk cs ^ key -> a permutation of the row's chunks
+        cpr = rowb // 16
+        for row in range(64):
+            assert sorted((cs & ~15) | ((cs ^ row) & 15) for cs in range(cpr)) == list(range(cpr))          # K
+            assert sorted(cs ^ ((row & 3) << 2) for cs in range(cpr)) == list(range(cpr))                   # V
+    for grp in B128_GROUPS:                                  # parked Q fragments
+        assert conflict_free([lane * 16 for lane in grp], 16)
