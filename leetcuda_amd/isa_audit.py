@@ -21,6 +21,10 @@ one does not hold:
       does not know that the statement is an MFMA and inserts no wait states; the hardware does not interlock; a bare
       `asm volatile("s_nop ...")` is no fence for compiler-scheduled VALU code (the round-2 attention kernels read Sᵀ one
       k-step short that way — only when issue was back to back, so results depended on instruction-cache state)
+  R7  counted-wait protocol: LDS operations return in order, so `s_waitcnt lgkmcnt(N)` retires all but the N youngest; an
+      instruction that names the destination of an asm-issued LDS read which is still among the outstanding ones at that
+      point (queue replayed in file order; reads issued by hipcc itself count in the queue but are hipcc's business)
+      is a violation — this is what checks the `lgkmcnt(6)` / `lgkmcnt(14)`-style waits inside the attention statements
   R6  no asm-issued MFMA reads an arch VGPR that a VALU instruction wrote fewer than VALU_TO_MFMA_STATES wait states
       earlier (hipcc pads this for its own MFMAs — LLVM's "legacy VALU write VGPR -> MFMA read" rule — but not in front of
       an asm statement: a v_cvt_pk of the P fragment scheduled right in front of the statement that consumes it made
@@ -93,6 +97,7 @@ def audit_asm(path: Path) -> list[KernelReport]:
     pending: set[int] = set()     # VGPR destinations of asm loads not yet retired by a wait
     mfma_busy: dict[int, int] = {}   # arch VGPR written by an asm MFMA -> wait states until its result is readable
     valu_fresh: dict[int, int] = {}  # arch VGPR written by a VALU instruction -> wait states until an MFMA may read it
+    lgkm: list[tuple[frozenset, bool]] = []   # outstanding LDS operations in issue order: (VGPR destinations, asm-issued)
     for ln, raw in enumerate(lines, 1):
         line = raw.split(";", 1)[0] if not raw.lstrip().startswith(";;#") else raw
         s = line.strip()
@@ -109,6 +114,7 @@ def audit_asm(path: Path) -> list[KernelReport]:
             pending = set()
             mfma_busy = {}
             valu_fresh = {}
+            lgkm = []
             continue
         if s.startswith(".Lfunc_end"):
             cur = None
@@ -134,6 +140,30 @@ def audit_asm(path: Path) -> list[KernelReport]:
             continue
         if not s or s.endswith(":") or s.startswith("."):
             continue
+        # ---- R7: counted lgkmcnt waits vs asm-issued LDS reads
+        m7 = re.search(r"lgkmcnt\((\d+)\)", s) if s.startswith("s_waitcnt") else None
+        if m7:
+            keep = int(m7.group(1))
+            if len(lgkm) > keep:
+                lgkm = lgkm[len(lgkm) - keep:] if keep else []
+        elif s.startswith("ds_"):
+            if lgkm:
+                named = {("v", r) for r in _regs(s, "v")} | {("a", r) for r in _regs(s, "a")}
+                for dst, from_asm in lgkm:
+                    if from_asm and dst & named:
+                        cur.violations.append(f"R7 {path.name}:{ln}: `{s}` names {sorted(k + str(n) for k, n in dst & named)[:4]} while the asm LDS read "
+                                              "that writes it is still outstanding")
+            is_read = s.startswith(("ds_read", "ds_load", "ds_bpermute", "ds_permute", "ds_swizzle"))
+            d0 = s.split(None, 1)[1].split(",")[0]
+            dst = frozenset({("v", r) for r in _regs(d0, "v")} | {("a", r) for r in _regs(d0, "a")}) if is_read else frozenset()
+            lgkm.append((dst, in_asm))
+        elif lgkm and not s.startswith("s_"):
+            named = {("v", r) for r in _regs(s, "v")} | {("a", r) for r in _regs(s, "a")}
+            for dst, from_asm in lgkm:
+                if from_asm and dst & named:
+                    cur.violations.append(f"R7 {path.name}:{ln}: `{s}` names {sorted(k + str(n) for k, n in dst & named)[:4]} while the asm LDS read "
+                                          "that writes it is still outstanding")
+                    break
         # ---- R6: VALU write -> asm MFMA read
         if s.startswith("v_mfma"):
             if in_asm and valu_fresh:

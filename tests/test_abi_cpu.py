@@ -94,7 +94,7 @@ _ZN2lc16hgemm_w4b_kernelILb0EEEvv:
     f.write_text(asm)
     reps, bad = isa_audit.audit_files([f])
     kinds = sorted(b.split()[0] for b in bad)
-    assert kinds == ["R1", "R2", "R3"], bad            # v5 after the wait is fine; v4 before it is not
+    assert kinds == ["R1", "R2", "R3", "R7"], bad      # v5 after the wait is fine; v4 before it is not (R3 and its counted twin R7)
 
 
 def test_isa_audit_detects_early_read_of_asm_mfma_result(tmp_path):
@@ -132,6 +132,27 @@ def test_isa_audit_detects_valu_write_in_front_of_asm_mfma(tmp_path):
     assert len(bad) == 1 and bad[0].startswith("R6") and "v[112]" in bad[0], bad
     assert isa_audit.audit_files([tmp_path / "good.s"])[1] == []
     assert isa_audit.audit_files([tmp_path / "other.s"])[1] == []
+
+
+def test_isa_audit_checks_counted_lgkmcnt_waits(tmp_path):
+    """Rule R7: LDS operations return in order; `s_waitcnt lgkmcnt(N)` retires all but the N youngest.  Eight transpose
+    reads in fragment order, then the MFMA of fragment 0: lgkmcnt(6) is enough, lgkmcnt(7) is one read short; a younger
+    LDS operation of hipcc's in between counts in the queue — it makes a counted wait retire MORE of the older reads."""
+    from leetcuda_amd import isa_audit
+    head = "\t.type\t_ZN2lc21attn_fwd_bigd2_kernelILi512ELb0EEEvv,@function\n_ZN2lc21attn_fwd_bigd2_kernelILi512ELb0EEEvv:\n"
+    tail = ".Lfunc_end0:\n"
+    reads = "\t;;#ASMSTART\n" + "".join(
+        f"\tds_read_b64_tr_b16 v[{240 + 2 * i}:{241 + 2 * i}], v{100 + i // 2} offset:{4096 * (i & 1)}\n" for i in range(8)) + "\t;;#ASMEND\n"
+    step = "\t;;#ASMSTART\n\ts_nop 1\n\ts_waitcnt lgkmcnt({n})\n\tv_mfma_f32_32x32x16_f16 a[0:15], v[240:243], v[112:115], a[0:15]\n\t;;#ASMEND\n"
+    ok = head + reads + step.format(n=6) + tail
+    short = head + reads + step.format(n=7) + tail
+    shifted = head + reads + "\tds_read_b128 v[20:23], v9\n" + step.format(n=7) + tail     # 9 outstanding: 7 retires both of fragment 0
+    for name, text in (("ok.s", ok), ("short.s", short), ("shifted.s", shifted)):
+        (tmp_path / name).write_text(text)
+    assert isa_audit.audit_files([tmp_path / "ok.s"])[1] == []
+    assert isa_audit.audit_files([tmp_path / "shifted.s"])[1] == []
+    _, bad = isa_audit.audit_files([tmp_path / "short.s"])
+    assert len(bad) == 1 and bad[0].startswith("R7") and "v242" in bad[0], bad
 
 
 def test_status_strings_and_argument_errors(built):
