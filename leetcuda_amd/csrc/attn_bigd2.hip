@@ -86,7 +86,6 @@ LC_DEVINL void bd2_pv4(half8_t v0, half8_t v1, half8_t v2, half8_t v3, half8_t p
 // VALU write needs two wait states before an MFMA reads the register (rule R6 of the ISA audit).
 template <int R0, bool BF16, bool RD, int OFF, int HOFF>
 LC_DEVINL void bd2_pv4_fix(half8_t& f0, half8_t& f1, half8_t& f2, half8_t& f3, half8_t p, const uint32_t (&vx)[4]) {
-#define LC_BD2_RD2(Q, A) "ds_read_b64_tr_b16 v[" #Q ":" #Q "+1], " A " offset:%17\n\tds_read_b64_tr_b16 v[" #Q "+2:" #Q "+3], " A " offset:%18\n\t"
 #define LC_BD2_STEP(OP, W0, W1, W2, W3, R0_, R1_, R2_, R3_)                                                            \
   asm volatile("s_nop 1\n\ts_waitcnt lgkmcnt(" #W0 ")\n\t" OP " a[%9:%10], v[240:243], %4, a[%9:%10]\n\t" R0_                          \
                "s_waitcnt lgkmcnt(" #W1 ")\n\t" OP " a[%11:%12], v[244:247], %4, a[%11:%12]\n\t" R1_                        \
@@ -110,7 +109,6 @@ LC_DEVINL void bd2_pv4_fix(half8_t& f0, half8_t& f1, half8_t& f2, half8_t& f3, h
   }
 #undef LC_BD2_RDS
 #undef LC_BD2_STEP
-#undef LC_BD2_RD2
 }
 // step 0's fragments: eight transpose reads, in fragment order, into the fixed quads
 template <int HOFF>
