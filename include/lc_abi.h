@@ -109,7 +109,8 @@ const char* lc_build_info(int* is_diag);
  *   "w4y_sched"    schedule 0..2 of LC_HGEMM_MFMA256W4Y's generated loop body (tools/gen_hgemm_w4y.py; same bits, A/B knob)
  *   "hgemm_auto"   kernel LC_HGEMM_AUTO launches on large 256-tileable shapes (a 256-tile lc_hgemm_variant value)
  *   "fp8_mx"       fp8 GEMM: 1 = MX-scaled K = 64 MFMA, 4-wave kernel (default); 2 = MX, 8-wave kernel; 0 = plain K = 16
- *   "attn_d512"    D = 512 kernel: 0 = auto (one workgroup owns all 512 output columns), 1 = round-1 column-split kernel
+ *   "attn_d512"    D = 256 / 512 kernel: 0 = auto (one workgroup owns all D output columns), 1 = round-1 column-split kernel,
+ *                  2 = EXPERIMENTAL 32-row double-buffered tiles (attn_bigd3.hip; not validated on hardware yet)
  * Diagnosis keys (include/lc_diag.h) are rejected with LC_ERR_ARG unless the library was built with LC_DIAG=1. */
 int lc_tune_set(const char* key, int value);
 

@@ -29,6 +29,7 @@ int g_tune_attn_ablate = 0;      // attention ablation / stamp builds (diagnosis
 int g_tune_w4_abl = 0;           // hgemm_w4 ablation bits (diagnosis only, LC_DIAG)
 int g_tune_w4y_sched = 1;        // hgemm_w4y_kernel loop schedule 0..2 (lc_tune_set "w4y_sched")
 int g_tune_hgemm_stamps = 0;     // GEMM cycle-stamp builds (diagnosis only, LC_DIAG)
+int g_tune_attn_d512 = 0;        // D = 256 / 512: 0 = auto (attn_bigd2), 1 = column-split kernel, 2 = attn_bigd3 (experimental)
 }  // namespace lc
 
 namespace {
@@ -36,7 +37,6 @@ namespace {
 // run-time tuning knobs (lc_tune_set): experiments and A/B benches, never required for correctness
 int g_tune_fp8_mx = 1;                       // fp8 GEMM: 1 = MX-scaled K=64 MFMA, 4-wave kernel; 2 = MX, 8-wave kernel; 0 = plain K=16 MFMA
 int g_tune_attn_nw = 0;                    // attention kernel for D = 128: 0 = auto, 128 / 64 / 8 / 4 / 2 (lc_abi.h)
-int g_tune_attn_d512 = 0;                  // D = 512: 0 = auto (full-width workgroup), 1 = column-split kernel
 int g_tune_hgemm_auto = LC_HGEMM_MFMA256W4Y;   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -292,7 +292,7 @@ int launch_attn_bigd(const half_t* Q, const half_t* K, const half_t* V, half_t* 
 // "attn_d512" = 1 asks for round 1's column-split kernel (kept as the independently written cross-check; it also
 // serves D = 1024, V-transposed inputs and N % 128 != 0).
 bool use_bigd2(int D, bool vt, int N) {
-  return (D == 256 || D == 512) && !vt && N % 128 == 0 && g_tune_attn_d512 == 0;
+  return (D == 256 || D == 512) && !vt && N % 128 == 0 && g_tune_attn_d512 != 1;   // (2: attn_bigd3, same launcher)
 }
 
 template <int D, bool VT>
@@ -422,7 +422,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
     return LC_OK;
   }
   if (use_bigd2(D, v_transposed != 0, N)) {
-    snprintf(buf, buflen, "attn_fwd_bigd2_kernel<%d,%s>", D, bf16 ? "true" : "false");
+    snprintf(buf, buflen, "attn_fwd_bigd%d_kernel<%d,%s>", g_tune_attn_d512 == 2 ? 3 : 2, D, bf16 ? "true" : "false");
     return LC_OK;
   }
   if (D == 256 || D == 512 || (D == 1024 && !bf16)) {
@@ -446,7 +446,7 @@ int lc_tune_set(const char* key, int value) {
     return LC_OK;
   }
   if (strcmp(key, "attn_d512") == 0) {
-    if (value < 0 || value > 1) return LC_ERR_ARG;
+    if (value < 0 || value > 2) return LC_ERR_ARG;
     g_tune_attn_d512 = value;
     return LC_OK;
   }
