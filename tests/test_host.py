@@ -173,3 +173,34 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
             assert r["traffic"] == pmc[key]["hbm_bytes_per_launch"] and "profiles/" in r["traffic_source"]
         else:
             assert bench.pmc_traffic(key) is None and bench.roofline(key, 1.0e12, 4.0e8, 1.0, profiled_config=True)["traffic_source"] is None
+
+
+def test_steady_state_loops_keep_their_instruction_mix(built):
+    """tools/isa_count.py on the audited device assembly of the shipped kernels: the generated GEMM
+    loop is exactly its 128 MFMAs + 32 LDS reads + 16 DMA pieces with no nop and (almost) no VALU; the attention loops keep
+    their MFMA count per tile and stay near 3 VALU per score element.  A compiler or flag change that moves these shows up
+    here before it shows up as TFLOP/s."""
+    import sys
+    from collections import Counter
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import isa_count as ic
+    obj = built["abi"].parent / "obj"
+
+    def mix(unit, rx):
+        name, lines = ic.kernel_lines(obj / unit, rx)
+        assert lines, rx
+        body, _ = ic.loop_mix(lines)
+        c = Counter(ic.classify(x.split()[0]) for x in body)
+        return c, c["valu"] + c["valu_trans"] + c["valu_accvgpr"]
+
+    g, gv = mix("tu_w4.s", r"hgemm_w4y_kernelILb0ELi1E")
+    assert (g["mfma"], g["lds"], g["vmem"], g["s_barrier"], g["s_nop"]) == (128, 32, 16, 1, 0), g
+    assert gv <= 8, g
+    n, nv = mix("tu_attn_w4.s", r"attn_fwd_w4n_kernel")            # one 64-key tile: 64 score elements per lane
+    assert n["mfma"] == 128 and n["valu_trans"] == 64 and n["s_barrier"] == 1, n
+    assert nv / 64 <= 3.2, (nv, n)
+    m, mv = mix("tu_attn_w4.s", r"attn_fwd_w4m_kernel")
+    assert m["mfma"] == 64 and m["valu_trans"] == 64, m
+    assert mv / 64 <= 3.2, (mv, m)
+    b, _ = mix("tu_attn_big.s", r"attn_fwd_bigd2_kernelILi512ELb0")  # two 64-key tiles per loop iteration
+    assert b["mfma"] == 256 and b["s_barrier"] == 4 and b["valu_trans"] == 64, b
