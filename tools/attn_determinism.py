@@ -60,7 +60,7 @@ if mode == "cold":
         q2, k2, v2 = (t[:1, :2].contiguous() for t in (q, k, v))
         run(fn, q2, k2, v2)
         res["after idle + tiny launch"] = torch.equal(run(fn, q, k, v), first)
-        print(f"{name:10s} {capi.attn_kernel_name(shape[2], shape[3]):34s} equal to the first launch: {res}", flush=True)
+        print(f"{name:10s} {capi.attn_kernel_name(shape[2], shape[3], False, dt == torch.bfloat16):34s} equal to the first launch: {res}", flush=True)
         del q, k, v, first
 elif mode == "classes":
     for shape in ((1, 1, 256, 128), (1, 1, 8192, 128), (1, 8, 8192, 128), (4, 32, 4096, 128), (4, 32, 8192, 128)):
