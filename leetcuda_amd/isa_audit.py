@@ -96,7 +96,7 @@ def audit_asm(path: Path) -> list[KernelReport]:
     in_asm = False
     pending: set[int] = set()     # VGPR destinations of asm loads not yet retired by a wait
     mfma_busy: dict[int, int] = {}   # arch VGPR written by an asm MFMA -> wait states until its result is readable
-    valu_fresh: dict[int, int] = {}  # arch VGPR written by a VALU instruction -> wait states until an MFMA may read it
+    valu_fresh: dict[tuple, int] = {}  # ("v" | "a", n) written by a VALU instruction -> wait states until an MFMA may read it
     lgkm: list[tuple[frozenset, bool]] = []   # outstanding LDS operations in issue order: (VGPR destinations, asm-issued)
     for ln, raw in enumerate(lines, 1):
         line = raw.split(";", 1)[0] if not raw.lstrip().startswith(";;#") else raw
@@ -164,12 +164,13 @@ def audit_asm(path: Path) -> list[KernelReport]:
                     cur.violations.append(f"R7 {path.name}:{ln}: `{s}` names {sorted(k + str(n) for k, n in dst & named)[:4]} while the asm LDS read "
                                           "that writes it is still outstanding")
                     break
-        # ---- R6: VALU write -> asm MFMA read
+        # ---- R6: VALU write (arch VGPR, or AGPR through v_accvgpr_write) -> asm MFMA read
         if s.startswith("v_mfma"):
             if in_asm and valu_fresh:
-                hit = _regs(s.split(None, 1)[1], "v") & valu_fresh.keys()
+                ops = s.split(None, 1)[1]
+                hit = ({("v", r) for r in _regs(ops, "v")} | {("a", r) for r in _regs(ops, "a")}) & valu_fresh.keys()
                 if hit:
-                    cur.violations.append(f"R6 {path.name}:{ln}: asm `{s}` reads v{sorted(hit)[:4]} "
+                    cur.violations.append(f"R6 {path.name}:{ln}: asm `{s}` reads {sorted(k + str(n) for k, n in hit)[:4]} "
                                           f"{max(valu_fresh[h] for h in hit)} wait states too early after a VALU write")
             valu_fresh = {}
         else:
@@ -177,8 +178,11 @@ def audit_asm(path: Path) -> list[KernelReport]:
             adv6 = int(m6.group(1)) + 1 if m6 else 1
             valu_fresh = {r: n - adv6 for r, n in valu_fresh.items() if n - adv6 > 0}
             if s.startswith("v_") and not s.startswith(("v_cmp", "v_cmpx")):
-                for r in _regs(s.split(None, 1)[1].split(",")[0], "v"):
-                    valu_fresh[r] = VALU_TO_MFMA_STATES
+                d6 = s.split(None, 1)[1].split(",")[0]
+                for r in _regs(d6, "v"):
+                    valu_fresh[("v", r)] = VALU_TO_MFMA_STATES
+                for r in _regs(d6, "a"):
+                    valu_fresh[("a", r)] = VALU_TO_MFMA_STATES
         # ---- R5: result latency of asm-issued MFMAs that write arch VGPRs
         if mfma_busy:
             if not s.startswith("v_mfma") and not s.startswith("s_"):
