@@ -85,6 +85,9 @@ def build_abi(force: bool = False, audit: bool = True) -> Path:
     gen = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_hgemm_w4y.py"), "--check"], capture_output=True, text=True)
     if gen.returncode != 0:
         raise RuntimeError("generated sources are stale: " + gen.stderr.strip())
+    if os.environ.get("LC_DIAG") == "1":   # the ablation loops (results WRONG by design) exist only inside a diagnosis build
+        subprocess.run([sys.executable, str(ROOT / "tools" / "gen_hgemm_w4y.py"), "--diag", str(LIBDIR / "gen")], check=True)
+        flags = flags + [f"-I{LIBDIR / 'gen'}"]
     if not force and _newer(out, srcs) and _stamp_ok(stamp, flags):
         return out
     # translation units (lc_abi.hip + the compile-heavy literal-AGPR kernels in tu_*.hip), compiled in parallel; each

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd3_kernel(
       __builtin_amdgcn_sched_barrier(0);
     });
     float psum = ps0 + ps1;
-    if (!__all(psum < 16384.0f) || !HAS_PV) {        // overflow guard / first tile: establish the true max
+    if (!__all(psum_below(psum, 16384.0f)) || !HAS_PV) {        // overflow guard / first tile: establish the true max
       float mx = s[0][0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);

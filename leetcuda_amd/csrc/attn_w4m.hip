@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4m_kernel(
     finish_pair(std::integral_constant<int, 15>{}, pp0, pp1);
     // ---------------- overflow guard: m is only a scale; redo this half-tile with the true max when P got large
     const float t0 = ps[0][0] + ps[0][1], t1 = ps[1][0] + ps[1][1];
-    if (!__all(t0 < AM_PSUM_LIMIT && t1 < AM_PSUM_LIMIT)) {     // (NaN / inf compare false: they take this path too)
+    if (!__all(psum_below(t0, AM_PSUM_LIMIT) && psum_below(t1, AM_PSUM_LIMIT))) {   // (NaN / inf: bit-pattern compare, lc_common.h)
       am_drain(sw[0], sw[1]);                                  // every MFMA of this phase has written its result
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {

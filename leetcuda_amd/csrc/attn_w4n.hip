@@ -299,10 +299,13 @@ __global__ __launch_bounds__(256) void attn_fwd_w4n_kernel(
     pair_sum(std::integral_constant<int, 15>{}, I1{}, e1);
     pair_pack(std::integral_constant<int, 15>{}, e0, e1);
     // ---------------- overflow guard: m is only a scale; redo this half-tile with the true max when P got large
-    bool ok = true;
+    // (bit patterns of non-negative floats order like unsigned integers, NaN / inf sit above every finite limit: ONE integer
+    // compare of the largest pattern decides for the four query blocks — lc_common.h psum_below)
+    uint32_t worst_bits = 0;
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) ok = ok && (ps[qb][0] + ps[qb][1] < AM_PSUM_LIMIT);
-    if (!__all(ok)) {                                          // (NaN / inf compare false: they take this path too)
+    for (int qb = 0; qb < 4; ++qb) worst_bits = max(worst_bits, __builtin_bit_cast(uint32_t, ps[qb][0] + ps[qb][1]));
+    const bool ok = worst_bits < __builtin_bit_cast(uint32_t, AM_PSUM_LIMIT);
+    if (!__all(ok)) {                                          // NaN / inf take this path too
       am_drain(sw);                                            // every MFMA of this phase has written its result
       {
         float worst = 0.f;
@@ -310,8 +313,8 @@ __global__ __launch_bounds__(256) void attn_fwd_w4n_kernel(
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
           const float x = ps[qb][0] + ps[qb][1];
-          fin = fin && __builtin_isfinite(x);
-          if (!(x < AM_PSUM_LIMIT)) worst = x;
+          fin = fin && finite_bits(x);
+          if (!psum_below(x, AM_PSUM_LIMIT)) worst = x;
         }
         const unsigned long long culprit = __ballot(!ok);
         if (lane == (int)__builtin_ctzll(culprit | (1ull << 63))) {

@@ -412,6 +412,7 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
 
 int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int buflen) {
   if (!buf || buflen < 8 || N <= 0 || N % KVB != 0) return LC_ERR_ARG;
+  if (D > 0 && (size_t)N * (size_t)D * 2 >= 0x80000000ull) return LC_ERR_SHAPE;   // (mirrors lc_attn_fwd_f16)
   const char* vt = v_transposed ? "true" : "false";
   if (D == 32 || D == 64 || D == 96 || D == 128) {
     if (bf16) return LC_ERR_HEADDIM;
@@ -574,6 +575,7 @@ int lc_attn_fwd_f16(const void* Q, const void* K, const void* V, void* O, int B,
   if (B <= 0 || H <= 0 || N <= 0 || D <= 0) return LC_ERR_SHAPE;
   if (N % KVB != 0) return LC_ERR_SHAPE;
   if ((size_t)B * H * (size_t)(N / 64) > 0x7fffffffull) return LC_ERR_SHAPE;  // 1-D grid of workgroups
+  if ((size_t)N * (size_t)D * 2 >= 0x80000000ull) return LC_ERR_SHAPE;   // one head's K / V must fit the 32-bit buffer offsets of the LDS-DMA kernels
   if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O)) return LC_ERR_SHAPE;
   if (int rc = launch_guard()) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -590,6 +592,7 @@ int lc_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, int B
   if (!Q || !K || !V || !O) return LC_ERR_ARG;
   if (B <= 0 || H <= 0 || N <= 0 || D <= 0 || N % KVB != 0) return LC_ERR_SHAPE;
   if ((size_t)B * H * (size_t)(N / 64) * 4 > 0x7fffffffull) return LC_ERR_SHAPE;
+  if ((size_t)N * (size_t)D * 2 >= 0x80000000ull) return LC_ERR_SHAPE;   // 32-bit buffer offsets inside one head (as lc_attn_fwd_f16)
   if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O)) return LC_ERR_SHAPE;
   if (int rc = launch_guard()) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);

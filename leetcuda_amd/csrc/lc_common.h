@@ -104,6 +104,16 @@ LC_DEVINL half_t cvt16(float x) {   // round-to-nearest-even to fp16 or bf16, re
     return (half_t)x;
 }
 
+// Overflow guards of the attention kernels ("is this row sum of exponentials still below the limit?") decided on the BIT
+// PATTERN: every unit is compiled with -fno-honor-nans, under which the compiler may rewrite !(a < b) as a >= b or fold
+// isfinite(), so a float compare is not a reliable route for NaN / inf into the slow path.  x is >= 0 or not a number:
+// non-negative floats order like unsigned integers, and +inf, every NaN and anything with the sign bit set compare ABOVE
+// every finite positive limit.
+LC_DEVINL bool psum_below(float x, float limit) {
+  return __builtin_bit_cast(uint32_t, x) < __builtin_bit_cast(uint32_t, limit);
+}
+LC_DEVINL bool finite_bits(float x) { return (__builtin_bit_cast(uint32_t, x) & 0x7f800000u) != 0x7f800000u; }
+
 // raw s_barrier the compiler may not move code across (no implied memory waits: pair it with explicit s_waitcnt)
 LC_DEVINL void raw_barrier() {
   __builtin_amdgcn_sched_barrier(0);

@@ -85,3 +85,27 @@ def test_self_spawn_two_ranks_gloo(tmp_path, monkeypatch):
     res = json.loads((tmp_path / "out.json").read_text())
     assert res["size"] == 2 and res["max"] == 2.0
     assert res["rows"] == [[0.0, 16.0, 32.0, 0.0], [1.0, 16.0, 32.0, 512.0]]
+
+
+def test_forced_single_rank_group_gloo(tmp_path):
+    """LC_DIST_FORCE=1: a ONE-rank process group is created so that the collective branch (barrier, all_gather_into_tensor)
+    executes without a second rank — on the GPU box the same switch drives the RCCL branch (tests/test_gpu_dist.py)."""
+    import json
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent("""
+        import json, sys
+        sys.path.insert(0, %r)
+        import torch.distributed as dist
+        from leetcuda_amd import dist as lcd
+        w = lcd.init("gloo")
+        assert w.group and w.is_dist and w.size == 1 and dist.is_initialized()
+        lcd.barrier(w)
+        print("RESULT " + json.dumps({"rows": lcd.gather_row(w, [1.5, 2.5]).tolist(), "max": lcd.max_over_ranks(w, 4.0)}))
+        lcd.shutdown(w)
+    """) % str(ROOT))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "LC_DIST_INIT")}
+    env["LC_DIST_FORCE"] = "1"
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    assert res == {"rows": [[1.5, 2.5]], "max": 4.0}

@@ -317,7 +317,7 @@ def test_full_width_large_head_dim_kernel(oracle, D, dtype):
         (lambda a, b, c, o: capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", a, b, c, o, 2))
     for kk in (k, k2):
         outs = []
-        for knob in (0, 1):
+        for knob in (0, 1, 2):
             capi.tune("attn_d512", knob)
             try:
                 o = torch.full_like(q, float("nan"))
@@ -330,5 +330,68 @@ def test_full_width_large_head_dim_kernel(oracle, D, dtype):
         for o in outs:
             d = np.abs(o - truth)
             assert np.isfinite(d).all() and d.max() < tol_max, d.max()
-        assert np.abs(outs[0] - outs[1]).max() < tol_max
+        assert np.abs(outs[0] - outs[1]).max() < tol_max and np.abs(outs[0] - outs[2]).max() < tol_max
     assert capi.attn_kernel_name(N, D, False, bf).startswith("attn_fwd_bigd2_kernel")
+
+
+@pytest.mark.parametrize("D,N", [(128, 256), (256, 128)])
+def test_every_entry_name_at_its_head_dim_limits(oracle, D, N):
+    """Every reference entry name x stages {1, 2} at D = 128 and D = 256 — the boundary values of the wrappers' switch(d)
+    (flash_attn_mma_share_kv.cu:869-921: shared_kv / shared_qkv take d <= 128 with stages 2 and d <= 256 with stages 1;
+    split_q / split_kv stop at 128; tiling_* go to 1024; *_tiling_qk_swizzle_qkv stops at 256; flash_attn_cute at 256) —
+    with V handed over as [B,H,D,N] for the three *_swizzle_qkv entries that take it that way."""
+    capi = _capi()
+    B, H = 1, 2
+    torch.manual_seed(1000 + D)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    tv = v.transpose(-2, -1).contiguous()
+    truth = oracle.attn(q, k, v, B, H, N, D, mode="f32")
+    n_ok = n_rej = n_vt = 0
+    for name, fam, vt, acc, d2, d1, nargs in capi.attn_entries():
+        for stages in (1, 2):
+            limit = d2 if (stages > 1 or nargs == 4) else d1
+            o = torch.full_like(q, float("nan"))
+            if D > limit:
+                with pytest.raises(capi.LcError) as e:
+                    capi.attn_call(name, q, k, tv if vt else v, o, stages)
+                assert e.value.status == capi.LC_ERR_HEADDIM, (name, stages)
+                assert torch.isnan(o).all()                       # nothing was launched
+                n_rej += 1
+                continue
+            capi.attn_call(name, q, k, tv if vt else v, o, stages)
+            torch.cuda.synchronize()
+            d = np.abs(o.float().cpu().numpy() - truth).max()
+            assert d < tol.ATTN_MAX_ABS, (name, stages, d)
+            n_ok += 1
+            n_vt += int(bool(vt))
+    assert n_ok + n_rej == 2 * len(capi.attn_entries()) and n_vt >= 2
+    if D == 256:
+        assert n_rej >= 2 * 2 + 8      # split_kv / split_q at both stage counts; the shared_* entries with stages = 2
+
+
+def test_non_finite_scores_take_the_slow_path(oracle):
+    """the overflow guards must route NaN / inf row sums into the slow path by construction (bit-pattern
+    compare, lc_common.h psum_below), not by what -fno-honor-nans lets the compiler do with !(a < b).  One K row of one
+    head is +inf: that head's slow-path counter must tick with the non-finite flag, every OTHER head must stay exact."""
+    capi = _capi()
+    B, H, N, D = 1, 3, 512, 128
+    torch.manual_seed(9)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda").abs()      # q > 0 so that q . (+inf row) = +inf, not NaN
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k[0, 1, 300] = float("inf")
+    assert capi.attn_kernel_name(N, D).startswith("attn_fwd_w4n_kernel")
+    capi.attn_slowpath_stats(reset=True)
+    o = torch.zeros_like(q)
+    capi.attn_fwd(q, k, v, o)
+    torch.cuda.synchronize()
+    st = capi.attn_slowpath_stats(reset=True)
+    assert st[0] >= 1 and st[2] >= 1, st                     # executions, of which with a non-finite row sum
+    good = [0, 2]
+    truth = oracle.attn(q[:, good].contiguous(), k[:, good].contiguous(), v[:, good].contiguous(), B, 2, N, D, mode="f32")
+    d = np.abs(o[:, good].float().cpu().numpy() - truth)
+    assert np.isfinite(d).all() and d.max() < tol.ATTN_MAX_ABS
+    # the poisoned head follows IEEE like the reference would (exp(inf - inf) = NaN in its rows): not finite, not silently wrong
+    assert not torch.isfinite(o[0, 1]).all()

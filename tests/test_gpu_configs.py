@@ -159,3 +159,42 @@ def test_config5a_bf16_full_shape(oracle):
     capi.attn_fwd_bf16(q, k, vc, o)
     torch.cuda.synchronize()
     assert (o.float() - 0.75).abs().max().item() < 4e-3     # 0.75 is exact in bf16; P's bf16 rounding remains
+
+
+# ---- the reference's own published FlashAttention shapes (README.md:124-127: (1,8,8192,64) and (1,48,8192,64)) and the
+# other head dims its dispatchers instantiate (flash_attn_mma_split_q.cu:769-815: 32, 64, 96, 128)
+@pytest.mark.parametrize("B,H,N,D", [(1, 8, 8192, 64), (1, 48, 8192, 64), (1, 8, 8192, 96), (1, 8, 8192, 32)])
+def test_reference_published_shapes_small_head_dims(oracle, B, H, N, D):
+    capi = _capi()
+    torch.manual_seed(64 + D + H)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    # a spike late in the sequence (forces whatever rescale path the kernel has) on one head
+    k[0, H - 1, 7000] = 3.0 * q[0, H - 1, 33]
+    v[0, H - 1, 7000] = 5.0
+    o = torch.full_like(q, float("nan"))
+    capi.attn_call("flash_attn_mma_stages_split_q", q, k, v, o, 2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o).all()
+    heads = sorted({(0, 0), (0, H // 2), (0, H - 1)})
+    _sampled_rows_check(oracle, q, k, v, o, heads, ROWS_8K + [33], tol.ATTN_MAX_ABS)
+    # two launches on the same inputs are bit-identical; the shared-QKV / tiling entries take the same path at D <= 128
+    o2 = torch.full_like(q, float("nan"))
+    capi.attn_call("flash_attn_mma_stages_split_q_shared_qkv", q, k, v, o2, 2)
+    torch.cuda.synchronize()
+    assert _same_up_to_rounding(o, o2)
+    # V = const => O = const on every row
+    vc = torch.full_like(v, -0.375)
+    capi.attn_call("flash_attn_mma_stages_split_q", q, k, vc, o, 2)
+    torch.cuda.synchronize()
+    assert (o.float() + 0.375).abs().max().item() < 1e-3
+    # linearity in V on exactly representable values
+    v1 = (torch.randint(-8, 9, v.shape, device="cuda").half() / 8)
+    v2 = (torch.randint(-8, 9, v.shape, device="cuda").half() / 8)
+    o1, o12 = torch.zeros_like(q), torch.zeros_like(q)
+    capi.attn_fwd(q, k, v1, o1)
+    capi.attn_fwd(q, k, v2, o2)
+    capi.attn_fwd(q, k, v1 + v2, o12)
+    torch.cuda.synchronize()
+    assert (o12.float() - o1.float() - o2.float()).abs().max().item() < 2e-3

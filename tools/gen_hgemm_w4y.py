@@ -18,7 +18,9 @@ MFMA-busy where a hand-ordered stream of the same work reaches > 90 %.  This scr
   needs one wait state before the LDS-DMA that uses it).
 Ring, swizzles, piece order and the vmcnt(8) count are those of hgemm_w4b_kernel (hgemm_w4.hip).
 
-usage: tools/gen_hgemm_w4y.py [--check]     (--check: exit 1 if the committed .inc differs from what would be generated)"""
+usage: tools/gen_hgemm_w4y.py [--check]     (--check: exit 1 if the committed .inc differs from what would be generated)
+       tools/gen_hgemm_w4y.py --diag DIR   (LC_DIAG builds only: write the ablation loops 3..5 — results WRONG by design, never
+                                            committed — into DIR, which leetcuda_amd/build.py puts on the include path)"""
 import sys
 from pathlib import Path
 
@@ -28,8 +30,8 @@ NDIAG = 3   # LC_DIAG-only ablations of schedule 1 (results are WRONG): 3 = no D
             # for, 5 = no fragment reads (profiles/r2_w4y_ablation.log)
 
 
-def out_path(sched):
-    return ROOT / "leetcuda_amd" / "csrc" / f"hgemm_w4y_loop{sched}.inc"
+def out_path(sched, diag_dir=None):
+    return (Path(diag_dir) if diag_dir else ROOT / "leetcuda_amd" / "csrc") / f"hgemm_w4y_loop{sched}.inc"
 
 VA, VB = "v124", "v125"          # fragment read addresses (slot base + lane part)
 FRAG0 = 128                      # first literal fragment VGPR
@@ -303,7 +305,13 @@ def render(sched):
 
 def main():
     rc = 0
-    todo = [(render(sched), out_path(sched)) for sched in range(NSCHED + NDIAG)]
+    if "--diag" in sys.argv:
+        d = Path(sys.argv[sys.argv.index("--diag") + 1])
+        d.mkdir(parents=True, exist_ok=True)
+        for sched in range(NSCHED, NSCHED + NDIAG):
+            out_path(sched, d).write_text(render(sched))
+        return 0
+    todo = [(render(sched), out_path(sched)) for sched in range(NSCHED)]
     todo.append((render_nn(), ROOT / "leetcuda_amd" / "csrc" / "hgemm_w4y_loop_nn.inc"))
     for text, out in todo:
         if "--check" in sys.argv:

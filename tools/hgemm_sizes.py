@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Variant x size table (square fp16 GEMM, TN and NN) incl. hipBLASLt: data for the LC_HGEMM_AUTO heuristic."""
+"""Variant x size table (square fp16 GEMM, TN and NN) incl. hipBLASLt: data for the LC_HGEMM_AUTO heuristic.
+
+    tools/hgemm_sizes.py [sizes,comma,separated] [variants,comma,separated] [seconds]
+    tools/hgemm_sizes.py published      the sizes the reference publishes its C++-bench numbers on (kernels/hgemm/README.md:159-185:
+                                        12544, 15360, 15616, 15872, 16128, 16384) + 8192, AUTO and hipBLASLt, 0.6 s sustained per cell"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -8,12 +12,23 @@ from leetcuda_amd import capi, host  # noqa: E402
 
 capi.load()
 capi.vendor_init()
-sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1024, 2048, 3072, 4096, 6144, 8192]
 V = {"mfma128": capi.HGEMM_MFMA128, "pingpong2": capi.HGEMM_MFMA256P2, "w4c": capi.HGEMM_MFMA256W4C,
      "w4y": capi.HGEMM_MFMA256W4Y, "auto": capi.HGEMM_AUTO}
+SECONDS = 0.3
+if len(sys.argv) > 1 and sys.argv[1] == "published":
+    sizes = [8192, 12544, 15360, 15616, 15872, 16128, 16384]
+    V = {"auto": capi.HGEMM_AUTO}
+    SECONDS = 0.6
+else:
+    sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1024, 2048, 3072, 4096, 6144, 8192]
+    if len(sys.argv) > 2:
+        V = {k: V[k] for k in sys.argv[2].split(",")}
+    if len(sys.argv) > 3:
+        SECONDS = float(sys.argv[3])
 
 
-def rate(step, fl, seconds=0.3):
+def rate(step, fl, seconds=None):
+    seconds = SECONDS if seconds is None else seconds
     """>= `seconds` of back-to-back launches (both sides run at the power cap from ~4096^3 on: short bursts mislead)"""
     for _ in range(3):
         step()
@@ -43,5 +58,5 @@ for n in sizes:
                 continue
             row.append(f"{name} {rate(lambda: capi.hgemm(a, b2, c, layout=lay, variant=var, swizzle_stride=st), fl):7.1f}")
         row.append(f"hipBLASLt {rate(lambda: capi.hgemm_vendor(a, b2, c, lay), fl):7.1f}")
-        print(f"n={n:5d} {lname}: " + " | ".join(row), flush=True)
+        print(f"n={n:5d} {lname} (block-swizzle stride {st}): " + " | ".join(row), flush=True)
 capi.vendor_destroy()
