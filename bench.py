@@ -23,7 +23,8 @@ A "step" is one pass of the hot path over one batch of synthetic input already r
 The default run reports HGEMM as `value` and carries, in the same JSON line: "vendor_tflops" (same-run hipBLASLt TN /
 NN = the reference's cuBLAS comparator), "uniform_tflops" (the same kernel on uniform[-1,1) operands, the fill the
 programming guide quotes), "sustained" (>= 2 s of back-to-back launches with the effective shader clock),
-"attention" (config 3), "attention_cfg4" (config 4, aggregate over ranks) and "attention_d512" (config 5a).
+"attention" (config 3), "attention_cfg4" (config 4, aggregate over ranks), "attention_d512" (config 5a),
+"attention_d64" (the reference's published shape (1,48,8192,64)) and "fp8_gemm" (config 5b, 16384^3, roofline vs 5 PF).
 No data-path collective exists: the only collectives are the barrier bracketing the timed region and the gather of
 per-rank timings.  W warm-up steps, then EXACTLY K timed steps between barrier + torch.cuda.synchronize() on both
 sides; time = MAX over ranks; rank 0 prints ONE JSON line.
@@ -107,11 +108,24 @@ def timed_region(w, step, steps, warmup, prewarm=PREWARM):
     return time.perf_counter() - t0
 
 
-def pmc_traffic(kernel: str):
+# Which launch shape each kernel was profiled on by tools/prof_kernels.py (the target of the committed --pmc passes): a
+# per-launch byte count is only comparable with the SAME shape.  New PMC summaries carry the key themselves
+# ("workload", written by tools/summarize_prof.py); the table covers the files committed before that field existed.
+LEGACY_PMC_WORKLOAD = {"hgemm_w4y_kernel": "hgemm_8192", "attn_fwd_w4n_kernel": "attn_cfg3", "attn_fwd_w4m_kernel": "attn_cfg3",
+                       "attn_fwd_bigd2_kernel<512,false>": "attn_d512_fp16", "attn_fwd_bigd2_kernel<512,true>": "attn_d512_bf16",
+                       "gemm_fp8_w4_kernel": "fp8_8192"}
+
+
+def pmc_traffic(kernel: str, workload: str | None = None):
     """Fabric bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (written by
-    tools/summarize_prof.py: FETCH_SIZE x2 + WRITE_SIZE), or None when that kernel was not profiled."""
+    tools/summarize_prof.py: FETCH_SIZE x2 + WRITE_SIZE), or None when that kernel was not profiled on `workload`."""
     try:
-        return json.loads((ROOT / PMC_FILE).read_text())[kernel]["hbm_bytes_per_launch"]
+        ent = json.loads((ROOT / PMC_FILE).read_text())[kernel]
+        if workload is not None:
+            have = ent.get("workload") or next((w for k, w in LEGACY_PMC_WORKLOAD.items() if kernel.startswith(k)), None)
+            if have != workload:
+                return None
+        return ent["hbm_bytes_per_launch"]
     except Exception:
         return None
 
@@ -128,14 +142,15 @@ def hgemm_traffic_model(M, N, K, tile=256, xcds=8, cus_per_xcd=32, panel_w=8):
     return waves * panels * tile * K * 2 + M * N * 2
 
 
-def roofline(kernel, flops, nbytes, ms_kernel, profiled_config=False):
-    """profiled_config: this launch is one of the two the committed --pmc passes were taken on (HGEMM 8192^3, attention
-    config 3); a per-launch byte count of another shape would be meaningless, so traffic stays null elsewhere."""
+def roofline(kernel, flops, nbytes, ms_kernel, workload=None, peak=PEAK):
+    """workload: key of the launch shape (hgemm_8192, attn_cfg3, attn_d512_fp16, ...); `traffic` is printed when the committed
+    --pmc passes hold a counter for this kernel ON THAT SHAPE, with traffic_ratio = traffic / algorithmic bytes (1.0 = every
+    byte crosses the fabric once; well above 1 = re-reads past L2)."""
     ach = flops / (ms_kernel * 1e-3) * 1e-12
-    t = pmc_traffic(kernel) if profiled_config else None
-    return {"bound": "mfma", "achieved": ach, "peak": PEAK, "unit": "TFLOP/s", "frac": ach / PEAK,
+    t = pmc_traffic(kernel, workload) if workload else None
+    return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             "kernel_ms": ms_kernel, "kernel": kernel, "algorithmic_flops_per_launch": flops,
-            "algorithmic_bytes_per_launch": nbytes, "traffic": t,
+            "algorithmic_bytes_per_launch": nbytes, "traffic": t, "traffic_ratio": (t / nbytes) if t else None,
             "power_cap_note": "both paths run at the 1400 W board cap on random data; an MFMA-only v_mfma_f32_16x16x32_f16 stream "
                               "sustains 1854 TFLOP/s there, 32x32x16 1625 (profiles/r2_power_probe.log, DESIGN.md 4.10)",
             "traffic_source": (PMC_FILE + " (committed rocprofv3 --pmc passes, not a same-run counter)") if t else None}
@@ -187,7 +202,7 @@ def bench_hgemm(w, args):
         "workload": f"HGEMM M=N=K={n} fp16 {args.layout.upper()} (BASELINE config 2), randn inputs, "
                     f"variant={args.variant}, block-swizzle stride {stride}",
         "scaling": "weak",
-        "roofline": roofline(kname, flops, 3.0 * n * n * 2, ms_kernel, profiled_config=(n == 8192)),
+        "roofline": roofline(kname, flops, 3.0 * n * n * 2, ms_kernel, workload=f"hgemm_{n}"),
     }
     if n % 2048 == 0:
         res["roofline"]["traffic_model"] = {
@@ -215,8 +230,9 @@ def bench_hgemm(w, args):
         # uniform[-1,1) operands: the fill /opt/skills/guides/cdna_hip_programming.md quotes its 8192^3 figures on
         au = (torch.rand((n, n), device="cuda") * 2 - 1).half()
         bu = (torch.rand((n, n), device="cuda") * 2 - 1).half()
-        ms_u = capi.hgemm_time(au, bu, c, lay, var, 2, stride, warmup=5, iters=max(10, args.steps))
-        res["uniform_tflops"] = flops / ms_u * 1e-9
+        su = sustained(lambda: capi.hgemm(au, bu, c, layout=lay, variant=var, stages=2, swizzle_stride=stride), flops, 1.0)
+        res["uniform_tflops"] = su["tflops"]      # >= 1 s of back-to-back launches, like every other figure at the power cap
+        res["uniform_eff_clock_ghz"] = su["eff_clock_ghz"]
         del au, bu
         res["sustained"] = sustained(step, flops, args.sustain_seconds)
     if args.sweep and w.rank == 0:
@@ -251,7 +267,7 @@ def bench_attn(w, args, cfg4=False, steps=None, warmup=None, prewarm=PREWARM):
     torch.manual_seed(0 + w.rank)
     q, k, v, o, _ = host.get_qkvo(b_loc, h_loc, N, D)            # flash_attn_mma.py:417-435
     entry = "flash_attn_mma_stages_split_q_shared_qkv" if cfg4 else "flash_attn_mma_stages_split_q"
-    fam = capi.ATTN_SHARED_QKV if cfg4 else capi.ATTN_SPLIT_Q
+    tag = "cfg4" if cfg4 else "cfg3"
     step = lambda: capi.attn_call(entry, q, k, v, o, 2)          # noqa: E731   the reference's entry NAME
     secs = timed_region(w, step, steps, warmup, prewarm)
     secs = lcd.max_over_ranks(w, secs)
@@ -269,7 +285,7 @@ def bench_attn(w, args, cfg4=False, steps=None, warmup=None, prewarm=PREWARM):
         "scaling": "strong",
         "n_ranks": w.size,
         "roofline": roofline(capi.attn_kernel_name(N, D), flops_local, 4.0 * b_loc * h_loc * N * D * 2, ms_kernel,
-                             profiled_config=(not cfg4 and w.size == 1)),
+                             workload=(f"attn_{tag}" if w.size == 1 else None)),
     }
 
 
@@ -297,10 +313,54 @@ def bench_attn_d512(w, args, steps=3):
         ms_kernel = lcd.max_over_ranks(w, timed_region.event_ms / steps)
         out[name] = {"value": flops_total * steps / secs * 1e-12, "ms_per_step": secs / steps * 1e3, "steps": steps,
                      "roofline": roofline(capi.attn_kernel_name(N, D, False, dt == torch.bfloat16), flops_local,
-                                          4.0 * B * h_loc * N * D * 2, ms_kernel)}
+                                          4.0 * B * h_loc * N * D * 2, ms_kernel,
+                                          workload=(f"attn_d512_{name}" if w.size == 1 else None))}
         del q, k, v, o
     out["value"] = out["fp16"]["value"]
     return out
+
+
+def bench_fp8(w, args, steps=10):
+    """Config 5b: fp8 (OCP e4m3fn) GEMM M=N=K=16384, TN, fp32 accumulate, fp16 out (lc_gemm_fp8_e4m3: MX-scaled
+    v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales = the plain e4m3 product).  Roofline: the MX fp8 rate,
+    5 PFLOP/s dense (MI355X_MICROARCH.md).  Replicas per rank, like HGEMM."""
+    n = 16384
+    torch.manual_seed(8 + w.rank)
+    a8 = torch.randn(n, n, device="cuda").to(torch.float8_e4m3fn)
+    b8 = torch.randn(n, n, device="cuda").to(torch.float8_e4m3fn)
+    c8 = torch.zeros(n, n, dtype=torch.half, device="cuda")
+    step = lambda: capi.gemm_fp8(a8, b8, c8, alpha=1 / 16, swizzle_stride=2048)   # noqa: E731
+    secs = lcd.max_over_ranks(w, timed_region(w, step, steps, 2, prewarm=3))
+    ms_kernel = lcd.max_over_ranks(w, timed_region.event_ms / steps)
+    flops = 2.0 * n ** 3
+    out = {"value": w.size * flops * steps / secs * 1e-12, "ms_per_step": secs / steps * 1e3, "steps": steps, "scaling": "weak",
+           "dtype": "fp8 e4m3fn in, fp32 MFMA accumulate, f16 out",
+           "workload": f"GEMM M=N=K={n} fp8 e4m3 TN (BASELINE config 5b), randn inputs cast to e4m3, alpha 1/16",
+           "roofline": roofline("gemm_fp8_w4_kernel", flops, 2.0 * n * n + 2.0 * n * n, ms_kernel, workload=f"fp8_{n}",
+                                peak=host.MI355X_FP8_MX_DENSE_PEAK_TFLOPS)}
+    del a8, b8, c8
+    return out
+
+
+def bench_attn_d64(w, args, steps=10):
+    """The reference's own published FlashAttention shape (README.md:124-127): (B,H,N,D) = (1,48,8192,64), split-Q entry;
+    the 48 heads are sharded over the ranks."""
+    B, H, N, D = 1, 48, 8192, 64
+    lo, hi = host.shard_bounds(H, w.size, w.rank)
+    h_loc = hi - lo
+    torch.manual_seed(64 + w.rank)
+    q, k, v, o, _ = host.get_qkvo(B, h_loc, N, D)
+    step = lambda: capi.attn_call("flash_attn_mma_stages_split_q", q, k, v, o, 2)   # noqa: E731
+    secs = lcd.max_over_ranks(w, timed_region(w, step, steps, 2))
+    ms_kernel = lcd.max_over_ranks(w, timed_region.event_ms / steps)
+    flops_total, flops_local = host.mha_matmul_flops(B, H, N, D), host.mha_matmul_flops(B, h_loc, N, D)
+    return {"value": flops_total * steps / secs * 1e-12, "ms_per_step": secs / steps * 1e3, "steps": steps,
+            "tflops_reference_formula": host.get_mha_tflops(B, H, N, D, secs / steps),
+            "workload": f"FlashAttention-2 fwd B={B} H={H} S={N} D={D} fp16 (the reference's published shape, README.md:126-127), "
+                        f"randn inputs, {h_loc} heads per rank, entry flash_attn_mma_stages_split_q",
+            "scaling": "strong", "n_ranks": w.size,
+            "roofline": roofline(capi.attn_kernel_name(N, D), flops_local, 4.0 * B * h_loc * N * D * 2, ms_kernel,
+                                 workload=("attn_d64" if w.size == 1 else None))}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -324,55 +384,105 @@ def _cpu_quota():
         return None
 
 
+def _cpu_model():
+    try:
+        for ln in Path("/proc/cpuinfo").read_text().splitlines():
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return None
+
+
 def _pick_threads():
-    """fp16 CPU matmul with torch's default thread count (half the logical CPUs) collapses on big hosts (round 1: 1.4 s
-    for 1024^3 on 128 threads): probe a few thread counts on 512^3 and keep the fastest; the count used is reported."""
+    """Thread count that MAXIMISES fp16 torch.matmul at 1024^3 (config 1's size) among the cgroup quota, torch's default
+    and a few fixed counts; ties (within 5 %) go to the quota — the cores this container may actually use.  Every probe
+    is one warm-up + one timed run, capped so that a host without a fast fp16 kernel cannot eat the budget."""
     default = torch.get_num_threads()
-    a = torch.randn(512, 512, dtype=torch.half)
+    quota = _cpu_quota()
+    cands = sorted({default, 64, 32, 16, 8} | ({int(quota)} if quota and quota >= 1 else set()))
+    cands = [c for c in cands if c <= max(default, int(quota or 0))]
+    n = 1024
+    a = torch.randn(n, n, dtype=torch.half)
+    torch.set_num_threads(cands[0])
+    small = a[:256, :256].contiguous()
+    torch.matmul(small, small)                        # (first call: thread pool / dispatch set-up)
+    t0 = time.perf_counter()
+    torch.matmul(small, small)
+    slow = (time.perf_counter() - t0) > 0.05          # 256^3 = 33 MFLOP: > 50 ms means ~GFLOP/s-class fp16 (no vector kernel)
+    if slow:
+        n = 512
+        a = a[:n, :n].contiguous()
     probe = {}
-    for th in sorted({default, 64, 32, 16, 8}):
-        if th > default:
-            continue
+    for th in cands:
         torch.set_num_threads(th)
         torch.matmul(a, a)
         t0 = time.perf_counter()
         torch.matmul(a, a)
         probe[th] = time.perf_counter() - t0
-    best = min(probe, key=probe.get)
+    fastest = min(probe.values())
+    near = [th for th, t in probe.items() if t <= 1.05 * fastest]
+    best = int(quota) if quota and int(quota) in near else min(near, key=lambda th: probe[th])
     torch.set_num_threads(best)
-    return best, default, probe
+    return best, default, {"n": n, "seconds": probe}
 
 
-def cpu_baseline_hgemm(budget_s: float = 10.0):
-    """torch.matmul on fp16 CPU tensors = the reference's `--torch` baseline callable (hgemm.py:1088), SURVEY §8(d):
-    all host cores (thread count stated), 1 warm-up + 3 timed at 1024^3 (config 1's size) and at the largest cube of
-    the 8192^3 problem whose 4 runs fit `budget_s`."""
+def _side_note(dtype, n, a32, b32, budget_s):
+    """fp32 / bf16 torch.matmul of the SAME operand values (BASELINE.md section 4 "side notes")."""
+    a, b = a32.to(dtype), b32.to(dtype)
+    t0 = time.perf_counter()
+    torch.matmul(a, b)
+    first = time.perf_counter() - t0
+    if first * 3 > budget_s:
+        return {"n": n, "tflops": 2.0 * n ** 3 / first * 1e-12, "runs_s": [first], "note": "single cold run (budget)"}
+    med, ts = _timed3(lambda: torch.matmul(a, b))
+    return {"n": n, "tflops": 2.0 * n ** 3 / med * 1e-12, "runs_s": ts}
+
+
+def cpu_baseline_hgemm(budget_s: float = 12.0):
+    """torch.matmul on fp16 CPU tensors = the reference's `--torch` baseline callable (hgemm.py:1088), SURVEY section 8(d):
+    the thread count that maximises 1024^3 (stated), 1 warm-up + 3 timed at 1024^3 (config 1's size) and at the largest
+    cube of the 8192^3 problem whose 4 runs fit the budget; fp32 and bf16 matmul of the same operands as side notes
+    (BASELINE.md section 4).  On hosts whose CPU has no fp16 vector path (no AVX512-FP16 / AMX-FP16) torch's fp16 matmul
+    is a scalar-conversion loop (~1-2 GFLOP/s): that is what the reference's own CPU baseline would show on this box, and
+    `sample` says so next to the fp32 figure."""
     threads, default_threads, probe = _pick_threads()
     torch.manual_seed(0)
     runs = {}
     n = 1024
-    a = torch.randn(n, n, dtype=torch.half)
-    b = torch.randn(n, n, dtype=torch.half)
+    a32 = torch.randn(n, n)
+    b32 = torch.randn(n, n)
+    a, b = a32.half(), b32.half()
     med, ts = _timed3(lambda: torch.matmul(a, b))
     runs[str(n)] = {"median_s": med, "runs_s": ts, "tflops": 2.0 * n ** 3 / med * 1e-12}
+    spent = sum(ts) + med
     big = n
     for cand in (8192, 4096, 2048):     # x1.5 safety: larger cubes fall out of cache and run slower per FLOP
-        if 4 * 1.5 * med * (cand / n) ** 3 <= budget_s:
+        if 4 * 1.5 * med * (cand / n) ** 3 <= max(0.0, budget_s - spent):
             big = cand
             break
     if big != n:
-        a = torch.randn(big, big, dtype=torch.half)
-        b = torch.randn(big, big, dtype=torch.half)
-        med2, ts2 = _timed3(lambda: torch.matmul(a, b))
+        a2 = torch.randn(big, big, dtype=torch.half)
+        b2 = torch.randn(big, big, dtype=torch.half)
+        med2, ts2 = _timed3(lambda: torch.matmul(a2, b2))
         runs[str(big)] = {"median_s": med2, "runs_s": ts2, "tflops": 2.0 * big ** 3 / med2 * 1e-12}
+        del a2, b2
     head = runs[str(big)]
-    out = {"value": head["tflops"], "unit": "TFLOP/s", "cores": threads, "host_cpus": os.cpu_count(),
+    side_n = 2048
+    s32 = torch.randn(side_n, side_n)
+    t32 = torch.randn(side_n, side_n)
+    side = {"fp32": _side_note(torch.float32, side_n, s32, t32, 4.0), "bf16": _side_note(torch.bfloat16, side_n, s32, t32, 4.0)}
+    fp16_is_scalar = head["tflops"] < 0.1 * side["fp32"]["tflops"]
+    out = {"value": head["tflops"], "unit": "TFLOP/s", "cores": threads, "host_cpus": os.cpu_count(), "cpu_model": _cpu_model(),
            "cpu_quota_cores": _cpu_quota(), "torch_default_threads": default_threads,
-           "thread_probe_512cubed_s": {str(k): v for k, v in probe.items()},
-           "kind": "reference", "runs": runs,
-           "sample": f"torch.matmul fp16 on CPU tensors, {threads} threads, 1 warm-up + 3 timed (median), M=N=K={big} "
-                     f"(1/{(8192 // big) ** 3} of the 8192^3 work) and 1024^3; the reference bench's own torch "
-                     f"baseline callable (hgemm.py:1088)"}
+           "thread_probe": {"n": probe["n"], "seconds": {str(k): v for k, v in probe["seconds"].items()}},
+           "kind": "reference", "runs": runs, "side_notes": side,
+           "sample": f"torch.matmul fp16 on CPU tensors, {threads} threads (fastest of the probe at {probe['n']}^3), 1 warm-up + 3 timed "
+                     f"(median), M=N=K={big} (1/{(8192 // big) ** 3} of the 8192^3 work)"
+                     + ("" if big == 1024 else " and 1024^3") + "; the reference bench's own torch baseline callable "
+                     f"(hgemm.py:1088). Same operands at {side_n}^3: fp32 {side['fp32']['tflops']:.3f}, bf16 {side['bf16']['tflops']:.3f} TFLOP/s"
+                     + ("; fp16 runs > 10x below fp32 here: this host CPU has no fp16 vector path, torch converts element-wise"
+                        if fp16_is_scalar else "")}
     try:  # the C oracle ("port"), fp64 accumulate: 64 output rows of the 8192^3 problem
         from tests import oracle_lib
         orc = oracle_lib.load()
@@ -440,6 +550,9 @@ def run(args):
             if not args.quick:
                 blocks["attention_cfg4"] = bench_attn(w, args, cfg4=True, steps=3, warmup=1, prewarm=1)
                 blocks["attention_d512"] = bench_attn_d512(w, args)
+                blocks["attention_d64"] = bench_attn_d64(w, args)
+        if not args.quick:
+            blocks["fp8_gemm"] = bench_fp8(w, args)
     elif args.workload == "attn":
         main_res = bench_attn(w, args, cfg4=False)
     elif args.workload == "attn_cfg4":
@@ -473,7 +586,7 @@ def run(args):
             out[key] = main_res[key]
     for name, blk in blocks.items():
         blk = dict(blk)
-        blk["frac_of_peak"] = blk["value"] / (PEAK * w.size)
+        blk["frac_of_peak"] = blk["value"] / ((blk.get("roofline") or {}).get("peak", PEAK) * w.size)
         out[name] = blk
     if w.rank == 0 and w.size == 1 and not args.no_cpu_baseline and not args.quick:
         out["cpu_baseline"] = cpu_baseline_hgemm() if args.workload == "hgemm" else cpu_baseline_attn()

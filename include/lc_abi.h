@@ -102,11 +102,16 @@ int lc_device_check(int* num_cus);
 const char* lc_build_info(int* is_diag);
 
 /* Run-time selection knobs for A-B benches (not part of the reference surface; correctness never depends on them):
- *   "attn_nw"      attention kernel for D = 128: 0 = auto (= 512 when N % 256 == 0), 512 = merged-phase kernel with 16x16x32
- *                  MFMAs (attn_w4n.hip), 256 = the same with 32x32x16 MFMAs, 4 waves x 64
+ *   "attn_nw"      attention kernel for D <= 128: 0 = auto (D = 128: 512, D = 64: 513, when N % 256 == 0), 513 = the merged-phase
+ *                  kernel generalised over the head dim (attn_w4g.hip: D = 64, and D = 128 as a cross-check that must equal
+ *                  512 bit for bit), 512 = merged-phase kernel with 16x16x32
+ *                  MFMAs (attn_w4n.hip, D = 128), 256 = the same with 32x32x16 MFMAs, 4 waves x 64
  *                  query rows, one wave per SIMD (attn_w4m.hip; 260 = its A/B twin with padded Q.K^T MFMAs),
  *                  8 / 4 / 2 = lock-step kernel with that many waves (any N % (32 x waves) == 0, every D <= 128)
  *   "w4y_sched"    schedule 0..2 of LC_HGEMM_MFMA256W4Y's generated loop body (tools/gen_hgemm_w4y.py; same bits, A/B knob)
+ *   "hgemm_raster" block -> C tile map of the tiled GEMM kernels: 0 = the reference's block swizzle (N panels of swizzle_stride
+ *                  columns, every XCD a contiguous id range), 1 = XCD super-block raster (16 x 16 tile steps shared through
+ *                  the Infinity Cache, 4 x 8 per XCD; swizzle_stride ignored)
  *   "hgemm_auto"   kernel LC_HGEMM_AUTO launches on large 256-tileable shapes (a 256-tile lc_hgemm_variant value)
  *   "fp8_mx"       fp8 GEMM: 1 = MX-scaled K = 64 MFMA, 4-wave kernel (default); 2 = MX, 8-wave kernel; 0 = plain K = 16
  *   "attn_d512"    D = 256 / 512 kernel: 0 = auto (one workgroup owns all D output columns), 1 = round-1 column-split kernel,

@@ -33,7 +33,11 @@ namespace lc {
 // introspection (lc_attn_slowpath_stats): how often the overflow slow path ran — [0] executions, [1] sum of half-tile indices
 // j, [2] how many of them saw a non-finite row sum, [3] bit pattern of the last offending row sum.  One atomic per execution
 // of a path that N(0,1) inputs never take.
-__device__ unsigned int g_an_slowpath[4];
+// (one counter block per translation unit that instantiates these kernels: LC_AN_SLOWPATH_SYM names it)
+#ifndef LC_AN_SLOWPATH_SYM
+#define LC_AN_SLOWPATH_SYM g_an_slowpath
+#endif
+__device__ unsigned int LC_AN_SLOWPATH_SYM[4];
 
 constexpr int AN_O = 0, AN_K = 128, AN_Q = 192;
 
@@ -318,10 +322,10 @@ __global__ __launch_bounds__(256) void attn_fwd_w4n_kernel(
         }
         const unsigned long long culprit = __ballot(!ok);
         if (lane == (int)__builtin_ctzll(culprit | (1ull << 63))) {
-          atomicAdd(&g_an_slowpath[0], 1u);
-          atomicAdd(&g_an_slowpath[1], (unsigned)(2 * t + H));
-          if (!fin) atomicAdd(&g_an_slowpath[2], 1u);
-          g_an_slowpath[3] = __builtin_bit_cast(unsigned, worst);
+          atomicAdd(&LC_AN_SLOWPATH_SYM[0], 1u);
+          atomicAdd(&LC_AN_SLOWPATH_SYM[1], (unsigned)(2 * t + H));
+          if (!fin) atomicAdd(&LC_AN_SLOWPATH_SYM[2], 1u);
+          LC_AN_SLOWPATH_SYM[3] = __builtin_bit_cast(unsigned, worst);
         }
       }
       static_for<4>([&](auto qc) {

@@ -132,8 +132,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pingpong2_kernel(const uint8_
   const int wave = wave_id();
   const int wr = wave >> 2, wc = wave & 3;
 
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const TileCoord tc = raster(id, tiles_m, tiles_n, panel_w);
+  const TileCoord tc = block_tile(blockIdx.x, gridDim.x, tiles_m, tiles_n, panel_w);
   const int m0 = tc.tm * BM, n0 = tc.tn * BN;
 
   PPSrc8 src;
@@ -231,8 +230,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_w4_kernel(const uint8_t* __restr
   const int wr = wave >> 1, wc = wave & 1;
   const int l32 = lane & 31, hi = lane >> 5;
 
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const TileCoord tc = raster(id, tiles_m, tiles_n, panel_w);
+  const TileCoord tc = block_tile(blockIdx.x, gridDim.x, tiles_m, tiles_n, panel_w);
   const int m0 = tc.tm * BM, n0 = tc.tn * BN;
   const int KT = K / BK8;
 

@@ -24,8 +24,7 @@ __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __r
   const int wr = wave >> 1, wc = wave & 1;
   const int i16 = lane & 15, g = lane >> 4;
 
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const TileCoord tc = raster(id, tiles_m, tiles_n, panel_w);
+  const TileCoord tc = block_tile(blockIdx.x, gridDim.x, tiles_m, tiles_n, panel_w);
   const int m0 = tc.tm * BM1, n0 = tc.tn * BN1;
 
   // ---- LDS-DMA sources: 16 + 16 pieces of 1 KiB per K tile, 4 + 4 per wave

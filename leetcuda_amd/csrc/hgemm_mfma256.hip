@@ -45,6 +45,52 @@ LC_DEVINL TileCoord raster(int id, int tiles_m, int tiles_n, int panel_w) {
   return t;
 }
 
+// ---- XCD super-block raster (round 3; panel_w < 0 selects it, lc_tune_set "hgemm_raster").
+// Block b runs on XCD b % 8 (observed; speed only) and blocks start in index order, so at any moment the chip works on ~256
+// consecutive block ids = one "step".  The panel raster above gives every XCD its own contiguous id range: good for the
+// XCD's L2 (its 32 concurrent tiles are a 4 x 8 block: 12 operand panels), but the 8 XCDs work on regions that share
+// nothing — at 16384^3 the step's working set is 8 x 8 B tile-columns + 4 A tile-rows = 544 MiB, twice the 256 MiB Infinity
+// Cache, and every B panel is re-streamed from HBM once per step (~1.5 TB/s of HBM traffic ~ 150 W at the 1400 W cap).
+// Here a step is ONE compact 16 x 16 block of C tiles (16 + 16 panels = 256 MiB at K = 16384, B panels kept across the steps
+// of a 16-column panel) and XCD x owns the 4 x 8 sub-block (x >> 1, x & 1) of it: same 12 panels per XCD from L2's point of
+// view, 3x fewer HBM bytes.  Ragged edges (tile grid not a multiple of 16, < 256 trailing blocks) fall back to row-major
+// inside the 16-wide panel / identity, so the map is a bijection for every grid (tests/test_layouts.py).
+LC_DEVINL TileCoord raster_xcd16(int b, int nwg, int tiles_m, int tiles_n) {
+  const int full = nwg & ~255;
+  int id = b;
+  if (b < full) {
+    const int x = b & 7, idx = b >> 3;
+    id = ((idx >> 5) << 8) + (x << 5) + (idx & 31);   // step, XCD, slot
+  }
+  const int per_panel = 16 * tiles_m;
+  const int panel = id / per_panel;
+  const int rem = id - panel * per_panel;
+  const int pn0 = panel * 16;
+  const int w = min(16, tiles_n - pn0);
+  TileCoord t;
+  if (w == 16) {
+    const int grp = rem >> 8, r2 = rem & 255;
+    if (16 * grp + 16 <= tiles_m) {
+      const int sub = r2 >> 5, cc = r2 & 31;
+      t.tm = 16 * grp + 4 * (sub >> 1) + (cc >> 3);
+      t.tn = pn0 + 8 * (sub & 1) + (cc & 7);
+    } else {
+      t.tm = 16 * grp + (r2 >> 4);
+      t.tn = pn0 + (r2 & 15);
+    }
+  } else {
+    t.tm = rem / w;
+    t.tn = pn0 + (rem - t.tm * w);
+  }
+  return t;
+}
+
+// block index -> C tile: the reference's block swizzle (panel_w >= 1: XCD-contiguous ids + N panels) or the XCD super-block raster
+LC_DEVINL TileCoord block_tile(int b, int nwg, int tiles_m, int tiles_n, int panel_w) {
+  if (panel_w < 0) return raster_xcd16(b, nwg, tiles_m, tiles_n);
+  return raster(xcd_remap(b, nwg), tiles_m, tiles_n, panel_w);
+}
+
 template <bool B_KN>
 struct StageSrc {
   const half_t* a[4];
@@ -190,8 +236,7 @@ __global__ __launch_bounds__(512, 2) void hgemm_mfma256_kernel(const half_t* __r
   const int wave = wave_id();
   const int wr = wave >> 2, wc = wave & 3;
 
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const TileCoord tc = raster(id, tiles_m, tiles_n, panel_w);
+  const TileCoord tc = block_tile(blockIdx.x, gridDim.x, tiles_m, tiles_n, panel_w);
   const int m0 = tc.tm * BM, n0 = tc.tn * BN;
 
   StageSrc<B_KN> src;

@@ -220,8 +220,7 @@ __global__ __launch_bounds__(512, 2) void hgemm_pingpong2_kernel(const half_t* _
   const int wave = wave_id();
   const int wr = wave >> 2, wc = wave & 3;
 
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const TileCoord tc = raster(id, tiles_m, tiles_n, panel_w);
+  const TileCoord tc = block_tile(blockIdx.x, gridDim.x, tiles_m, tiles_n, panel_w);
   const int m0 = tc.tm * BM, n0 = tc.tn * BN;
 
   PPSrc<B_KN> src;

@@ -90,8 +90,7 @@ __global__ __launch_bounds__(256) void hgemm_w4x_kernel(const half_t* __restrict
   const int wave = wave_id();
   const int wr = wave >> 1, wc = wave & 1;
 
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const TileCoord tc = raster(id, tiles_m, tiles_n, panel_w);
+  const TileCoord tc = block_tile(blockIdx.x, gridDim.x, tiles_m, tiles_n, panel_w);
   const int m0 = tc.tm * BM, n0 = tc.tn * BN;
 
   // ---- DMA: identical to hgemm_w4b_kernel<false, true, false> (pieces g = 0..7 A, 8..15 B; tile clamped past the end)

@@ -38,6 +38,7 @@ namespace {
 int g_tune_fp8_mx = 1;                       // fp8 GEMM: 1 = MX-scaled K=64 MFMA, 4-wave kernel; 2 = MX, 8-wave kernel; 0 = plain K=16 MFMA
 int g_tune_attn_nw = 0;                    // attention kernel for D = 128: 0 = auto, 128 / 64 / 8 / 4 / 2 (lc_abi.h)
 int g_tune_hgemm_auto = LC_HGEMM_MFMA256W4Y;   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
+int g_tune_hgemm_raster = 0;                 // 0 = the reference's block swizzle (N panels from swizzle_stride, XCD-contiguous ids), 1 = XCD super-block raster (hgemm_mfma256.hip raster_xcd16)
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -158,6 +159,7 @@ bool is_w4_variant(int v) {
 }
 
 int panel_tiles(int swizzle_stride, int tiles_n, int tile_n) {
+  if (g_tune_hgemm_raster == 1) return -1;  // XCD super-block raster: the kernel ignores the stride (block_tile)
   if (swizzle_stride <= 1) return tiles_n;  // no thread-block swizzle: plain N-major raster
   int w = swizzle_stride / tile_n;
   if (w < 1) w = 1;
@@ -226,7 +228,8 @@ int launch_attn(const half_t* Q, const half_t* K, const half_t* V, half_t* O, in
   return check_launch();
 }
 
-// Which kernel serves a D <= 128 problem: 512 = merged-phase 4-wave x 64-row kernel with 16x16x32 MFMAs (attn_w4n.hip),
+// Which kernel serves a D <= 128 problem: 513 = the merged-phase kernel generalised over D (attn_w4g.hip: default for D = 64,
+// cross-check for D = 128), 512 = merged-phase 4-wave x 64-row kernel with 16x16x32 MFMAs (attn_w4n.hip),
 // 256 = the same with 32x32x16 MFMAs (attn_w4m.hip; 260 = its padded A/B twin), 8 / 4 / 2 = lock-step kernel with that many
 // waves (the 8-wave four-cluster kernel, 64, was retired at the end of round 2).  ONE function for the launcher and lc_attn_kernel_name().  Default for D = 128,
 // N % 256 == 0: 512 (sustained, one box, config 3 / config 4's shard: 1235 / 1311 TFLOP/s at 2.08 GHz against 1220 / 1260 at
@@ -235,8 +238,10 @@ int choose_attn_nw(int D, bool vt, int N) {
   const int want = g_tune_attn_nw;   // 0 = auto
   if (D == 128 && !vt && N % 256 == 0) {
     if (want == 0 && g_tune_attn_ablate == 0) return 512;
-    if (want == 256 || want == 260 || want == 512) return want;
+    if (want == 256 || want == 260 || want == 512 || want == 513) return want;
   }
+  // D = 64: the head-dim-generalised merged-phase kernel (attn_w4g.hip, 513) unless a lock-step kernel is asked for
+  if (D == 64 && !vt && N % 256 == 0 && (want == 0 || want >= 256)) return 513;
   if (N % 256 == 0 && (want == 0 || want >= 8)) return 8;   // (also what 256 / 512 fall back to for D < 128)
   if (N % 128 == 0 && (want == 0 || want >= 4)) return 4;
   return 2;
@@ -249,6 +254,9 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   if constexpr (D == 128 && !VT) {
     if (nw == 256 || nw == 260) return launch_attn_w4m_d128(Q, K, V, O, B, H, N, nw == 260, st);
     if (nw == 512) return launch_attn_w4n_d128(Q, K, V, O, B, H, N, st);
+  }
+  if constexpr ((D == 128 || D == 64) && !VT) {
+    if (nw == 513) return launch_attn_w4g(Q, K, V, O, B, H, N, D, st);
   }
   if constexpr (D == 128 && !VT) {   // perf-diagnosis instantiations (lc_tune_set "attn_ablate")
     switch (g_tune_attn_ablate) {
@@ -419,6 +427,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
     const int nw = choose_attn_nw(D, v_transposed != 0, N);
     if (nw == 256 || nw == 260) snprintf(buf, buflen, "attn_fwd_w4m_kernel<%d,%d>", D, nw == 260 ? 4 : 0);
     else if (nw == 512) snprintf(buf, buflen, "attn_fwd_w4n_kernel<%d>", D);
+    else if (nw == 513) snprintf(buf, buflen, "attn_fwd_w4g_kernel<%d>", D);
     else snprintf(buf, buflen, "attn_fwd_kernel<%d,%d,%s,0>", D, nw, vt);
     return LC_OK;
   }
@@ -437,7 +446,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
 int lc_tune_set(const char* key, int value) {
   if (!key) return LC_ERR_ARG;
   if (strcmp(key, "attn_nw") == 0) {
-    if (value != 0 && value != 256 && value != 260 && value != 512 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
+    if (value != 0 && value != 256 && value != 260 && value != 512 && value != 513 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
     g_tune_attn_nw = value;
     return LC_OK;
   }
@@ -458,6 +467,11 @@ int lc_tune_set(const char* key, int value) {
     if (value < 0 || value > 2) return LC_ERR_ARG;
 #endif
     g_tune_w4y_sched = value;
+    return LC_OK;
+  }
+  if (strcmp(key, "hgemm_raster") == 0) {
+    if (value < 0 || value > 1) return LC_ERR_ARG;
+    g_tune_hgemm_raster = value;
     return LC_OK;
   }
   if (strcmp(key, "hgemm_auto") == 0) {
@@ -728,5 +742,8 @@ int lc_clock_probe(void* out_u64x2, void* stream) {
 
 }  // extern "C"
 
-extern "C" int lc_attn_slowpath_stats(unsigned* out4, int reset) { return lc::diag_attn_slowpath(out4, reset); }
+extern "C" int lc_attn_slowpath_stats(unsigned* out4, int reset) {
+  if (int rc = lc::diag_attn_slowpath(out4, reset)) return rc;
+  return lc::diag_attn_slowpath_g(out4, reset);
+}
 

@@ -1,0 +1,42 @@
+// tu_attn_w4g.hip — translation unit of the head-dim-generalised merged-phase attention kernel (attn_w4g.hip) — see lc_launch.h
+#include <math.h>
+
+#include "lc_launch.h"
+#define LC_AN_SLOWPATH_SYM g_ag_slowpath
+#include "attn_w4g.hip"
+
+namespace lc {
+namespace {
+template <int D>
+int launch_w4g_t(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, hipStream_t st) {
+  const int nqb = N / 256;
+  const dim3 grid((unsigned)((size_t)nqb * B * H)), block(256);
+  const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+  auto kern = attn_fwd_w4g_kernel<D>;
+  if (int rc = set_dyn_lds(kern, W4G<D>::LDS)) return rc;
+  hipLaunchKernelGGL(kern, grid, block, W4G<D>::LDS, st, Q, K, V, O, N, nqb, sl2);
+  return check_launch();
+}
+}  // namespace
+
+// D in {64, 128}, N % 256 == 0, V as [B,H,N,D]
+int launch_attn_w4g(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, hipStream_t st) {
+  if (D == 64) return launch_w4g_t<64>(Q, K, V, O, B, H, N, st);
+  if (D == 128) return launch_w4g_t<128>(Q, K, V, O, B, H, N, st);
+  return LC_ERR_HEADDIM;
+}
+// slow-path counters of THIS unit's kernels, added onto out4[0..2] (out4[3]: last offender, taken when this unit has one)
+int diag_attn_slowpath_g(unsigned* out4, int reset) {
+  unsigned mine[4] = {0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(mine, HIP_SYMBOL(g_ag_slowpath), 16) != hipSuccess) return LC_ERR_LAUNCH;
+  if (out4) {
+    for (int i = 0; i < 3; ++i) out4[i] += mine[i];
+    if (mine[0]) out4[3] = mine[3];
+  }
+  if (reset) {
+    const unsigned z[4] = {0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ag_slowpath), z, 16) != hipSuccess) return LC_ERR_LAUNCH;
+  }
+  return LC_OK;
+}
+}  // namespace lc

@@ -13,6 +13,7 @@ from __future__ import annotations
 import torch
 
 MI355X_FP16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+MI355X_FP8_MX_DENSE_PEAK_TFLOPS = 5000.0  # same table: "Peak FP8 MFMA ~5 PF dense" (MX-scaled K = 64 / 128 forms)
 MI355X_HBM_PEAK_GBS = 8000.0
 
 

@@ -25,6 +25,12 @@ one does not hold:
       instruction that names the destination of an asm-issued LDS read which is still among the outstanding ones at that
       point (queue replayed in file order; reads issued by hipcc itself count in the queue but are hipcc's business)
       is a violation — this is what checks the `lgkmcnt(6)` / `lgkmcnt(14)`-style waits inside the attention statements
+  Control flow: the rules replay their hazard state (MFMA results in flight, fresh VALU writes, the in-order LDS queue,
+  un-retired asm loads) in FILE order; in addition, at every BACKWARD branch the first REPLAY_WINDOW instructions behind the
+  branch target are re-checked with the state as it stands at the branch — the hazard between the last instructions of a loop
+  body and the first of the next iteration.  Forward branches (the if / else of the overflow slow paths)
+  are still followed in file order only: the fall-through state reaches the join, the taken-branch state does not; the
+  bit-equality / determinism GPU tests remain the guard for those.
   R6  no asm-issued MFMA reads an arch VGPR that a VALU instruction wrote fewer than VALU_TO_MFMA_STATES wait states
       earlier (hipcc pads this for its own MFMAs — LLVM's "legacy VALU write VGPR -> MFMA read" rule — but not in front of
       an asm statement: a v_cvt_pk of the P fragment scheduled right in front of the statement that consumes it made
@@ -40,7 +46,7 @@ from pathlib import Path
 OWNED_AGPRS = [
     (re.compile(r"hgemm_w4b_kernel|hgemm_w4x_kernel|hgemm_w4y_kernel|gemm_fp8_w4_kernel"), [(0, 255)]),
     (re.compile(r"attn_fwd_w4_kernel"), [(0, 127), (192, 255)]),      # a[128:191] stay with hipcc (AGPR spills)
-    (re.compile(r"attn_fwd_w4m_kernel|attn_fwd_w4n_kernel|attn_fwd_bigd2_kernel|attn_fwd_bigd3_kernel"), [(0, 255)]),
+    (re.compile(r"attn_fwd_w4m_kernel|attn_fwd_w4n_kernel|attn_fwd_w4g_kernel|attn_fwd_bigd2_kernel|attn_fwd_bigd3_kernel"), [(0, 255)]),
 ]
 
 # kernel-name regex -> literal arch VGPR range owned by the kernel's asm (inclusive)
@@ -49,6 +55,7 @@ OWNED_VGPRS = [
 ]
 
 VALU_TO_MFMA_STATES = 2
+REPLAY_WINDOW = 96      # instructions re-checked behind the target of a backward branch (covers the longest latency budget)
 MFMA_STATES = {"16x16": 12, "32x32": 20, "4x4": 8}   # result latency budget per MFMA shape family (wait states)
 
 _REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
@@ -87,6 +94,115 @@ def _owned(name: str):
     return None
 
 
+_BRANCH = re.compile(r"s_c?branch\w*\s+(\.L[\w$]+)")
+
+
+def _viol(cur, tag, msg):
+    msg += tag
+    if msg not in cur.violations:
+        cur.violations.append(msg)
+
+
+def _step(st, cur, path, rec, owned, owned_v, count=True, tag=""):
+    """Apply the hazard rules to ONE instruction.  st = {"pending", "mfma_busy", "valu_fresh", "lgkm"} (module docstring);
+    count=False on the loop-back-edge replay (statistics are counted once)."""
+    s, in_asm, ln = rec
+    pending, mfma_busy, valu_fresh, lgkm = st["pending"], st["mfma_busy"], st["valu_fresh"], st["lgkm"]
+    # ---- R7: counted lgkmcnt waits vs asm-issued LDS reads
+    m7 = re.search(r"lgkmcnt\((\d+)\)", s) if s.startswith("s_waitcnt") else None
+    if m7:
+        keep = int(m7.group(1))
+        if len(lgkm) > keep:
+            st['lgkm'] = lgkm = lgkm[len(lgkm) - keep:] if keep else []
+    elif s.startswith("ds_"):
+        if lgkm:
+            named = {("v", r) for r in _regs(s, "v")} | {("a", r) for r in _regs(s, "a")}
+            for dst, from_asm in lgkm:
+                if from_asm and dst & named:
+                    _viol(cur, tag, f"R7 {path.name}:{ln}: `{s}` names {sorted(k + str(n) for k, n in dst & named)[:4]} while the asm LDS read "
+                                          "that writes it is still outstanding")
+        is_read = s.startswith(("ds_read", "ds_load", "ds_bpermute", "ds_permute", "ds_swizzle"))
+        d0 = s.split(None, 1)[1].split(",")[0]
+        dst = frozenset({("v", r) for r in _regs(d0, "v")} | {("a", r) for r in _regs(d0, "a")}) if is_read else frozenset()
+        lgkm.append((dst, in_asm))
+    elif lgkm and not s.startswith("s_"):
+        named = {("v", r) for r in _regs(s, "v")} | {("a", r) for r in _regs(s, "a")}
+        for dst, from_asm in lgkm:
+            if from_asm and dst & named:
+                _viol(cur, tag, f"R7 {path.name}:{ln}: `{s}` names {sorted(k + str(n) for k, n in dst & named)[:4]} while the asm LDS read "
+                                      "that writes it is still outstanding")
+                break
+    # ---- R6: VALU write (arch VGPR, or AGPR through v_accvgpr_write) -> asm MFMA read
+    if s.startswith("v_mfma"):
+        if in_asm and valu_fresh:
+            ops = s.split(None, 1)[1]
+            hit = ({("v", r) for r in _regs(ops, "v")} | {("a", r) for r in _regs(ops, "a")}) & valu_fresh.keys()
+            if hit:
+                _viol(cur, tag, f"R6 {path.name}:{ln}: asm `{s}` reads {sorted(k + str(n) for k, n in hit)[:4]} "
+                                      f"{max(valu_fresh[h] for h in hit)} wait states too early after a VALU write")
+        st['valu_fresh'] = valu_fresh = {}
+    else:
+        m6 = re.match(r"s_nop\s+(\d+)", s)
+        adv6 = int(m6.group(1)) + 1 if m6 else 1
+        st['valu_fresh'] = valu_fresh = {r: n - adv6 for r, n in valu_fresh.items() if n - adv6 > 0}
+        if s.startswith("v_") and not s.startswith(("v_cmp", "v_cmpx")):
+            d6 = s.split(None, 1)[1].split(",")[0]
+            for r in _regs(d6, "v"):
+                valu_fresh[("v", r)] = VALU_TO_MFMA_STATES
+            for r in _regs(d6, "a"):
+                valu_fresh[("a", r)] = VALU_TO_MFMA_STATES
+    # ---- R5: result latency of asm-issued MFMAs that write arch VGPRs
+    if mfma_busy:
+        if not s.startswith("v_mfma") and not s.startswith("s_"):
+            hit = _regs(s, "v") & mfma_busy.keys()
+            if hit:
+                _viol(cur, tag, f"R5 {path.name}:{ln}: `{s}` names v{sorted(hit)[:4]} "
+                                      f"{max(mfma_busy[h] for h in hit)} wait states before the asm MFMA result is there")
+                for h in hit:
+                    del mfma_busy[h]
+        m = re.match(r"s_nop\s+(\d+)", s)
+        adv = int(m.group(1)) + 1 if m else (4 if s.startswith("v_mfma") else 1)
+        st['mfma_busy'] = mfma_busy = {r: n - adv for r, n in mfma_busy.items() if n - adv > 0}
+    if s.startswith("v_mfma"):
+        cur.mfma += int(count)
+        if in_asm:
+            dst = s.split(None, 1)[1].split(",")[0]
+            need = next((v for k, v in MFMA_STATES.items() if k in s.split()[0]), 20)
+            for r in _regs(dst, "v"):
+                mfma_busy[r] = need
+    is_wait = s.startswith("s_waitcnt") and ("lgkmcnt(0)" in s or "vmcnt(0)" in s)
+    if is_wait:
+        # a counted wait retires everything older in program order; a plain lgkmcnt(0) retires LDS reads, a
+        # vmcnt(0) global ones — asm loads in these kernels are LDS reads, global asm loads are followed by
+        # vmcnt waits written next to them
+        pending.clear()
+        return
+    if in_asm:
+        m = _ASM_LOAD.match(s)
+        if m and " lds" not in s and not s.rstrip().endswith("lds"):
+            dst = m.group(2).split(",")[0]
+            pending |= _regs(dst, "v")
+            cur.asm_loads += int(count)
+        return
+    # ---- compiler-emitted instruction
+    if owned_v:
+        hit = _regs(s, "v") & owned_v
+        if hit:
+            _viol(cur, tag, f"R4 {path.name}:{ln}: compiler `{s}` names asm-owned VGPR(s) v{sorted(hit)[:4]}")
+    if s.startswith("v_accvgpr_"):
+        cur.compiler_accvgpr += int(count)
+        if owned is not None:
+            hit = _regs(s, "a") & owned
+            if hit:
+                _viol(cur, tag, f"R1 {path.name}:{ln}: compiler `{s}` touches asm-owned AGPR(s) {sorted(hit)[:4]}")
+    if pending:
+        hit = _regs(s, "v") & pending
+        if hit:
+            _viol(cur, tag, f"R3 {path.name}:{ln}: compiler `{s}` uses v{sorted(hit)[:4]} before the wait "
+                                  "that retires the asm load writing it")
+            pending -= hit     # report each register once
+
+
 def audit_asm(path: Path) -> list[KernelReport]:
     lines = Path(path).read_text().splitlines()
     reports: dict[str, KernelReport] = {}
@@ -97,7 +213,11 @@ def audit_asm(path: Path) -> list[KernelReport]:
     pending: set[int] = set()     # VGPR destinations of asm loads not yet retired by a wait
     mfma_busy: dict[int, int] = {}   # arch VGPR written by an asm MFMA -> wait states until its result is readable
     valu_fresh: dict[tuple, int] = {}  # ("v" | "a", n) written by a VALU instruction -> wait states until an MFMA may read it
+    # (the four hazard states live in `st`, one dict per function, so that a loop back-edge can replay with a copy)
     lgkm: list[tuple[frozenset, bool]] = []   # outstanding LDS operations in issue order: (VGPR destinations, asm-issued)
+    st = {"pending": pending, "mfma_busy": mfma_busy, "valu_fresh": valu_fresh, "lgkm": lgkm}
+    fn_ins: list[tuple[str, bool, int]] = []     # instructions of the current function in file order
+    fn_labels: dict[str, int] = {}               # label -> index into fn_ins of the first instruction behind it
     for ln, raw in enumerate(lines, 1):
         line = raw.split(";", 1)[0] if not raw.lstrip().startswith(";;#") else raw
         s = line.strip()
@@ -111,10 +231,8 @@ def audit_asm(path: Path) -> list[KernelReport]:
                 if rx.search(name):
                     owned_v = set(range(lo, hi + 1))
             in_asm = False
-            pending = set()
-            mfma_busy = {}
-            valu_fresh = {}
-            lgkm = []
+            st = {"pending": set(), "mfma_busy": {}, "valu_fresh": {}, "lgkm": []}
+            fn_ins, fn_labels = [], {}
             continue
         if s.startswith(".Lfunc_end"):
             cur = None
@@ -138,101 +256,24 @@ def audit_asm(path: Path) -> list[KernelReport]:
         if raw.lstrip().startswith(";;#ASMEND"):
             in_asm = False
             continue
+        ml = re.match(r"(\.L[\w$]+):", s)
+        if ml:
+            fn_labels[ml.group(1)] = len(fn_ins)
         if not s or s.endswith(":") or s.startswith("."):
             continue
-        # ---- R7: counted lgkmcnt waits vs asm-issued LDS reads
-        m7 = re.search(r"lgkmcnt\((\d+)\)", s) if s.startswith("s_waitcnt") else None
-        if m7:
-            keep = int(m7.group(1))
-            if len(lgkm) > keep:
-                lgkm = lgkm[len(lgkm) - keep:] if keep else []
-        elif s.startswith("ds_"):
-            if lgkm:
-                named = {("v", r) for r in _regs(s, "v")} | {("a", r) for r in _regs(s, "a")}
-                for dst, from_asm in lgkm:
-                    if from_asm and dst & named:
-                        cur.violations.append(f"R7 {path.name}:{ln}: `{s}` names {sorted(k + str(n) for k, n in dst & named)[:4]} while the asm LDS read "
-                                              "that writes it is still outstanding")
-            is_read = s.startswith(("ds_read", "ds_load", "ds_bpermute", "ds_permute", "ds_swizzle"))
-            d0 = s.split(None, 1)[1].split(",")[0]
-            dst = frozenset({("v", r) for r in _regs(d0, "v")} | {("a", r) for r in _regs(d0, "a")}) if is_read else frozenset()
-            lgkm.append((dst, in_asm))
-        elif lgkm and not s.startswith("s_"):
-            named = {("v", r) for r in _regs(s, "v")} | {("a", r) for r in _regs(s, "a")}
-            for dst, from_asm in lgkm:
-                if from_asm and dst & named:
-                    cur.violations.append(f"R7 {path.name}:{ln}: `{s}` names {sorted(k + str(n) for k, n in dst & named)[:4]} while the asm LDS read "
-                                          "that writes it is still outstanding")
-                    break
-        # ---- R6: VALU write (arch VGPR, or AGPR through v_accvgpr_write) -> asm MFMA read
-        if s.startswith("v_mfma"):
-            if in_asm and valu_fresh:
-                ops = s.split(None, 1)[1]
-                hit = ({("v", r) for r in _regs(ops, "v")} | {("a", r) for r in _regs(ops, "a")}) & valu_fresh.keys()
-                if hit:
-                    cur.violations.append(f"R6 {path.name}:{ln}: asm `{s}` reads {sorted(k + str(n) for k, n in hit)[:4]} "
-                                          f"{max(valu_fresh[h] for h in hit)} wait states too early after a VALU write")
-            valu_fresh = {}
-        else:
-            m6 = re.match(r"s_nop\s+(\d+)", s)
-            adv6 = int(m6.group(1)) + 1 if m6 else 1
-            valu_fresh = {r: n - adv6 for r, n in valu_fresh.items() if n - adv6 > 0}
-            if s.startswith("v_") and not s.startswith(("v_cmp", "v_cmpx")):
-                d6 = s.split(None, 1)[1].split(",")[0]
-                for r in _regs(d6, "v"):
-                    valu_fresh[("v", r)] = VALU_TO_MFMA_STATES
-                for r in _regs(d6, "a"):
-                    valu_fresh[("a", r)] = VALU_TO_MFMA_STATES
-        # ---- R5: result latency of asm-issued MFMAs that write arch VGPRs
-        if mfma_busy:
-            if not s.startswith("v_mfma") and not s.startswith("s_"):
-                hit = _regs(s, "v") & mfma_busy.keys()
-                if hit:
-                    cur.violations.append(f"R5 {path.name}:{ln}: `{s}` names v{sorted(hit)[:4]} "
-                                          f"{max(mfma_busy[h] for h in hit)} wait states before the asm MFMA result is there")
-                    for h in hit:
-                        del mfma_busy[h]
-            m = re.match(r"s_nop\s+(\d+)", s)
-            adv = int(m.group(1)) + 1 if m else (4 if s.startswith("v_mfma") else 1)
-            mfma_busy = {r: n - adv for r, n in mfma_busy.items() if n - adv > 0}
-        if s.startswith("v_mfma"):
-            cur.mfma += 1
-            if in_asm:
-                dst = s.split(None, 1)[1].split(",")[0]
-                need = next((v for k, v in MFMA_STATES.items() if k in s.split()[0]), 20)
-                for r in _regs(dst, "v"):
-                    mfma_busy[r] = need
-        is_wait = s.startswith("s_waitcnt") and ("lgkmcnt(0)" in s or "vmcnt(0)" in s)
-        if is_wait:
-            # a counted wait retires everything older in program order; a plain lgkmcnt(0) retires LDS reads, a
-            # vmcnt(0) global ones — asm loads in these kernels are LDS reads, global asm loads are followed by
-            # vmcnt waits written next to them
-            pending.clear()
-            continue
-        if in_asm:
-            m = _ASM_LOAD.match(s)
-            if m and " lds" not in s and not s.rstrip().endswith("lds"):
-                dst = m.group(2).split(",")[0]
-                pending |= _regs(dst, "v")
-                cur.asm_loads += 1
-            continue
-        # ---- compiler-emitted instruction
-        if owned_v:
-            hit = _regs(s, "v") & owned_v
-            if hit:
-                cur.violations.append(f"R4 {path.name}:{ln}: compiler `{s}` names asm-owned VGPR(s) v{sorted(hit)[:4]}")
-        if s.startswith("v_accvgpr_"):
-            cur.compiler_accvgpr += 1
-            if owned is not None:
-                hit = _regs(s, "a") & owned
-                if hit:
-                    cur.violations.append(f"R1 {path.name}:{ln}: compiler `{s}` touches asm-owned AGPR(s) {sorted(hit)[:4]}")
-        if pending:
-            hit = _regs(s, "v") & pending
-            if hit:
-                cur.violations.append(f"R3 {path.name}:{ln}: compiler `{s}` uses v{sorted(hit)[:4]} before the wait "
-                                      "that retires the asm load writing it")
-                pending -= hit     # report each register once
+        rec = (s, in_asm, ln)
+        fn_ins.append(rec)
+        _step(st, cur, path, rec, owned, owned_v, count=True)
+        mb = _BRANCH.match(s)
+        if mb and mb.group(1) in fn_labels:
+            # backward branch: re-check the head of the loop with the state carried over from its tail
+            st2 = {"pending": set(st["pending"]), "mfma_busy": dict(st["mfma_busy"]), "valu_fresh": dict(st["valu_fresh"]),
+                   "lgkm": list(st["lgkm"])}
+            t0 = fn_labels[mb.group(1)]
+            for rec2 in fn_ins[t0:t0 + REPLAY_WINDOW]:
+                if _BRANCH.match(rec2[0]) and rec2 is not rec and not rec2[0].startswith("s_cbranch"):
+                    break                      # an unconditional jump inside the window: file order says nothing beyond it
+                _step(st2, cur, path, rec2, owned, owned_v, count=False, tag=" [loop back-edge]")
     # metadata block: .name / .vgpr_count / .agpr_count
     txt = "\n".join(lines)
     for blk in re.split(r"\n  - \.agpr_count:", txt)[1:]:

@@ -64,7 +64,7 @@ def test_isa_audit_report_is_clean(built):
     rep = json.loads((built["abi"].parent / "obj" / "isa_audit.json").read_text())
     names = " ".join(r["kernel"] for r in rep)
     for k in ("hgemm_w4b_kernel", "hgemm_w4x_kernel", "hgemm_w4y_kernel", "gemm_fp8_w4_kernel", "attn_fwd_w4m_kernel",
-              "attn_fwd_w4n_kernel", "attn_fwd_bigd2_kernel", "hgemm_pingpong2_kernel"):
+              "attn_fwd_w4n_kernel", "attn_fwd_w4g_kernel", "attn_fwd_bigd2_kernel", "hgemm_pingpong2_kernel"):
         assert k in names, k
     assert all(r["scratch"] == 0 and not r["violations"] for r in rep)
     w4 = [r for r in rep if "hgemm_w4b_kernel" in r["kernel"] or "hgemm_w4y_kernel" in r["kernel"]]
@@ -114,6 +114,31 @@ def test_isa_audit_detects_early_read_of_asm_mfma_result(tmp_path):
     assert len(bad) == 1 and bad[0].startswith("R5") and "v_max_f32_e32 v1, v2, v3" in bad[0], bad
     _, bad = isa_audit.audit_files([tmp_path / "late.s"])
     assert bad == [], bad
+
+
+def test_isa_audit_replays_hazards_across_a_loop_back_edge(tmp_path):
+    """the hazard state used to be replayed in file order only, so a hazard between the LAST instruction of
+    a loop body and the FIRST of the next iteration was invisible.  A loop whose tail is an asm MFMA writing v[2:5] and whose
+    head reads v2 with a VALU instruction is clean in file order (the head comes first) and wrong on the back edge; with the
+    wait states in front of the branch it is clean on both."""
+    from leetcuda_amd import isa_audit
+    head = "\t.type\t_ZN2lc19attn_fwd_w4n_kernelILi128EEEvv,@function\n_ZN2lc19attn_fwd_w4n_kernelILi128EEEvv:\n"
+    tail = ".Lfunc_end0:\n"
+    loop = (".LBB0_1:\n\tv_max_f32_e32 v1, v2, v3\n\ts_nop 7\n"
+            "\t;;#ASMSTART\n\tv_mfma_f32_16x16x32_f16 v[2:5], a[0:3], a[4:7], v[2:5]\n\t;;#ASMEND\n"
+            "{pad}\ts_add_i32 s4, s4, -1\n\ts_cmp_lg_u32 s4, 0\n\ts_cbranch_scc1 .LBB0_1\n")
+    (tmp_path / "bad.s").write_text(head + loop.format(pad="") + tail)
+    (tmp_path / "good.s").write_text(head + loop.format(pad="\t;;#ASMSTART\n\ts_nop 15\n\t;;#ASMEND\n") + tail)
+    _, bad = isa_audit.audit_files([tmp_path / "bad.s"])
+    assert len(bad) == 1 and bad[0].startswith("R5") and "[loop back-edge]" in bad[0] and "v_max_f32_e32 v1, v2, v3" in bad[0], bad
+    assert isa_audit.audit_files([tmp_path / "good.s"])[1] == []
+    # the same for an asm LDS read left outstanding at the loop end (R3 / R7 on the back edge)
+    loop2 = (".LBB0_2:\n\tv_add_u32_e32 v8, v6, v1\n\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n\t;;#ASMEND\n"
+             "\t;;#ASMSTART\n\tds_read_b64_tr_b16 v[6:7], v9 offset:0\n\t;;#ASMEND\n"
+             "\ts_add_i32 s4, s4, -1\n\ts_cmp_lg_u32 s4, 0\n\ts_cbranch_scc1 .LBB0_2\n")
+    (tmp_path / "bad2.s").write_text(head + loop2 + tail)
+    _, bad = isa_audit.audit_files([tmp_path / "bad2.s"])
+    assert bad and all("[loop back-edge]" in b for b in bad) and {b.split()[0] for b in bad} == {"R3", "R7"}, bad
 
 
 def test_isa_audit_detects_valu_write_in_front_of_asm_mfma(tmp_path):

@@ -48,12 +48,12 @@ def test_attn_vs_oracle(oracle, D, N):
     assert (o.float() - o2.float()).abs().max().item() < 1e-3
 
 
-@pytest.mark.parametrize("nw", [256, 260, 512, 8, 4, 2])
+@pytest.mark.parametrize("nw", [256, 260, 512, 513, 8, 4, 2])
 @pytest.mark.parametrize("D", [128, 64, 96, 32])
 def test_workgroup_shapes_agree(oracle, nw, D):
-    """The same problem through the merged-phase 4-wave kernel (256 = the default; 260 = its padded A/B twin), the
-    8-, 4-, 2-wave lock-step kernels (lc_tune_set "attn_nw");
-    D < 128 always runs the lock-step kernel."""
+    """The same problem through the merged-phase 4-wave kernels (512 = the D = 128 default; 256 = its 32x32x16 twin, 260 = that
+    one's padded A/B twin; 513 = the head-dim-generalised kernel, default for D = 64) and the 8-, 4-, 2-wave lock-step kernels
+    (lc_tune_set "attn_nw"); D = 96 / 32 always run the lock-step kernel."""
     capi = _capi()
     B, H, N = 1, 3, 768
     torch.manual_seed(77 + D)
@@ -395,3 +395,71 @@ def test_non_finite_scores_take_the_slow_path(oracle):
     assert np.isfinite(d).all() and d.max() < tol.ATTN_MAX_ABS
     # the poisoned head follows IEEE like the reference would (exp(inf - inf) = NaN in its rows): not finite, not silently wrong
     assert not torch.isfinite(o[0, 1]).all()
+
+
+def test_generalised_kernel_reproduces_the_d128_kernel_bit_for_bit(oracle):
+    """attn_fwd_w4g_kernel<128> (attn_w4g.hip, the merged-phase kernel with every D-dependent count spelled out) must equal
+    attn_fwd_w4n_kernel<128> BIT FOR BIT — same instruction order, same rounding points — on random data and on inputs that
+    take the overflow slow path; this is what licenses the D = 64 instantiation of the same source."""
+    capi = _capi()
+    B, H, N, D = 2, 3, 2048, 128
+    torch.manual_seed(513)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k2 = k.clone()
+    k2[:, :, 1500] = 3.0 * q[:, :, 33]
+    k2[:, :, :32] = 2.0 * q[:, :, :32]
+    for kk in (k, k2):
+        outs = {}
+        for nw in (512, 513):
+            capi.tune("attn_nw", nw)
+            try:
+                assert capi.attn_kernel_name(N, D).startswith("attn_fwd_w4n_kernel" if nw == 512 else "attn_fwd_w4g_kernel<128>")
+                o = torch.full_like(q, float("nan"))
+                capi.attn_fwd(q, kk, v, o)
+                torch.cuda.synchronize()
+            finally:
+                capi.tune("attn_nw", 0)
+            outs[nw] = o
+        assert torch.equal(outs[512], outs[513])
+        _check(oracle, q, kk, v, outs[513], max_abs=6e-3)
+
+
+@pytest.mark.parametrize("nw", [0, 8])
+def test_scale_jumps_and_spikes_d64(oracle, nw):
+    """The D = 64 instantiation of the merged-phase kernel (running max = a mere scale, corrected by the overflow slow path):
+    the inputs of test_scale_jumps_and_extreme_scores / test_forced_rescale_spike at D = 64, against the lock-step kernel too."""
+    capi = _capi()
+    B, H, N, D = 1, 2, 1024, 64
+    torch.manual_seed(640)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    assert capi.attn_kernel_name(N, D) == "attn_fwd_w4g_kernel<64>"
+    cases = {"plain": (q, k)}
+    ramp = torch.linspace(0.0, 8.0, N, device="cuda").half()
+    cases["ramp"] = (q, (k + ramp[None, None, :, None] * q[:, :, :1].sign()).contiguous())
+    cases["level"] = (torch.full_like(q, 8.0), torch.full_like(q, 8.0))              # s = 64*64/8 = 512 (x log2 e)
+    k2 = k.clone()
+    k2[:, :, :32] = 5.0 * q[:, :, :32]
+    cases["first"] = (q, k2)
+    k3 = k.clone()
+    k3[:, :, N - 7] = 4.0 * q[:, :, 100]
+    k3[:, :, 5 * 64 + 17] = 4.0 * q[:, :, 33]
+    k3[:, :, N - 40] = 3.0 * q[:, :, 900]
+    cases["spikes"] = (q, k3)
+    capi.tune("attn_nw", nw)
+    try:
+        capi.attn_slowpath_stats(reset=True)
+        for name, (qq, kk) in cases.items():
+            o = torch.full_like(q, float("nan"))
+            capi.attn_fwd(qq, kk, v, o)
+            torch.cuda.synchronize()
+            truth = oracle.attn(qq, kk, v, B, H, N, D, mode="f32")
+            d = np.abs(o.float().cpu().numpy() - truth)
+            assert np.isfinite(d).all() and d.max() < 8e-3, (name, d.max())
+        st = capi.attn_slowpath_stats(reset=True)
+        assert (st[0] > 0) == (nw == 0), st          # the merged-phase kernel took its slow path on these inputs
+    finally:
+        capi.tune("attn_nw", 0)

@@ -290,3 +290,29 @@ def test_auto_large_nn_b_uses_64bit_dma_addresses():
     b[-1].add_(1.0)
     c3, _ = _run(capi, a, b, capi.LAYOUT_NN, 0, 2048)
     assert (c3.float() - c1.float()).abs().max().item() > 0.1
+
+
+@pytest.mark.parametrize("layout", ["nn", "tn"])
+def test_xcd_super_block_raster_computes_the_same_bits(layout):
+    """lc_tune_set "hgemm_raster" = 1 only changes WHICH workgroup computes which C tile (hgemm_mfma256.hip raster_xcd16):
+    outputs must equal the block-swizzle raster's bit for bit on full 16 x 16 tile grids, ragged grids (tile rows / columns not
+    a multiple of 16, < 256 trailing blocks) and the 128-tile kernel's grid."""
+    from leetcuda_amd import capi, host
+    capi.load()
+    lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
+    for M, N, K in ((4096, 4096, 128), (3072, 3328, 128), (256 * 17, 256 * 9, 64), (256 * 33, 256 * 18, 64), (1024, 1280, 256)):
+        torch.manual_seed(M + N)
+        a = torch.randn(M, K, dtype=torch.half, device="cuda")
+        b = torch.randn(K, N, dtype=torch.half, device="cuda")
+        bb = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
+        outs = []
+        for knob in (0, 1):
+            capi.tune("hgemm_raster", knob)
+            try:
+                c = torch.full((M, N), float("nan"), dtype=torch.half, device="cuda")
+                capi.hgemm(a, bb, c, layout=lay, variant=capi.HGEMM_AUTO, swizzle_stride=1024)
+                torch.cuda.synchronize()
+            finally:
+                capi.tune("hgemm_raster", 0)
+            outs.append(c)
+        assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1]), (M, N, K)

@@ -160,19 +160,28 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     assert capi.attn_kernel_name(4096, 128) == "attn_fwd_w4n_kernel<128>"
     assert capi.attn_kernel_name(4096 + 128, 128) == "attn_fwd_kernel<128,4,false,0>"      # N % 256 != 0
     assert capi.attn_kernel_name(192, 64, True) == "attn_fwd_kernel<64,2,true,0>"
+    assert capi.attn_kernel_name(8192, 64) == "attn_fwd_w4g_kernel<64>"                       # the reference's published shapes
+    assert capi.attn_kernel_name(8192, 64, True) == "attn_fwd_kernel<64,8,true,0>"            # V handed over transposed: lock-step
+    assert capi.attn_kernel_name(8192, 96) == "attn_fwd_kernel<96,8,false,0>"
     assert capi.attn_kernel_name(8192, 512, False, True) == "attn_fwd_bigd2_kernel<512,true>"
     assert capi.attn_kernel_name(192, 512, False, False).startswith("attn_fwd_bigd_kernel<512,")     # N % 128 != 0
     assert sump.short("_ZN2lc16hgemm_w4b_kernelILb0ELb1ELi0EEEvPKDF16_S2_PDF16_iiiiii") == \
         "hgemm_w4b_kernel<false,true,0>"
     assert sump.short("_ZN2lc19attn_fwd_w4n_kernelILi128EEEvPKDF16_S2_S2_PDF16_iif") == "attn_fwd_w4n_kernel<128>"
     pmc = json.loads((root / "profiles" / "latest_pmc.json").read_text())
-    for key in (capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN), capi.attn_kernel_name(4096, 128)):
-        if key in pmc:
+    for key, wl, other in ((capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN), "hgemm_8192", "hgemm_4096"),
+                           (capi.attn_kernel_name(4096, 128), "attn_cfg3", "attn_cfg4"),
+                           (capi.attn_kernel_name(8192, 512), "attn_d512_fp16", "attn_d512_bf16")):
+        if key in pmc and "hbm_bytes_per_launch" in pmc[key]:
             assert bench.pmc_traffic(key) == pmc[key]["hbm_bytes_per_launch"] > 0
-            r = bench.roofline(key, 1.0e12, 4.0e8, 1.0, profiled_config=True)
+            r = bench.roofline(key, 1.0e12, 4.0e8, 1.0, workload=wl)
             assert r["traffic"] == pmc[key]["hbm_bytes_per_launch"] and "profiles/" in r["traffic_source"]
+            assert r["traffic_ratio"] == pytest.approx(r["traffic"] / 4.0e8)
+            # a per-launch byte count is only printed next to the shape it was measured on
+            assert bench.roofline(key, 1.0e12, 4.0e8, 1.0, workload=other)["traffic"] is None
+            assert bench.roofline(key, 1.0e12, 4.0e8, 1.0)["traffic"] is None
         else:
-            assert bench.pmc_traffic(key) is None and bench.roofline(key, 1.0e12, 4.0e8, 1.0, profiled_config=True)["traffic_source"] is None
+            assert bench.pmc_traffic(key) is None and bench.roofline(key, 1.0e12, 4.0e8, 1.0, workload=wl)["traffic_source"] is None
 
 
 def test_steady_state_loops_keep_their_instruction_mix(built):
@@ -196,6 +205,9 @@ def test_steady_state_loops_keep_their_instruction_mix(built):
     g, gv = mix("tu_w4.s", r"hgemm_w4y_kernelILb0ELi1E")
     assert (g["mfma"], g["lds"], g["vmem"], g["s_barrier"], g["s_nop"]) == (128, 32, 16, 1, 0), g
     assert gv <= 8, g
+    g64, g64v = mix("tu_attn_w4g.s", r"attn_fwd_w4g_kernelILi64")   # D = 64: one tile = 64 MFMAs for the same 64 score elements
+    assert g64["mfma"] == 64 and g64["valu_trans"] == 64 and g64["s_barrier"] == 1, g64
+    assert g64v / 64 <= 3.0, (g64v, g64)
     n, nv = mix("tu_attn_w4.s", r"attn_fwd_w4n_kernel")            # one 64-key tile: 64 score elements per lane
     assert n["mfma"] == 128 and n["valu_trans"] == 64 and n["s_barrier"] == 1, n
     assert nv / 64 <= 3.2, (nv, n)

@@ -219,3 +219,76 @@ def test_bigd2_tiles_on_long_rows():
             assert sorted(cs ^ ((row & 3) << 2) for cs in range(cpr)) == list(range(cpr))                   # V
     for grp in B128_GROUPS:                                  # parked Q fragments
         assert conflict_free([lane * 16 for lane in grp], 16)
+
+
+def test_xcd_super_block_raster_is_a_bijection_with_compact_steps():
+    """hgemm_mfma256.hip raster_xcd16 restated: block b (XCD b % 8, slot b >> 3) -> C tile.  (1) a bijection onto the tile
+    grid for every grid incl. ragged ones (49 x 49 = 12544 / 256, 60 x 60, rectangular); (2) on a grid of full 16 x 16 blocks
+    every step of 256 consecutive blocks is ONE 16 x 16 block of tiles and every XCD's 32 tiles of the step a 4 x 8 block."""
+    def tile(b, nwg, tm_, tn_):
+        full = nwg & ~255
+        i = b
+        if b < full:
+            x, idx = b & 7, b >> 3
+            i = ((idx >> 5) << 8) + (x << 5) + (idx & 31)
+        per_panel = 16 * tm_
+        panel, rem = divmod(i, per_panel)
+        pn0 = panel * 16
+        w = min(16, tn_ - pn0)
+        if w == 16:
+            grp, r2 = rem >> 8, rem & 255
+            if 16 * grp + 16 <= tm_:
+                sub, cc = r2 >> 5, r2 & 31
+                return 16 * grp + 4 * (sub >> 1) + (cc >> 3), pn0 + 8 * (sub & 1) + (cc & 7)
+            return 16 * grp + (r2 >> 4), pn0 + (r2 & 15)
+        return rem // w, pn0 + rem % w
+    for tm_, tn_ in ((32, 32), (64, 64), (49, 49), (60, 60), (61, 63), (16, 48), (13, 7), (3, 100), (24, 40)):
+        nwg = tm_ * tn_
+        seen = {tile(b, nwg, tm_, tn_) for b in range(nwg)}
+        assert len(seen) == nwg and all(0 <= a < tm_ and 0 <= c < tn_ for a, c in seen), (tm_, tn_)
+    tm_ = tn_ = 64
+    nwg = tm_ * tn_
+    for step in range(nwg // 256):
+        tiles = [tile(b, nwg, tm_, tn_) for b in range(256 * step, 256 * step + 256)]
+        rows, cols = {a for a, _ in tiles}, {c for _, c in tiles}
+        assert len(rows) == 16 and len(cols) == 16 and max(rows) - min(rows) == 15 and max(cols) - min(cols) == 15
+        for x in range(8):
+            mine = [tile(b, nwg, tm_, tn_) for b in range(256 * step, 256 * step + 256) if b % 8 == x]
+            assert len({a for a, _ in mine}) == 4 and len({c for _, c in mine}) == 8
+
+
+def test_attention_tiles_d64_for_16x16x32_fragments():
+    """attn_w4g.hip at D = 64 (128-B rows: two rows per 256-B bank row).  K: 16-B chunk c of row r at slot c ^ ((r >> 1) & 7);
+    fragment lane -> row 16 kvb + (l & 15), chunk 4 ds + (l >> 4).  V: 32-B pair p of row r at pair slot p ^ ((r >> 1) & 3);
+    transpose read: lane i of 16-lane group g supplies row 32 H + 16 x + 4 g + (i >> 2), 8 bytes at column 4 (i & 3) of pair
+    db.  DMA: a 1-KiB piece = 8 rows; wave w stages pieces w, w + 4, so row & 15 = 8 (w & 1) + rr for both of them."""
+    for ds, kvb in itertools.product(range(2), range(4)):
+        for grp in B128_GROUPS:
+            addrs = []
+            for l in grp:
+                row = 16 * kvb + (l & 15)
+                a = row * 128 + (((4 * ds + (l >> 4)) ^ ((row >> 1) & 7)) * 16)
+                assert a == (16 * kvb) * 128 + (l & 15) * 128 + (((4 * ds + (l >> 4)) ^ (((l & 15) >> 1) & 7)) * 16)   # kernel form
+                addrs.append(a)
+            assert conflict_free(addrs, 16), (ds, kvb)
+    def key(r):
+        return (r >> 1) & 3
+    for db, hh, x in itertools.product(range(4), range(2), range(2)):
+        for grp in TR_GROUPS:
+            addrs = []
+            for lane in grp:
+                i, g = lane & 15, lane >> 4
+                r = 32 * hh + 16 * x + 4 * g + (i >> 2)
+                assert key(r) == (((g & 1) << 1) | (i >> 3))            # the kernel's lane-constant form
+                addrs.append(r * 128 + (db ^ key(r)) * 32 + (i & 3) * 8)
+            assert conflict_free(addrs, 8), (db, hh, x)
+    for r in range(64):
+        assert sorted(c ^ ((r >> 1) & 7) for c in range(8)) == list(range(8))
+        assert sorted(p ^ key(r) for p in range(4)) == list(range(4))
+    for w, i2, rr, cs in itertools.product(range(4), range(2), range(8), range(8)):
+        r = 8 * (w + 4 * i2) + rr
+        assert ((r >> 1) & 7) == 4 * (w & 1) + (rr >> 1) and key(r) == ((rr >> 1) & 3)
+        chunk = cs ^ ((r >> 1) & 7)                                   # the lane filling slot cs fetches this logical chunk
+        assert chunk ^ ((r >> 1) & 7) == cs
+        vchunk = (((cs >> 1) ^ key(r)) << 1) | (cs & 1)
+        assert ((vchunk >> 1) ^ key(r)) == (cs >> 1) and (vchunk & 1) == (cs & 1)

@@ -40,6 +40,12 @@ if a.what in ("all", "attn"):
     capi.tune("attn_nw", 0)
     torch.cuda.synchronize()
     del q, k, v, o, tv
+    # the reference's published shape (1,48,8192,64) (tools/prof_workloads.py: "attn_d64")
+    q, k, v, o, tv = host.get_qkvo(1, 48, 8192, 64, seed=0)
+    for _ in range(a.iters):
+        capi.attn_fwd(q, k, v, o)
+    torch.cuda.synchronize()
+    del q, k, v, o, tv
     # config 5a: FFPA shape, fp16 through the tiling-QKV entry and bf16 (full-width kernel attn_bigd2.hip)
     q = torch.randn(1, 48, 8192, 512, device="cuda").half()
     k = torch.randn(1, 48, 8192, 512, device="cuda").half()
@@ -52,7 +58,7 @@ if a.what in ("all", "attn"):
         capi.attn_fwd_bf16(qb, kb, vb, ob)
     torch.cuda.synchronize()
     del q, k, v, o, qb, kb, vb, ob
-    n = 8192   # config-5 extension: fp8 e4m3 GEMM
+    n = 16384   # config 5b: fp8 e4m3 GEMM (tools/prof_workloads.py: "fp8_16384")
     a8 = torch.randn(n, n, device="cuda").to(torch.float8_e4m3fn)
     b8 = torch.randn(n, n, device="cuda").to(torch.float8_e4m3fn)
     c8 = torch.zeros(n, n, dtype=torch.half, device="cuda")

@@ -1,0 +1,17 @@
+"""Which launch shape tools/prof_kernels.py profiles each kernel on: kernel-name prefix (as tools/summarize_prof.py
+shortens it) -> workload key.  bench.py prints a committed per-launch byte count only next to the same key
+(roofline(..., workload=...)): a byte count of another shape would be meaningless."""
+WORKLOADS = [
+    ("hgemm_", "hgemm_8192"), ("hipblaslt:", "hgemm_8192"),
+    ("gemm_fp8_", "fp8_16384"),
+    ("attn_fwd_w4n_kernel<128", "attn_cfg3"), ("attn_fwd_w4m_kernel<128", "attn_cfg3"), ("attn_fwd_kernel<128", "attn_cfg3"),
+    ("attn_fwd_w4g_kernel<128", "attn_cfg3"),
+    ("attn_fwd_w4n_kernel<64", "attn_d64"), ("attn_fwd_w4g_kernel<64", "attn_d64"), ("attn_fwd_kernel<64", "attn_d64"),
+    ("attn_fwd_bigd2_kernel<512,false", "attn_d512_fp16"), ("attn_fwd_bigd2_kernel<512,true", "attn_d512_bf16"),
+    ("attn_fwd_bigd3_kernel<512,false", "attn_d512_fp16"), ("attn_fwd_bigd3_kernel<512,true", "attn_d512_bf16"),
+    ("attn_fwd_bigd4_kernel<512,false", "attn_d512_fp16"), ("attn_fwd_bigd4_kernel<512,true", "attn_d512_bf16"),
+]
+
+
+def workload_of(short_name: str):
+    return next((w for p, w in WORKLOADS if short_name.startswith(p)), None)

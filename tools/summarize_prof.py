@@ -17,6 +17,8 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from prof_workloads import workload_of  # noqa: E402
 
 
 def short(name: str) -> str:
@@ -71,6 +73,7 @@ def main(tag: str):
         for name, cname, val, cnt in rows:
             pmc[short(name)][cname] = val
     for k, c in pmc.items():
+        c["workload"] = workload_of(k)      # the launch shape of tools/prof_kernels.py (bench.py matches on it)
         if "FETCH_SIZE" in c:
             c["hbm_read_bytes_fetch_x2"] = c["FETCH_SIZE"] * 1024 * 2
         if "WRITE_SIZE" in c:
