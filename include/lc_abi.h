@@ -109,9 +109,10 @@ const char* lc_build_info(int* is_diag);
  *                  query rows, one wave per SIMD (attn_w4m.hip; 260 = its A/B twin with padded Q.K^T MFMAs),
  *                  8 / 4 / 2 = lock-step kernel with that many waves (any N % (32 x waves) == 0, every D <= 128)
  *   "w4y_sched"    schedule 0..2 of LC_HGEMM_MFMA256W4Y's generated loop body (tools/gen_hgemm_w4y.py; same bits, A/B knob)
- *   "hgemm_raster" block -> C tile map of the tiled GEMM kernels: 0 = the reference's block swizzle (N panels of swizzle_stride
- *                  columns, every XCD a contiguous id range), 1 = XCD super-block raster (16 x 16 tile steps shared through
- *                  the Infinity Cache, 4 x 8 per XCD; swizzle_stride ignored)
+ *   "hgemm_raster" block -> C tile map of the tiled GEMM kernels: 0 = auto (2 when A + B exceed the 256 MiB Infinity Cache by half,
+ *                  else 1), 1 = the reference's block swizzle (N panels of swizzle_stride columns, every XCD a contiguous id
+ *                  range), 2 = XCD super-block raster (16 x 16 tile steps shared through the Infinity Cache, 4 x 8 per XCD;
+ *                  swizzle_stride ignored)
  *   "hgemm_auto"   kernel LC_HGEMM_AUTO launches on large 256-tileable shapes (a 256-tile lc_hgemm_variant value)
  *   "fp8_mx"       fp8 GEMM: 1 = MX-scaled K = 64 MFMA, 4-wave kernel (default); 2 = MX, 8-wave kernel; 0 = plain K = 16
  *   "attn_d512"    D = 256 / 512 kernel: 0 = auto (one workgroup owns all D output columns), 1 = round-1 column-split kernel,

@@ -80,9 +80,13 @@ def build_abi(force: bool = False, audit: bool = True) -> Path:
     srcs.append(ROOT / "include" / "lc_abi.h")
     srcs.append(PKG / "isa_audit.py")
     srcs.append(ROOT / "tools" / "gen_hgemm_w4y.py")
+    srcs.append(ROOT / "tools" / "gen_attn_w4i.py")
     flags = _flags()
     # the generated K loops (hgemm_w4y_loop*.inc) must be what tools/gen_hgemm_w4y.py emits today
     gen = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_hgemm_w4y.py"), "--check"], capture_output=True, text=True)
+    if gen.returncode != 0:
+        raise RuntimeError("generated sources are stale: " + gen.stderr.strip())
+    gen = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_attn_w4i.py"), "--check"], capture_output=True, text=True)
     if gen.returncode != 0:
         raise RuntimeError("generated sources are stale: " + gen.stderr.strip())
     if os.environ.get("LC_DIAG") == "1":   # the ablation loops (results WRONG by design) exist only inside a diagnosis build

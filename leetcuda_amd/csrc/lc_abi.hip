@@ -38,7 +38,8 @@ namespace {
 int g_tune_fp8_mx = 1;                       // fp8 GEMM: 1 = MX-scaled K=64 MFMA, 4-wave kernel; 2 = MX, 8-wave kernel; 0 = plain K=16 MFMA
 int g_tune_attn_nw = 0;                    // attention kernel for D = 128: 0 = auto, 128 / 64 / 8 / 4 / 2 (lc_abi.h)
 int g_tune_hgemm_auto = LC_HGEMM_MFMA256W4Y;   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
-int g_tune_hgemm_raster = 0;                 // 0 = the reference's block swizzle (N panels from swizzle_stride, XCD-contiguous ids), 1 = XCD super-block raster (hgemm_mfma256.hip raster_xcd16)
+int g_tune_hgemm_raster = 0;                 // block -> C tile map: 0 = auto (by operand footprint, panel_tiles), 1 = the reference's block swizzle (N panels from
+                                             // swizzle_stride, XCD-contiguous ids), 2 = XCD super-block raster (hgemm_mfma256.hip raster_xcd16)
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -158,8 +159,15 @@ bool is_w4_variant(int v) {
          v == LC_HGEMM_MFMA256W4Y;
 }
 
-int panel_tiles(int swizzle_stride, int tiles_n, int tile_n) {
-  if (g_tune_hgemm_raster == 1) return -1;  // XCD super-block raster: the kernel ignores the stride (block_tile)
+// Block -> C tile map handed to the tiled kernels (block_tile, hgemm_mfma256.hip): >= 1 = the reference's block swizzle with
+// that many tile columns per N panel, -1 = XCD super-block raster.  Auto rule (measured, profiles/r3b_hgemm_raster_ab.log,
+// 0.5 s sustained per cell, 3 interleaved rounds): operands that fit the 256 MiB Infinity Cache are served from it whatever
+// the order (8192^3: A + B = 256 MiB, block swizzle 1441 / xcd16 1435 TFLOP/s TN; 4096^3 +0.2 %), beyond it the super-block
+// raster streams every panel from HBM about a third as often: 12544^3 +5.7 %, 15360^3 +8.3 %, 16384^3 +5.3 % TN (+4.7 ... 6.9 %
+// NN), which is what lifts AUTO from 4 ... 9 % behind hipBLASLt TN to level with it on the reference's published sizes.
+int panel_tiles(int swizzle_stride, int tiles_n, int tile_n, size_t operand_bytes) {
+  const bool xcd16 = g_tune_hgemm_raster == 2 || (g_tune_hgemm_raster == 0 && operand_bytes > ((size_t)384 << 20));
+  if (xcd16) return -1;                     // the kernel ignores the stride
   if (swizzle_stride <= 1) return tiles_n;  // no thread-block swizzle: plain N-major raster
   int w = swizzle_stride / tile_n;
   if (w < 1) w = 1;
@@ -171,7 +179,7 @@ template <bool B_KN>
 int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant,
                    int swizzle_stride, hipStream_t st) {
   const int tiles_m = M / BM, tiles_n = N / BN;
-  const int pw = panel_tiles(swizzle_stride, tiles_n, BN);
+  const int pw = panel_tiles(swizzle_stride, tiles_n, BN, ((size_t)M + N) * K * 2);
   const dim3 grid(tiles_m * tiles_n), block(512);
   if (is_w4_variant(variant))
     return launch_w4_family(A, B, C, M, N, K, variant, B_KN, tiles_m, tiles_n, pw, st);
@@ -198,7 +206,7 @@ template <bool B_KN>
 int launch_mfma128(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int swizzle_stride,
                    hipStream_t st) {
   const int tiles_m = M / BM1, tiles_n = N / BN1;
-  const int pw = panel_tiles(swizzle_stride, tiles_n, BN1);
+  const int pw = panel_tiles(swizzle_stride, tiles_n, BN1, ((size_t)M + N) * K * 2);
   auto kern = hgemm_mfma128_kernel<B_KN>;
   if (int rc = set_dyn_lds(kern, HGEMM128_LDS)) return rc;
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), HGEMM128_LDS, st, A, B, C, M, N, K, tiles_m,
@@ -238,10 +246,10 @@ int choose_attn_nw(int D, bool vt, int N) {
   const int want = g_tune_attn_nw;   // 0 = auto
   if (D == 128 && !vt && N % 256 == 0) {
     if (want == 0 && g_tune_attn_ablate == 0) return 512;
-    if (want == 256 || want == 260 || want == 512 || want == 513) return want;
+    if (want == 256 || want == 260 || want == 512 || want == 513 || want == 514) return want;
   }
   // D = 64: the head-dim-generalised merged-phase kernel (attn_w4g.hip, 513) unless a lock-step kernel is asked for
-  if (D == 64 && !vt && N % 256 == 0 && (want == 0 || want >= 256)) return 513;
+  if (D == 64 && !vt && N % 256 == 0 && (want == 0 || want >= 256)) return want == 514 ? 514 : 513;
   if (N % 256 == 0 && (want == 0 || want >= 8)) return 8;   // (also what 256 / 512 fall back to for D < 128)
   if (N % 128 == 0 && (want == 0 || want >= 4)) return 4;
   return 2;
@@ -257,6 +265,7 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   }
   if constexpr ((D == 128 || D == 64) && !VT) {
     if (nw == 513) return launch_attn_w4g(Q, K, V, O, B, H, N, D, st);
+    if (nw == 514) return launch_attn_w4i(Q, K, V, O, B, H, N, D, st);
   }
   if constexpr (D == 128 && !VT) {   // perf-diagnosis instantiations (lc_tune_set "attn_ablate")
     switch (g_tune_attn_ablate) {
@@ -428,6 +437,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
     if (nw == 256 || nw == 260) snprintf(buf, buflen, "attn_fwd_w4m_kernel<%d,%d>", D, nw == 260 ? 4 : 0);
     else if (nw == 512) snprintf(buf, buflen, "attn_fwd_w4n_kernel<%d>", D);
     else if (nw == 513) snprintf(buf, buflen, "attn_fwd_w4g_kernel<%d>", D);
+    else if (nw == 514) snprintf(buf, buflen, "attn_fwd_w4i_kernel<%d>", D);
     else snprintf(buf, buflen, "attn_fwd_kernel<%d,%d,%s,0>", D, nw, vt);
     return LC_OK;
   }
@@ -446,7 +456,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
 int lc_tune_set(const char* key, int value) {
   if (!key) return LC_ERR_ARG;
   if (strcmp(key, "attn_nw") == 0) {
-    if (value != 0 && value != 256 && value != 260 && value != 512 && value != 513 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
+    if (value != 0 && value != 256 && value != 260 && value != 512 && value != 513 && value != 514 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
     g_tune_attn_nw = value;
     return LC_OK;
   }
@@ -470,7 +480,7 @@ int lc_tune_set(const char* key, int value) {
     return LC_OK;
   }
   if (strcmp(key, "hgemm_raster") == 0) {
-    if (value < 0 || value > 1) return LC_ERR_ARG;
+    if (value < 0 || value > 2) return LC_ERR_ARG;
     g_tune_hgemm_raster = value;
     return LC_OK;
   }
@@ -544,7 +554,7 @@ int lc_gemm_fp8_e4m3(const void* A, const void* B, void* C, int M, int N, int K,
   if (M % BM || N % BN || K % 128 || !aligned16(A) || !aligned16(B) || !aligned16(C)) return LC_ERR_SHAPE;
   if (int rc = launch_guard()) return rc;
   const int tiles_m = M / BM, tiles_n = N / BN;
-  const int pw = panel_tiles(swizzle_stride, tiles_n, BN);
+  const int pw = panel_tiles(swizzle_stride, tiles_n, BN, ((size_t)M + N) * K);   // (fp8: one byte per element)
   return launch_gemm_fp8(static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), static_cast<half_t*>(C), M, N, K,
                          alpha, tiles_m, tiles_n, pw, g_tune_fp8_mx, static_cast<hipStream_t>(stream));
 }

@@ -46,12 +46,16 @@ from pathlib import Path
 OWNED_AGPRS = [
     (re.compile(r"hgemm_w4b_kernel|hgemm_w4x_kernel|hgemm_w4y_kernel|gemm_fp8_w4_kernel"), [(0, 255)]),
     (re.compile(r"attn_fwd_w4_kernel"), [(0, 127), (192, 255)]),      # a[128:191] stay with hipcc (AGPR spills)
-    (re.compile(r"attn_fwd_w4m_kernel|attn_fwd_w4n_kernel|attn_fwd_w4g_kernel|attn_fwd_bigd2_kernel|attn_fwd_bigd3_kernel"), [(0, 255)]),
+    (re.compile(r"attn_fwd_w4m_kernel|attn_fwd_w4n_kernel|attn_fwd_w4g_kernel|attn_fwd_w4i_kernel|attn_fwd_bigd2_kernel|attn_fwd_bigd3_kernel"), [(0, 255)]),
 ]
 
 # kernel-name regex -> literal arch VGPR range owned by the kernel's asm (inclusive)
 OWNED_VGPRS = [
     (re.compile(r"hgemm_w4y_kernel"), (108, 255)),
+    # attn_w4i: v[LB:255] are RESERVED registers (amdgpu_num_vgpr(LB)) holding the softmax state under literal names across
+    # statements (tools/gen_attn_w4i.py register map): no compiler instruction may ever name one
+    (re.compile(r"attn_fwd_w4i_kernelILi64E"), (104, 255)),
+    (re.compile(r"attn_fwd_w4i_kernelILi128E"), (80, 255)),
 ]
 
 VALU_TO_MFMA_STATES = 2

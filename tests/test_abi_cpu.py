@@ -64,7 +64,7 @@ def test_isa_audit_report_is_clean(built):
     rep = json.loads((built["abi"].parent / "obj" / "isa_audit.json").read_text())
     names = " ".join(r["kernel"] for r in rep)
     for k in ("hgemm_w4b_kernel", "hgemm_w4x_kernel", "hgemm_w4y_kernel", "gemm_fp8_w4_kernel", "attn_fwd_w4m_kernel",
-              "attn_fwd_w4n_kernel", "attn_fwd_w4g_kernel", "attn_fwd_bigd2_kernel", "hgemm_pingpong2_kernel"):
+              "attn_fwd_w4n_kernel", "attn_fwd_w4g_kernel", "attn_fwd_w4i_kernel", "attn_fwd_bigd2_kernel", "hgemm_pingpong2_kernel"):
         assert k in names, k
     assert all(r["scratch"] == 0 and not r["violations"] for r in rep)
     w4 = [r for r in rep if "hgemm_w4b_kernel" in r["kernel"] or "hgemm_w4y_kernel" in r["kernel"]]

@@ -48,12 +48,13 @@ def test_attn_vs_oracle(oracle, D, N):
     assert (o.float() - o2.float()).abs().max().item() < 1e-3
 
 
-@pytest.mark.parametrize("nw", [256, 260, 512, 513, 8, 4, 2])
+@pytest.mark.parametrize("nw", [256, 260, 512, 513, 514, 8, 4, 2])
 @pytest.mark.parametrize("D", [128, 64, 96, 32])
 def test_workgroup_shapes_agree(oracle, nw, D):
     """The same problem through the merged-phase 4-wave kernels (512 = the D = 128 default; 256 = its 32x32x16 twin, 260 = that
     one's padded A/B twin; 513 = the head-dim-generalised kernel, default for D = 64) and the 8-, 4-, 2-wave lock-step kernels
-    (lc_tune_set "attn_nw"); D = 96 / 32 always run the lock-step kernel."""
+    (lc_tune_set "attn_nw"; 514 = the same kernel with each phase as one generated asm statement, attn_w4i.hip); D = 96 / 32
+    always run the lock-step kernel."""
     capi = _capi()
     B, H, N = 1, 3, 768
     torch.manual_seed(77 + D)
@@ -129,7 +130,7 @@ def test_golden_fixtures(oracle, golden):
         assert d.max() < tol.ATTN_MAX_ABS, d.max()
 
 
-@pytest.mark.parametrize("nw", [0, 256, 260, 512, 8])
+@pytest.mark.parametrize("nw", [0, 256, 260, 512, 513, 514, 8])
 def test_forced_rescale_spike(oracle, nw):
     """One K row matches one Q row so strongly that the running max jumps by >> 8 in the middle of the
     sequence (tile 5 of 8): every row's accumulator must be rescaled exactly once (rule 26)."""
@@ -259,7 +260,7 @@ def test_full_size_config3_properties(oracle):
     assert (o12.float() - o1.float() - o2.float()).abs().max().item() < 2e-3
 
 
-@pytest.mark.parametrize("nw", [256, 512, 8])
+@pytest.mark.parametrize("nw", [256, 512, 514, 8])
 def test_scale_jumps_and_extreme_scores(oracle, nw):
     """The merged-phase kernel treats the running max as a mere SCALE and only corrects it when a half-tile's row sums
     get large (attn_w4m.hip).  Inputs that force that path in many places: (a) scores that grow steadily along the
@@ -397,36 +398,48 @@ def test_non_finite_scores_take_the_slow_path(oracle):
     assert not torch.isfinite(o[0, 1]).all()
 
 
-def test_generalised_kernel_reproduces_the_d128_kernel_bit_for_bit(oracle):
-    """attn_fwd_w4g_kernel<128> (attn_w4g.hip, the merged-phase kernel with every D-dependent count spelled out) must equal
-    attn_fwd_w4n_kernel<128> BIT FOR BIT — same instruction order, same rounding points — on random data and on inputs that
-    take the overflow slow path; this is what licenses the D = 64 instantiation of the same source."""
+@pytest.mark.parametrize("D", [128, 64])
+def test_generalised_and_generated_kernels_reproduce_the_reference_kernel_bit_for_bit(oracle, D):
+    """attn_fwd_w4g_kernel (attn_w4g.hip: the merged-phase kernel with every D-dependent count spelled out, 513) and
+    attn_fwd_w4i_kernel (attn_w4i.hip: each phase ONE generated asm statement on reserved registers, uniform padded loop, 514)
+    must equal attn_fwd_w4n_kernel<128> (512) BIT FOR BIT at D = 128 — same MFMA order per accumulator, same exp2 / row-sum /
+    pack sequence — and each other at D = 64, on random data and on inputs that take the overflow slow path (spike rows, a
+    dominant first half-tile, a growing ramp), with the slow-path counter confirming the path was taken."""
     capi = _capi()
-    B, H, N, D = 2, 3, 2048, 128
-    torch.manual_seed(513)
+    B, H, N = 2, 3, 2048
+    torch.manual_seed(513 + D)
     q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     k2 = k.clone()
-    k2[:, :, 1500] = 3.0 * q[:, :, 33]
-    k2[:, :, :32] = 2.0 * q[:, :, :32]
-    for kk in (k, k2):
+    k2[:, :, 1500] = 4.0 * q[:, :, 33]
+    k2[:, :, N - 3] = 4.0 * q[:, :, 700]
+    k2[:, :, :32] = 3.0 * q[:, :, :32]
+    ramp = torch.linspace(0.0, 8.0, N, device="cuda").half()
+    k3 = (k + ramp[None, None, :, None] * q[:, :, :1].sign()).contiguous()
+    kernels = (512, 513, 514) if D == 128 else (513, 514)
+    for ci, kk in enumerate((k, k2, k3)):
         outs = {}
-        for nw in (512, 513):
+        for nw in kernels:
             capi.tune("attn_nw", nw)
             try:
-                assert capi.attn_kernel_name(N, D).startswith("attn_fwd_w4n_kernel" if nw == 512 else "attn_fwd_w4g_kernel<128>")
+                want = {512: "attn_fwd_w4n_kernel", 513: "attn_fwd_w4g_kernel", 514: "attn_fwd_w4i_kernel"}[nw]
+                assert capi.attn_kernel_name(N, D).startswith(want)
+                capi.attn_slowpath_stats(reset=True)
                 o = torch.full_like(q, float("nan"))
                 capi.attn_fwd(q, kk, v, o)
                 torch.cuda.synchronize()
+                st = capi.attn_slowpath_stats(reset=True)
             finally:
                 capi.tune("attn_nw", 0)
+            assert (st[0] > 0) == (ci > 0), (nw, ci, st)
             outs[nw] = o
-        assert torch.equal(outs[512], outs[513])
-        _check(oracle, q, kk, v, outs[513], max_abs=6e-3)
+        for nw in kernels[1:]:
+            assert torch.equal(outs[kernels[0]], outs[nw]), (D, ci, nw)
+        _check(oracle, q, kk, v, outs[514], max_abs=8e-3)
 
 
-@pytest.mark.parametrize("nw", [0, 8])
+@pytest.mark.parametrize("nw", [0, 514, 8])
 def test_scale_jumps_and_spikes_d64(oracle, nw):
     """The D = 64 instantiation of the merged-phase kernel (running max = a mere scale, corrected by the overflow slow path):
     the inputs of test_scale_jumps_and_extreme_scores / test_forced_rescale_spike at D = 64, against the lock-step kernel too."""
@@ -436,7 +449,6 @@ def test_scale_jumps_and_spikes_d64(oracle, nw):
     q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
-    assert capi.attn_kernel_name(N, D) == "attn_fwd_w4g_kernel<64>"
     cases = {"plain": (q, k)}
     ramp = torch.linspace(0.0, 8.0, N, device="cuda").half()
     cases["ramp"] = (q, (k + ramp[None, None, :, None] * q[:, :, :1].sign()).contiguous())
@@ -460,6 +472,6 @@ def test_scale_jumps_and_spikes_d64(oracle, nw):
             d = np.abs(o.float().cpu().numpy() - truth)
             assert np.isfinite(d).all() and d.max() < 8e-3, (name, d.max())
         st = capi.attn_slowpath_stats(reset=True)
-        assert (st[0] > 0) == (nw == 0), st          # the merged-phase kernel took its slow path on these inputs
+        assert (st[0] > 0) == (nw != 8), st          # the merged-phase kernels took their slow path on these inputs
     finally:
         capi.tune("attn_nw", 0)

@@ -306,7 +306,7 @@ def test_xcd_super_block_raster_computes_the_same_bits(layout):
         b = torch.randn(K, N, dtype=torch.half, device="cuda")
         bb = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
         outs = []
-        for knob in (0, 1):
+        for knob in (1, 2):
             capi.tune("hgemm_raster", knob)
             try:
                 c = torch.full((M, N), float("nan"), dtype=torch.half, device="cuda")

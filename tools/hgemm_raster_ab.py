@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of the block -> C tile map (lc_tune_set "hgemm_raster": 0 = the reference's block swizzle with XCD-contiguous ids,
-1 = XCD super-block raster), interleaved rounds, >= S seconds sustained per cell, TN and NN, hipBLASLt alongside.
+"""A/B of the block -> C tile map (lc_tune_set "hgemm_raster": 1 = the reference's block swizzle with XCD-contiguous ids,
+2 = XCD super-block raster; 0 = auto), interleaved rounds, >= S seconds sustained per cell, TN and NN, hipBLASLt alongside.
 usage: hgemm_raster_ab.py [sizes,comma] [seconds] [rounds]"""
 import sys
 from pathlib import Path
@@ -42,7 +42,7 @@ for n in sizes:
         b2 = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
         res = {"swizzle": [], "xcd16": [], "vendor": []}
         for r in range(rounds):
-            for name, knob in (("swizzle", 0), ("xcd16", 1)):
+            for name, knob in (("swizzle", 1), ("xcd16", 2)):
                 capi.tune("hgemm_raster", knob)
                 try:
                     res[name].append(rate(lambda: capi.hgemm(a, b2, c, layout=lay, variant=capi.HGEMM_AUTO, swizzle_stride=st), fl))
