@@ -144,14 +144,42 @@ def build_abi(force: bool = False, audit: bool = True) -> Path:
 
 
 def build_diag(force: bool = False) -> Path:
-    """liblc_diag.so: the hardware probes of include/lc_diag.h (tests / tools only; not part of the drop-in library)."""
+    """liblc_diag.so: the hardware probes of include/lc_diag.h + the ablated copies of the generated attention stream (tests /
+    tools only; not part of the drop-in library).  The ablated phase statements are generated into lib/gen/ (never tracked)."""
     LIBDIR.mkdir(parents=True, exist_ok=True)
     out = LIBDIR / "liblc_diag.so"
-    srcs = sorted((CSRC / "diag").glob("*.hip")) + [CSRC / "lc_common.h", ROOT / "include" / "lc_diag.h"]
+    srcs = sorted((CSRC / "diag").glob("*.hip")) + [CSRC / "lc_common.h", ROOT / "include" / "lc_diag.h", CSRC / "attn_w4i.hip",
+                                                     CSRC / "attn_w4g.hip", CSRC / "attn_w4n.hip", CSRC / "attn_w4m.hip",
+                                                     ROOT / "tools" / "gen_attn_w4i.py"]
     if not force and _newer(out, srcs):
         return out
-    _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-Wno-inline-asm",
-          f"-I{ROOT / 'include'}", "-o", out, CSRC / "diag" / "lc_diag.hip"])
+    gen = LIBDIR / "gen"
+    subprocess.run([sys.executable, str(ROOT / "tools" / "gen_attn_w4i.py"), "--diag", str(gen)], check=True)
+    sys.path.insert(0, str(ROOT / "tools"))
+    try:
+        import gen_attn_w4i
+        abls = gen_attn_w4i.ABLATIONS
+    finally:
+        sys.path.pop(0)
+    objdir = LIBDIR / "obj"
+    objdir.mkdir(exist_ok=True)
+    base = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-inline-asm",
+            "-fno-honor-nans", "-mno-amdgpu-ieee", f"-I{ROOT / 'include'}", f"-I{gen}", f"-I{CSRC}"]
+    jobs = [(objdir / "diag_main.o", [*base, "-c", "-o", objdir / "diag_main.o", CSRC / "diag" / "lc_diag.hip"])]
+    for k in abls:
+        o = objdir / f"diag_w4i_abl{k}.o"
+        jobs.append((o, [*base, f"-DW4I_ABL={k}", f'-DW4I_INC64="attn_w4i_d64_abl{k}.inc"', f'-DW4I_INC128="attn_w4i_d128_abl{k}.inc"',
+                         "-c", "-o", o, CSRC / "diag" / "attn_w4i_abl.hip"]))
+    procs = []
+    for o, cmd in jobs:
+        print("[build]", " ".join(str(c) for c in cmd), flush=True)
+        procs.append((o, subprocess.Popen([str(c) for c in cmd], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for o, pr in procs:
+        log, _ = pr.communicate()
+        if pr.returncode != 0:
+            sys.stdout.write(log[-6000:])
+            raise subprocess.CalledProcessError(pr.returncode, pr.args)
+    _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *[o for o, _ in jobs]])
     return out
 
 

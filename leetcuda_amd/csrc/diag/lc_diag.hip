@@ -111,3 +111,25 @@ int lc_diag_pollute(unsigned pattern, int what, void* stream) {
   return check_launch();
 }
 
+
+// ---- ablated copies of the generated attention stream (attn_w4i_abl.hip, one translation unit per ablation)
+extern "C" {
+int lc_diag_attn_w4i_abl1(const void*, const void*, const void*, void*, int, int, int, int, void*);
+int lc_diag_attn_w4i_abl2(const void*, const void*, const void*, void*, int, int, int, int, void*);
+int lc_diag_attn_w4i_abl3(const void*, const void*, const void*, void*, int, int, int, int, void*);
+int lc_diag_attn_w4i_abl4(const void*, const void*, const void*, void*, int, int, int, int, void*);
+int lc_diag_attn_w4i_abl7(const void*, const void*, const void*, void*, int, int, int, int, void*);
+int lc_diag_attn_w4i_abl8(const void*, const void*, const void*, void*, int, int, int, int, void*);
+
+int lc_diag_attn_w4i(int abl, const void* Q, const void* K, const void* V, void* O, int B, int H, int N, int D, void* stream) {
+  switch (abl) {
+    case 1: return lc_diag_attn_w4i_abl1(Q, K, V, O, B, H, N, D, stream);
+    case 2: return lc_diag_attn_w4i_abl2(Q, K, V, O, B, H, N, D, stream);
+    case 3: return lc_diag_attn_w4i_abl3(Q, K, V, O, B, H, N, D, stream);
+    case 4: return lc_diag_attn_w4i_abl4(Q, K, V, O, B, H, N, D, stream);
+    case 7: return lc_diag_attn_w4i_abl7(Q, K, V, O, B, H, N, D, stream);
+    case 8: return lc_diag_attn_w4i_abl8(Q, K, V, O, B, H, N, D, stream);
+    default: return ERR_ARG;
+  }
+}
+}

@@ -36,6 +36,7 @@ namespace {
 
 // run-time tuning knobs (lc_tune_set): experiments and A/B benches, never required for correctness
 int g_tune_fp8_mx = 1;                       // fp8 GEMM: 1 = MX-scaled K=64 MFMA, 4-wave kernel; 2 = MX, 8-wave kernel; 0 = plain K=16 MFMA
+int g_tune_attn_w4i_sched = 0;              // schedule of attn_fwd_w4i_kernel's generated phase statements (tools/gen_attn_w4i.py NSCHED; same bits)
 int g_tune_attn_nw = 0;                    // attention kernel for D = 128: 0 = auto, 128 / 64 / 8 / 4 / 2 (lc_abi.h)
 int g_tune_hgemm_auto = LC_HGEMM_MFMA256W4Y;   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
 int g_tune_hgemm_raster = 0;                 // block -> C tile map: 0 = auto (by operand footprint, panel_tiles), 1 = the reference's block swizzle (N panels from
@@ -265,7 +266,7 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   }
   if constexpr ((D == 128 || D == 64) && !VT) {
     if (nw == 513) return launch_attn_w4g(Q, K, V, O, B, H, N, D, st);
-    if (nw == 514) return launch_attn_w4i(Q, K, V, O, B, H, N, D, st);
+    if (nw == 514) return launch_attn_w4i(Q, K, V, O, B, H, N, D, g_tune_attn_w4i_sched, st);
   }
   if constexpr (D == 128 && !VT) {   // perf-diagnosis instantiations (lc_tune_set "attn_ablate")
     switch (g_tune_attn_ablate) {
@@ -437,7 +438,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
     if (nw == 256 || nw == 260) snprintf(buf, buflen, "attn_fwd_w4m_kernel<%d,%d>", D, nw == 260 ? 4 : 0);
     else if (nw == 512) snprintf(buf, buflen, "attn_fwd_w4n_kernel<%d>", D);
     else if (nw == 513) snprintf(buf, buflen, "attn_fwd_w4g_kernel<%d>", D);
-    else if (nw == 514) snprintf(buf, buflen, "attn_fwd_w4i_kernel<%d>", D);
+    else if (nw == 514) snprintf(buf, buflen, "attn_fwd_w4i_kernel<%d,%d>", D, g_tune_attn_w4i_sched);
     else snprintf(buf, buflen, "attn_fwd_kernel<%d,%d,%s,0>", D, nw, vt);
     return LC_OK;
   }
@@ -458,6 +459,11 @@ int lc_tune_set(const char* key, int value) {
   if (strcmp(key, "attn_nw") == 0) {
     if (value != 0 && value != 256 && value != 260 && value != 512 && value != 513 && value != 514 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
     g_tune_attn_nw = value;
+    return LC_OK;
+  }
+  if (strcmp(key, "attn_w4i_sched") == 0) {
+    if (value < 0 || value > 1) return LC_ERR_ARG;
+    g_tune_attn_w4i_sched = value;
     return LC_OK;
   }
   if (strcmp(key, "fp8_mx") == 0) {

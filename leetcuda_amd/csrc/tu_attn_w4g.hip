@@ -20,19 +20,19 @@ int launch_w4g_t(const half_t* Q, const half_t* K, const half_t* V, half_t* O, i
 }
 }  // namespace
 
-template <int D>
+template <int D, int SCHED>
 int launch_w4i_t(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, hipStream_t st) {
   const int nqb = N / 256;
   const dim3 grid((unsigned)((size_t)nqb * B * H)), block(256);
   const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
-  auto kern = attn_fwd_w4i_kernel<D>;
+  auto kern = attn_fwd_w4i_kernel<D, SCHED>;
   if (int rc = set_dyn_lds(kern, W4G<D>::LDS)) return rc;
   hipLaunchKernelGGL(kern, grid, block, W4G<D>::LDS, st, Q, K, V, O, N, nqb, sl2);
   return check_launch();
 }
-int launch_attn_w4i(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, hipStream_t st) {
-  if (D == 64) return launch_w4i_t<64>(Q, K, V, O, B, H, N, st);
-  if (D == 128) return launch_w4i_t<128>(Q, K, V, O, B, H, N, st);
+int launch_attn_w4i(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, int sched, hipStream_t st) {
+  if (D == 64) return sched ? launch_w4i_t<64, 1>(Q, K, V, O, B, H, N, st) : launch_w4i_t<64, 0>(Q, K, V, O, B, H, N, st);
+  if (D == 128) return sched ? launch_w4i_t<128, 1>(Q, K, V, O, B, H, N, st) : launch_w4i_t<128, 0>(Q, K, V, O, B, H, N, st);
   return LC_ERR_HEADDIM;
 }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sustained rate of the attention forward at arbitrary shapes, interleaved A/B over tuning knobs.
 usage: attn_rate.py [--seconds S] [--rounds R] spec...
-   spec = B,H,N,D[:bf16][:zero][:nw=K][:d512=K][:d64=K]   (knobs = lc_tune_set keys attn_nw / attn_d512 / attn_d64)
+   spec = B,H,N,D[:bf16][:zero][:nw=K][:d512=K][:sched=K]   (knobs = lc_tune_set keys attn_nw / attn_d512 / attn_w4i_sched)
 Every spec runs >= S seconds of back-to-back launches per round; R rounds interleave the specs (within-probe A/B,
 cdna_hip_programming.md rule 24); prints the kernel name the dispatcher reports, median and best TFLOP/s (matmul FLOPs)."""
 import sys
@@ -23,7 +23,7 @@ while args and args[0].startswith("--"):
         raise SystemExit(f"unknown option {args[0]}")
     args = args[2:]
 capi.load()
-KNOBS = {"nw": "attn_nw", "d512": "attn_d512", "d64": "attn_d64"}
+KNOBS = {"nw": "attn_nw", "d512": "attn_d512", "sched": "attn_w4i_sched"}
 cache = {}
 
 

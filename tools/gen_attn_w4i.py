@@ -29,7 +29,10 @@ later; Sᵀ(j) was written by the previous phase's MFMAs >= 16 slots before its 
 the next phase's MFMAs; an M0 write is followed by an MFMA before the LDS-DMA that uses it; MFMA operands written by VALU in
 front of the statement (slow path, prologue) are covered by the s_nop the C++ side issues.
 
-usage: tools/gen_attn_w4i.py [--check]"""
+usage: tools/gen_attn_w4i.py [--check]
+       tools/gen_attn_w4i.py --diag DIR    (liblc_diag.so only: ablated copies attn_w4i_d<D>_abl<K>.inc of the phase statements —
+                                            K bits: 1 no LDS-DMA, 2 no LDS reads, 4 no softmax VALU, 8 no MFMA; results WRONG by
+                                            design, timing only: tools/attn_w4i_ablate.py)"""
 import sys
 from pathlib import Path
 
@@ -83,6 +86,10 @@ def a(n, cnt=4):
     return f"a[{n}:{n + cnt - 1}]"
 
 
+NSCHED = 2   # 0: reads from slot 0, LDS-DMA pieces every 8 slots from slot 3 (they share slots with the reads of the first quarter);
+             # 1: the same reads, LDS-DMA pieces only in slots that carry no LDS read
+
+
 def read_schedule(c):
     rd, first = {}, []
     for i in range(max(c.NRK, c.NRV)):
@@ -102,7 +109,7 @@ def pair(p):
     return p >> 3, (p >> 1) & 3, p & 1      # kvb, qb, k2
 
 
-def gen_phase(c, H):
+def gen_phase(c, H, sched=0):
     """-> (asm lines, operand description).  Operands: [kaN] [vcN] [vpN] [vodd] VGPR inputs; H = 0 only: [koff] [voff] VGPR,
     [rk] [rv] SGPR descriptor tuples, [m0b] [sob] SGPR, [st] SGPR temporary; [worst] VGPR output."""
     L = []
@@ -177,13 +184,19 @@ def gen_phase(c, H):
     # ---- LDS-DMA pieces of tile t + 2 (H = 0): piece i = K pieces 0 .. PPW − 1, then V pieces; wave w stages piece w + 4 i'
     dma = {}
     if H == 0:
-        for i in range(2 * c.PPW):
+        if sched == 0:
+            starts = [8 * i + 3 for i in range(2 * c.PPW)]
+        else:       # read-free slots: between the first-half reads and NS / 2, then behind the set A reads
+            free = [s for s in range(nfirst + 1, c.NS // 2 - 1)] + [s for s in range(c.NS // 2 + c.NRV + 1, c.NS - 2)]
+            step = max(2, len(free) // (2 * c.PPW))
+            starts = [free[min(i * step, len(free) - 2)] for i in range(2 * c.PPW)]
+            assert len(set(starts)) == 2 * c.PPW and all(b - a >= 2 for a, b in zip(starts, starts[1:])), starts
+        for i, s0 in enumerate(starts):
             is_v, ii = i >= c.PPW, i % c.PPW
-            s0 = 8 * i + 3
             dma.setdefault(s0, []).append(f"s_add_u32 m0, %[m0b], {(c.TILE if is_v else 0) + 4096 * ii}")
             dma.setdefault(s0, []).append(f"s_add_u32 %[st], %[sob], {4096 * ii}")
             dma.setdefault(s0 + 1, []).append(f"buffer_load_dwordx4 %[{'voff' if is_v else 'koff'}], %[{'rv' if is_v else 'rk'}], %[st] offen lds")
-        assert 8 * (2 * c.PPW - 1) + 4 < c.NS
+        assert max(starts) + 1 < c.NS
 
     e("s_waitcnt lgkmcnt(0)")
     for ins in fill[-1]:
@@ -243,7 +256,26 @@ def cstr(lines):
     return "\n".join(f'    "{ln}\\n\\t"' for ln in lines)
 
 
-def render(D):
+ABLATIONS = (1, 2, 3, 4, 7, 8)
+
+
+def ablate(lines, abl):
+    out = []
+    for ln in lines:
+        op = ln.split()[0]
+        if abl & 1 and (op.startswith("buffer_load") or ln.startswith("s_add_u32 m0") or ln.startswith("s_add_u32 %[st]")):
+            continue
+        if abl & 2 and op.startswith("ds_read"):
+            continue
+        if abl & 4 and op in ("v_exp_f32", "v_add_f32", "v_cvt_pk_f16_f32", "v_mov_b32"):
+            continue
+        if abl & 8 and op.startswith("v_mfma"):
+            continue
+        out.append(ln)
+    return out
+
+
+def render(D, abl=0):
     c = Cfg(D)
     vclob = ", ".join(f'"v{r}"' for r in range(c.LB, 256))
     out = []
@@ -252,27 +284,31 @@ def render(D):
     w(f"#if W4I_PART == 0   // ---- register map (v[{c.LB}:255] are reserved: the kernel is compiled with amdgpu_num_vgpr({c.LB}))")
     for name in ("LB", "SA", "SB", "PA", "PB", "VF", "NEGM", "PS", "SUM", "LRUN"):
         w(f"static constexpr int {name} = {getattr(c, name)};")
+    w(f"static constexpr int NSCHED = {NSCHED};")
     w(f"#define W4I_VCLOB_{D} {vclob}")
     for H in (0, 1):
-        lines = gen_phase(c, H)
-        n_mfma = sum(x.startswith("v_mfma") for x in lines)
-        n_valu = sum(x.startswith("v_") and not x.startswith("v_mfma") for x in lines)
-        w(f"#elif W4I_PART == {1 + H}   // ---- phase H = {H}: {len(lines)} instructions, {n_mfma} MFMA, {n_valu} VALU")
-        w("asm volatile(")
-        w(cstr(lines))
-        ops_in = [f'[ka{i}] "v"(ka[{i}])' for i in range(c.NDS)] + [f'[vc{i}] "v"(vc[{i}])' for i in range(c.NVX)]
-        if H == 0:
-            ops_in += [f'[vp{i}] "v"(vp[{i}])' for i in range(c.NVX)]
-        if c.ODD and H == 0:
-            ops_in.append('[vodd] "v"(vodd)')
-        outs = ['[worst] "=v"(worst)']
-        if H == 0:
-            ops_in += ['[koff] "v"(k_off)', '[voff] "v"(v_off)', '[rk] "s"(w4i_rk)', '[rv] "s"(w4i_rv)', '[m0b] "s"(w4i_m0b)', '[sob] "s"(w4i_sob)']
-            outs.append('[st] "=&s"(w4i_st)')
-        w("    : " + ", ".join(outs))
-        w("    : " + ", ".join(ops_in))
-        w(f'    : "memory", "scc", W4I_VCLOB_{D}, LC_AGPR_ALL);')
-    lines = gen_tail(c)
+        w(f"#elif W4I_PART == {1 + H}   // ---- phase H = {H} (one statement per schedule, selected by the kernel's SCHED)")
+        for sched in range(NSCHED):
+            lines = ablate(gen_phase(c, H, sched), abl)
+            n_mfma = sum(x.startswith("v_mfma") for x in lines)
+            n_valu = sum(x.startswith("v_") and not x.startswith("v_mfma") for x in lines)
+            w(("if" if sched == 0 else "} else if") + f" constexpr (SCHED == {sched}) {{   // {len(lines)} instructions, {n_mfma} MFMA, {n_valu} VALU")
+            w("asm volatile(")
+            w(cstr(lines))
+            ops_in = [f'[ka{i}] "v"(ka[{i}])' for i in range(c.NDS)] + [f'[vc{i}] "v"(vc[{i}])' for i in range(c.NVX)]
+            if H == 0:
+                ops_in += [f'[vp{i}] "v"(vp[{i}])' for i in range(c.NVX)]
+            if c.ODD and H == 0:
+                ops_in.append('[vodd] "v"(vodd)')
+            outs = ['[worst] "=v"(worst)']
+            if H == 0:
+                ops_in += ['[koff] "v"(k_off)', '[voff] "v"(v_off)', '[rk] "s"(w4i_rk)', '[rv] "s"(w4i_rv)', '[m0b] "s"(w4i_m0b)', '[sob] "s"(w4i_sob)']
+                outs.append('[st] "=&s"(w4i_st)')
+            w("    : " + ", ".join(outs))
+            w("    : " + ", ".join(ops_in))
+            w(f'    : "memory", "scc", W4I_VCLOB_{D}, LC_AGPR_ALL);')
+        w("}")
+    lines = ablate(gen_tail(c), abl & 10)
     w(f"#elif W4I_PART == 3   // ---- tail: {len(lines)} instructions")
     w("asm volatile(")
     w(cstr(lines))
@@ -285,6 +321,13 @@ def render(D):
 
 def main():
     rc = 0
+    if "--diag" in sys.argv:
+        d = Path(sys.argv[sys.argv.index("--diag") + 1])
+        d.mkdir(parents=True, exist_ok=True)
+        for D in (64, 128):
+            for k in ABLATIONS:
+                (d / f"attn_w4i_d{D}_abl{k}.inc").write_text(render(D, k))
+        return 0
     for D in (64, 128):
         text, out = render(D), out_path(D)
         if "--check" in sys.argv:
