@@ -109,6 +109,8 @@ const char* lc_build_info(int* is_diag);
  *                  query rows, one wave per SIMD (attn_w4m.hip; 260 = its A/B twin with padded Q.K^T MFMAs),
  *                  8 / 4 / 2 = lock-step kernel with that many waves (any N % (32 x waves) == 0, every D <= 128)
  *   "w4y_sched"    schedule 0..2 of LC_HGEMM_MFMA256W4Y's generated loop body (tools/gen_hgemm_w4y.py; same bits, A/B knob)
+ *   "hgemm_tail"   1 (default) = when the 256-tile grid's last wave holds at most 128 tiles, the generated-loop kernel computes the
+ *                  full waves and the 128-tile kernel the four quadrants of each remaining tile; 0 = one launch
  *   "hgemm_raster" block -> C tile map of the tiled GEMM kernels: 0 = auto (2 when A + B exceed the 256 MiB Infinity Cache by half,
  *                  else 1), 1 = the reference's block swizzle (N panels of swizzle_stride columns, every XCD a contiguous id
  *                  range), 2 = XCD super-block raster (16 x 16 tile steps shared through the Infinity Cache, 4 x 8 per XCD;

@@ -39,8 +39,8 @@ int lc_probe_mfma_war(int delay, int kind, int queued, const void* a32x16, const
 int lc_diag_pollute(unsigned pattern, int what, void* stream);
 
 /* attn_fwd_w4i_kernel (D = 64 / 128, N % 256 == 0) with a class of instructions REMOVED from the generated phase statements
- * (tools/gen_attn_w4i.py --diag): abl bits 1 = no LDS-DMA, 2 = no LDS reads, 4 = no softmax VALU, 8 = no MFMA; available:
- * 1, 2, 3, 4, 7, 8.  Results are WRONG by design: timing only (tools/attn_w4i_ablate.py). */
+ * (tools/gen_attn_w4i.py --diag): abl bits 1 = no LDS-DMA, 2 = no LDS reads, 4 = no softmax VALU, 8 = no MFMA, 16 = no per-tile
+ * wait + barrier, 32 = no guard decision; available: 1, 2, 3, 4, 7, 8, 23, 55.  Results are WRONG by design: timing only (tools/attn_w4i_ablate.py). */
 int lc_diag_attn_w4i(int abl, const void* Q, const void* K, const void* V, void* O, int B, int H, int N, int D, void* stream);
 
 #ifdef __cplusplus

@@ -120,6 +120,8 @@ int lc_diag_attn_w4i_abl3(const void*, const void*, const void*, void*, int, int
 int lc_diag_attn_w4i_abl4(const void*, const void*, const void*, void*, int, int, int, int, void*);
 int lc_diag_attn_w4i_abl7(const void*, const void*, const void*, void*, int, int, int, int, void*);
 int lc_diag_attn_w4i_abl8(const void*, const void*, const void*, void*, int, int, int, int, void*);
+int lc_diag_attn_w4i_abl23(const void*, const void*, const void*, void*, int, int, int, int, void*);
+int lc_diag_attn_w4i_abl55(const void*, const void*, const void*, void*, int, int, int, int, void*);
 
 int lc_diag_attn_w4i(int abl, const void* Q, const void* K, const void* V, void* O, int B, int H, int N, int D, void* stream) {
   switch (abl) {
@@ -129,6 +131,8 @@ int lc_diag_attn_w4i(int abl, const void* Q, const void* K, const void* V, void*
     case 4: return lc_diag_attn_w4i_abl4(Q, K, V, O, B, H, N, D, stream);
     case 7: return lc_diag_attn_w4i_abl7(Q, K, V, O, B, H, N, D, stream);
     case 8: return lc_diag_attn_w4i_abl8(Q, K, V, O, B, H, N, D, stream);
+    case 23: return lc_diag_attn_w4i_abl23(Q, K, V, O, B, H, N, D, stream);
+    case 55: return lc_diag_attn_w4i_abl55(Q, K, V, O, B, H, N, D, stream);
     default: return ERR_ARG;
   }
 }

@@ -17,15 +17,27 @@ template <bool B_KN>
 __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __restrict__ A,
                                                                const half_t* __restrict__ B,
                                                                half_t* __restrict__ C, int M, int N, int K,
-                                                               int tiles_m, int tiles_n, int panel_w) {
+                                                               int tiles_m, int tiles_n, int panel_w, int rem_base) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = wave_id();
   const int wr = wave >> 1, wc = wave & 1;
   const int i16 = lane & 15, g = lane >> 4;
 
-  const TileCoord tc = block_tile(blockIdx.x, gridDim.x, tiles_m, tiles_n, panel_w);
-  const int m0 = tc.tm * BM1, n0 = tc.tn * BN1;
+  // rem_base < 0: this kernel's own grid of 128 x 128 tiles.  rem_base >= 0 (the 256-tile kernels' ragged last wave, lc_abi.hip
+  // launch_mfma256): tiles_m / tiles_n / panel_w describe the 256 x 256 tile grid, block b computes quadrant b & 3 of the 256-tile
+  // whose raster id is rem_base + (b >> 2) — the ids the big kernel's truncated grid left out.
+  int m0, n0;
+  if (rem_base < 0) {
+    const TileCoord tc = block_tile(blockIdx.x, gridDim.x, tiles_m, tiles_n, panel_w);
+    m0 = tc.tm * BM1;
+    n0 = tc.tn * BN1;
+  } else {
+    const int id = rem_base + ((int)blockIdx.x >> 2), qd = blockIdx.x & 3;
+    const TileCoord tc = panel_w < 0 ? raster_xcd16(id, tiles_m * tiles_n, tiles_m, tiles_n) : raster(id, tiles_m, tiles_n, panel_w);
+    m0 = tc.tm * 256 + (qd >> 1) * BM1;
+    n0 = tc.tn * 256 + (qd & 1) * BN1;
+  }
 
   // ---- LDS-DMA sources: 16 + 16 pieces of 1 KiB per K tile, 4 + 4 per wave
   const half_t* sa[4];

@@ -39,6 +39,7 @@ int g_tune_fp8_mx = 1;                       // fp8 GEMM: 1 = MX-scaled K=64 MFM
 int g_tune_attn_w4i_sched = 0;              // schedule of attn_fwd_w4i_kernel's generated phase statements (tools/gen_attn_w4i.py NSCHED; same bits)
 int g_tune_attn_nw = 0;                    // attention kernel for D = 128: 0 = auto, 128 / 64 / 8 / 4 / 2 (lc_abi.h)
 int g_tune_hgemm_auto = LC_HGEMM_MFMA256W4Y;   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
+int g_tune_hgemm_tail = 1;                   // 1 = hand the ragged last wave of the 256-tile kernel to the 128-tile kernel (launch_mfma256), 0 = one launch
 int g_tune_hgemm_raster = 0;                 // block -> C tile map: 0 = auto (by operand footprint, panel_tiles), 1 = the reference's block swizzle (N panels from
                                              // swizzle_stride, XCD-contiguous ids), 2 = XCD super-block raster (hgemm_mfma256.hip raster_xcd16)
 
@@ -182,8 +183,21 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   const int tiles_m = M / BM, tiles_n = N / BN;
   const int pw = panel_tiles(swizzle_stride, tiles_n, BN, ((size_t)M + N) * K * 2);
   const dim3 grid(tiles_m * tiles_n), block(512);
-  if (is_w4_variant(variant))
-    return launch_w4_family(A, B, C, M, N, K, variant, B_KN, tiles_m, tiles_n, pw, st);
+  if (is_w4_variant(variant)) {
+    // Ragged last wave (lc_tune_set "hgemm_tail"): T tiles on 256 CUs run ceil(T / 256) tile periods, the last one with T % 256
+    // workgroups.  When that remainder R is at most half a wave, the generated-loop kernel computes the first T − R raster
+    // ids and the 128-tile kernel the four quadrants of each of the other R (4 R <= 512 workgroups at two per CU: ONE period of
+    // a quarter-size tile) — 6144^3: 2.25 waves -> 2 + a short one instead of 3 (profiles/r3e_hgemm_tail.log).
+    const int T = tiles_m * tiles_n, R = T % 256;
+    const bool split = g_tune_hgemm_tail != 0 && T > 256 && R > 0 && R <= 128 &&
+                       w4_effective_variant(variant, B_KN, N, K) == LC_HGEMM_MFMA256W4Y;
+    if (!split) return launch_w4_family(A, B, C, M, N, K, variant, B_KN, tiles_m, tiles_n, pw, -1, st);
+    if (int rc = launch_w4_family(A, B, C, M, N, K, variant, B_KN, tiles_m, tiles_n, pw, T - R, st)) return rc;
+    auto kern = hgemm_mfma128_kernel<B_KN>;
+    if (int rc = set_dyn_lds(kern, HGEMM128_LDS)) return rc;
+    hipLaunchKernelGGL(kern, dim3(4 * R), dim3(256), HGEMM128_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw, T - R);
+    return check_launch();
+  }
   if (false) {
 #ifdef LC_DIAG
   } else if (variant == LC_HGEMM_MFMA256P2 && g_tune_hgemm_stamps) {
@@ -211,7 +225,7 @@ int launch_mfma128(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   auto kern = hgemm_mfma128_kernel<B_KN>;
   if (int rc = set_dyn_lds(kern, HGEMM128_LDS)) return rc;
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), HGEMM128_LDS, st, A, B, C, M, N, K, tiles_m,
-                     tiles_n, pw);
+                     tiles_n, pw, -1);
   return check_launch();
 }
 
@@ -483,6 +497,11 @@ int lc_tune_set(const char* key, int value) {
     if (value < 0 || value > 2) return LC_ERR_ARG;
 #endif
     g_tune_w4y_sched = value;
+    return LC_OK;
+  }
+  if (strcmp(key, "hgemm_tail") == 0) {
+    if (value < 0 || value > 1) return LC_ERR_ARG;
+    g_tune_hgemm_tail = value;
     return LC_OK;
   }
   if (strcmp(key, "hgemm_raster") == 0) {

@@ -44,8 +44,9 @@ extern int g_tune_w4y_sched;   // schedule of hgemm_w4y_kernel's generated loop 
 // launchers living in their own translation units
 // tu_w4.hip: LC_HGEMM_MFMA256W4 / W4S / W4B / W4C (M, N % 256 == 0, K % 64 == 0 checked by the caller)
 int w4_effective_variant(int variant, bool b_kn, int N, int K);   // W4C / W4X / W4Y -> W4B when 32-bit DMA offsets could overflow
+// nblk > 0: launch only the first nblk blocks (hgemm_w4y_kernel only; the caller hands the remaining raster ids to the 128-tile kernel)
 int launch_w4_family(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant, bool b_kn,
-                     int tiles_m, int tiles_n, int panel_w, hipStream_t st);
+                     int tiles_m, int tiles_n, int panel_w, int nblk, hipStream_t st);
 // tu_attn_w4.hip: 4-wave x 64-row merged-phase attention kernel, D = 128, N % 256 == 0; pad = A/B knob (0 / 4 wait states)
 // tu_valu.hip: the vector-ALU ladder (hgemm_valu.hip), rung = LC_HGEMM_VALU_*
 int launch_valu_rung(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int rung, hipStream_t st);

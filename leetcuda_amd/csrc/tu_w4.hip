@@ -13,6 +13,8 @@ int launch_w4_one(const half_t* A, const half_t* B, half_t* C, int M, int N, int
   return check_launch();
 }
 
+int g_w4_nblk = -1;   // blocks to launch (< tiles_m * tiles_n when the ragged last wave goes to the 128-tile kernel); set per call
+
 template <bool B_KN, int Y>   // Y: -1 = hgemm_w4x_kernel, 0.. = hgemm_w4y_kernel<.., Y>
 int launch_w4x_one(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int tiles_m, int tiles_n, int pw,
                    hipStream_t st) {
@@ -21,7 +23,8 @@ int launch_w4x_one(const half_t* A, const half_t* B, half_t* C, int M, int N, in
     else return hgemm_w4y_kernel<B_KN, Y>;
   }();
   if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
+  hipLaunchKernelGGL(kern, dim3(g_w4_nblk > 0 ? g_w4_nblk : tiles_m * tiles_n), dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m,
+                     tiles_n, pw);
   return check_launch();
 }
 
@@ -77,7 +80,8 @@ int w4_effective_variant(int variant, bool b_kn, int N, int K) {
 }
 
 int launch_w4_family(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant, bool b_kn,
-                     int tiles_m, int tiles_n, int panel_w, hipStream_t st) {
+                     int tiles_m, int tiles_n, int panel_w, int nblk, hipStream_t st) {
+  g_w4_nblk = (nblk > 0 && nblk < tiles_m * tiles_n && w4_effective_variant(variant, b_kn, N, K) == LC_HGEMM_MFMA256W4Y) ? nblk : -1;
   return b_kn ? launch_w4_t<true>(A, B, C, M, N, K, variant, tiles_m, tiles_n, panel_w, st)
               : launch_w4_t<false>(A, B, C, M, N, K, variant, tiles_m, tiles_n, panel_w, st);
 }

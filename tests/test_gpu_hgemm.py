@@ -316,3 +316,41 @@ def test_xcd_super_block_raster_computes_the_same_bits(layout):
                 capi.tune("hgemm_raster", 0)
             outs.append(c)
         assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1]), (M, N, K)
+
+
+@pytest.mark.parametrize("layout", ["nn", "tn"])
+@pytest.mark.parametrize("raster", [1, 2])
+def test_ragged_last_wave_goes_to_the_128_tile_kernel(oracle, layout, raster):
+    """lc_tune_set "hgemm_tail" = 1 (default): when the 256-tile grid's last wave holds at most 128 tiles, hgemm_w4y_kernel runs the
+    full waves and hgemm_mfma128_kernel the four quadrants of every remaining tile (lc_abi.hip launch_mfma256).  Every element is
+    written exactly once, both halves agree with the one-launch result to fp16 rounding of differently ordered fp32 sums, and
+    sampled rows match the oracle — with both block -> tile maps (the remainder ids differ between them)."""
+    from leetcuda_amd import capi, host
+    capi.load()
+    lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
+    for M, N, K in ((256 * 18, 256 * 18, 256), (256 * 17, 256 * 19, 192), (256 * 9, 256 * 29, 128)):   # T % 256 = 68, 67, 5
+        assert 0 < (M // 256) * (N // 256) % 256 <= 128
+        torch.manual_seed(M + N + K)
+        a = torch.randn(M, K, dtype=torch.half, device="cuda")
+        b = torch.randn(K, N, dtype=torch.half, device="cuda")
+        bb = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
+        outs = []
+        capi.tune("hgemm_raster", raster)
+        try:
+            for tail in (0, 1):
+                capi.tune("hgemm_tail", tail)
+                c = torch.full((M, N), float("nan"), dtype=torch.half, device="cuda")
+                capi.hgemm(a, bb, c, layout=lay, variant=capi.HGEMM_MFMA256W4Y, swizzle_stride=2048)
+                torch.cuda.synchronize()
+                outs.append(c)
+        finally:
+            capi.tune("hgemm_tail", 1)
+            capi.tune("hgemm_raster", 0)
+        assert torch.isfinite(outs[1]).all()
+        d = (outs[0].float() - outs[1].float()).abs()
+        assert d.max().item() <= 0.0625 and (d > 0).float().mean().item() < 0.2, (d.max().item(), (d > 0).float().mean().item())
+        assert (d > 0).any()                                     # the remainder really went through the other kernel
+        rows = [0, 255, 256, M // 2 + 3, M - 1]
+        truth = oracle.hgemm(a[rows].contiguous(), b, len(rows), N, K, 0, "f32")
+        ok, mx, _ = tol.hgemm_close(outs[1][rows].float().cpu().numpy(), truth, K)
+        assert ok, mx

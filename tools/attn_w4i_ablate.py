@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Price the instruction classes of the generated attention stream (attn_fwd_w4i_kernel) on hardware: the full kernel against
 copies with one class REMOVED from the phase statements (liblc_diag.so, lc_diag_attn_w4i; results WRONG by design).
-  abl bits: 1 no LDS-DMA, 2 no LDS reads, 4 no softmax VALU, 8 no MFMA      (0 = the shipped kernel through the C-ABI)
+  abl bits: 1 no LDS-DMA, 2 no LDS reads, 4 no softmax VALU, 8 no MFMA, 16 no per-tile wait + barrier, 32 no guard decision      (0 = the shipped kernel through the C-ABI)
 usage: attn_w4i_ablate.py [--seconds S]      prints TFLOP/s-equivalent (matmul FLOPs / time) on randn and on zero-filled inputs"""
 import sys
 from pathlib import Path
@@ -35,7 +35,8 @@ def rate(step, flops):
     return flops / (e0.elapsed_time(e1) / n) * 1e-9
 
 
-NAMES = {0: "full", 1: "no DMA", 2: "no LDS reads", 3: "no DMA, no reads", 4: "no softmax VALU", 7: "MFMA only", 8: "no MFMA"}
+NAMES = {0: "full", 1: "no DMA", 2: "no LDS reads", 3: "no DMA, no reads", 4: "no softmax VALU", 7: "MFMA only", 8: "no MFMA",
+         23: "MFMA only, no barrier", 55: "MFMA only, no barrier, no guard"}
 for shape in ((4, 32, 4096, 128), (1, 48, 8192, 64)):
     B, H, N, D = shape
     fl = host.mha_matmul_flops(B, H, N, D)
@@ -46,7 +47,7 @@ for shape in ((4, 32, 4096, 128), (1, 48, 8192, 64)):
         q, k, v = mk(), mk(), mk()
         o = torch.zeros_like(q)
         row = []
-        for abl in (0, 1, 2, 3, 4, 7, 8):
+        for abl in (0, 1, 2, 3, 4, 7, 8, 23, 55):
             if abl == 0:
                 capi.tune("attn_nw", 514)
                 try:

@@ -31,7 +31,8 @@ front of the statement (slow path, prologue) are covered by the s_nop the C++ si
 
 usage: tools/gen_attn_w4i.py [--check]
        tools/gen_attn_w4i.py --diag DIR    (liblc_diag.so only: ablated copies attn_w4i_d<D>_abl<K>.inc of the phase statements —
-                                            K bits: 1 no LDS-DMA, 2 no LDS reads, 4 no softmax VALU, 8 no MFMA; results WRONG by
+                                            K bits: 1 no LDS-DMA, 2 no LDS reads, 4 no softmax VALU, 8 no MFMA, 16 no per-tile wait + barrier, 32 no guard decision
+                                            (the last two act in attn_w4i.hip); results WRONG by
                                             design, timing only: tools/attn_w4i_ablate.py)"""
 import sys
 from pathlib import Path
@@ -256,7 +257,7 @@ def cstr(lines):
     return "\n".join(f'    "{ln}\\n\\t"' for ln in lines)
 
 
-ABLATIONS = (1, 2, 3, 4, 7, 8)
+ABLATIONS = (1, 2, 3, 4, 7, 8, 23, 55)   # + 16: no per-tile wait + barrier, + 32: no guard decision (attn_w4i.hip W4I_ABL)
 
 
 def ablate(lines, abl):
