@@ -420,10 +420,11 @@ def test_generalised_and_generated_kernels_reproduce_the_reference_kernel_bit_fo
     kernels = (512, 513, 514) if D == 128 else (513, 514)
     for ci, kk in enumerate((k, k2, k3)):
         outs = {}
-        for nw in kernels:
+        for nw, sched in [(k_, 0) for k_ in kernels] + [(514, 1)]:        # (514, 1): the generated kernel's second schedule
             capi.tune("attn_nw", nw)
+            capi.tune("attn_w4i_sched", sched)
             try:
-                want = {512: "attn_fwd_w4n_kernel", 513: "attn_fwd_w4g_kernel", 514: "attn_fwd_w4i_kernel"}[nw]
+                want = {512: "attn_fwd_w4n_kernel", 513: "attn_fwd_w4g_kernel", 514: f"attn_fwd_w4i_kernel<{D},{sched}>"}[nw]
                 assert capi.attn_kernel_name(N, D).startswith(want)
                 capi.attn_slowpath_stats(reset=True)
                 o = torch.full_like(q, float("nan"))
@@ -432,11 +433,13 @@ def test_generalised_and_generated_kernels_reproduce_the_reference_kernel_bit_fo
                 st = capi.attn_slowpath_stats(reset=True)
             finally:
                 capi.tune("attn_nw", 0)
-            assert (st[0] > 0) == (ci > 0), (nw, ci, st)
-            outs[nw] = o
-        for nw in kernels[1:]:
-            assert torch.equal(outs[kernels[0]], outs[nw]), (D, ci, nw)
-        _check(oracle, q, kk, v, outs[514], max_abs=8e-3)
+                capi.tune("attn_w4i_sched", 0)
+            assert (st[0] > 0) == (ci > 0), (nw, sched, ci, st)
+            outs[(nw, sched)] = o
+        ref = outs[(kernels[0], 0)]
+        for key, o in outs.items():
+            assert torch.equal(ref, o), (D, ci, key)
+        _check(oracle, q, kk, v, outs[(514, 1)], max_abs=8e-3)
 
 
 @pytest.mark.parametrize("nw", [0, 514, 8])

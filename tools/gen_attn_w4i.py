@@ -71,6 +71,9 @@ class Cfg:
         self.E = alloc(4)
         self.VCO = alloc(4) if self.ODD else None     # vc[u] + vodd
         self.VPO = alloc(4) if self.ODD else None     # vp[u] + vodd
+        self.KA = alloc(self.NDS)                     # schedule 1: this tile period's K(t+1) fragment addresses ...
+        self.VC = alloc(4)                            # ... Vᵀ addresses of tile t ...
+        self.VP = alloc(4)                            # ... and of tile t − 1 (kept in registers, advanced inside the H = 1 statement)
         self.T = alloc(3)                             # temporaries
         self.LB = top[0] & ~7                         # first reserved register = amdgpu_num_vgpr
 
@@ -87,8 +90,11 @@ def a(n, cnt=4):
     return f"a[{n}:{n + cnt - 1}]"
 
 
-NSCHED = 2   # 0: reads from slot 0, LDS-DMA pieces every 8 slots from slot 3 (they share slots with the reads of the first quarter);
-             # 1: the same reads, LDS-DMA pieces only in slots that carry no LDS read
+NSCHED = 2   # 0: softmax pairs spread over the whole phase, LDS addresses of a tile period computed by hipcc between the statements;
+             # 1: (a) the softmax finishes early (D = 128: a pair every 3 slots instead of 4), so the block totals and the guard's
+             #    v_max sit in MFMA shadows and the statement ends with MFMAs only; (b) the tile period's LDS addresses live in
+             #    reserved registers and are advanced for tile t + 1 inside the H = 1 statement (no address arithmetic in the gap
+             #    between two tiles); (c) LDS-DMA pieces only in slots that carry no LDS read
 
 
 def read_schedule(c):
@@ -135,25 +141,45 @@ def gen_phase(c, H, sched=0):
     def Er(setp, i):
         return v(c.E + 2 * (setp & 1) + i)
 
+    def areg(arr, u):
+        """address register u of `arr` (ka / vc / vp): an operand (schedule 0) or a reserved register (schedule 1)"""
+        if sched == 0:
+            return f"%[{arr}{u}]"
+        return v({"ka": c.KA, "vc": c.VC, "vp": c.VP}[arr] + u)
+
     def vaddr(arr, db):
         """register holding the transpose-read address of column block db of the tile `arr` points at"""
         if not c.ODD:
-            return f"%[{arr}{db}]"
+            return areg(arr, db)
         if db & 1:
             return v((c.VCO if arr == "vc" else c.VPO) + (db >> 1))
-        return f"%[{arr}{db >> 1}]"
+        return areg(arr, db >> 1)
 
     fill = {s: [] for s in range(-1, c.NS + 1)}     # slot -> filler instructions behind its MFMA (−1: before the first MFMA)
 
     # ---- l += totals of the previous phase (SUM), per block, anywhere before the block's totals are rewritten (its last pair's sums)
     for qb in range(4):
-        fill[c.SPP * 2 * qb].append(f"v_add_f32 {v(c.LRUN + qb)}, {v(c.LRUN + qb)}, {v(c.SUM + qb)}")
+        fill[(3 if (sched == 1 and c.SPP == 4) else c.SPP) * 2 * qb].append(f"v_add_f32 {v(c.LRUN + qb)}, {v(c.LRUN + qb)}, {v(c.SUM + qb)}")
     # ---- odd-pair Vᵀ addresses of this tile period (D = 128): H = 0 computes both sets, H = 1 reuses VCO
-    if c.ODD and H == 0:
+    if c.ODD and H == 0 and sched == 0:
         for u in range(4):
             fill[-1].append(f"v_add_u32 {v(c.VPO + u)}, %[vp{u}], %[vodd]")      # needed from slot 1 on (set B reads)
         for u in range(4):
             fill[2 + 2 * u].append(f"v_add_u32 {v(c.VCO + u)}, %[vc{u}], %[vodd]")   # needed from slot NS / 2 on
+    # ---- schedule 1, H = 1: advance the address registers to tile t + 1 once their last readers of this tile period are issued
+    # (K fragments: first half; Vᵀ set A of tile t: slots NS / 2 .. NS / 2 + NRV − 1; VP / VPO are read by H = 0 only)
+    if sched == 1 and H == 1:
+        upd = [f"v_mov_b32 {v(c.VP + u)}, {v(c.VC + u)}" for u in range(4)]
+        if c.ODD:
+            upd += [f"v_mov_b32 {v(c.VPO + u)}, {v(c.VCO + u)}" for u in range(4)]
+        upd += [f"v_add_u32 {v(c.VC + u)}, %[sbn1], %[vx{u}]" for u in range(4)]
+        if c.ODD:
+            upd += [f"v_add_u32 {v(c.VCO + u)}, {v(c.VC + u)}, %[vodd]" for u in range(4)]
+        upd += [f"v_add_u32 {v(c.KA + d)}, %[sbn2], %[kx{d}]" for d in range(c.NDS)]
+        s0 = c.NS // 2 + c.NRV + 1
+        assert s0 + len(upd) <= c.NS, (s0, len(upd))
+        for i, ins in enumerate(upd):
+            fill[s0 + i].append(ins)
     # ---- softmax.  A block's FIRST pair (p = 2 qb) exponentiates straight into the block's two row-sum registers PS[qb][0 / 1]
     # (0 + e = e: no move); the later pairs go through the exp sets and are added on.  The pack of the first pair reads the PS
     # registers before the second pair's sums change them (pack of pair p and sums of pair p + 1 sit in different pairs' slots).
@@ -161,8 +187,9 @@ def gen_phase(c, H, sched=0):
         kvb, qb, k2 = pair(p)
         return PSr(qb, i) if (kvb == 0 and k2 == 0) else Er(p, i)
 
+    spp = 3 if (sched == 1 and c.SPP == 4) else c.SPP
     for p in range(17):
-        base = c.SPP * p
+        base = spp * p
         if c.SPP == 4:
             plan = {"a0": base, "x0": base, "a1": base + 1, "c": base + 2, "x1": base + 2}
         else:
@@ -220,7 +247,7 @@ def gen_phase(c, H, sched=0):
             kind, ci = rd[s]
             if kind == "k":
                 kr = c.K + c.KBUF * H + 4 * ci
-                e(f"ds_read_b128 {a(kr)}, %[ka{ci % c.NDS}] offset:{H * 32 * c.ROWB + (ci // c.NDS) * 16 * c.ROWB}")
+                e(f"ds_read_b128 {a(kr)}, {areg('ka', ci % c.NDS)} offset:{H * 32 * c.ROWB + (ci // c.NDS) * 16 * c.ROWB}")
             else:
                 set_a = kind == "va"
                 rdb, rx = (0 if set_a else c.NDB // 2) + (ci >> 1), ci & 1
@@ -232,18 +259,29 @@ def gen_phase(c, H, sched=0):
             e(ins)
     for ins in fill[c.NS]:
         e(ins)
-    # ---- the overflow guard's input: the largest bit pattern of the four block totals (non-negative floats order like integers)
-    e(f"v_max3_u32 {v(c.T)}, {v(c.SUM)}, {v(c.SUM + 1)}, {v(c.SUM + 2)}")
-    e(f"v_max_u32 %[worst], {v(c.T)}, {v(c.SUM + 3)}")
+    # ---- the overflow guard's input: the largest bit pattern of the four block totals (non-negative floats order like integers);
+    # when the softmax finished inside the phase (schedule 1, D = 128) the two v_max are moved up behind the last total
+    gmax = [f"v_max3_u32 {v(c.T)}, {v(c.SUM)}, {v(c.SUM + 1)}, {v(c.SUM + 2)}", f"v_max_u32 %[worst], {v(c.T)}, {v(c.SUM + 3)}"]
+    last_total = max(i for i, ln in enumerate(L) if ln.startswith(f"v_add_f32 {v(c.SUM + 3)},"))
+    nxt = [i for i, ln in enumerate(L) if i > last_total and ln.startswith("v_mfma")]
+    if sched == 1 and len(nxt) >= 4:
+        L.insert(nxt[0] + 1, gmax[0])          # behind the next MFMA ...
+        L.insert(nxt[1] + 2, gmax[1])          # ... and the one after it (indices shift by the first insertion)
+    else:
+        L.extend(gmax)
     return L
 
 
-def gen_tail(c):
-    """Oᵀ += Vᵀ(2T−1)·Pᵀ(2T−1) after the loop: P in buffer B, set A already in registers, set B (second half of the last tile) read here."""
+def gen_tail(c, sched=0):
+    """Oᵀ += Vᵀ(2T−1)·Pᵀ(2T−1) after the loop: P in buffer B, set A already in registers, set B (second half of the last tile) read here.
+    (schedule 1: the last H = 1 statement has advanced VC to the next tile; the last tile's addresses are in VP / VPO)"""
     L = ["s_waitcnt lgkmcnt(0)"]
     for ci in range(c.NRV):
         rdb, rx = c.NDB // 2 + (ci >> 1), ci & 1
-        addr = f"%[vc{rdb}]" if not c.ODD else (v(c.VCO + (rdb >> 1)) if rdb & 1 else f"%[vc{rdb >> 1}]")
+        if sched == 0:
+            addr = f"%[vc{rdb}]" if not c.ODD else (v(c.VCO + (rdb >> 1)) if rdb & 1 else f"%[vc{rdb >> 1}]")
+        else:
+            addr = v(c.VP + rdb) if not c.ODD else (v(c.VPO + (rdb >> 1)) if rdb & 1 else v(c.VP + (rdb >> 1)))
         L.append(f"ds_read_b64_tr_b16 {v(c.VF + 4 * rdb + 2 * rx, 2)}, {addr} offset:{32 * c.ROWB + rx * 16 * c.ROWB}")
     L.append("s_waitcnt lgkmcnt(0)")
     for i in range(4 * c.NDB):
@@ -283,7 +321,7 @@ def render(D, abl=0):
     w = out.append
     w(f"// GENERATED by tools/gen_attn_w4i.py (D = {D}) — do not edit.  Register map + the two phase statements + the tail statement.")
     w(f"#if W4I_PART == 0   // ---- register map (v[{c.LB}:255] are reserved: the kernel is compiled with amdgpu_num_vgpr({c.LB}))")
-    for name in ("LB", "SA", "SB", "PA", "PB", "VF", "NEGM", "PS", "SUM", "LRUN"):
+    for name in ("LB", "SA", "SB", "PA", "PB", "VF", "NEGM", "PS", "SUM", "LRUN", "KA", "VC", "VP") + (("VCO", "VPO") if c.ODD else ()):
         w(f"static constexpr int {name} = {getattr(c, name)};")
     w(f"static constexpr int NSCHED = {NSCHED};")
     w(f"#define W4I_VCLOB_{D} {vclob}")
@@ -296,12 +334,18 @@ def render(D, abl=0):
             w(("if" if sched == 0 else "} else if") + f" constexpr (SCHED == {sched}) {{   // {len(lines)} instructions, {n_mfma} MFMA, {n_valu} VALU")
             w("asm volatile(")
             w(cstr(lines))
-            ops_in = [f'[ka{i}] "v"(ka[{i}])' for i in range(c.NDS)] + [f'[vc{i}] "v"(vc[{i}])' for i in range(c.NVX)]
-            if H == 0:
-                ops_in += [f'[vp{i}] "v"(vp[{i}])' for i in range(c.NVX)]
-            if c.ODD and H == 0:
-                ops_in.append('[vodd] "v"(vodd)')
-            outs = ['[worst] "=v"(worst)']
+            outs = ['[worst] "=&v"(worst)']      # (written before the statement's last operand reads: early clobber)
+            if sched == 0:
+                ops_in = [f'[ka{i}] "v"(ka[{i}])' for i in range(c.NDS)] + [f'[vc{i}] "v"(vc[{i}])' for i in range(c.NVX)]
+                if H == 0:
+                    ops_in += [f'[vp{i}] "v"(vp[{i}])' for i in range(c.NVX)]
+                if c.ODD and H == 0:
+                    ops_in.append('[vodd] "v"(vodd)')
+            elif H == 1:
+                ops_in = [f'[kx{i}] "v"(kx[{i}])' for i in range(c.NDS)] + [f'[vx{i}] "v"(vx[{i}])' for i in range(c.NVX)]
+                ops_in += ['[sbn1] "s"(w4i_sbn1)', '[sbn2] "s"(w4i_sbn2)'] + (['[vodd] "v"(vodd)'] if c.ODD else [])
+            else:
+                ops_in = []
             if H == 0:
                 ops_in += ['[koff] "v"(k_off)', '[voff] "v"(v_off)', '[rk] "s"(w4i_rk)', '[rv] "s"(w4i_rv)', '[m0b] "s"(w4i_m0b)', '[sob] "s"(w4i_sob)']
                 outs.append('[st] "=&s"(w4i_st)')
@@ -309,13 +353,16 @@ def render(D, abl=0):
             w("    : " + ", ".join(ops_in))
             w(f'    : "memory", "scc", W4I_VCLOB_{D}, LC_AGPR_ALL);')
         w("}")
-    lines = ablate(gen_tail(c), abl & 10)
-    w(f"#elif W4I_PART == 3   // ---- tail: {len(lines)} instructions")
-    w("asm volatile(")
-    w(cstr(lines))
-    w("    :")
-    w("    : " + ", ".join(f'[vc{i}] "v"(vc[{i}])' for i in range(c.NVX)))
-    w(f'    : "memory", W4I_VCLOB_{D}, LC_AGPR_ALL);')
+    w("#elif W4I_PART == 3   // ---- tail")
+    for sched in range(NSCHED):
+        lines = ablate(gen_tail(c, sched), abl & 10)
+        w(("if" if sched == 0 else "} else if") + f" constexpr (SCHED == {sched}) {{   // {len(lines)} instructions")
+        w("asm volatile(")
+        w(cstr(lines))
+        w("    :")
+        w("    : " + (", ".join(f'[vc{i}] "v"(vc[{i}])' for i in range(c.NVX)) if sched == 0 else '[zero] "n"(0)'))
+        w(f'    : "memory", W4I_VCLOB_{D}, LC_AGPR_ALL);')
+    w("}")
     w("#endif")
     return "\n".join(out) + "\n"
 
