@@ -34,6 +34,35 @@ def _newer(target: Path, sources) -> bool:
     return all(Path(s).stat().st_mtime <= t for s in sources)
 
 
+def _digest(paths, extra="") -> str:
+    """sha256 over the CONTENTS of `paths` (+ `extra`): what decides whether a built artefact is current.  mtimes do not survive
+    the snapshot that carries the tree to a GPU box (every box used to rebuild the library for ~140 s before its first test)."""
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for q in sorted(Path(x) for x in paths):
+        h.update(str(q.relative_to(ROOT) if q.is_relative_to(ROOT) else q).encode())
+        h.update(q.read_bytes() if q.exists() else b"<missing>")
+    return h.hexdigest()
+
+
+def _stamps() -> dict:
+    try:
+        return json.loads((LIBDIR / "stamps.json").read_text())
+    except Exception:
+        return {}
+
+
+def _fresh(target: Path, key: str, digest: str) -> bool:
+    return target.exists() and _stamps().get(key) == digest
+
+
+def _mark(key: str, digest: str):
+    LIBDIR.mkdir(parents=True, exist_ok=True)
+    st = _stamps()
+    st[key] = digest
+    (LIBDIR / "stamps.json").write_text(json.dumps(st, indent=1))
+
+
 def _run(cmd, **kw):
     print("[build]", " ".join(str(c) for c in cmd), flush=True)
     subprocess.run([str(c) for c in cmd], check=True, **kw)
@@ -92,7 +121,8 @@ def build_abi(force: bool = False, audit: bool = True) -> Path:
     if os.environ.get("LC_DIAG") == "1":   # the ablation loops (results WRONG by design) exist only inside a diagnosis build
         subprocess.run([sys.executable, str(ROOT / "tools" / "gen_hgemm_w4y.py"), "--diag", str(LIBDIR / "gen")], check=True)
         flags = flags + [f"-I{LIBDIR / 'gen'}"]
-    if not force and _newer(out, srcs) and _stamp_ok(stamp, flags):
+    dg = _digest(srcs, " ".join(str(f) for f in flags))
+    if not force and _fresh(out, "abi", dg) and _stamp_ok(stamp, flags):
         return out
     # translation units (lc_abi.hip + the compile-heavy literal-AGPR kernels in tu_*.hip), compiled in parallel; each
     # is compiled twice: to an object and (device side only) to assembly for the audit
@@ -140,6 +170,7 @@ def build_abi(force: bool = False, audit: bool = True) -> Path:
             raise RuntimeError("ISA audit failed (leetcuda_amd/isa_audit.py):\n  " + "\n  ".join(bad))
     _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, "-ldl"])
     stamp.write_text(json.dumps({"flags": [str(f) for f in flags]}))
+    _mark("abi", dg)
     return out
 
 
@@ -151,7 +182,8 @@ def build_diag(force: bool = False) -> Path:
     srcs = sorted((CSRC / "diag").glob("*.hip")) + [CSRC / "lc_common.h", ROOT / "include" / "lc_diag.h", CSRC / "attn_w4i.hip",
                                                      CSRC / "attn_w4g.hip", CSRC / "attn_w4n.hip", CSRC / "attn_w4m.hip",
                                                      ROOT / "tools" / "gen_attn_w4i.py"]
-    if not force and _newer(out, srcs):
+    dg = _digest(srcs)
+    if not force and _fresh(out, "diag", dg):
         return out
     gen = LIBDIR / "gen"
     subprocess.run([sys.executable, str(ROOT / "tools" / "gen_attn_w4i.py"), "--diag", str(gen)], check=True)
@@ -180,6 +212,7 @@ def build_diag(force: bool = False) -> Path:
             sys.stdout.write(log[-6000:])
             raise subprocess.CalledProcessError(pr.returncode, pr.args)
     _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *[o for o, _ in jobs]])
+    _mark("diag", dg)
     return out
 
 
@@ -187,10 +220,12 @@ def build_cpp_bench(force: bool = False) -> Path:
     """tools/cpp/hgemm_bench.bin: the torch-free C++ bench / error-check harness; links only the C-ABI."""
     d = ROOT / "tools" / "cpp"
     out = d / "hgemm_bench.bin"
-    abi = build_abi(False)
-    if not force and _newer(out, [d / "hgemm_bench.cpp", d / "Makefile", ROOT / "include" / "lc_abi.h", abi]):
+    build_abi(False)
+    dg = _digest([d / "hgemm_bench.cpp", d / "Makefile", ROOT / "include" / "lc_abi.h"])   # (links the C-ABI dynamically: the .so's contents do not matter)
+    if not force and _fresh(out, "cpp_bench", dg):
         return out
     _run(["make", "-C", d, "-B"])
+    _mark("cpp_bench", dg)
     return out
 
 
@@ -198,11 +233,13 @@ def build_oracle(force: bool = False) -> Path:
     """gcc -> oracle/liblc_oracle.so (CPU restatement of the reference algorithms; TEST INFRASTRUCTURE)."""
     out = ORACLE / ORACLE_NAME
     srcs = [ORACLE / "lc_oracle.c", ORACLE / "lc_oracle.h"]
-    if not force and _newer(out, srcs):
+    dg = _digest(srcs)
+    if not force and _fresh(out, "oracle", dg):
         return out
     cc = shutil.which("gcc") or "cc"
     _run([cc, "-O3", "-mavx2", "-mfma", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-o", out,
           ORACLE / "lc_oracle.c", "-lm"])
+    _mark("oracle", dg)
     return out
 
 
@@ -224,7 +261,8 @@ def build_torch_ext(force: bool = False):
     for name in ("toy_hgemm", "flash_attn_lib"):
         src = CSRC / "torch" / f"{name}.cpp"
         out = PKG / f"{name}{suffix}"
-        if not force and _newer(out, [src, CSRC / "torch" / "torch_shim.h", abi]):
+        dg = _digest([src, CSRC / "torch" / "torch_shim.h", ROOT / "include" / "lc_abi.h"])
+        if not force and _fresh(out, f"torch_{name}", dg):
             outs.append(out)
             continue
         cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1",
@@ -234,6 +272,7 @@ def build_torch_ext(force: bool = False):
                "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-ltorch_python",
                f"-Wl,-rpath,{torch_lib}"]
         _run(cmd)
+        _mark(f"torch_{name}", dg)
         outs.append(out)
     return outs
 

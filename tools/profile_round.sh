@@ -9,5 +9,8 @@ pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES
 pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+# summarise ON the box (the databases can exceed what gpurun merges back) and ship the summaries inside gpurun_out/
+python tools/summarize_prof.py $TAG > $OUT/summary.log 2>&1; echo "summary rc=$?" | tee -a $OUT/steps.log
+cp profiles/${TAG}_* $OUT/ 2>/dev/null
 find $OUT -name "*.db" -size +20M -delete
 du -sh $OUT | tee -a $OUT/steps.log
