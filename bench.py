@@ -130,7 +130,7 @@ def pmc_traffic(kernel: str, workload: str | None = None):
         return None
 
 
-def hgemm_traffic_model(M, N, K, tile=256, xcds=8, cus_per_xcd=32, panel_w=8):
+def hgemm_traffic_model(M, N, K, tile=256, xcds=8, cus_per_xcd=32, panel_w=8, in_bytes=2, out_bytes=2):
     """L2-compulsory fabric bytes of the 256x256-tile GEMM with the XCD-aware raster: the cus_per_xcd tiles an XCD runs at
     one time form a (cus_per_xcd / panel_w) x panel_w block of C tiles, so one "XCD wave" fetches that many A row panels
     and panel_w B column panels (tile x K halves each) once into its L2; plus one write of C.  8192^3: 32 waves x 12
@@ -139,7 +139,7 @@ def hgemm_traffic_model(M, N, K, tile=256, xcds=8, cus_per_xcd=32, panel_w=8):
     tiles = (M // tile) * (N // tile)
     waves = tiles / (xcds * cus_per_xcd) * xcds
     panels = cus_per_xcd // panel_w + panel_w
-    return waves * panels * tile * K * 2 + M * N * 2
+    return waves * panels * tile * K * in_bytes + M * N * out_bytes
 
 
 def roofline(kernel, flops, nbytes, ms_kernel, workload=None, peak=PEAK):
@@ -337,6 +337,11 @@ def bench_fp8(w, args, steps=10):
            "workload": f"GEMM M=N=K={n} fp8 e4m3 TN (BASELINE config 5b), randn inputs cast to e4m3, alpha 1/16",
            "roofline": roofline("gemm_fp8_w4_kernel", flops, 2.0 * n * n + 2.0 * n * n, ms_kernel, workload=f"fp8_{n}",
                                 peak=host.MI355X_FP8_MX_DENSE_PEAK_TFLOPS)}
+    out["roofline"]["traffic_model"] = {
+        "bytes": hgemm_traffic_model(n, n, n, in_bytes=1),
+        "note": "L2-compulsory fabric bytes of 256x256 tiles with 4 x 8 tiles per XCD (12 one-byte panels per 32 tiles + C once): what the "
+                "counter reads; under the XCD super-block raster the 8 XCDs of a step share 16 + 16 panels through the Infinity Cache, "
+                "so HBM sees about a third of it (DESIGN.md 4.13c)"}
     del a8, b8, c8
     return out
 
