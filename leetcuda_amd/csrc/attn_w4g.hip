@@ -27,7 +27,9 @@ LC_DEVINL void w4g_wait_v4(half4_t& a, half4_t& b, half4_t& c, half4_t& d) {   /
 
 template <int D>
 struct W4G {
-  static constexpr int NDS = D / 32, NDB = D / 16, ROWB = 2 * D;
+  // ROWB = bytes per K / V row IN LDS; GROWB = in global memory.  D = 96 (attn_w4i.hip only) keeps D = 128's 256-B LDS rows — 12 of
+  // the 16 chunks are real, the LDS-DMA lanes of the other four re-fetch a valid chunk — so every layout formula of D = 128 holds.
+  static constexpr int NDS = D / 32, NDB = D / 16, GROWB = 2 * D, ROWB = D == 96 ? 256 : 2 * D;
   static constexpr int TILE = KVB * ROWB, SLOT = 2 * TILE, LDS = 4 * SLOT;
   static constexpr int NS = 16 * NDS;                 // MFMA slots per phase
   static constexpr int NRV = NDB, NRK = 2 * NDS;      // transpose reads per Vᵀ set (NDB / 2 blocks x 2), K fragments per half-tile
@@ -35,8 +37,8 @@ struct W4G {
   static constexpr int PPW = TILE / 1024 / 4;         // pieces per wave and operand
   static constexpr int KBUF = 8 * NDS;                // AGPRs per K half-tile buffer
   static constexpr int O = 0, K = 16 * NDB, Q = K + 2 * KBUF;
-  static constexpr int EPI_STRIDE = ROWB + 16;
-  static_assert(D == 64 || D == 128, "w4g attention kernel: D = 64 or 128");
+  static constexpr int EPI_STRIDE = GROWB + 16;
+  static_assert(D == 64 || D == 96 || D == 128, "merged-phase geometry: D = 64, 96 or 128");
   static_assert(4 * 64 * EPI_STRIDE <= LDS, "epilogue staging must fit the ring");
 };
 
@@ -44,6 +46,7 @@ template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_w4g_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
     half_t* __restrict__ O, int N, int nqb, float sl2) {
+  static_assert(D == 64 || D == 128, "w4g attention kernel: D = 64 or 128 (D = 96: attn_w4i.hip)");
   using G = W4G<D>;
   constexpr int NDS = G::NDS, NDB = G::NDB, ROWB = G::ROWB, TILE = G::TILE, SLOT = G::SLOT, NS = G::NS;
   constexpr int NRV = G::NRV, NRK = G::NRK, PPW = G::PPW, KBUF = G::KBUF;

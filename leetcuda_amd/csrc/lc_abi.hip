@@ -36,7 +36,7 @@ namespace {
 
 // run-time tuning knobs (lc_tune_set): experiments and A/B benches, never required for correctness
 int g_tune_fp8_mx = 1;                       // fp8 GEMM: 1 = MX-scaled K=64 MFMA, 4-wave kernel; 2 = MX, 8-wave kernel; 0 = plain K=16 MFMA
-int g_tune_attn_w4i_sched = 0;              // schedule of attn_fwd_w4i_kernel's generated phase statements (tools/gen_attn_w4i.py NSCHED; same bits)
+int g_tune_attn_w4i_sched = 1;              // schedule of attn_fwd_w4i_kernel's generated phase statements (tools/gen_attn_w4i.py NSCHED; same bits)
 int g_tune_attn_nw = 0;                    // attention kernel for D = 128: 0 = auto, 128 / 64 / 8 / 4 / 2 (lc_abi.h)
 int g_tune_hgemm_auto = LC_HGEMM_MFMA256W4Y;   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
 int g_tune_hgemm_tail = 1;                   // 1 = hand the ragged last wave of the 256-tile kernel to the 128-tile kernel (launch_mfma256), 0 = one launch
@@ -265,6 +265,8 @@ int choose_attn_nw(int D, bool vt, int N) {
   }
   // D = 64: the head-dim-generalised merged-phase kernel (attn_w4g.hip, 513) unless a lock-step kernel is asked for
   if (D == 64 && !vt && N % 256 == 0 && (want == 0 || want >= 256)) return want == 514 ? 514 : 513;
+  // D = 96: only the generated kernel (attn_w4i.hip, 514) has a merged-phase instantiation (256-B padded LDS rows)
+  if (D == 96 && !vt && N % 256 == 0 && (want == 0 || want >= 256)) return 514;
   if (N % 256 == 0 && (want == 0 || want >= 8)) return 8;   // (also what 256 / 512 fall back to for D < 128)
   if (N % 128 == 0 && (want == 0 || want >= 4)) return 4;
   return 2;
@@ -280,6 +282,8 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   }
   if constexpr ((D == 128 || D == 64) && !VT) {
     if (nw == 513) return launch_attn_w4g(Q, K, V, O, B, H, N, D, st);
+  }
+  if constexpr ((D == 128 || D == 96 || D == 64) && !VT) {
     if (nw == 514) return launch_attn_w4i(Q, K, V, O, B, H, N, D, g_tune_attn_w4i_sched, st);
   }
   if constexpr (D == 128 && !VT) {   // perf-diagnosis instantiations (lc_tune_set "attn_ablate")

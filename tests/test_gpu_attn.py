@@ -398,7 +398,7 @@ def test_non_finite_scores_take_the_slow_path(oracle):
     assert not torch.isfinite(o[0, 1]).all()
 
 
-@pytest.mark.parametrize("D", [128, 64])
+@pytest.mark.parametrize("D", [128, 64, 96])
 def test_generalised_and_generated_kernels_reproduce_the_reference_kernel_bit_for_bit(oracle, D):
     """attn_fwd_w4g_kernel (attn_w4g.hip: the merged-phase kernel with every D-dependent count spelled out, 513) and
     attn_fwd_w4i_kernel (attn_w4i.hip: each phase ONE generated asm statement on reserved registers, uniform padded loop, 514)
@@ -417,7 +417,7 @@ def test_generalised_and_generated_kernels_reproduce_the_reference_kernel_bit_fo
     k2[:, :, :32] = 3.0 * q[:, :, :32]
     ramp = torch.linspace(0.0, 8.0, N, device="cuda").half()
     k3 = (k + ramp[None, None, :, None] * q[:, :, :1].sign()).contiguous()
-    kernels = (512, 513, 514) if D == 128 else (513, 514)
+    kernels = (512, 513, 514) if D == 128 else ((513, 514) if D == 64 else (514,))   # D = 96: the two schedules of the generated kernel
     for ci, kk in enumerate((k, k2, k3)):
         outs = {}
         for nw, sched in [(k_, 0) for k_ in kernels] + [(514, 1)]:        # (514, 1): the generated kernel's second schedule
@@ -433,7 +433,7 @@ def test_generalised_and_generated_kernels_reproduce_the_reference_kernel_bit_fo
                 st = capi.attn_slowpath_stats(reset=True)
             finally:
                 capi.tune("attn_nw", 0)
-                capi.tune("attn_w4i_sched", 0)
+                capi.tune("attn_w4i_sched", 1)      # (the default)
             assert (st[0] > 0) == (ci > 0), (nw, sched, ci, st)
             outs[(nw, sched)] = o
         ref = outs[(kernels[0], 0)]
@@ -442,20 +442,22 @@ def test_generalised_and_generated_kernels_reproduce_the_reference_kernel_bit_fo
         _check(oracle, q, kk, v, outs[(514, 1)], max_abs=8e-3)
 
 
+@pytest.mark.parametrize("D", [64, 96])
 @pytest.mark.parametrize("nw", [0, 514, 8])
-def test_scale_jumps_and_spikes_d64(oracle, nw):
+def test_scale_jumps_and_spikes_d64(oracle, nw, D):
     """The D = 64 instantiation of the merged-phase kernel (running max = a mere scale, corrected by the overflow slow path):
-    the inputs of test_scale_jumps_and_extreme_scores / test_forced_rescale_spike at D = 64, against the lock-step kernel too."""
+    the inputs of test_scale_jumps_and_extreme_scores / test_forced_rescale_spike at D = 64 and D = 96 (generated kernel only, on
+    256-B padded LDS rows), against the lock-step kernel too."""
     capi = _capi()
-    B, H, N, D = 1, 2, 1024, 64
-    torch.manual_seed(640)
+    B, H, N = 1, 2, 1024
+    torch.manual_seed(640 + D)
     q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     cases = {"plain": (q, k)}
     ramp = torch.linspace(0.0, 8.0, N, device="cuda").half()
     cases["ramp"] = (q, (k + ramp[None, None, :, None] * q[:, :, :1].sign()).contiguous())
-    cases["level"] = (torch.full_like(q, 8.0), torch.full_like(q, 8.0))              # s = 64*64/8 = 512 (x log2 e)
+    cases["level"] = (torch.full_like(q, 8.0), torch.full_like(q, 8.0))              # s = 64 D / sqrt(D) = 512 at D = 64 (x log2 e)
     k2 = k.clone()
     k2[:, :, :32] = 5.0 * q[:, :, :32]
     cases["first"] = (q, k2)

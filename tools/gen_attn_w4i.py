@@ -44,17 +44,20 @@ KVB = 64
 class Cfg:
     def __init__(self, D):
         self.D = D
-        self.NDS, self.NDB, self.ROWB = D // 32, D // 16, 2 * D
+        self.NDS, self.NDB = D // 32, D // 16
+        self.GROWB = 2 * D                          # bytes per K / V row in global memory
+        self.ROWB = 256 if D == 96 else 2 * D       # ... and in LDS (D = 96 keeps D = 128's 256-B rows: attn_w4g.hip W4G)
         self.NS = 16 * self.NDS
         self.NRV, self.NRK = self.NDB, 2 * self.NDS
         self.TILE = KVB * self.ROWB
         self.PPW = self.TILE // 1024 // 4
+        self.GPIECE = (1024 // self.ROWB) * self.GROWB   # one LDS-DMA piece (1 KiB of LDS rows) in global memory
         self.KBUF = 8 * self.NDS
         self.O, self.K = 0, 16 * self.NDB
         self.Q = self.K + 2 * self.KBUF
         self.SPP = self.NS // 16
         self.NVX = 4                       # Vᵀ address registers per tile (D = 128: pair 2 u; D = 64: pair u)
-        self.ODD = D == 128                # odd column pairs sit at ±32 B from the even pair's slot (lane-dependent sign)
+        self.ODD = D != 64                 # odd column pairs sit at ±32 B from the even pair's slot (lane-dependent sign)
         # ---- literal register map, from v255 downwards
         top = [256]
 
@@ -177,9 +180,10 @@ def gen_phase(c, H, sched=0):
             upd += [f"v_add_u32 {v(c.VCO + u)}, {v(c.VC + u)}, %[vodd]" for u in range(4)]
         upd += [f"v_add_u32 {v(c.KA + d)}, %[sbn2], %[kx{d}]" for d in range(c.NDS)]
         s0 = c.NS // 2 + c.NRV + 1
-        assert s0 + len(upd) <= c.NS, (s0, len(upd))
-        for i, ins in enumerate(upd):
-            fill[s0 + i].append(ins)
+        nslots = c.NS - s0
+        per = -(-len(upd) // nslots)                 # instructions per slot (1, or 2 where the phase is short: D = 96)
+        for i, ins in enumerate(upd):                # (order matters: VP <- VC before VC is advanced, VCO after VC)
+            fill[s0 + i // per].append(ins)
     # ---- softmax.  A block's FIRST pair (p = 2 qb) exponentiates straight into the block's two row-sum registers PS[qb][0 / 1]
     # (0 + e = e: no move); the later pairs go through the exp sets and are added on.  The pack of the first pair reads the PS
     # registers before the second pair's sums change them (pack of pair p and sums of pair p + 1 sit in different pairs' slots).
@@ -192,6 +196,8 @@ def gen_phase(c, H, sched=0):
         base = spp * p
         if c.SPP == 4:
             plan = {"a0": base, "x0": base, "a1": base + 1, "c": base + 2, "x1": base + 2}
+        elif c.SPP == 3:
+            plan = {"a0": base, "x0": base, "a1": base + 1, "c": base + 2, "x1": base + 1}
         else:
             plan = {"a0": base, "x0": base, "a1": base + 1, "c": base + 1, "x1": base + 1}
         if p >= 1:       # sums and pack of pair p − 1
@@ -213,7 +219,7 @@ def gen_phase(c, H, sched=0):
     dma = {}
     if H == 0:
         if sched == 0:
-            starts = [8 * i + 3 for i in range(2 * c.PPW)]
+            starts = [(c.NS // (2 * c.PPW)) * i + 3 for i in range(2 * c.PPW)]
         else:       # read-free slots: between the first-half reads and NS / 2, then behind the set A reads
             free = [s for s in range(nfirst + 1, c.NS // 2 - 1)] + [s for s in range(c.NS // 2 + c.NRV + 1, c.NS - 2)]
             step = max(2, len(free) // (2 * c.PPW))
@@ -222,7 +228,7 @@ def gen_phase(c, H, sched=0):
         for i, s0 in enumerate(starts):
             is_v, ii = i >= c.PPW, i % c.PPW
             dma.setdefault(s0, []).append(f"s_add_u32 m0, %[m0b], {(c.TILE if is_v else 0) + 4096 * ii}")
-            dma.setdefault(s0, []).append(f"s_add_u32 %[st], %[sob], {4096 * ii}")
+            dma.setdefault(s0, []).append(f"s_add_u32 %[st], %[sob], {4 * c.GPIECE * ii}")
             dma.setdefault(s0 + 1, []).append(f"buffer_load_dwordx4 %[{'voff' if is_v else 'koff'}], %[{'rv' if is_v else 'rk'}], %[st] offen lds")
         assert max(starts) + 1 < c.NS
 
@@ -372,11 +378,11 @@ def main():
     if "--diag" in sys.argv:
         d = Path(sys.argv[sys.argv.index("--diag") + 1])
         d.mkdir(parents=True, exist_ok=True)
-        for D in (64, 128):
+        for D in (64, 96, 128):
             for k in ABLATIONS:
                 (d / f"attn_w4i_d{D}_abl{k}.inc").write_text(render(D, k))
         return 0
-    for D in (64, 128):
+    for D in (64, 96, 128):
         text, out = render(D), out_path(D)
         if "--check" in sys.argv:
             if not out.exists() or out.read_text() != text:

@@ -39,7 +39,7 @@ if a.what in ("all", "attn"):
         for _ in range(a.iters):
             capi.attn_fwd(q, k, v, o)
     capi.tune("attn_nw", 0)
-    capi.tune("attn_w4i_sched", 0)
+    capi.tune("attn_w4i_sched", 1)
     torch.cuda.synchronize()
     del q, k, v, o, tv
     # the reference's published shape (1,48,8192,64) (tools/prof_workloads.py: "attn_d64")
