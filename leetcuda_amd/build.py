@@ -81,11 +81,16 @@ def _flags():
             "-mno-amdgpu-ieee", *(["-DLC_DIAG"] if diag else []), f"-I{ROOT / 'include'}"]
 
 
+def _portable(flags):
+    """flags with the checkout's absolute path replaced: the GPU box runs the same tree from another directory"""
+    return [str(f).replace(str(ROOT), "$ROOT") for f in flags]
+
+
 def _stamp_ok(stamp: Path, flags) -> bool:
     """The .so is only current if it was built with THESE flags (toggling LC_DIAG must rebuild: a diagnosis library
     cannot be told from a production one by mtimes)."""
     try:
-        return json.loads(stamp.read_text())["flags"] == [str(f) for f in flags]
+        return json.loads(stamp.read_text())["flags"] == _portable(flags)
     except Exception:
         return False
 
@@ -121,7 +126,7 @@ def build_abi(force: bool = False, audit: bool = True) -> Path:
     if os.environ.get("LC_DIAG") == "1":   # the ablation loops (results WRONG by design) exist only inside a diagnosis build
         subprocess.run([sys.executable, str(ROOT / "tools" / "gen_hgemm_w4y.py"), "--diag", str(LIBDIR / "gen")], check=True)
         flags = flags + [f"-I{LIBDIR / 'gen'}"]
-    dg = _digest(srcs, " ".join(str(f) for f in flags))
+    dg = _digest(srcs, " ".join(_portable(flags)))
     if not force and _fresh(out, "abi", dg) and _stamp_ok(stamp, flags):
         return out
     # translation units (lc_abi.hip + the compile-heavy literal-AGPR kernels in tu_*.hip), compiled in parallel; each
@@ -169,7 +174,7 @@ def build_abi(force: bool = False, audit: bool = True) -> Path:
                 out.unlink()     # never leave a library around whose hidden-state invariants do not hold
             raise RuntimeError("ISA audit failed (leetcuda_amd/isa_audit.py):\n  " + "\n  ".join(bad))
     _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, "-ldl"])
-    stamp.write_text(json.dumps({"flags": [str(f) for f in flags]}))
+    stamp.write_text(json.dumps({"flags": _portable(flags)}))
     _mark("abi", dg)
     return out
 

@@ -196,6 +196,13 @@ def test_status_strings_and_argument_errors(built):
     assert lib.lc_hgemm_call(b"no_such_entry", one, one, one, 256, 256, 256, 2, 0, 1, None) == capi.LC_ERR_ARG
     assert lib.lc_attn_fwd_f16(one, one, one, one, 1, 1, 100, 64, 0, 0, 0, 2, None) == capi.LC_ERR_SHAPE
     assert lib.lc_attn_fwd_f16(one, one, one, one, 1, 1, 128, 64, 0, 99, 0, 2, None) == capi.LC_ERR_ARG
+    # one head's K / V must fit the 32-bit buffer offsets of the LDS-DMA kernels: N * D * 2 >= 2^31 is refused,
+    # by the entry points and by the kernel-name query alike, before anything is launched
+    buf = C.create_string_buffer(128)
+    assert lib.lc_attn_fwd_f16(one, one, one, one, 1, 1, 1 << 23, 128, 0, 0, 0, 2, None) == capi.LC_ERR_SHAPE
+    assert lib.lc_attn_fwd_bf16(one, one, one, one, 1, 1, 1 << 21, 512, None) == capi.LC_ERR_SHAPE
+    assert lib.lc_attn_kernel_name(1 << 23, 128, 0, 0, buf, 128) == capi.LC_ERR_SHAPE
+    assert lib.lc_attn_kernel_name((1 << 23) - 256, 128, 0, 0, buf, 128) == capi.LC_OK and buf.value.startswith(b"attn_fwd_w4n_kernel")
     # head-dim limits of the reference dispatchers (split_q: 128; share_qkv stage2: 128, stage1: 256)
     assert lib.lc_attn_call(b"flash_attn_mma_stages_split_q", one, one, one, one, 1, 1, 128, 256, 2, None) \
         == capi.LC_ERR_HEADDIM
