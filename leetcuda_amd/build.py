@@ -205,7 +205,7 @@ def build_diag(force: bool = False) -> Path:
     jobs = [(objdir / "diag_main.o", [*base, "-c", "-o", objdir / "diag_main.o", CSRC / "diag" / "lc_diag.hip"])]
     for k in abls:
         o = objdir / f"diag_w4i_abl{k}.o"
-        jobs.append((o, [*base, f"-DW4I_ABL={k}", f'-DW4I_INC64="attn_w4i_d64_abl{k}.inc"', f'-DW4I_INC96="attn_w4i_d96_abl{k}.inc"', f'-DW4I_INC128="attn_w4i_d128_abl{k}.inc"',
+        jobs.append((o, [*base, f"-DW4I_ABL={k}", f'-DW4I_INC32="attn_w4i_d32_abl{k}.inc"', f'-DW4I_INC64="attn_w4i_d64_abl{k}.inc"', f'-DW4I_INC96="attn_w4i_d96_abl{k}.inc"', f'-DW4I_INC128="attn_w4i_d128_abl{k}.inc"',
                          "-c", "-o", o, CSRC / "diag" / "attn_w4i_abl.hip"]))
     procs = []
     for o, cmd in jobs:

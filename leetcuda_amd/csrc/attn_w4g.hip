@@ -27,9 +27,10 @@ LC_DEVINL void w4g_wait_v4(half4_t& a, half4_t& b, half4_t& c, half4_t& d) {   /
 
 template <int D>
 struct W4G {
-  // ROWB = bytes per K / V row IN LDS; GROWB = in global memory.  D = 96 (attn_w4i.hip only) keeps D = 128's 256-B LDS rows — 12 of
-  // the 16 chunks are real, the LDS-DMA lanes of the other four re-fetch a valid chunk — so every layout formula of D = 128 holds.
-  static constexpr int NDS = D / 32, NDB = D / 16, GROWB = 2 * D, ROWB = D == 96 ? 256 : 2 * D;
+  // ROWB = bytes per K / V row IN LDS; GROWB = in global memory.  D = 96 / 32 (attn_w4i.hip only) keep the 256-B / 128-B LDS rows of
+  // D = 128 / 64 — 12 of 16 (4 of 8) chunks are real, the LDS-DMA lanes of the others re-fetch a valid chunk — so every layout formula
+  // of the wider head dim holds.
+  static constexpr int NDS = D / 32, NDB = D / 16, GROWB = 2 * D, ROWB = D > 64 ? 256 : 128;
   static constexpr int TILE = KVB * ROWB, SLOT = 2 * TILE, LDS = 4 * SLOT;
   static constexpr int NS = 16 * NDS;                 // MFMA slots per phase
   static constexpr int NRV = NDB, NRK = 2 * NDS;      // transpose reads per Vᵀ set (NDB / 2 blocks x 2), K fragments per half-tile
@@ -38,7 +39,7 @@ struct W4G {
   static constexpr int KBUF = 8 * NDS;                // AGPRs per K half-tile buffer
   static constexpr int O = 0, K = 16 * NDB, Q = K + 2 * KBUF;
   static constexpr int EPI_STRIDE = GROWB + 16;
-  static_assert(D == 64 || D == 96 || D == 128, "merged-phase geometry: D = 64, 96 or 128");
+  static_assert(D == 32 || D == 64 || D == 96 || D == 128, "merged-phase geometry: D = 32, 64, 96 or 128");
   static_assert(4 * 64 * EPI_STRIDE <= LDS, "epilogue staging must fit the ring");
 };
 

@@ -5,7 +5,7 @@
 
 #define LC_PASTE2(a, b) a##b
 #define LC_PASTE(a, b) LC_PASTE2(a, b)
-#if !defined(W4I_INC64) || !defined(W4I_INC96) || !defined(W4I_INC128)
+#if !defined(W4I_INC32) || !defined(W4I_INC64) || !defined(W4I_INC96) || !defined(W4I_INC128)
 #error "compile with -DW4I_ABL=K -DW4I_INC64=\"attn_w4i_d64_ablK.inc\" -DW4I_INC128=... (leetcuda_amd/build.py build_diag)"
 #endif
 #if (W4I_ABL & 1)

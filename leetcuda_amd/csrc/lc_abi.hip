@@ -265,8 +265,8 @@ int choose_attn_nw(int D, bool vt, int N) {
   }
   // D = 64: the head-dim-generalised merged-phase kernel (attn_w4g.hip, 513) unless a lock-step kernel is asked for
   if (D == 64 && !vt && N % 256 == 0 && (want == 0 || want >= 256)) return want == 514 ? 514 : 513;
-  // D = 96: only the generated kernel (attn_w4i.hip, 514) has a merged-phase instantiation (256-B padded LDS rows)
-  if (D == 96 && !vt && N % 256 == 0 && (want == 0 || want >= 256)) return 514;
+  // D = 96 / 32: only the generated kernel (attn_w4i.hip, 514) has a merged-phase instantiation (256-B / 128-B padded LDS rows)
+  if ((D == 96 || D == 32) && !vt && N % 256 == 0 && (want == 0 || want >= 256)) return 514;
   if (N % 256 == 0 && (want == 0 || want >= 8)) return 8;   // (also what 256 / 512 fall back to for D < 128)
   if (N % 128 == 0 && (want == 0 || want >= 4)) return 4;
   return 2;
@@ -283,7 +283,7 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   if constexpr ((D == 128 || D == 64) && !VT) {
     if (nw == 513) return launch_attn_w4g(Q, K, V, O, B, H, N, D, st);
   }
-  if constexpr ((D == 128 || D == 96 || D == 64) && !VT) {
+  if constexpr (!VT) {
     if (nw == 514) return launch_attn_w4i(Q, K, V, O, B, H, N, D, g_tune_attn_w4i_sched, st);
   }
   if constexpr (D == 128 && !VT) {   // perf-diagnosis instantiations (lc_tune_set "attn_ablate")

@@ -31,6 +31,7 @@ int launch_w4i_t(const half_t* Q, const half_t* K, const half_t* V, half_t* O, i
   return check_launch();
 }
 int launch_attn_w4i(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, int sched, hipStream_t st) {
+  if (D == 32) return sched ? launch_w4i_t<32, 1>(Q, K, V, O, B, H, N, st) : launch_w4i_t<32, 0>(Q, K, V, O, B, H, N, st);
   if (D == 64) return sched ? launch_w4i_t<64, 1>(Q, K, V, O, B, H, N, st) : launch_w4i_t<64, 0>(Q, K, V, O, B, H, N, st);
   if (D == 96) return sched ? launch_w4i_t<96, 1>(Q, K, V, O, B, H, N, st) : launch_w4i_t<96, 0>(Q, K, V, O, B, H, N, st);
   if (D == 128) return sched ? launch_w4i_t<128, 1>(Q, K, V, O, B, H, N, st) : launch_w4i_t<128, 0>(Q, K, V, O, B, H, N, st);

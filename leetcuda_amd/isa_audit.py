@@ -54,6 +54,7 @@ OWNED_VGPRS = [
     (re.compile(r"hgemm_w4y_kernel"), (108, 255)),
     # attn_w4i: v[LB:255] are RESERVED registers (amdgpu_num_vgpr(LB)) holding the softmax state under literal names across
     # statements (tools/gen_attn_w4i.py register map): no compiler instruction may ever name one
+    (re.compile(r"attn_fwd_w4i_kernelILi32E"), (104, 255)),
     (re.compile(r"attn_fwd_w4i_kernelILi64E"), (88, 255)),
     (re.compile(r"attn_fwd_w4i_kernelILi96E"), (72, 255)),
     (re.compile(r"attn_fwd_w4i_kernelILi128E"), (64, 255)),

@@ -398,7 +398,7 @@ def test_non_finite_scores_take_the_slow_path(oracle):
     assert not torch.isfinite(o[0, 1]).all()
 
 
-@pytest.mark.parametrize("D", [128, 64, 96])
+@pytest.mark.parametrize("D", [128, 64, 96, 32])
 def test_generalised_and_generated_kernels_reproduce_the_reference_kernel_bit_for_bit(oracle, D):
     """attn_fwd_w4g_kernel (attn_w4g.hip: the merged-phase kernel with every D-dependent count spelled out, 513) and
     attn_fwd_w4i_kernel (attn_w4i.hip: each phase ONE generated asm statement on reserved registers, uniform padded loop, 514)
@@ -417,7 +417,7 @@ def test_generalised_and_generated_kernels_reproduce_the_reference_kernel_bit_fo
     k2[:, :, :32] = 3.0 * q[:, :, :32]
     ramp = torch.linspace(0.0, 8.0, N, device="cuda").half()
     k3 = (k + ramp[None, None, :, None] * q[:, :, :1].sign()).contiguous()
-    kernels = (512, 513, 514) if D == 128 else ((513, 514) if D == 64 else (514,))   # D = 96: the two schedules of the generated kernel
+    kernels = (512, 513, 514) if D == 128 else ((513, 514) if D == 64 else (514,))   # D = 96 / 32: the two schedules of the generated kernel
     for ci, kk in enumerate((k, k2, k3)):
         outs = {}
         for nw, sched in [(k_, 0) for k_ in kernels] + [(514, 1)]:        # (514, 1): the generated kernel's second schedule
@@ -442,7 +442,7 @@ def test_generalised_and_generated_kernels_reproduce_the_reference_kernel_bit_fo
         _check(oracle, q, kk, v, outs[(514, 1)], max_abs=8e-3)
 
 
-@pytest.mark.parametrize("D", [64, 96])
+@pytest.mark.parametrize("D", [64, 96, 32])
 @pytest.mark.parametrize("nw", [0, 514, 8])
 def test_scale_jumps_and_spikes_d64(oracle, nw, D):
     """The D = 64 instantiation of the merged-phase kernel (running max = a mere scale, corrected by the overflow slow path):

@@ -164,6 +164,7 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     assert capi.attn_kernel_name(8192, 64, True) == "attn_fwd_kernel<64,8,true,0>"            # V handed over transposed: lock-step
     assert capi.attn_kernel_name(8192, 96) == "attn_fwd_w4i_kernel<96,1>"                     # only the generated kernel has a D = 96 instantiation
     assert capi.attn_kernel_name(8192 + 64, 96) == "attn_fwd_kernel<96,2,false,0>"            # N % 256 != 0: lock-step
+    assert capi.attn_kernel_name(8192, 32) == "attn_fwd_w4i_kernel<32,1>"
     assert capi.attn_kernel_name(8192, 512, False, True) == "attn_fwd_bigd2_kernel<512,true>"
     assert capi.attn_kernel_name(192, 512, False, False).startswith("attn_fwd_bigd_kernel<512,")     # N % 128 != 0
     assert sump.short("_ZN2lc16hgemm_w4b_kernelILb0ELb1ELi0EEEvPKDF16_S2_PDF16_iiiiii") == \

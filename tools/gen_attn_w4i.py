@@ -46,7 +46,7 @@ class Cfg:
         self.D = D
         self.NDS, self.NDB = D // 32, D // 16
         self.GROWB = 2 * D                          # bytes per K / V row in global memory
-        self.ROWB = 256 if D == 96 else 2 * D       # ... and in LDS (D = 96 keeps D = 128's 256-B rows: attn_w4g.hip W4G)
+        self.ROWB = 256 if D > 64 else 128          # ... and in LDS (D = 96 / 32 keep the 256-B / 128-B rows of D = 128 / 64: attn_w4g.hip W4G)
         self.NS = 16 * self.NDS
         self.NRV, self.NRK = self.NDB, 2 * self.NDS
         self.TILE = KVB * self.ROWB
@@ -57,7 +57,7 @@ class Cfg:
         self.Q = self.K + 2 * self.KBUF
         self.SPP = self.NS // 16
         self.NVX = 4                       # Vᵀ address registers per tile (D = 128: pair 2 u; D = 64: pair u)
-        self.ODD = D != 64                 # odd column pairs sit at ±32 B from the even pair's slot (lane-dependent sign)
+        self.ODD = D > 64                  # odd column pairs sit at ±32 B from the even pair's slot (lane-dependent sign)
         # ---- literal register map, from v255 downwards
         top = [256]
 
@@ -198,8 +198,10 @@ def gen_phase(c, H, sched=0):
             plan = {"a0": base, "x0": base, "a1": base + 1, "c": base + 2, "x1": base + 2}
         elif c.SPP == 3:
             plan = {"a0": base, "x0": base, "a1": base + 1, "c": base + 2, "x1": base + 1}
-        else:
+        elif c.SPP == 2:
             plan = {"a0": base, "x0": base, "a1": base + 1, "c": base + 1, "x1": base + 1}
+        else:          # one slot per pair (D = 32): everything of pair p − 1, then both exps of pair p
+            plan = {"a0": base, "x0": base, "a1": base, "c": base, "x1": base}
         if p >= 1:       # sums and pack of pair p − 1
             kvb, qb, k2 = pair(p - 1)
             first = kvb == 0 and k2 == 0
@@ -218,13 +220,14 @@ def gen_phase(c, H, sched=0):
     # ---- LDS-DMA pieces of tile t + 2 (H = 0): piece i = K pieces 0 .. PPW − 1, then V pieces; wave w stages piece w + 4 i'
     dma = {}
     if H == 0:
-        if sched == 0:
-            starts = [(c.NS // (2 * c.PPW)) * i + 3 for i in range(2 * c.PPW)]
-        else:       # read-free slots: between the first-half reads and NS / 2, then behind the set A reads
+        step0 = c.NS // (2 * c.PPW)
+        starts = [step0 * i + (3 if step0 >= 5 else step0 - 2) for i in range(2 * c.PPW)]      # schedule 0: evenly from the phase start
+        if sched == 1:       # read-free slots: between the first-half reads and NS / 2, then behind the set A reads (when the phase has enough of them)
             free = [s for s in range(nfirst + 1, c.NS // 2 - 1)] + [s for s in range(c.NS // 2 + c.NRV + 1, c.NS - 2)]
             step = max(2, len(free) // (2 * c.PPW))
-            starts = [free[min(i * step, len(free) - 2)] for i in range(2 * c.PPW)]
-            assert len(set(starts)) == 2 * c.PPW and all(b - a >= 2 for a, b in zip(starts, starts[1:])), starts
+            cand = [free[min(i * step, len(free) - 2)] for i in range(2 * c.PPW)] if len(free) >= 2 else []
+            if len(set(cand)) == 2 * c.PPW and all(b - a >= 2 for a, b in zip(cand, cand[1:])):
+                starts = cand
         for i, s0 in enumerate(starts):
             is_v, ii = i >= c.PPW, i % c.PPW
             dma.setdefault(s0, []).append(f"s_add_u32 m0, %[m0b], {(c.TILE if is_v else 0) + 4096 * ii}")
@@ -378,11 +381,11 @@ def main():
     if "--diag" in sys.argv:
         d = Path(sys.argv[sys.argv.index("--diag") + 1])
         d.mkdir(parents=True, exist_ok=True)
-        for D in (64, 96, 128):
+        for D in (32, 64, 96, 128):
             for k in ABLATIONS:
                 (d / f"attn_w4i_d{D}_abl{k}.inc").write_text(render(D, k))
         return 0
-    for D in (64, 96, 128):
+    for D in (32, 64, 96, 128):
         text, out = render(D), out_path(D)
         if "--check" in sys.argv:
             if not out.exists() or out.read_text() != text:
