@@ -1,0 +1,459 @@
+// attn_w4p.hip — FlashAttention-2 forward, D = 64 / 128: the merged-phase 4-wave kernel of attn_w4g.hip as a PERSISTENT
+// workgroup (round 3; lc_tune_set "attn_nw" = 515).
+//
+// Same semantics / entry points as attn_fwd.hip (reference: kernels/flash-attn/mma/basic/flash_attn_mma_split_q.cu:55-699,
+// dispatcher :769-815; flash_attn_mma_share_qkv.cu:46-769).  Same arithmetic as attn_fwd_w4g_kernel, instruction for
+// instruction inside a block — the results are bit-identical (GPU test) — what changes is what happens BETWEEN two 256-row
+// query blocks.  DESIGN.md §4.13b measured the fixed cost of a block (workgroup launch, the first two K/V tiles' DMA latency,
+// the Q loads, Sᵀ(0), O through LDS) at ≈ 6 % of config 3 and ≈ 3 % at S = 8192: one wave per SIMD and one workgroup per CU
+// means nothing else runs on the CU while a workgroup starts or drains.  Here
+//   * the grid is one workgroup per CU (min(#blocks, 256)); workgroup w walks the virtual block ids w, w + G, w + 2G, … and
+//     maps each through the same XCD-aware remap as the one-block-per-workgroup launch (w + kG ≡ w mod 8: a workgroup's
+//     blocks stay on the XCD whose L2 holds their heads' K / V);
+//   * the K/V stream is continuous across the seam: the LDS-DMA of "tile T" and "tile T + 1" (issued in the tile periods
+//     T − 2 and T − 1, where the one-block kernel has nothing left to fetch) stages tiles 0 and 1 of the NEXT block into ring
+//     slots 0 and 1 — exactly where the next prologue reads them (T % 4 == 0);
+//   * the next block's Q rows are requested right after the last P·V MFMAs are issued and land during the O epilogue;
+//   * the O staging area moves behind ring slots 0 / 1 (D = 128: bytes 64 Ki … 132 Ki), so the epilogue never touches the
+//     slots that are being filled; no vmcnt wait at the epilogue (the pieces in flight do not concern it).
+// One extra barrier per block (all waves are done with the staging area before tile 2 of the next block is staged).
+#pragma once
+#include "attn_w4g.hip"
+
+namespace lc {
+
+template <int D>
+struct W4P {
+  using G = W4G<D>;
+  static constexpr int EPI_OFF = 2 * G::SLOT;                                // staging behind ring slots 0, 1
+  static constexpr int EPI_BYTES = 4 * 64 * G::EPI_STRIDE;
+  static constexpr int LDS = (EPI_OFF + EPI_BYTES > G::LDS) ? EPI_OFF + EPI_BYTES : G::LDS;
+  static_assert(LDS <= 160 * 1024, "ring + staging must fit a CU's LDS");
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_w4p_kernel(
+    const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
+    half_t* __restrict__ O, int N, int nqb, float sl2, int nblk, int nwg) {
+  static_assert(D == 64 || D == 128, "w4p attention kernel: D = 64 or 128");
+  using G = W4G<D>;
+  constexpr int NDS = G::NDS, NDB = G::NDB, ROWB = G::ROWB, TILE = G::TILE, SLOT = G::SLOT, NS = G::NS;
+  constexpr int NRV = G::NRV, NRK = G::NRK, PPW = G::PPW, KBUF = G::KBUF;
+  constexpr int GO = G::O, GK = G::K, GQ = G::Q;
+  constexpr int NQ = 4 * NDS;   // Q fragments (16 bytes each) per lane
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  const int g4 = lane >> 4, l16 = lane & 15;
+  const int T = N / KVB;
+  const uint32_t smem32 = lds_addr32(smem);
+  const size_t head_elems = (size_t)N * D;
+
+  // ---- LDS-DMA lane offsets (attn_w4g.hip)
+  unsigned k_off, v_off;
+  if constexpr (D == 128) {
+    const int rr = lane >> 4, cs = lane & 15;
+    k_off = (unsigned)(rr * 256 + ((cs ^ (4 * wave + rr)) * 16));
+    v_off = (unsigned)(rr * 256 + (((((cs >> 1) ^ ((rr << 1) | (wave & 1))) << 1) | (cs & 1)) * 16));
+  } else {
+    const int rr = lane >> 3, cs = lane & 7;
+    k_off = (unsigned)(rr * 128 + ((cs ^ (4 * (wave & 1) + (rr >> 1))) * 16));
+    v_off = (unsigned)(rr * 128 + (((((cs >> 1) ^ ((rr >> 1) & 3)) << 1) | (cs & 1)) * 16));
+  }
+  // ---- fragment read offsets inside a ring slot (attn_w4g.hip)
+  uint32_t kx[NDS];
+#pragma unroll
+  for (int ds = 0; ds < NDS; ++ds)
+    kx[ds] = (uint32_t)(l16 * ROWB + (((4 * ds + g4) ^ (D == 128 ? l16 : ((l16 >> 1) & 7))) * 16));
+  constexpr int NVX = D == 128 ? 4 : NDB;
+  uint32_t vx[NVX];
+#pragma unroll
+  for (int u = 0; u < NVX; ++u) {
+    if constexpr (D == 128)
+      vx[u] = (uint32_t)(TILE + (4 * g4 + (l16 >> 2)) * 256 + (((2 * u) ^ (((l16 >> 2) << 1) | (g4 & 1))) * 32) + 8 * (l16 & 3));
+    else
+      vx[u] = (uint32_t)(TILE + (4 * g4 + (l16 >> 2)) * 128 + ((u ^ (((g4 & 1) << 1) | (l16 >> 3))) * 32) + 8 * (l16 & 3));
+  }
+  const uint32_t vodd = (uint32_t)((g4 & 1) ? -32 : 32);
+
+  // ---- block walk: virtual block vb -> (head, first query row of this wave)
+  int vb = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+  auto head_of = [&](int v, int& q0w) -> size_t {
+    const int id = xcd_remap(v, nblk);
+    const int bh = id / nqb;
+    q0w = (id - bh * nqb) * 256 + wave * 64;
+    return (size_t)bh;
+  };
+  int q0;
+  size_t bh = head_of(vb, q0);
+
+  // DMA of one K / V piece of the tile this period stages: descriptor + tile index chosen once per tile period (make_rsrc
+  // reads the chosen base through readfirstlane: a descriptor hipcc cannot prove wave-uniform gets a waterfall loop per piece)
+  buf_rsrc_t dk = make_rsrc(K + bh * head_elems), dv = make_rsrc(V + bh * head_elems);
+  unsigned d_so = 0;
+  char* d_slot = smem;
+  auto issue_piece = [&](int i) {   // i = 0 .. 2 PPW−1: K pieces, then V pieces
+    const int p = wave + 4 * (i % PPW);
+    const unsigned so = d_so + (unsigned)p * 1024u;
+    if (i < PPW)
+      blds16(dk, k_off, so, d_slot + p * 1024);
+    else
+      blds16(dv, v_off, so, d_slot + TILE + p * 1024);
+  };
+  // Q rows of a block as raw fp16 (16 bytes per fragment): requested one block ahead
+  half8_t qraw[NQ];
+  auto load_q = [&](size_t h, int q0w) {
+    const half_t* Qb = Q + h * head_elems;
+    static_for<NQ>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, qb = i / NDS, ds = i % NDS;
+      qraw[i] = *(const half8_t*)(Qb + (size_t)(q0w + 16 * qb + l16) * D + 32 * ds + 8 * g4);
+    });
+  };
+
+  // first block: tiles 0, 1 and Q from scratch
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    d_so = (unsigned)t * TILE;
+    d_slot = smem + t * SLOT;
+#pragma unroll
+    for (int i = 0; i < 2 * PPW; ++i) issue_piece(i);
+  }
+  load_q(bh, q0);
+
+  for (;;) {
+    // ---- the block after this one (or this one again when there is none: every address stays valid, nothing of it is used)
+    const int vbn = __builtin_amdgcn_readfirstlane(vb + nwg);   // (nwg = gridDim.x as a kernel argument: provably wave-uniform, the block walk stays in SGPRs)
+    const bool has_next = vbn < nblk;
+    int q0n;
+    const size_t bhn = head_of(has_next ? vbn : vb, q0n);
+    half_t* Ob = O + bh * head_elems;
+    // tile t2 >= T of this block = tile t2 − T of the next one (no next block: the last tile again, into a dead slot)
+    auto set_dma_tile = [&](int t2) {
+      const bool own = t2 < T;
+      const size_t h = own ? bh : bhn;
+      dk = make_rsrc(K + h * head_elems);
+      dv = make_rsrc(V + h * head_elems);
+      const int te = own ? t2 : (has_next ? t2 - T : T - 1);
+      d_so = (unsigned)__builtin_amdgcn_readfirstlane(te * TILE);   // (provably wave-uniform: no waterfall loop around the pieces)
+      d_slot = smem + (t2 & 3) * SLOT;
+    };
+
+    // ---- Q~ = fp16(Q * scale*log2e) -> AGPRs
+    static_for<NQ>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const half8_t q = qraw[i];
+      half8_t qs;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qs[e] = (half_t)((float)q[e] * sl2);
+      const u32x4_t w = __builtin_bit_cast(u32x4_t, qs);
+      am_acc_write<GQ + 4 * i + 0>(w[0]);
+      am_acc_write<GQ + 4 * i + 1>(w[1]);
+      am_acc_write<GQ + 4 * i + 2>(w[2]);
+      am_acc_write<GQ + 4 * i + 3>(w[3]);
+    });
+    static_for<16 * NDB>([&](auto r) { am_acc_zero<decltype(r)::value>(); });
+
+    uint32_t ka[NDS], vc[NVX], vp[NVX];
+    auto set_tile_addrs = [&](int t) {
+      const uint32_t sb_cur = smem32 + (uint32_t)((t & 3) * SLOT), sb_nxt = smem32 + (uint32_t)(((t + 1) & 3) * SLOT);
+#pragma unroll
+      for (int u = 0; u < NVX; ++u) {
+        vp[u] = vc[u];
+        vc[u] = vx[u] + sb_cur;
+      }
+#pragma unroll
+      for (int ds = 0; ds < NDS; ++ds) ka[ds] = kx[ds] + sb_nxt;
+    };
+#pragma unroll
+    for (int u = 0; u < NVX; ++u) vc[u] = vx[u] + smem32;
+
+    f32x4_t sA[2][4], sB[2][4];
+    f32x4_t negm[4];
+    half8_t pA[4], pB[4];
+    half4_t vlo[NDB], vhi[NDB];
+    float l_run[4] = {0.f, 0.f, 0.f, 0.f};
+
+    auto read_k_all = [&](auto bufc, uint32_t sbase, auto hc) {
+      constexpr int BUF = decltype(bufc)::value, H = decltype(hc)::value;
+      static_for<NRK>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, kvb = c / NDS, ds = c % NDS;
+        am_read_k<GK + KBUF * BUF + 4 * c, H * 32 * ROWB + kvb * 16 * ROWB>(kx[ds] + sbase);
+      });
+    };
+    auto vaddr_of = [&](const uint32_t (&va)[NVX], int db) -> uint32_t {
+      if constexpr (D == 128) return va[db >> 1] + ((db & 1) ? vodd : 0u);
+      else return va[db];
+    };
+    auto wait_vset = [&](auto firstc) {
+      constexpr int first = decltype(firstc)::value;
+      if constexpr (NDB == 8) am_wait_v8(reinterpret_cast<half4_t(&)[4]>(vlo[first]), reinterpret_cast<half4_t(&)[4]>(vhi[first]));
+      else w4g_wait_v4(vlo[first], vlo[first + 1], vhi[first], vhi[first + 1]);
+    };
+
+    // ---- prologue: this block's tiles 0, 1 landed (own pieces; the previous block's O stores too); every wave has left the
+    // previous block's staging area
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    raw_barrier();
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using IB = std::integral_constant<int, NDB / 2>;
+    read_k_all(I0{}, smem32, I0{});
+    read_k_all(I1{}, smem32, I1{});
+    am_lgkm0();
+    static_for<8 * NDS>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, ds = i >> 3, kvb = (i >> 2) & 1, qb = i & 3;
+      if constexpr (ds == 0) an_qk_zero<GK + 4 * (NDS * kvb + ds), GQ + 4 * (NDS * qb + ds)>(sA[kvb][qb]);
+      else an_qk<GK + 4 * (NDS * kvb + ds), GQ + 4 * (NDS * qb + ds)>(sA[kvb][qb]);
+    });
+    am_drain(sA);
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      float mx = sA[0][qb][0];
+#pragma unroll
+      for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sA[kvb][qb][r]);
+      mx = an_x4_max(mx);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sA[0][qb][r] -= mx;
+        sA[1][qb][r] -= mx;
+        negm[qb][r] = -mx;
+      }
+    }
+
+    // ---- one merged phase (attn_w4g.hip; F bit 8 = issue this period's DMA pieces, target set by set_dma_tile)
+    auto phase = [&](auto hc, auto fc, int t, f32x4_t (&sr)[2][4], f32x4_t (&sw)[2][4], half8_t (&pw)[4], half8_t (&pr)[4]) {
+      constexpr int H = decltype(hc)::value, F = decltype(fc)::value;
+      constexpr bool HAS_PV = (F & 1) != 0, HAS_QK = (F & 2) != 0, HAS_KRD = (F & 4) != 0, HAS_DMA = (F & 8) != 0;
+      constexpr int KQ = GK + KBUF * (1 - H);
+      constexpr int KRB = H;
+      uint32_t (&vb_a)[NVX] = H == 0 ? vp : vc;
+      constexpr int VB_H = H == 0 ? 1 : 0;
+      wait_vset(I0{});
+      float ps[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+      float e0 = 0.f, e1 = 0.f, c0 = 0.f, c1 = 0.f;
+      auto pair_sum = [&](auto pc, auto wc, float a) {
+        constexpr int qb = (decltype(pc)::value >> 1) & 3, w = decltype(wc)::value;
+        ps[qb][w] += a;
+        asm volatile("" : "+v"(ps[qb][w]));
+      };
+      auto pair_pack = [&](auto pc, float a, float b) {
+        constexpr int p = decltype(pc)::value, kvb = p >> 3, qb = (p >> 1) & 3, k2 = p & 1;
+        half2_t h2 = {(half_t)a, (half_t)b};
+        asm volatile("" : "+v"(h2));
+        pw[qb][4 * kvb + 2 * k2] = h2[0];
+        pw[qb][4 * kvb + 2 * k2 + 1] = h2[1];
+      };
+      static_for<NS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value, i = s >> 1;
+        constexpr bool RVB = s < NRV && HAS_PV, RK = s < NRK && HAS_KRD, RVA = s >= NS / 2 && s < NS / 2 + NRV;
+        constexpr int RD = ((RVB || RVA) ? 1 : 0) | (RK ? 2 : 0);
+        constexpr int c = RVA ? s - NS / 2 : (s % NRV), rdb = (RVA ? 0 : NDB / 2) + (c >> 1), rx = c & 1;
+        constexpr int VOF = (RVA ? H : VB_H) * 32 * ROWB + rx * 16 * ROWB;
+        half4_t& vout = rx ? vhi[rdb] : vlo[rdb];
+        const uint32_t vaddr = RVA ? vaddr_of(vc, rdb) : vaddr_of(vb_a, rdb);
+        constexpr int kc = s % NRK;
+        constexpr int KR = GK + KBUF * KRB + 4 * kc, KOF = H * 32 * ROWB + (kc / NDS) * 16 * ROWB;
+        if constexpr ((s & 1) == 0) {
+          constexpr int ds = i >> 3, kvb = (i >> 2) & 1, qb = i & 3;
+          constexpr int KIND = HAS_QK ? (ds == 0 ? 0 : 1) : 3;
+          if constexpr (KIND != 3 || RD != 0)
+            an_slot<KIND, RD, KQ + 4 * (NDS * kvb + ds), GQ + 4 * (NDS * qb + ds), VOF, KR, KOF>(
+                sw[kvb][qb], negm[qb], half8_t{}, half8_t{}, vout, vaddr, ka[kc % NDS]);
+        } else {
+          constexpr int db = i >> 2, qb = i & 3;
+          constexpr int KIND = HAS_PV ? 2 : 3;
+          if constexpr (KIND != 3 || RD != 0)
+            an_slot<KIND, RD, GO + 4 * (4 * db + qb), 0, VOF, KR, KOF>(sw[0][0], negm[0], cat4(vlo[db], vhi[db]), pr[qb], vout,
+                                                                       vaddr, ka[kc % NDS]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (s == NS / 2 - 1 && HAS_PV) wait_vset(IB{});
+        if constexpr (HAS_DMA && (s & 7) == 7) issue_piece(s >> 3);
+        if constexpr (NS == 64) {
+          if constexpr ((s & 3) == 0) {
+            constexpr int p = s >> 2, kvb = p >> 3, qb = (p >> 1) & 3, k2 = p & 1;
+            if constexpr (p >= 1) {
+              pair_sum(std::integral_constant<int, p - 1>{}, I0{}, e0);
+              c0 = e0;
+              c1 = e1;
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            e0 = __builtin_amdgcn_exp2f(sr[kvb][qb][2 * k2]);
+            asm volatile("" : "+v"(e0));
+          } else if constexpr ((s & 3) == 1) {
+            if constexpr (s >= 5) pair_sum(std::integral_constant<int, (s >> 2) - 1>{}, I1{}, c1);
+          } else if constexpr ((s & 3) == 2) {
+            constexpr int p = s >> 2, kvb = p >> 3, qb = (p >> 1) & 3, k2 = p & 1;
+            if constexpr (p >= 1) {
+              pair_pack(std::integral_constant<int, p - 1>{}, c0, c1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            e1 = __builtin_amdgcn_exp2f(sr[kvb][qb][2 * k2 + 1]);
+            asm volatile("" : "+v"(e1));
+          }
+        } else {
+          constexpr int p = s >> 1, kvb = p >> 3, qb = (p >> 1) & 3, k2 = p & 1;
+          if constexpr ((s & 1) == 0) {
+            if constexpr (p >= 1) {
+              pair_sum(std::integral_constant<int, p - 1>{}, I0{}, e0);
+              c0 = e0;
+              c1 = e1;
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            e0 = __builtin_amdgcn_exp2f(sr[kvb][qb][2 * k2]);
+            asm volatile("" : "+v"(e0));
+          } else {
+            if constexpr (p >= 1) {
+              pair_sum(std::integral_constant<int, p - 1>{}, I1{}, c1);
+              pair_pack(std::integral_constant<int, p - 1>{}, c0, c1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            e1 = __builtin_amdgcn_exp2f(sr[kvb][qb][2 * k2 + 1]);
+            asm volatile("" : "+v"(e1));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      pair_sum(std::integral_constant<int, 15>{}, I0{}, e0);
+      pair_sum(std::integral_constant<int, 15>{}, I1{}, e1);
+      pair_pack(std::integral_constant<int, 15>{}, e0, e1);
+      // ---------------- overflow guard (attn_w4g.hip)
+      uint32_t worst_bits = 0;
+#pragma unroll
+      for (int qb = 0; qb < 4; ++qb) worst_bits = max(worst_bits, __builtin_bit_cast(uint32_t, ps[qb][0] + ps[qb][1]));
+      const bool ok = worst_bits < __builtin_bit_cast(uint32_t, AM_PSUM_LIMIT);
+      if (!__all(ok)) {
+        am_drain(sw);
+        {
+          float worst = 0.f;
+          bool fin = true;
+#pragma unroll
+          for (int qb = 0; qb < 4; ++qb) {
+            const float x = ps[qb][0] + ps[qb][1];
+            fin = fin && finite_bits(x);
+            if (!psum_below(x, AM_PSUM_LIMIT)) worst = x;
+          }
+          const unsigned long long culprit = __ballot(!ok);
+          if (lane == (int)__builtin_ctzll(culprit | (1ull << 63))) {
+            atomicAdd(&LC_AN_SLOWPATH_SYM[0], 1u);
+            atomicAdd(&LC_AN_SLOWPATH_SYM[1], (unsigned)(2 * t + H));
+            if (!fin) atomicAdd(&LC_AN_SLOWPATH_SYM[2], 1u);
+            LC_AN_SLOWPATH_SYM[3] = __builtin_bit_cast(unsigned, worst);
+          }
+        }
+        static_for<4>([&](auto qc) {
+          constexpr int qb = decltype(qc)::value;
+          float mx = sr[0][qb][0];
+#pragma unroll
+          for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sr[kvb][qb][r]);
+          mx = an_x4_max(mx);
+          const float delta = fmaxf(mx, 0.f);
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          l_run[qb] *= alpha;
+          ps[qb][0] = 0.f;
+          ps[qb][1] = 0.f;
+#pragma unroll
+          for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if constexpr (HAS_QK) sw[kvb][qb][r] -= delta;
+              const float pv = __builtin_amdgcn_exp2f(sr[kvb][qb][r] - delta);
+              ps[qb][r & 1] += pv;
+              pw[qb][4 * kvb + r] = (half_t)pv;
+            }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) negm[qb][r] -= delta;
+          static_for<NDB>([&](auto dc) {
+            constexpr int db = decltype(dc)::value;
+            static_for<4>([&](auto rc) { am_acc_scale<GO + 4 * (4 * db + qb) + decltype(rc)::value>(alpha); });
+          });
+        });
+        asm volatile("s_nop 3" ::: "memory");
+      }
+#pragma unroll
+      for (int qb = 0; qb < 4; ++qb) l_run[qb] += ps[qb][0] + ps[qb][1];
+    };
+    using F_FIRST0 = std::integral_constant<int, 2 | 4 | 8>;
+    using F_MID = std::integral_constant<int, 1 | 2 | 4 | 8>;
+    using F_MID1 = std::integral_constant<int, 1 | 2 | 4>;
+    using F_LAST0 = std::integral_constant<int, 1 | 2 | 8>;        // j = 2T−2: stages "tile T + 1" = the next block's tile 1
+    using F_LAST1 = std::integral_constant<int, 1>;
+
+    set_tile_addrs(0);
+    set_dma_tile(2);
+    phase(I0{}, F_FIRST0{}, 0, sA, sB, pA, pB);
+    phase(I1{}, F_MID1{}, 0, sB, sA, pB, pA);
+    for (int t = 1; t + 1 < T; ++t) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      raw_barrier();
+      set_tile_addrs(t);
+      set_dma_tile(t + 2);
+      phase(I0{}, F_MID{}, t, sA, sB, pA, pB);
+      phase(I1{}, F_MID1{}, t, sB, sA, pB, pA);
+    }
+    {
+      const int t = T - 1;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      raw_barrier();
+      set_tile_addrs(t);
+      set_dma_tile(t + 2);
+      phase(I0{}, F_LAST0{}, t, sA, sB, pA, pB);
+      phase(I1{}, F_LAST1{}, t, sB, sA, pB, pA);
+      static_for<NRV>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, db = NDB / 2 + (c >> 1);
+        if constexpr ((c & 1) == 0) vlo[db] = lds_tr16_asm<32 * ROWB>(vaddr_of(vc, db));
+        else vhi[db] = lds_tr16_asm<32 * ROWB + 16 * ROWB>(vaddr_of(vc, db));
+      });
+      wait_vset(I0{});
+      wait_vset(IB{});
+      static_for<4 * NDB>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, db = i >> 2, qb = i & 3;
+        an_pv<GO + 4 * (4 * db + qb)>(cat4(vlo[db], vhi[db]), pB[qb]);
+      });
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load_q(bhn, q0n);                  // the next block's Q rows: in flight during the epilogue
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue: O = Oᵀ / l through LDS (whole rows, 16-B stores); staging behind ring slots 0 / 1
+    am_drain();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    raw_barrier();                     // every wave is done with ring slots 2, 3
+    float inv[4];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) inv[qb] = 1.0f / an_x4_sum(l_run[qb]);
+    char* stg = smem + W4P<D>::EPI_OFF + wave * (64 * G::EPI_STRIDE);
+    static_for<4>([&](auto qc) {
+      constexpr int qb = decltype(qc)::value;
+      static_for<NDB>([&](auto dc) {
+        constexpr int db = decltype(dc)::value;
+        constexpr int base = GO + 4 * (4 * db + qb);
+        half4_t h;
+        h[0] = (half_t)(am_acc_read<base + 0>() * inv[qb]);
+        h[1] = (half_t)(am_acc_read<base + 1>() * inv[qb]);
+        h[2] = (half_t)(am_acc_read<base + 2>() * inv[qb]);
+        h[3] = (half_t)(am_acc_read<base + 3>() * inv[qb]);
+        *(half4_t*)(stg + (16 * qb + l16) * G::EPI_STRIDE + (16 * db + 4 * g4) * 2) = h;
+      });
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    half_t* ow = Ob + (size_t)q0 * D;
+    constexpr int LPR = ROWB / 16, RPI = 64 / LPR;
+#pragma unroll
+    for (int it = 0; it < 64 / RPI; ++it) {
+      const int row = it * RPI + lane / LPR;
+      const u32x4_t v = *(const u32x4_t*)(stg + row * G::EPI_STRIDE + (lane % LPR) * 16);
+      *(u32x4_t*)(ow + (size_t)row * D + (lane % LPR) * 8) = v;
+    }
+    if (!has_next) break;
+    vb = vbn;
+    bh = bhn;
+    q0 = q0n;
+  }
+}
+
+}  // namespace lc

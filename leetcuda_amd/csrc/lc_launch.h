@@ -61,6 +61,10 @@ int launch_attn_w4n_d128(const half_t* Q, const half_t* K, const half_t* V, half
 int diag_attn_slowpath_g(unsigned* out4, int reset);   // + the slow-path counters of the w4g kernels
 int launch_attn_w4i(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, int sched, hipStream_t st);   // attn_w4i.hip (phase = one generated asm statement)
 int launch_attn_w4g(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, hipStream_t st);
+// tu_attn_w4p.hip: the same kernel as a persistent workgroup (attn_w4p.hip: one workgroup per CU walks the query blocks, K / V / Q
+// streams continue across block seams): D in {64, 128}, N % 256 == 0
+int launch_attn_w4p(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, hipStream_t st);
+int diag_attn_slowpath_p(unsigned* out4, int reset);   // + the slow-path counters of the w4p kernels
 // tu_attn_big.hip: full-width large-head-dim kernel, D in {256, 512}, N % 128 == 0, V as [B,H,N,D]; fp16 or bf16
 int launch_attn_bigd2(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, bool bf16,
                       hipStream_t st);

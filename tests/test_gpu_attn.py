@@ -442,6 +442,47 @@ def test_generalised_and_generated_kernels_reproduce_the_reference_kernel_bit_fo
         _check(oracle, q, kk, v, outs[(514, 1)], max_abs=8e-3)
 
 
+@pytest.mark.parametrize("D", [128, 64])
+@pytest.mark.parametrize("shape", [(1, 37, 2048), (3, 43, 1024), (2, 3, 2048), (1, 130, 512)])
+def test_persistent_kernel_equals_the_one_block_kernel_bit_for_bit(oracle, D, shape):
+    """attn_fwd_w4p_kernel (attn_w4p.hip, lc_tune_set "attn_nw" = 515): one workgroup per CU walks the 256-row query blocks, the
+    K / V tiles 0 / 1 and the Q rows of the NEXT block are fetched while the current one finishes, O is staged behind ring slots
+    0 / 1.  Inside a block it is attn_fwd_w4g_kernel instruction for instruction, so the outputs must be identical — with more
+    blocks than CUs (296, 516: a workgroup runs 1-3 blocks, the last ones without a successor), fewer (48), heads that take the
+    overflow slow path right before / after a seam, and from launch to launch."""
+    capi = _capi()
+    B, H, N = shape
+    torch.manual_seed(515 + D + N)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k2 = k.clone()
+    k2[:, ::3, N - 3] = 4.0 * q[:, ::3, 300]          # last tile of every third head: slow path in the phases next to the seam
+    k2[:, 1::5, :32] = 3.0 * q[:, 1::5, :32]          # dominant first half-tile: slow path right behind the seam
+    for ci, kk in enumerate((k, k2)):
+        outs = {}
+        for nw in (513, 515, 515):
+            capi.tune("attn_nw", nw)
+            try:
+                want = {513: "attn_fwd_w4g_kernel", 515: "attn_fwd_w4p_kernel"}[nw]
+                assert capi.attn_kernel_name(N, D).startswith(want)
+                capi.attn_slowpath_stats(reset=True)
+                o = torch.full_like(q, float("nan"))
+                capi.attn_fwd(q, kk, v, o)
+                torch.cuda.synchronize()
+                st = capi.attn_slowpath_stats(reset=True)
+            finally:
+                capi.tune("attn_nw", 0)
+            assert (st[0] > 0) == (ci > 0), (nw, ci, st)
+            outs.setdefault(nw, []).append((o, st[0]))
+        ref, ref_slow = outs[513][0]
+        for o, slow in outs[515]:
+            assert torch.equal(ref, o), (D, shape, ci)
+            assert slow == ref_slow, (D, shape, ci, slow, ref_slow)      # the same half-tiles took the slow path
+        if ci == 0 and H <= 43:
+            _check(oracle, q[:, :2].contiguous(), kk[:, :2].contiguous(), v[:, :2].contiguous(), ref[:, :2].contiguous(), max_abs=8e-3)
+
+
 @pytest.mark.parametrize("D", [64, 96, 32])
 @pytest.mark.parametrize("nw", [0, 514, 8])
 def test_scale_jumps_and_spikes_d64(oracle, nw, D):
