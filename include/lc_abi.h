@@ -102,7 +102,7 @@ int lc_device_check(int* num_cus);
 const char* lc_build_info(int* is_diag);
 
 /* Run-time selection knobs for A-B benches (not part of the reference surface; correctness never depends on them):
- *   "attn_nw"      attention kernel for D <= 128: 0 = auto (D = 128: 512, D = 64: 513, when N % 256 == 0), 513 = the merged-phase
+ *   "attn_nw"      attention kernel for D <= 128: 0 = auto (D = 128: 515 up to N = 4096, 512 beyond; D = 64: 513; when N % 256 == 0), 513 = the merged-phase
  *                  kernel generalised over the head dim (attn_w4g.hip: D = 64, and D = 128 as a cross-check that must equal
  *                  512 bit for bit), 515 = the same kernel as a persistent workgroup per CU (attn_w4p.hip: K / V / Q streams
  *                  continue across query-block seams; D = 64 / 128, bit-identical to 513), 512 = merged-phase kernel with 16x16x32

@@ -260,7 +260,10 @@ int launch_attn(const half_t* Q, const half_t* K, const half_t* V, half_t* O, in
 int choose_attn_nw(int D, bool vt, int N) {
   const int want = g_tune_attn_nw;   // 0 = auto
   if (D == 128 && !vt && N % 256 == 0) {
-    if (want == 0 && g_tune_attn_ablate == 0) return 512;
+    // auto: up to N = 4096 the persistent workgroup (attn_w4p.hip, 515: same arithmetic, the next block's K / V / Q fetched across
+    // the seam; config 3 +1.7 %, N = 2048 +1.0 %), beyond that the one-block-per-workgroup launch (the fixed cost of a block is < 3 %
+    // there and the hardware's dynamic dispatch balances 16+ blocks per CU better than a static walk: N = 8192 -0.5 %)
+    if (want == 0 && g_tune_attn_ablate == 0) return N <= 4096 ? 515 : 512;
     if (want == 256 || want == 260 || want == 512 || want == 513 || want == 514 || want == 515) return want;
   }
   // D = 64: the head-dim-generalised merged-phase kernel (attn_w4g.hip, 513) unless a lock-step kernel is asked for

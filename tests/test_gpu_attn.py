@@ -383,7 +383,7 @@ def test_non_finite_scores_take_the_slow_path(oracle):
     k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     k[0, 1, 300] = float("inf")
-    assert capi.attn_kernel_name(N, D).startswith("attn_fwd_w4n_kernel")
+    assert capi.attn_kernel_name(N, D).startswith("attn_fwd_w4p_kernel")
     capi.attn_slowpath_stats(reset=True)
     o = torch.zeros_like(q)
     capi.attn_fwd(q, k, v, o)

@@ -157,7 +157,8 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_NN, capi.HGEMM_MFMA256P2) == "hgemm_pingpong2_kernel<true,false>"
     assert capi.hgemm_kernel_name(1024, 1024, 1024, capi.LAYOUT_NN) == "hgemm_mfma128_kernel<true>"
     assert capi.hgemm_kernel_name(1000, 1024, 1024, capi.LAYOUT_NN) == "hgemm_generic_kernel<true>"
-    assert capi.attn_kernel_name(4096, 128) == "attn_fwd_w4n_kernel<128>"
+    assert capi.attn_kernel_name(4096, 128) == "attn_fwd_w4p_kernel<128>"                    # config 3: the persistent workgroup
+    assert capi.attn_kernel_name(8192, 128) == "attn_fwd_w4n_kernel<128>"                    # config 4: one block per workgroup
     assert capi.attn_kernel_name(4096 + 128, 128) == "attn_fwd_kernel<128,4,false,0>"      # N % 256 != 0
     assert capi.attn_kernel_name(192, 64, True) == "attn_fwd_kernel<64,2,true,0>"
     assert capi.attn_kernel_name(8192, 64) == "attn_fwd_w4g_kernel<64>"                       # the reference's published shapes

@@ -33,7 +33,7 @@ if a.what in ("all", "hgemm"):
     torch.cuda.synchronize()
 if a.what in ("all", "attn"):
     q, k, v, o, tv = host.get_qkvo(4, 32, 4096, 128, seed=0)
-    for nw in (0, 514, 256, 8):     # default (merged-phase 16x16x32), its generated one-statement-per-phase twin, 32x32x16, lock-step
+    for nw in (0, 512, 514, 256, 8):     # default (persistent merged-phase 16x16x32), the one-block launch of it, its generated one-statement-per-phase twin, 32x32x16, lock-step
         capi.tune("attn_nw", nw)
         capi.tune("attn_w4i_sched", 1 if nw == 514 else 0)
         for _ in range(a.iters):
