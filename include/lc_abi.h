@@ -110,6 +110,10 @@ const char* lc_build_info(int* is_diag);
  *                  query rows, one wave per SIMD (attn_w4m.hip; 260 = its A/B twin with padded Q.K^T MFMAs),
  *                  8 / 4 / 2 = lock-step kernel with that many waves (any N % (32 x waves) == 0, every D <= 128)
  *   "w4y_sched"    schedule 0..2 of LC_HGEMM_MFMA256W4Y's generated loop body (tools/gen_hgemm_w4y.py; same bits, A/B knob)
+ *   "hgemm_stagger" K-loop stagger of LC_HGEMM_MFMA256W4Y (hgemm_w4y.hip): the workgroup starts its K walk at tile ((index & mask)
+ *                  * step) mod (K / 64) and wraps, index = cx * XCD + cm * tile row + cn * tile column.  0 = auto (cx = 1, mask 7, step
+ *                  K / 64 / 8: the eight XCDs start an eighth of K apart), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 |
+ *                  mask << 20.  Only the fp32 accumulation order changes: results agree with the unstaggered walk to fp16 rounding
  *   "hgemm_tail"   1 (default) = when the 256-tile grid's last wave holds at most 128 tiles, the generated-loop kernel computes the
  *                  full waves and the 128-tile kernel the four quadrants of each remaining tile; 0 = one launch
  *   "hgemm_raster" block -> C tile map of the tiled GEMM kernels: 0 = auto (2 when A + B exceed the 256 MiB Infinity Cache by half,

@@ -39,6 +39,7 @@ int set_dyn_lds(KernelT kernel, int bytes) {
 // tuning globals (defined in lc_abi.hip, lc_tune_set)
 extern int g_tune_attn_ablate, g_tune_w4_abl, g_tune_hgemm_stamps;
 extern int g_tune_attn_d512;   // D = 256 / 512 attention kernel choice (lc_tune_set "attn_d512")
+extern int g_tune_hgemm_stagger;   // K-loop stagger of hgemm_w4y_kernel: 0 = auto (by XCD, step K / 64 / 8), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 | mask << 20 (hgemm_w4y.hip)
 extern int g_tune_w4y_sched;   // schedule of hgemm_w4y_kernel's generated loop body (all of them compute the same bits)
 
 // launchers living in their own translation units

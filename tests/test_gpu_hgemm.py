@@ -240,7 +240,15 @@ def test_full_size_config2_properties(oracle, layout):
         assert ((outs[name].float() - ref).abs() <= ulp).all(), name
     assert torch.equal(outs["w4b"], outs["w4c"])   # same MFMA order, glds vs buffer DMA
     if layout == "tn":
-        assert torch.equal(outs["w4x"], outs["w4y"])   # 16x16x32 kernels: compiler-scheduled vs hand-ordered stream
+        # 16x16x32 kernels, compiler-scheduled vs hand-ordered stream: same bits when both walk K from tile 0 (the default
+        # hgemm_w4y launch staggers the walk per XCD: same products, another fp32 summation order)
+        capi.tune("hgemm_stagger", 1 << 27)
+        try:
+            plain, _ = _run(capi, a, b, lay, VARIANTS["w4y"], stride)
+        finally:
+            capi.tune("hgemm_stagger", 0)
+        assert torch.equal(outs["w4x"], plain)
+        assert not torch.equal(outs["w4y"], plain) and ((outs["w4y"].float() - plain.float()).abs() <= ulp).all()
         for sched in (0, 2):                            # the other generated schedules of the loop body: same bits
             capi.tune("w4y_sched", sched)
             try:
@@ -272,6 +280,42 @@ def test_full_size_config2_properties(oracle, layout):
         assert ok, mx
     finally:
         capi.vendor_destroy()
+
+
+@pytest.mark.parametrize("layout", ["nn", "tn"])
+def test_k_loop_stagger_walks_every_k_tile_once(oracle, layout):
+    """lc_tune_set "hgemm_stagger" (hgemm_w4y.hip): a workgroup starts its K walk at tile ((index & mask) * step) mod KT and wraps —
+    every product is still summed exactly once, only the fp32 accumulation order changes.  The default (0: by XCD, an eighth of K
+    apart), XCD / row / column / mixed indices, start tiles
+    beyond KT (reduced mod KT), KT = 1 / 2 / 3 (the clamped prefetch of the last iterations wraps too), against the unstaggered
+    walk (fp16 rounding) and the exact oracle; a K-dependent input (column k of A scaled by a ramp) makes a skipped or doubled
+    tile visible in every element."""
+    capi = _capi()
+    lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
+    for M, N, K in ((512, 768, 64), (512, 512, 128), (768, 512, 192), (1024, 1024, 1024), (2048, 2304, 4096)):
+        torch.manual_seed(K + M)
+        ramp = 1.0 + torch.arange(K, device="cuda").float() / K
+        a = (torch.randn(M, K, device="cuda") * ramp[None, :]).half()
+        b = torch.randn(K, N, dtype=torch.half, device="cuda")
+        capi.tune("hgemm_stagger", 1 << 27)          # reference: the plain walk from tile 0
+        try:
+            ref, _ = _run(capi, a, b, lay, VARIANTS["w4y"], 2048)
+        finally:
+            capi.tune("hgemm_stagger", 0)
+        rows = [0, M // 2 + 1, M - 1]
+        truth = oracle.hgemm(a[rows].contiguous(), b, len(rows), N, K, 0, "f32")
+        ulp = torch.clamp(ref.float().abs(), min=64.0) * 2.0 ** -10
+        for knob in (0, 1 | 16 << 12 | 7 << 20, 1 << 4 | 2 << 12 | 31 << 20, 1 << 8 | 2 << 12 | 31 << 20, 1 << 4 | 3 << 8 | 3 << 12 | 31 << 20,
+                     15 | 15 << 4 | 15 << 8 | 255 << 12 | 255 << 20):
+            capi.tune("hgemm_stagger", knob)
+            try:
+                got, _ = _run(capi, a, b, lay, VARIANTS["w4y"], 2048)
+            finally:
+                capi.tune("hgemm_stagger", 0)
+            assert torch.isfinite(got).all()
+            assert ((got.float() - ref.float()).abs() <= ulp).all(), (M, N, K, knob)
+            ok, mx, _ = tol.hgemm_close(got[rows].float().cpu().numpy(), truth, K)
+            assert ok, (M, N, K, knob, mx)
 
 
 def test_auto_large_nn_b_uses_64bit_dma_addresses():
@@ -308,12 +352,14 @@ def test_xcd_super_block_raster_computes_the_same_bits(layout):
         outs = []
         for knob in (1, 2):
             capi.tune("hgemm_raster", knob)
+            capi.tune("hgemm_stagger", 1 << 27)     # (the default K walk starts per XCD: another map = another summation order per tile)
             try:
                 c = torch.full((M, N), float("nan"), dtype=torch.half, device="cuda")
                 capi.hgemm(a, bb, c, layout=lay, variant=capi.HGEMM_AUTO, swizzle_stride=1024)
                 torch.cuda.synchronize()
             finally:
                 capi.tune("hgemm_raster", 0)
+                capi.tune("hgemm_stagger", 0)
             outs.append(c)
         assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1]), (M, N, K)
 

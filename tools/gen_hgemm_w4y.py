@@ -58,6 +58,23 @@ def mfma(ks, i, j):
     return f"v_mfma_f32_16x16x32_f16 {acc(i, j)}, {fb(ks, j)}, {fa(ks, i)}, {acc(i, j)}"
 
 
+# K-loop stagger (hgemm_w4y.hip: the workgroup walks the K tiles stg, stg + 1, ..., KT - 1, 0, ..., stg - 1): logical tile index in
+# swp -> memory tile index (swp + stg) mod KT, stg < KT.  The s_cmp / s_cselect pair must stay adjacent (SCC).
+STAGGER = ["s_add_u32 %[swp], %[swp], %[stg]", "s_cmp_ge_u32 %[swp], %[kt]", "s_cselect_b32 %[t2off], %[kt], 0",
+           "s_sub_u32 %[swp], %[swp], %[t2off]"]
+
+
+def place(rot, slots, after, what):
+    """rot: instruction groups (lists; a group stays in one gap), slots: free MFMA gaps in stream order.  Groups are merged from
+    the front while there are more groups than gaps."""
+    groups = [list(g) for g in rot]
+    while len(groups) > len(slots):
+        assert len(groups) >= 2, what
+        groups[0:2] = [groups[0] + groups[1]]
+    for g, m in zip(groups, slots):
+        after(m, *g)
+
+
 def gen_init():
     L = []
     e = L.append
@@ -77,6 +94,8 @@ def gen_init():
     # the tail of every iteration for the next one, so the loop top is the wait alone
     e("s_sub_u32 %[swp], %[kt], 1")
     e("s_min_u32 %[swp], %[swp], 2")
+    for ins in STAGGER:
+        e(ins)
     e("s_lshl_b32 %[t2off], %[swp], 7")
     e(f"v_add_u32_e32 {VA}, %[acur], %[ar1]")
     e(f"v_add_u32_e32 {VB}, %[b0], %[br1]")
@@ -132,15 +151,14 @@ def gen_body(sched):
         after(m + 1, f"buffer_load_dwordx4 %[ao{g & 1}], %[ra], %[soff] offen lds")
     # ring rotation, then the next iteration's t2off = 128 min(t + 3, KT - 1) and its k-step-1 read addresses: in the
     # empty gaps behind the last read / the first A piece (acur, b*, t2off, VA, VB are dead from there on)
-    rot = ["s_mov_b32 %[swp], %[b0]", "s_mov_b32 %[b0], %[b1]", "s_mov_b32 %[b1], %[b2]", "s_mov_b32 %[b2], %[swp]",
-           "s_mov_b32 %[swp], %[acur]", "s_mov_b32 %[acur], %[anxt]", "s_mov_b32 %[anxt], %[swp]",
-           "s_add_u32 %[swp], %[t], 3", "s_sub_u32 %[t2off], %[kt], 1", "s_min_u32 %[swp], %[swp], %[t2off]",
-           "s_lshl_b32 %[t2off], %[swp], 7", f"v_add_u32_e32 {VA}, %[acur], %[ar1]", f"v_add_u32_e32 {VB}, %[b0], %[br1]"]
+    rot = [["s_mov_b32 %[swp], %[b0]"], ["s_mov_b32 %[b0], %[b1]"], ["s_mov_b32 %[b1], %[b2]"], ["s_mov_b32 %[b2], %[swp]"],
+           ["s_mov_b32 %[swp], %[acur]"], ["s_mov_b32 %[acur], %[anxt]"], ["s_mov_b32 %[anxt], %[swp]"],
+           ["s_add_u32 %[swp], %[t], 3"], ["s_sub_u32 %[t2off], %[kt], 1"], ["s_min_u32 %[swp], %[swp], %[t2off]"],
+           [STAGGER[0]], STAGGER[1:3], [STAGGER[3]],
+           ["s_lshl_b32 %[t2off], %[swp], 7"], [f"v_add_u32_e32 {VA}, %[acur], %[ar1]"], [f"v_add_u32_e32 {VB}, %[b0], %[br1]"]]
     first = max(max(rd), dma[0] + 1) + 1
     slots = [m for m in range(first, 126) if m not in fill]
-    assert len(slots) >= len(rot), (sched, len(slots))
-    for ins, m in zip(rot, slots):
-        after(m, ins)
+    place(rot, slots, after, sched)
     after(126, "s_add_u32 %[t], %[t], 1", "s_cmp_lt_u32 %[t], %[kt]")
     for m in range(128):
         ks, i, j = m >> 6, (m >> 3) & 7, m & 7
@@ -208,6 +226,8 @@ def gen_nn():
         e(ins)
     e("s_sub_u32 %[swp], %[kt], 1")
     e("s_min_u32 %[swp], %[swp], 2")
+    for ins in STAGGER:
+        e(ins)
     e("s_lshl_b32 %[t2off], %[swp], 7")
     e("s_mul_i32 %[t2offb], %[swp], %[bkt]")
     e(f"v_add_u32_e32 {VA}, %[acur], %[ar1]")
@@ -243,15 +263,14 @@ def gen_nn():
     slots1 = [m for m in range(bar + 5, 126) if m not in [d + 1 for d in dma]][:24]
     for ins, m in zip(reads(0), slots1):
         after(m, ins)
-    rot = ["s_mov_b32 %[swp], %[b0]", "s_mov_b32 %[b0], %[b1]", "s_mov_b32 %[b1], %[b2]", "s_mov_b32 %[b2], %[swp]",
-           "s_mov_b32 %[swp], %[acur]", "s_mov_b32 %[acur], %[anxt]", "s_mov_b32 %[anxt], %[swp]",
-           "s_add_u32 %[swp], %[t], 3", "s_sub_u32 %[t2off], %[kt], 1", "s_min_u32 %[swp], %[swp], %[t2off]",
-           "s_lshl_b32 %[t2off], %[swp], 7", "s_mul_i32 %[t2offb], %[swp], %[bkt]", f"v_add_u32_e32 {VA}, %[acur], %[ar1]"]
+    rot = [["s_mov_b32 %[swp], %[b0]"], ["s_mov_b32 %[b0], %[b1]"], ["s_mov_b32 %[b1], %[b2]"], ["s_mov_b32 %[b2], %[swp]"],
+           ["s_mov_b32 %[swp], %[acur]"], ["s_mov_b32 %[acur], %[anxt]"], ["s_mov_b32 %[anxt], %[swp]"],
+           ["s_add_u32 %[swp], %[t], 3"], ["s_sub_u32 %[t2off], %[kt], 1"], ["s_min_u32 %[swp], %[swp], %[t2off]"],
+           [STAGGER[0]], STAGGER[1:3], [STAGGER[3]],
+           ["s_lshl_b32 %[t2off], %[swp], 7"], ["s_mul_i32 %[t2offb], %[swp], %[bkt]"], [f"v_add_u32_e32 {VA}, %[acur], %[ar1]"]]
     first = max(slots1) + 1
     slots = [m for m in range(first, 126) if m not in fill]
-    assert len(slots) >= len(rot), len(slots)
-    for ins, m in zip(rot, slots):
-        after(m, ins)
+    place(rot, slots, after, "nn")
     after(126, "s_add_u32 %[t], %[t], 1", "s_cmp_lt_u32 %[t], %[kt]")
     for m in range(128):
         ks, i, j = m >> 6, (m >> 3) & 7, m & 7
@@ -277,7 +296,7 @@ def render_nn():
             "    : [t] \"=&s\"(w4y_t), [acur] \"=&s\"(w4y_acur), [anxt] \"=&s\"(w4y_anxt), [b0] \"=&s\"(w4y_b0), [b1] \"=&s\"(w4y_b1),\n"
             "      [b2] \"=&s\"(w4y_b2), [soff] \"=&s\"(w4y_soff), [t2off] \"=&s\"(w4y_t2off), [t2offb] \"=&s\"(w4y_t2offb),\n"
             "      [tmp] \"=&s\"(w4y_tmp), [swp] \"=&s\"(w4y_swp)\n"
-            "    : [kt] \"s\"(KT), [a0] \"s\"(w4y_a0), [wv] \"s\"(w4y_wv), [wvb] \"s\"(w4y_wvb), [blk] \"s\"(w4y_blk), [bq] \"s\"(w4y_bq),\n"
+            "    : [kt] \"s\"(KT), [stg] \"s\"(w4y_stg), [a0] \"s\"(w4y_a0), [wv] \"s\"(w4y_wv), [wvb] \"s\"(w4y_wvb), [blk] \"s\"(w4y_blk), [bq] \"s\"(w4y_bq),\n"
             "      [bkt] \"s\"(w4y_bkt), [ra] \"s\"(w4y_ra), [rb] \"s\"(w4y_rb), [ao0] \"v\"(w4y_ao0), [ao1] \"v\"(w4y_ao1),\n"
             "      [bo0] \"v\"(w4y_bo0), [bo1] \"v\"(w4y_bo1), [ar0] \"v\"(fr.a_ad[0]), [ar1] \"v\"(fr.a_ad[1]), [bk] \"v\"(w4y_bk),\n"
             "      [key] \"v\"(w4y_key)\n"
@@ -290,13 +309,13 @@ def render(sched):
     vclob = ", ".join(f'"v{r}"' for r in VCLOB)
     n_mfma = sum(ln.startswith("v_mfma") for ln in lines)
     head = (f"// GENERATED by tools/gen_hgemm_w4y.py (schedule {sched}) — do not edit ({len(lines)} instructions, {n_mfma} MFMAs per K tile).\n"
-            "// Operands (hgemm_w4y.hip): kt, a0 (LDS address of A ring slot 0), wv (wave * 8192), blk (bytes between 8-row\n"
+            "// Operands (hgemm_w4y.hip): kt, stg (K-loop stagger in tiles, < kt), a0 (LDS address of A ring slot 0), wv (wave * 8192), blk (bytes between 8-row\n"
             "// blocks), ra / rb (buffer descriptors, u32x4 SGPR tuples), ao0 / ao1 (DMA lane offsets), ar0 / ar1 / br0 / br1\n"
             "// (fragment read lane offsets of k-step 0 / 1).\n")
     return (head + "asm volatile(\n" + body + "\n"
             "    : [t] \"=&s\"(w4y_t), [acur] \"=&s\"(w4y_acur), [anxt] \"=&s\"(w4y_anxt), [b0] \"=&s\"(w4y_b0), [b1] \"=&s\"(w4y_b1),\n"
             "      [b2] \"=&s\"(w4y_b2), [soff] \"=&s\"(w4y_soff), [t2off] \"=&s\"(w4y_t2off), [tmp] \"=&s\"(w4y_tmp), [swp] \"=&s\"(w4y_swp)\n"
-            "    : [kt] \"s\"(KT), [a0] \"s\"(w4y_a0), [wv] \"s\"(w4y_wv), [blk] \"s\"(w4y_blk), [ra] \"s\"(w4y_ra),\n"
+            "    : [kt] \"s\"(KT), [stg] \"s\"(w4y_stg), [a0] \"s\"(w4y_a0), [wv] \"s\"(w4y_wv), [blk] \"s\"(w4y_blk), [ra] \"s\"(w4y_ra),\n"
             "      [rb] \"s\"(w4y_rb),\n"
             "      [ao0] \"v\"(w4y_ao0), [ao1] \"v\"(w4y_ao1), [ar0] \"v\"(fr.a_ad[0]), [ar1] \"v\"(fr.a_ad[1]), [br0] \"v\"(fr.b_ad[0]),\n"
             "      [br1] \"v\"(fr.b_ad[1])\n"

@@ -13,6 +13,8 @@ from leetcuda_amd import capi, host  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--what", default="all", choices=["all", "hgemm", "attn"])
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--stagger", type=lambda v: int(v, 0), default=None, help="lc_tune_set hgemm_stagger for the GEMM launches")
+ap.add_argument("--only-auto", action="store_true", help="GEMM: only the default kernel + hipBLASLt")
 a = ap.parse_args()
 capi.load()
 torch.manual_seed(0)
@@ -22,7 +24,10 @@ if a.what in ("all", "hgemm"):
     B = torch.randn(n, n, dtype=torch.half, device="cuda")
     C = torch.zeros(n, n, dtype=torch.half, device="cuda")
     Bt = host.as_col_major(B)
-    for var in (capi.HGEMM_MFMA256W4Y, capi.HGEMM_MFMA256W4X, capi.HGEMM_MFMA256W4C, capi.HGEMM_MFMA256P2, capi.HGEMM_MFMA256):
+    if a.stagger is not None:
+        capi.tune("hgemm_stagger", a.stagger or 1 << 27)     # (0 on the command line = off)
+    for var in ((capi.HGEMM_MFMA256W4Y,) if a.only_auto else
+                (capi.HGEMM_MFMA256W4Y, capi.HGEMM_MFMA256W4X, capi.HGEMM_MFMA256W4C, capi.HGEMM_MFMA256P2, capi.HGEMM_MFMA256)):
         for lay, bb in ((capi.LAYOUT_TN, Bt), (capi.LAYOUT_NN, B)):
             for _ in range(a.iters):
                 capi.hgemm(A, bb, C, layout=lay, variant=var, swizzle_stride=2048)
