@@ -87,8 +87,10 @@ int w4_effective_variant(int variant, bool b_kn, int N, int K) {
   if (variant == LC_HGEMM_MFMA256W4X && b_kn) variant = LC_HGEMM_MFMA256W4C;   // the compiler-scheduled 16x16x32 kernel is TN only
   if (variant == LC_HGEMM_MFMA256W4C || variant == LC_HGEMM_MFMA256W4X ||
       variant == LC_HGEMM_MFMA256W4Y) {
-    const size_t max_off = b_kn ? (size_t)K * N * 2 + (size_t)N * 64 : (size_t)K * 2 * 130;
-    if (max_off >= ((size_t)1 << 31)) return LC_HGEMM_MFMA256W4B;
+    // (K-contiguous operands: a wave's pieces reach 64 rows past its base, 232 with hgemm_w4y's 32-row piece stride)
+    const size_t rows_off = (size_t)K * 2 * (variant == LC_HGEMM_MFMA256W4Y ? 260 : 130);
+    const size_t max_off = b_kn ? (size_t)K * N * 2 + (size_t)N * 64 : rows_off;
+    if (max_off >= ((size_t)1 << 31) || rows_off >= ((size_t)1 << 31)) return LC_HGEMM_MFMA256W4B;
   }
   return variant;
 }

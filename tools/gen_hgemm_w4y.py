@@ -33,6 +33,11 @@ NDIAG = 3   # LC_DIAG-only ablations of schedule 1 (results are WRONG): 3 = no D
 def out_path(sched, diag_dir=None):
     return (Path(diag_dir) if diag_dir else ROOT / "leetcuda_amd" / "csrc") / f"hgemm_w4y_loop{sched}.inc"
 
+# LDS-DMA piece map of the K-contiguous operands (A; B of TN): piece g of wave w = rows 32 g + 8 w .. + 8 of the 256-row tile — at
+# any moment the four waves of a workgroup ask for 32 CONSECUTIVE rows (the vendor kernel's map; with one 64-row band per wave the
+# concurrent requests sat 64 rows = 1 MiB apart at K = 8192 and held their L2 reads 1.6x longer, profiles/r3n_pmc_vmem.txt).  The
+# LDS image is row-major either way: piece g lands at g * 4096 + w * 1024 (operand wv = w * 1024).
+PIECE_STEP = 4096
 VA, VB = "v124", "v125"          # fragment read addresses (slot base + lane part)
 FRAG0 = 128                      # first literal fragment VGPR
 VCLOB = list(range(124, 256))    # literal VGPRs owned by the statement
@@ -123,7 +128,7 @@ def gen_body(sched):
     d0 = 32
     after(d0 - 1, "s_add_u32 %[tmp], %[b2], %[wv]")
     for p in range(8):
-        after(d0 + 4 * p, f"s_add_u32 m0, %[tmp], {p * 1024}",
+        after(d0 + 4 * p, f"s_add_u32 m0, %[tmp], {p * PIECE_STEP}",
               "s_mov_b32 %[soff], %[t2off]" if p == 0 else "s_add_u32 %[soff], %[soff], %[blk]")
         after(d0 + 1 + 4 * p, f"buffer_load_dwordx4 %[ao{p & 1}], %[rb], %[soff] offen lds")
     assert d0 + 1 + 4 * 7 < 64
@@ -146,7 +151,7 @@ def gen_body(sched):
         after(m, f"ds_read_b128 {fa(0, r)}, {VA} offset:{r * 2048}" if r < 8
               else f"ds_read_b128 {fb(0, r - 8)}, {VB} offset:{(r - 8) * 2048}")
     for g, m in enumerate(dma):
-        after(m, f"s_add_u32 m0, %[tmp], {g * 1024}",
+        after(m, f"s_add_u32 m0, %[tmp], {g * PIECE_STEP}",
               "s_mov_b32 %[soff], %[t2off]" if g == 0 else "s_add_u32 %[soff], %[soff], %[blk]")
         after(m + 1, f"buffer_load_dwordx4 %[ao{g & 1}], %[ra], %[soff] offen lds")
     # ring rotation, then the next iteration's t2off = 128 min(t + 3, KT - 1) and its k-step-1 read addresses: in the
@@ -257,7 +262,7 @@ def gen_nn():
         after(bar + 1 + (j >> 1), f"v_add_u32_e32 v{BJ + j}, %[b1], v{BJ0 + j}")
     dma = [bar + 2 + 4 * g for g in range(8)]
     for g, m in enumerate(dma):
-        after(m, f"s_add_u32 m0, %[tmp], {g * 1024}",
+        after(m, f"s_add_u32 m0, %[tmp], {g * PIECE_STEP}",
               "s_mov_b32 %[soff], %[t2off]" if g == 0 else "s_add_u32 %[soff], %[soff], %[blk]")
         after(m + 1, f"buffer_load_dwordx4 %[ao{g & 1}], %[ra], %[soff] offen lds")
     slots1 = [m for m in range(bar + 5, 126) if m not in [d + 1 for d in dma]][:24]
@@ -290,7 +295,7 @@ def render_nn():
     vclob = ", ".join(f'"v{r}"' for r in range(108, 256))
     n_mfma = sum(ln.startswith("v_mfma") for ln in lines)
     head = (f"// GENERATED by tools/gen_hgemm_w4y.py (NN) — do not edit ({len(lines)} instructions, {n_mfma} MFMAs per K tile).\n"
-            "// Operands (hgemm_w4y.hip): as the TN statement + wvb (wave * 4096), bq (bytes between 4-row B pieces), bkt (bytes\n"
+            "// Operands (hgemm_w4y.hip): as the TN statement + wvb (wave * 4096: NN B pieces), bq (bytes between 4-row B pieces), bkt (bytes\n"
             "// per B K tile), bo0 / bo1 (B DMA lane offsets), bk / key (B transpose-read lane offset and swizzle key).\n")
     return (head + "asm volatile(\n" + body + "\n"
             "    : [t] \"=&s\"(w4y_t), [acur] \"=&s\"(w4y_acur), [anxt] \"=&s\"(w4y_anxt), [b0] \"=&s\"(w4y_b0), [b1] \"=&s\"(w4y_b1),\n"
@@ -309,7 +314,7 @@ def render(sched):
     vclob = ", ".join(f'"v{r}"' for r in VCLOB)
     n_mfma = sum(ln.startswith("v_mfma") for ln in lines)
     head = (f"// GENERATED by tools/gen_hgemm_w4y.py (schedule {sched}) — do not edit ({len(lines)} instructions, {n_mfma} MFMAs per K tile).\n"
-            "// Operands (hgemm_w4y.hip): kt, stg (K-loop stagger in tiles, < kt), a0 (LDS address of A ring slot 0), wv (wave * 8192), blk (bytes between 8-row\n"
+            "// Operands (hgemm_w4y.hip): kt, stg (K-loop stagger in tiles, < kt), a0 (LDS address of A ring slot 0), wv (wave * 1024), blk (bytes between 32-row\n"
             "// blocks), ra / rb (buffer descriptors, u32x4 SGPR tuples), ao0 / ao1 (DMA lane offsets), ar0 / ar1 / br0 / br1\n"
             "// (fragment read lane offsets of k-step 0 / 1).\n")
     return (head + "asm volatile(\n" + body + "\n"
