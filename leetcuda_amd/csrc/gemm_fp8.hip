@@ -223,7 +223,7 @@ LC_DEVINL void w4_mfma_fp8mx(i32x8_t a, i32x8_t b, int scale) {   // a[16 IDX ..
 
 __global__ __launch_bounds__(256) void gemm_fp8_w4_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
                                                           half_t* __restrict__ C, int M, int N, int K, float alpha,
-                                                          int tiles_m, int tiles_n, int panel_w) {
+                                                          int tiles_m, int tiles_n, int panel_w, int stagger) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = wave_id();
@@ -234,18 +234,26 @@ __global__ __launch_bounds__(256) void gemm_fp8_w4_kernel(const uint8_t* __restr
   const int m0 = tc.tm * BM, n0 = tc.tn * BN;
   const int KT = K / BK8;
 
-  // DMA: 8-row blocks blk = 8*wave + p of the A / B tile; lane -> row lane>>3, 16-byte slot lane&7 (swizzle as hgemm_w4)
-  unsigned a_off[2];
-#pragma unroll
-  for (int par = 0; par < 2; ++par)
-    a_off[par] = (unsigned)(lane >> 3) * (unsigned)K + (unsigned)(((lane & 7) ^ (((lane >> 4) & 3) | (par << 2))) * 16);
-  const buf_rsrc_t ra = make_rsrc(A + (size_t)(m0 + wave * 64) * K);
-  const buf_rsrc_t rb = make_rsrc(B + (size_t)(n0 + wave * 64) * K);
-  const unsigned blk_bytes = 8u * (unsigned)K;
+  // DMA: piece p of this wave = the 8-row block 4 p + wave of the A / B tile (rows 32 p + 8 wave .. + 8: the four waves' concurrent
+  // requests cover 32 consecutive rows — hgemm_w4y.hip's piece map); lane -> row lane>>3, 16-byte slot lane&7 (swizzle as
+  // hgemm_w4: key ((row >> 1) & 7) = (lane >> 4) & 3 | (block & 1) << 2, block & 1 = wave & 1)
+  const unsigned a_off = (unsigned)(lane >> 3) * (unsigned)K + (unsigned)(((lane & 7) ^ (((lane >> 4) & 3) | ((wave & 1) << 2))) * 16);
+  const buf_rsrc_t ra = make_rsrc(A + (size_t)(m0 + wave * 8) * K);
+  const buf_rsrc_t rb = make_rsrc(B + (size_t)(n0 + wave * 8) * K);
+  const unsigned blk_bytes = 32u * (unsigned)K;
+  // K-loop stagger (hgemm_w4y.hip; lc_tune_set "hgemm_stagger"): the workgroup walks the K tiles stg, stg + 1, ..., wrapping
+  int stg;
+  {
+    const int cx = stagger & 15, cm = (stagger >> 4) & 15, cn = (stagger >> 8) & 15, step = (stagger >> 12) & 0xff, mask = (stagger >> 20) & 0xff;
+    const int idx = cx * __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7)) + cm * __builtin_amdgcn_readfirstlane(tc.tm) +
+                    cn * __builtin_amdgcn_readfirstlane(tc.tn);
+    stg = __builtin_amdgcn_readfirstlane((int)((unsigned)((idx & mask) * step) % (unsigned)KT));
+  }
   auto piece = [&](int g, int t, char* slot) {   // g < 8: A pieces, else B pieces; clamped past the end
-    const int te = t < KT ? t : KT - 1;
+    int te = (t < KT ? t : KT - 1) + stg;
+    if (te >= KT) te -= KT;
     const int p = g & 7;
-    blds16(g < 8 ? ra : rb, a_off[p & 1], (unsigned)p * blk_bytes + (unsigned)te * BK8, slot + (wave * 8 + p) * 1024);
+    blds16(g < 8 ? ra : rb, a_off, (unsigned)p * blk_bytes + (unsigned)te * BK8, slot + p * 4096 + wave * 1024);
   };
   auto a_slot = [&](int t) -> char* { return smem + (t & 1) * TILE_BYTES; };
   auto b_slot = [&](int bi) -> char* { return smem + (2 + bi) * TILE_BYTES; };
