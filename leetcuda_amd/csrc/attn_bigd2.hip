@@ -221,6 +221,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
   // fit beside Sᵀ, Q and two P sets.
   half8_t vf0, vf1, vf2, vf3;
   constexpr int NQ = NDT / 4, NST = 4 * NQ;
+  // DMA piece i of a phase is issued in k-step i * SPAN_A / NPIECE (Q·Kᵀ phase) / step i * SPAN_B / NPIECE (P·V phase)
+  constexpr int SPAN_A = D == 512 ? 3 * NKS / 4 : NKS / 2, SPAN_B = D == 512 ? 3 * NST / 4 : NST / 2;
   auto rd0 = [&]() { bd2_rd0<8 * ROWB>(vf0, vf1, vf2, vf3, vx); };
   auto pv_step = [&](auto stc, half8_t (&pf)[4]) {
     constexpr int st = decltype(stc)::value, g = st / NQ, dq = st % NQ;
@@ -254,12 +256,16 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
       static_for<NKS>([&](auto kc) {
         constexpr int ks = decltype(kc)::value;
         if constexpr (ks + 2 < NKS) ldk(std::integral_constant<int, ks + 2>{}, std::integral_constant<int, (ks + 2) % 3>{});
-        // V(t−1): two pieces per k-step, all of them in the first quarter of the phase — the tiles are single-buffered, so
-        // the phase ends with vmcnt(0) + barrier and a piece issued late exposes its whole L2 / HBM latency there
-        if constexpr (HAS_PV && 2 * ks < NPIECE) {
-          issue_v(2 * ks, t - 1);
-          issue_v(2 * ks + 1, t - 1);
-        }
+        // V(t−1): two pieces per three k-steps, the last one three quarters into the phase.  The tiles are single-buffered
+        // (the phase ends with vmcnt(0) + barrier: a piece issued late exposes its L2 / HBM latency there), but the texture-
+        // address unit takes 16 cycles per piece and serves four waves: two pieces per k-step and wave (round 2) asked for
+        // twice what it can take, and the waves stood at the full FIFO for 7 % of their cycles with the MFMAs queued behind
+        // the DMA (SQ_VMEM_TA_CMD_FIFO_FULL, profiles/r3u_pmc_attn.txt).  Now 2/3 of its rate.
+        // (D = 256: the phase is half as long — 1024 matrix-core cycles — and the L2 read latency is not: first half of the phase)
+        if constexpr (HAS_PV)
+          static_for<NPIECE>([&](auto ic) {
+            if constexpr (decltype(ic)::value * SPAN_A / NPIECE == ks) issue_v(decltype(ic)::value, t - 1);
+          });
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (ks < NRES) {
           bd2_qk<BF16, ks == 0>(s[0], kfr[ks % 3][0], qf[ks]);
@@ -281,12 +287,10 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
     if constexpr (HAS_PV) rd0();
     static_for<NST>([&](auto stc) {
       constexpr int st = decltype(stc)::value;
-      if constexpr (4 * st < NPIECE) {                    // K(t+1): four pieces per step, front-loaded like V's
-        issue_k(4 * st, t + 1);
-        issue_k(4 * st + 1, t + 1);
-        issue_k(4 * st + 2, t + 1);
-        issue_k(4 * st + 3, t + 1);
-      }
+      // K(t+1): spread the same way over the P·V steps (D = 512: 2, 1, 1 pieces per three steps)
+      static_for<NPIECE>([&](auto ic) {
+        if constexpr (decltype(ic)::value * SPAN_B / NPIECE == st) issue_k(decltype(ic)::value, t + 1);
+      });
       if constexpr (HAS_PV) pv_step(stc, po);
       __builtin_amdgcn_sched_barrier(0);
       // softmax(t) of score elements 32 st / NST .. : row sums from the unrounded P (tiling_qkv.cu keeps the same order)

@@ -125,25 +125,31 @@ def gen_body(sched):
     for r in range(16):
         after(2 * r, f"ds_read_b128 {fa(1, r)}, {VA} offset:{r * 2048}" if r < 8
               else f"ds_read_b128 {fb(1, r - 8)}, {VB} offset:{(r - 8) * 2048}")
-    d0 = 32
+    d0, dstep = (3, 8) if sched == 2 else (32, 4)
     after(d0 - 1, "s_add_u32 %[tmp], %[b2], %[wv]")
     for p in range(8):
-        after(d0 + 4 * p, f"s_add_u32 m0, %[tmp], {p * PIECE_STEP}",
+        after(d0 + dstep * p, f"s_add_u32 m0, %[tmp], {p * PIECE_STEP}",
               "s_mov_b32 %[soff], %[t2off]" if p == 0 else "s_add_u32 %[soff], %[soff], %[blk]")
-        after(d0 + 1 + 4 * p, f"buffer_load_dwordx4 %[ao{p & 1}], %[rb], %[soff] offen lds")
-    assert d0 + 1 + 4 * 7 < 64
+        after(d0 + 1 + dstep * p, f"buffer_load_dwordx4 %[ao{p & 1}], %[rb], %[soff] offen lds")
+    assert d0 + 1 + dstep * 7 < 64
     # k-step 1: addresses and reads of (t + 1, ks 0), A pieces of tile t + 2, ring rotation, loop counter.
     #   sched 0: reads first (66..96), A pieces late (97..126)
     #   sched 1: A pieces first, right behind the barrier (their data is needed one tile later, at the next barrier:
     #            late pieces leave < 1100 MFMA cycles of latency cover), reads interleaved with them
-    #   sched 2: sched 1 with the wait + barrier 8 MFMAs into the k-step (skew between the waves is absorbed by
-    #            MFMAs whose operands are already in registers)
-    bar = 72 if sched == 2 else 64
+    #   sched 2: the 16 pieces spread evenly over the tile period (B pieces one per 8 MFMAs through k-step 0, A pieces one per 7
+    #            behind the barrier): the texture-address unit serves the four waves at 16 cycles per piece, so bursts of one
+    #            piece per 4 MFMAs and wave run it at 100 % and fill its FIFO (SQ_VMEM_TA_CMD_FIFO_FULL); spread, it idles at 50 %.
+    #            (Round 2's schedule 2 — barrier 8 MFMAs into the k-step — measured level with 1 and was dropped.)
+    bar = 64
     after(bar, "s_barrier", f"v_add_u32_e32 {VA}, %[anxt], %[ar0]", "s_add_u32 %[tmp], %[acur], %[wv]")
     after(bar + 1, f"v_add_u32_e32 {VB}, %[b1], %[br0]")
     if sched == 0:
         rd = [66 + 2 * r for r in range(16)]
         dma = [97 + 4 * g for g in range(8)]
+    elif sched == 2:
+        dma = [bar + 2 + 7 * g for g in range(8)]
+        busy = {m for d in dma for m in (d, d + 1)}
+        rd = [m for m in range(bar + 4, 126) if m not in busy][:16]
     else:
         dma = [bar + 2 + 4 * g for g in range(8)]
         rd = [bar + 4 + 4 * (r >> 1) + (r & 1) for r in range(16)]
