@@ -111,7 +111,30 @@ def test_generated_hgemm_loops_are_current_and_well_formed():
     for sched in range(gen.NSCHED):
         assert gen.out_path(sched).read_text() == gen.render(sched)
     assert (root / "leetcuda_amd" / "csrc" / "hgemm_w4y_loop_nn.inc").read_text() == gen.render_nn()
-    bodies = [gen.gen_body(s) for s in range(3)]
+    # the K-loop stagger sequence (gen.STAGGER), interpreted: swp <- (swp + stg) mod kt for swp < kt, stg < kt; the compare and
+    # the select that reads its SCC are adjacent in every generated stream
+    def run_stagger(swp, kt, stg):
+        reg = {"swp": swp, "kt": kt, "stg": stg, "t2off": 0xdead}
+        scc = 0
+        val = lambda tok: reg[tok.strip("%[]")] if tok.startswith("%[") else int(tok, 0)
+        for ins in gen.STAGGER:
+            op, args = ins.split(None, 1)
+            d, *src = [a.strip() for a in args.split(",")]
+            if op == "s_add_u32":
+                reg[d.strip("%[]")] = (val(src[0]) + val(src[1])) & 0xffffffff
+            elif op == "s_sub_u32":
+                reg[d.strip("%[]")] = (val(src[0]) - val(src[1])) & 0xffffffff
+            elif op == "s_cmp_ge_u32":
+                scc = int(val(d) >= val(src[0]))
+            elif op == "s_cselect_b32":
+                reg[d.strip("%[]")] = val(src[0]) if scc else val(src[1])
+            else:
+                raise AssertionError(ins)
+        return reg["swp"]
+    for kt in (1, 2, 3, 16, 128):
+        for stg in range(kt):
+            assert [run_stagger(i, kt, stg) for i in range(kt)] == [(i + stg) % kt for i in range(kt)]
+        bodies = [gen.gen_body(s) for s in range(3)]
     nn = gen.gen_nn()
     bodies.append(nn[nn.index(".Lw4y_loop_%=:"):-1])
     for body in bodies:
@@ -121,8 +144,10 @@ def test_generated_hgemm_loops_are_current_and_well_formed():
         assert sum(l.startswith("buffer_load_dwordx4") for l in body) == 16 and body.count("s_barrier") == 1
         # an M0 write is never directly followed by the LDS-DMA that uses it (one wait state needed), and the loop counter's
         # s_cmp is followed only by MFMAs (nothing that writes SCC) up to the branch
+        assert sum(l.startswith("s_cmp_ge_u32") for l in body) == 1
         for a, b in zip(body, body[1:]):
             assert not (a.startswith("s_add_u32 m0") and b.startswith("buffer_load"))
+            assert not a.startswith("s_cmp_ge_u32") or b.startswith("s_cselect_b32")
         tail = body[[i for i, l in enumerate(body) if l.startswith("s_cmp_lt_u32")][-1] + 1:]
         assert tail[-1].startswith("s_cbranch_scc1") and all(l.startswith("v_mfma") for l in tail[:-1])
         # the counted wait: 8 pieces (B of tile t+2) are issued between the loop top and the barrier's wait, 8 (A) behind it

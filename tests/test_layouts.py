@@ -292,3 +292,52 @@ def test_attention_tiles_d64_for_16x16x32_fragments():
         assert chunk ^ ((r >> 1) & 7) == cs
         vchunk = (((cs >> 1) ^ key(r)) << 1) | (cs & 1)
         assert ((vchunk >> 1) ^ key(r)) == (cs >> 1) and (vchunk & 1) == (cs & 1)
+
+
+def test_hgemm_w4y_piece_map_covers_every_row_once_and_keeps_the_image():
+    """hgemm_w4y.hip / gemm_fp8.hip piece map (round 3): piece g of wave w stages rows 32 g + 8 w .. + 8 of the 256-row K-contiguous
+    tile — the four waves' concurrent requests are 32 CONSECUTIVE rows — into LDS bytes g * 4096 + w * 1024 .. + 1024 of the slot.
+    (1) every row of the tile is staged exactly once and lands at row * 128 (the row-major image the fragment reads assume);
+    (2) the source chunk a lane fetches is the one its LDS slot must hold under the st_2x8 swizzle (slot c of row r holds chunk
+        c ^ ((r >> 1) & 7)), with ONE lane-offset register per wave: the key's bit 2 is (8-row block & 1) = wave & 1 for every piece;
+    (3) at one piece index g the four waves cover a contiguous 32-row span."""
+    seen = {}
+    for wave in range(4):
+        for g in range(8):
+            first = 32 * g + 8 * wave
+            lds0 = g * 4096 + wave * 1024
+            for lane in range(64):
+                row = first + (lane >> 3)
+                slot = lane & 7
+                src_chunk = slot ^ (((lane >> 4) & 3) | ((wave & 1) << 2))        # a_off of the kernel (par = wave & 1)
+                lds = lds0 + lane * 16                                          # LDS-DMA writes lane-linearly
+                assert lds == row * 128 + slot * 16
+                assert src_chunk == slot ^ ((row >> 1) & 7)
+                assert (row, slot) not in seen
+                seen[(row, slot)] = src_chunk
+    assert len(seen) == 256 * 8
+    for row in range(256):
+        assert sorted(seen[(row, s)] for s in range(8)) == list(range(8))     # a permutation inside the row
+    for g in range(8):
+        rows = sorted(32 * g + 8 * w + i for w in range(4) for i in range(8))
+        assert rows == list(range(32 * g, 32 * g + 32))
+
+
+def test_k_loop_stagger_index_sequence_visits_every_tile_once():
+    """The generated K loop of hgemm_w4y (tools/gen_hgemm_w4y.py STAGGER) maps the logical tile index i — clamped to KT - 1 for the
+    prefetches past the end — to memory tile (i + stg) mod KT with stg < KT, using add / compare / conditional subtract.  Over a
+    whole walk every memory tile is the operand of exactly one logical tile, for every KT and stagger the launcher can produce
+    (auto: stg = XCD * max(1, KT / 8) mod KT)."""
+    def mem_tile(i, kt, stg):
+        x = min(i, kt - 1) + stg
+        return x - kt if x >= kt else x
+
+    for kt in list(range(1, 20)) + [32, 64, 128, 196, 256]:
+        step = max(1, kt // 8)
+        for xcd in range(8):
+            stg = (xcd & 7) * step % kt
+            assert 0 <= stg < kt
+            walk = [mem_tile(t, kt, stg) for t in range(kt)]
+            assert sorted(walk) == list(range(kt))
+            # the loop prefetches logical tiles t + 2 (clamped): always a valid tile of the matrix
+            assert all(0 <= mem_tile(t + 2, kt, stg) < kt for t in range(kt))
