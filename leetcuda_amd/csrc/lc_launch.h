@@ -40,6 +40,15 @@ int set_dyn_lds(KernelT kernel, int bytes) {
 extern int g_tune_attn_ablate, g_tune_w4_abl, g_tune_hgemm_stamps;
 extern int g_tune_attn_d512;   // D = 256 / 512 attention kernel choice (lc_tune_set "attn_d512")
 extern int g_tune_hgemm_stagger;   // K-loop stagger of hgemm_w4y_kernel: 0 = auto (by XCD, step K / 64 / 8), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 | mask << 20 (hgemm_w4y.hip)
+// the kernel argument of the K-loop stagger for a K walk of kt tiles: auto (knob 0) = by XCD, the eight start tiles spread evenly
+// over the K range (L2 sharing inside an XCD stays intact, fabric bytes unchanged: profiles/r3q_hgemm_stagger_ab.log); bit 27 = off
+inline int stagger_arg(int kt) {
+  const int knob = g_tune_hgemm_stagger;
+  if (knob & (1 << 27)) return 0;
+  if (knob != 0) return knob;
+  const int step = kt / 8;
+  return 1 | (step < 1 ? 1 : step > 255 ? 255 : step) << 12 | 7 << 20;
+}
 extern int g_tune_w4y_sched;   // schedule of hgemm_w4y_kernel's generated loop body (all of them compute the same bits)
 
 // launchers living in their own translation units

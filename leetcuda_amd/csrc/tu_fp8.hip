@@ -9,15 +9,8 @@ int launch_gemm_fp8(const uint8_t* A, const uint8_t* B, half_t* C, int M, int N,
   if (mx == 1 && (size_t)K * 260 < ((size_t)1 << 31)) {   // (a wave's pieces reach 232 rows past its base)
     auto kern = gemm_fp8_w4_kernel;
     if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
-    int stg = g_tune_hgemm_stagger;     // K-loop stagger, as launch_w4x_one (tu_w4.hip): auto = by XCD, an eighth of K apart
-    if (stg == 0) {
-      const int kt8 = K / BK8 / 8;
-      stg = 1 | (kt8 < 1 ? 1 : kt8 > 255 ? 255 : kt8) << 12 | 7 << 20;
-    } else if (stg & (1 << 27)) {
-      stg = 0;
-    }
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), W4B_LDS, st, A, B, C, M, N, K, alpha, tiles_m,
-                       tiles_n, pw, stg);
+                       tiles_n, pw, stagger_arg(K / BK8));   // K-loop stagger as hgemm_w4y (lc_launch.h)
   } else if (mx) {
     auto kern = gemm_fp8_pingpong2_kernel<true>;
     if (int rc = set_dyn_lds(kern, HGEMM256_LDS)) return rc;

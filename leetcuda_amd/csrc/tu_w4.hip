@@ -26,19 +26,8 @@ int launch_w4x_one(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   const dim3 grid(g_w4_nblk > 0 ? g_w4_nblk : tiles_m * tiles_n);
   if constexpr (Y < 0)
     hipLaunchKernelGGL(kern, grid, dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
-  else {
-    // K-loop stagger (hgemm_w4y.hip): auto = by XCD, the eight start tiles spread evenly over the K range (L2 sharing inside an
-    // XCD stays intact, fabric bytes unchanged; 8192^3: +4 % on zero-filled operands, +0.1 ... 0.4 % at the power cap —
-    // profiles/r3q_hgemm_stagger_ab.log); bit 27 of the knob = off
-    int stg = g_tune_hgemm_stagger;
-    if (stg == 0) {
-      const int kt8 = K / BK / 8;
-      stg = 1 | (kt8 < 1 ? 1 : kt8 > 255 ? 255 : kt8) << 12 | 7 << 20;
-    } else if (stg & (1 << 27)) {
-      stg = 0;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw, stg);
-  }
+  else
+    hipLaunchKernelGGL(kern, grid, dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw, stagger_arg(K / BK));
   return check_launch();
 }
 
