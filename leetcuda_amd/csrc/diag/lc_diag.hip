@@ -80,6 +80,20 @@ int lc_probe_coissue(int filler, int k, int mode, void* out_u64x16, void* stream
     default: return ERR_ARG;
   }
 }
+// waves: 4 or 8 per workgroup (one workgroup on one CU); mix: 0..4 (probe_attn_mix_kernel)
+int lc_probe_attn_mix(int waves, int mix, void* out_u64x16, void* stream) {
+  if (!out_u64x16 || (waves != 4 && waves != 8) || mix < 0 || mix > 4) return ERR_ARG;
+  unsigned long long* out = static_cast<unsigned long long*>(out_u64x16);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define LC_MIX(W, M) hipLaunchKernelGGL((probe_attn_mix_kernel<W, M>), dim3(1), dim3(W * 64), 0, st, out, 1.0f)
+  if (waves == 4) {
+    if (mix == 0) LC_MIX(4, 0); else if (mix == 1) LC_MIX(4, 1); else if (mix == 2) LC_MIX(4, 2); else if (mix == 3) LC_MIX(4, 3); else LC_MIX(4, 4);
+  } else {
+    if (mix == 0) LC_MIX(8, 0); else if (mix == 1) LC_MIX(8, 1); else if (mix == 2) LC_MIX(8, 2); else if (mix == 3) LC_MIX(8, 3); else LC_MIX(8, 4);
+  }
+#undef LC_MIX
+  return check_launch();
+}
 int lc_probe_mfma_war(int delay, int kind, int queued, const void* a, const void* b, float* d, void* stream) {
   if (!a || !b || !d) return ERR_ARG;
   const half_t* ah = static_cast<const half_t*>(a);

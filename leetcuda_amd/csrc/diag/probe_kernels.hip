@@ -122,6 +122,67 @@ __global__ __launch_bounds__(512) void probe_coissue_kernel(unsigned long long* 
 }
 
 
+// Does a second wave on the SIMD hide the softmax under the MFMAs?  (the 8-wave / 32-row attention design.)
+// WAVES = 4 (one per SIMD) or 8 (two per SIMD); every wave runs 512 iterations of 4 x { one v_mfma_f32_16x16x32_f16 on rotating
+// accumulators, then the softmax share of one MFMA slot }: MIX 0 = nothing, 1 = D = 128 (per TWO slots: 1 v_exp + 1 dependent v_add +
+// 1 v_fma + 1/2 v_cvt_pk + 1/2 ds_read_b128), 2 = D = 64 (that per ONE slot), 3 / 4 = MIX 2 / 1 without the LDS read (the probe
+// waits for its reads once per iteration, a real kernel a tile later: 3 / 4 are the honest figures).
+// out[wave] = s_memtime cycles of the loop: cycles per MFMA and SIMD = out / 2048 / (WAVES / 4).
+template <int WAVES, int MIX>
+__global__ __launch_bounds__(WAVES * 64) void probe_attn_mix_kernel(unsigned long long* out, float seed) {
+  __shared__ __attribute__((aligned(16))) float lbuf[64 * 4 * 8];
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  half8_t a, b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a[j] = (half_t)(seed + j);
+    b[j] = (half_t)(seed - j);
+  }
+  f32x4_t acc[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float x[8], sum[2] = {0.f, 0.f};
+  u32x4_t ld[2] = {u32x4_t{0, 0, 0, 0}, u32x4_t{0, 0, 0, 0}};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    x[j] = seed * 0.01f - j;
+    lbuf[lane * 4 + j * 256] = seed;
+  }
+  const float c = 0.999f;
+  const uint32_t la = lds_addr32(&lbuf[lane * 4]);
+  __syncthreads();
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < 512; ++it) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(a), "v"(b));
+      constexpr bool dummy = false;
+      (void)dummy;
+      const bool full = (MIX == 2 || MIX == 3) || (m & 1) == 0;            // MIX 1 / 4: the softmax share every other slot
+      if (MIX != 0 && full) {
+        asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[m]) : "v"(c));
+        asm volatile("v_exp_f32 %0, %1\n\tv_add_f32 %2, %2, %0" : "=&v"(x[4 + m]), "+v"(x[m]), "+v"(sum[m & 1]));
+        if (((MIX == 2 || MIX == 3) ? m : (m >> 1)) & 1) {
+          asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(x[4 + m]) : "v"(x[4 + (m ^ 1)]));
+          if (MIX < 3) asm volatile("ds_read_b128 %0, %1" : "=v"(ld[(m >> 1) & 1]) : "v"(la));
+        }
+      }
+    }
+    if (MIX == 1 || MIX == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float sink = sum[0] + sum[1];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sink += x[j];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) sink += acc[m][0];
+  sink += __builtin_bit_cast(float, ld[0][0]) + __builtin_bit_cast(float, ld[1][0]);
+  if (lane == 0) out[wave] = t1 - t0;
+  if (sink == 12345.678f) out[8 + wave] = 1;   // keep everything live
+}
+
 // Does an in-flight v_mfma_f32_32x32x16_f16 still read its A operand registers after issue?  One wave: a first MFMA
 // keeps the matrix pipe busy (QUEUED = 1) or not, then the probed MFMA is issued, then DELAY wait states, then VALU
 // (KIND 0: v_mov 0; 1: v_exp_f32; 2: an LDS load of zeros, ds_read_b128) overwrites the A operand registers; QUEUED = number

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""One wave per SIMD or two?  Cycles per v_mfma_f32_16x16x32_f16 and SIMD next to the softmax share of an MFMA slot
+(lc_probe_attn_mix in liblc_diag.so).  16 = the matrix core flat out."""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+from leetcuda_amd import capi  # noqa: E402
+
+lib = capi.load_diag()
+out = torch.zeros(16, dtype=torch.int64, device="cuda")
+names = {0: "MFMAs only", 1: "D = 128 share (exp + add + fma + cvt/2 + ds_read/2 per two slots)", 2: "D = 64 share (the same per slot)",
+         3: "D = 64 share without the LDS read", 4: "D = 128 share without the LDS read"}
+for mix in (0, 1, 2, 3, 4):
+    row = []
+    for waves in (4, 8):
+        for _ in range(3):
+            out.zero_()
+            rc = lib.lc_probe_attn_mix(waves, mix, out.data_ptr(), None)
+            assert rc == 0, rc
+            torch.cuda.synchronize()
+        t = out.cpu().numpy()[:waves]
+        row.append(f"{waves} waves: {t.max() / 2048 / (waves // 4):5.1f} cycles per MFMA and SIMD (per wave {t.max() / 2048:5.1f})")
+    print(f"{names[mix]:72s} | " + " | ".join(row), flush=True)
