@@ -341,3 +341,27 @@ def test_k_loop_stagger_index_sequence_visits_every_tile_once():
             assert sorted(walk) == list(range(kt))
             # the loop prefetches logical tiles t + 2 (clamped): always a valid tile of the matrix
             assert all(0 <= mem_tile(t + 2, kt, stg) < kt for t in range(kt))
+
+
+def test_persistent_attention_walk_visits_every_block_once_on_its_xcd():
+    """attn_w4p.hip: workgroup w of a G-workgroup grid (G = min(blocks, CUs)) walks the virtual block ids w, w + G, w + 2 G, ... and maps
+    each through xcd_remap(v, nblk) (lc_common.h: virtual id v lives on XCD v & 7; an XCD owns a contiguous range of real ids).  Every
+    real block is computed exactly once, and — G being a multiple of 8 whenever there is more than one round — all blocks of a
+    workgroup stay on ITS XCD, whose L2 holds their heads' K / V (the GPU tests run 296 / 516 / 48 / 260 blocks)."""
+    def xcd_remap(b, nwg):
+        q, r, xcd, idx = nwg >> 3, nwg & 7, b & 7, b >> 3
+        base = xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q
+        return base + idx
+
+    for ncu in (256, 64, 8):
+        for nblk in (1, 5, 48, 255, 256, 257, 260, 296, 516, 2048, 2051):
+            G = min(nblk, ncu)
+            seen = []
+            for w in range(G):
+                v = w
+                while v < nblk:
+                    seen.append(xcd_remap(v, nblk))
+                    if nblk > G:
+                        assert v & 7 == w & 7        # G % 8 == 0 here: the walk stays on the workgroup's XCD
+                    v += G
+            assert sorted(seen) == list(range(nblk)), (ncu, nblk)
