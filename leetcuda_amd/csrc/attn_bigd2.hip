@@ -127,7 +127,7 @@ LC_DEVINL half4_t bd2_tr(uint32_t addr) {   // asm transpose read (hipcc would g
   return r;
 }
 
-template <int D, bool BF16, int SP8 = (D == 512 ? 6 : 4)>   // SP8: eighths of a phase over which its DMA pieces are spread (measured flat from 4/8 to 6/8 at D = 512, 3/8 to 4/8 at D = 256; 7/8 resp. 6/8: - 1 ... - 2 %)
+template <int D, bool BF16>
 __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
     half_t* __restrict__ O, int N, int nqb, float sl2) {
@@ -222,6 +222,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
   half8_t vf0, vf1, vf2, vf3;
   constexpr int NQ = NDT / 4, NST = 4 * NQ;
   // DMA piece i of a phase is issued in k-step i * SPAN_A / NPIECE (Q·Kᵀ phase) / step i * SPAN_B / NPIECE (P·V phase)
+  // over SP8 eighths of the phase: measured flat from 4/8 to 6/8 at D = 512 and from 3/8 to 4/8 at D = 256, 7/8 resp. 6/8 cost 1 ... 2 %
+  // (profiles/r3aa_attn_bigd2_span_sweep.log)
+  constexpr int SP8 = D == 512 ? 6 : 4;
   constexpr int SPAN_A = SP8 * NKS / 8, SPAN_B = SP8 * NST / 8;
   auto rd0 = [&]() { bd2_rd0<8 * ROWB>(vf0, vf1, vf2, vf3, vx); };
   auto pv_step = [&](auto stc, half8_t (&pf)[4]) {

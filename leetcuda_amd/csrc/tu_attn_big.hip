@@ -7,9 +7,9 @@
 
 namespace lc {
 namespace {
-template <int D, bool BF16, int SP8 = (D == 512 ? 6 : 4)>
+template <int D, bool BF16>
 int launch_bigd2_t(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, hipStream_t st) {
-  auto kern = attn_fwd_bigd2_kernel<D, BF16, SP8>;
+  auto kern = attn_fwd_bigd2_kernel<D, BF16>;
   constexpr int lds = bigd2_lds_bytes<D>();
   if (int rc = set_dyn_lds(kern, lds)) return rc;
   const int nqb = N / 128;

@@ -4,7 +4,7 @@ shortens it) -> workload key.  bench.py prints a committed per-launch byte count
 WORKLOADS = [
     ("hgemm_", "hgemm_8192"), ("hipblaslt:", "hgemm_8192"),
     ("gemm_fp8_", "fp8_16384"),
-    ("attn_fwd_w4n_kernel<128", "attn_cfg3"), ("attn_fwd_w4m_kernel<128", "attn_cfg3"), ("attn_fwd_kernel<128", "attn_cfg3"),
+    ("attn_fwd_w4n_kernel<128", "attn_cfg4"), ("attn_fwd_w4m_kernel<128", "attn_cfg3"), ("attn_fwd_kernel<128", "attn_cfg3"),
     ("attn_fwd_w4g_kernel<128", "attn_cfg3"), ("attn_fwd_w4p_kernel<128", "attn_cfg3"), ("attn_fwd_w4i_kernel<128", "attn_cfg3"),
     ("attn_fwd_w4n_kernel<64", "attn_d64"), ("attn_fwd_w4g_kernel<64", "attn_d64"), ("attn_fwd_w4i_kernel<64", "attn_d64"), ("attn_fwd_kernel<64", "attn_d64"),
     ("attn_fwd_bigd2_kernel<512,false", "attn_d512_fp16"), ("attn_fwd_bigd2_kernel<512,true", "attn_d512_bf16"),
