@@ -44,8 +44,10 @@ __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __r
   const half_t* sb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int p = wave * 4 + i;
-    const int row = p * 8 + (lane >> 3);
+    // piece i of this wave = 8-row block 4 i + wave (K-contiguous operands): the four waves' concurrent requests cover 32 consecutive
+    // rows (hgemm_w4y.hip's piece map); NN B pieces (4 k rows of 256 B) keep one band per wave
+    const int p = wave * 4 + i, pk = 4 * i + wave;
+    const int row = pk * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     sa[i] = A + (size_t)(m0 + row) * K + c * 8;
     if constexpr (!B_KN) {
@@ -81,9 +83,9 @@ __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __r
   const size_t bstep = B_KN ? (size_t)BK * N : (size_t)BK;
   auto issue = [&](int t, char* slot) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(sa[i] + (size_t)t * BK, slot + (wave * 4 + i) * 1024);
+    for (int i = 0; i < 4; ++i) glds16(sa[i] + (size_t)t * BK, slot + (4 * i + wave) * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(sb[i] + (size_t)t * bstep, slot + TILE1_BYTES + (wave * 4 + i) * 1024);
+    for (int i = 0; i < 4; ++i) glds16(sb[i] + (size_t)t * bstep, slot + TILE1_BYTES + (B_KN ? wave * 4 + i : 4 * i + wave) * 1024);
   };
   issue(0, smem);
   for (int kt = 0; kt < KT; ++kt) {
