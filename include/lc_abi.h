@@ -105,7 +105,8 @@ const char* lc_build_info(int* is_diag);
  *   "attn_nw"      attention kernel for D <= 128: 0 = auto (D = 128: 515 up to N = 4096, 512 beyond; D = 64: 513; when N % 256 == 0), 513 = the merged-phase
  *                  kernel generalised over the head dim (attn_w4g.hip: D = 64, and D = 128 as a cross-check that must equal
  *                  512 bit for bit), 515 = the same kernel as a persistent workgroup per CU (attn_w4p.hip: K / V / Q streams
- *                  continue across query-block seams; D = 64 / 128, bit-identical to 513), 512 = merged-phase kernel with 16x16x32
+ *                  continue across query-block seams; D = 64 / 128, bit-identical to 513), 516 = D = 64 with eight waves of 32 query rows, two per
+ *                  SIMD (attn_w8g.hip: one wave's softmax runs under the other's MFMAs; bit-identical to 513), 512 = merged-phase kernel with 16x16x32
  *                  MFMAs (attn_w4n.hip, D = 128), 256 = the same with 32x32x16 MFMAs, 4 waves x 64
  *                  query rows, one wave per SIMD (attn_w4m.hip; 260 = its A/B twin with padded Q.K^T MFMAs),
  *                  8 / 4 / 2 = lock-step kernel with that many waves (any N % (32 x waves) == 0, every D <= 128)

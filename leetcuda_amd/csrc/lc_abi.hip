@@ -268,7 +268,7 @@ int choose_attn_nw(int D, bool vt, int N) {
     if (want == 256 || want == 260 || want == 512 || want == 513 || want == 514 || want == 515) return want;
   }
   // D = 64: the head-dim-generalised merged-phase kernel (attn_w4g.hip, 513) unless a lock-step kernel is asked for
-  if (D == 64 && !vt && N % 256 == 0 && (want == 0 || want >= 256)) return (want == 514 || want == 515) ? want : 513;
+  if (D == 64 && !vt && N % 256 == 0 && (want == 0 || want >= 256)) return (want == 514 || want == 515 || want == 516) ? want : 513;
   // D = 96 / 32: only the generated kernel (attn_w4i.hip, 514) has a merged-phase instantiation (256-B / 128-B padded LDS rows)
   if ((D == 96 || D == 32) && !vt && N % 256 == 0 && (want == 0 || want >= 256)) return 514;
   if (N % 256 == 0 && (want == 0 || want >= 8)) return 8;   // (also what 256 / 512 fall back to for D < 128)
@@ -287,6 +287,9 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   if constexpr ((D == 128 || D == 64) && !VT) {
     if (nw == 513) return launch_attn_w4g(Q, K, V, O, B, H, N, D, st);
     if (nw == 515) return launch_attn_w4p(Q, K, V, O, B, H, N, D, st);
+  }
+  if constexpr (D == 64 && !VT) {
+    if (nw == 516) return launch_attn_w8g(Q, K, V, O, B, H, N, D, st);
   }
   if constexpr (!VT) {
     if (nw == 514) return launch_attn_w4i(Q, K, V, O, B, H, N, D, g_tune_attn_w4i_sched, st);
@@ -463,6 +466,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
     else if (nw == 513) snprintf(buf, buflen, "attn_fwd_w4g_kernel<%d>", D);
     else if (nw == 514) snprintf(buf, buflen, "attn_fwd_w4i_kernel<%d,%d>", D, g_tune_attn_w4i_sched);
     else if (nw == 515) snprintf(buf, buflen, "attn_fwd_w4p_kernel<%d>", D);
+    else if (nw == 516) snprintf(buf, buflen, "attn_fwd_w8g_kernel<%d>", D);
     else snprintf(buf, buflen, "attn_fwd_kernel<%d,%d,%s,0>", D, nw, vt);
     return LC_OK;
   }
@@ -481,7 +485,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
 int lc_tune_set(const char* key, int value) {
   if (!key) return LC_ERR_ARG;
   if (strcmp(key, "attn_nw") == 0) {
-    if (value != 0 && value != 256 && value != 260 && value != 512 && value != 513 && value != 514 && value != 515 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
+    if (value != 0 && value != 256 && value != 260 && value != 512 && value != 513 && value != 514 && value != 515 && value != 516 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
     g_tune_attn_nw = value;
     return LC_OK;
   }
@@ -795,6 +799,7 @@ int lc_clock_probe(void* out_u64x2, void* stream) {
 extern "C" int lc_attn_slowpath_stats(unsigned* out4, int reset) {
   if (int rc = lc::diag_attn_slowpath(out4, reset)) return rc;
   if (int rc = lc::diag_attn_slowpath_g(out4, reset)) return rc;
-  return lc::diag_attn_slowpath_p(out4, reset);
+  if (int rc = lc::diag_attn_slowpath_p(out4, reset)) return rc;
+  return lc::diag_attn_slowpath_8(out4, reset);
 }
 

@@ -142,6 +142,9 @@ LC_DEVINL void static_for(F&& f) { static_for_impl(std::make_integer_sequence<in
 
 // clobber list naming every AGPR: statements that address accumulators literally (a[N:M]) carry it so that hipcc
 // never parks a value of its own in the accumulator half of the register file
+// (a translation unit whose kernels run TWO waves per SIMD defines a shorter list before including this header: a clobbered AGPR
+// counts towards the kernel's register allocation — tu_attn_w8g.hip)
+#ifndef LC_AGPR_ALL
 #define LC_AGPR_ALL \
   "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14",  \
   "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28",  \
@@ -164,6 +167,7 @@ LC_DEVINL void static_for(F&& f) { static_for_impl(std::make_integer_sequence<in
   "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242",  \
   "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254",  \
   "a255"
+#endif
 
 
 // a[0:127] + a[192:255]: the attention kernel's O accumulators and Q fragments; a[128:191] stay with hipcc (it

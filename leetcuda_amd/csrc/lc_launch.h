@@ -75,6 +75,9 @@ int launch_attn_w4g(const half_t* Q, const half_t* K, const half_t* V, half_t* O
 // streams continue across block seams): D in {64, 128}, N % 256 == 0
 int launch_attn_w4p(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, hipStream_t st);
 int diag_attn_slowpath_p(unsigned* out4, int reset);   // + the slow-path counters of the w4p kernels
+// tu_attn_w8g.hip: D = 64 with eight waves of 32 query rows, two per SIMD (attn_w8g.hip), N % 256 == 0
+int launch_attn_w8g(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, hipStream_t st);
+int diag_attn_slowpath_8(unsigned* out4, int reset);   // + the slow-path counters of the w8g kernel
 // tu_attn_big.hip: full-width large-head-dim kernel, D in {256, 512}, N % 128 == 0, V as [B,H,N,D]; fp16 or bf16
 int launch_attn_bigd2(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, bool bf16,
                       hipStream_t st);
