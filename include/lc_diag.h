@@ -32,6 +32,9 @@ int lc_probe_coissue(int filler, int k, int mode, void* out_u64x16, void* stream
 /* one workgroup of `waves` (4 or 8) wave64 on one CU, each running v_mfma_f32_16x16x32_f16 + the softmax share of an MFMA slot
  * (mix 0 none, 1 D = 128, 2 D = 64, 3 / 4 = 2 / 1 without the LDS read): out[wave] = cycles of 2048 MFMAs (tools/attn_mix_probe.py) */
 int lc_probe_attn_mix(int waves, int mix, void* out_u64x16, void* stream);
+/* v_mfma_f32_16x16x32_f16 with operands from VGPRs / AGPRs (form 0 all VGPR, 1 A/B AGPR + C/D VGPR, 2 A/B VGPR + C/D AGPR, 3 = 1 and 2
+ * alternating, 4 all AGPR): out[wave] = cycles of 4096 MFMAs, one wave per SIMD (tools/attn_mix_probe.py) */
+int lc_probe_mfma_form(int form, void* out_u64x16, void* stream);
 /* does an in-flight 32x32x16 MFMA still read its A operand after issue? (tools/mfma_war_probe.py): the A registers are
  * overwritten by VALU `delay`+1 wait states after the MFMA (kind 0 v_mov, 1 v_exp_f32; queued: behind another MFMA). */
 int lc_probe_mfma_war(int delay, int kind, int queued, const void* a32x16, const void* b32x16, float* d32x32,

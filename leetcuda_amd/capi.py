@@ -57,6 +57,7 @@ DIAG_SYMBOLS = {
     "lc_probe_tr16": (_i, [_vp, _vp, _vp]),
     "lc_probe_coissue": (_i, [_i, _i, _i, _vp, _vp]),
     "lc_probe_attn_mix": (_i, [_i, _i, _vp, _vp]),
+    "lc_probe_mfma_form": (_i, [_i, _vp, _vp]),
     "lc_probe_mfma_war": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "lc_diag_pollute": (_i, [C.c_uint, _i, _vp]),
     "lc_diag_attn_w4i": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -80,6 +80,18 @@ int lc_probe_coissue(int filler, int k, int mode, void* out_u64x16, void* stream
     default: return ERR_ARG;
   }
 }
+// form 0..4: register files of the MFMA operands (probe_mfma_form_kernel); out[wave] = cycles of 4096 MFMAs
+int lc_probe_mfma_form(int form, void* out_u64x16, void* stream) {
+  if (!out_u64x16 || form < 0 || form > 4) return ERR_ARG;
+  unsigned long long* out = static_cast<unsigned long long*>(out_u64x16);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (form == 0) hipLaunchKernelGGL(probe_mfma_form_kernel<0>, dim3(1), dim3(256), 0, st, out, 1.0f);
+  else if (form == 1) hipLaunchKernelGGL(probe_mfma_form_kernel<1>, dim3(1), dim3(256), 0, st, out, 1.0f);
+  else if (form == 2) hipLaunchKernelGGL(probe_mfma_form_kernel<2>, dim3(1), dim3(256), 0, st, out, 1.0f);
+  else if (form == 3) hipLaunchKernelGGL(probe_mfma_form_kernel<3>, dim3(1), dim3(256), 0, st, out, 1.0f);
+  else hipLaunchKernelGGL(probe_mfma_form_kernel<4>, dim3(1), dim3(256), 0, st, out, 1.0f);
+  return check_launch();
+}
 // waves: 4 or 8 per workgroup (one workgroup on one CU); mix: 0..4 (probe_attn_mix_kernel)
 int lc_probe_attn_mix(int waves, int mix, void* out_u64x16, void* stream) {
   if (!out_u64x16 || (waves != 4 && waves != 8) || mix < 0 || mix > 4) return ERR_ARG;

@@ -183,6 +183,50 @@ __global__ __launch_bounds__(WAVES * 64) void probe_attn_mix_kernel(unsigned lon
   if (sink == 12345.678f) out[8 + wave] = 1;   // keep everything live
 }
 
+// Which register file do the operands of a v_mfma_f32_16x16x32_f16 come from, and does it matter?  One wave per SIMD (4 waves), 512
+// iterations of 8 independent MFMAs.  FORM 0: A, B, C/D in VGPRs; 1: A, B in AGPRs, C/D in VGPRs (the attention kernels' Q·Kᵀ form);
+// 2: A, B in VGPRs, C/D in AGPRs (their P·V form); 3: forms 1 and 2 alternating (the merged phase); 4: all in AGPRs.
+// out[wave] = cycles of 4096 MFMAs.
+template <int FORM>
+__global__ __launch_bounds__(256) void probe_mfma_form_kernel(unsigned long long* out, float seed) {
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id();
+  half8_t a, b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a[j] = (half_t)(seed + j);
+    b[j] = (half_t)(seed - j);
+  }
+  f32x4_t acc[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const u32x4_t aw = __builtin_bit_cast(u32x4_t, a), bw = __builtin_bit_cast(u32x4_t, b);
+  // a[64:67] / a[68:71]: the A / B operands of the AGPR forms; a[0:31]: eight accumulator blocks
+  asm volatile("v_accvgpr_write_b32 a64, %0\n\tv_accvgpr_write_b32 a65, %1\n\tv_accvgpr_write_b32 a66, %2\n\tv_accvgpr_write_b32 a67, %3\n\t"
+               "v_accvgpr_write_b32 a68, %4\n\tv_accvgpr_write_b32 a69, %5\n\tv_accvgpr_write_b32 a70, %6\n\tv_accvgpr_write_b32 a71, %7"
+               :: "v"(aw[0]), "v"(aw[1]), "v"(aw[2]), "v"(aw[3]), "v"(bw[0]), "v"(bw[1]), "v"(bw[2]), "v"(bw[3]) : LC_AGPR_ALL);
+  static_for<32>([&](auto r) { asm volatile("v_accvgpr_write_b32 a[%0], 0" :: "n"(decltype(r)::value) : LC_AGPR_ALL); });
+  asm volatile("s_nop 7" ::: "memory");
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < 512; ++it) {
+    static_for<8>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int f = FORM == 3 ? 1 + (m & 1) : FORM;
+      if constexpr (f == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(a), "v"(b));
+      else if constexpr (f == 1) asm volatile("v_mfma_f32_16x16x32_f16 %0, a[64:67], a[68:71], %0" : "+v"(acc[m]) :: LC_AGPR_ALL);
+      else if constexpr (f == 2) asm volatile("v_mfma_f32_16x16x32_f16 a[%2:%3], %0, %1, a[%2:%3]" :: "v"(a), "v"(b), "n"(4 * m), "n"(4 * m + 3) : LC_AGPR_ALL);
+      else asm volatile("v_mfma_f32_16x16x32_f16 a[%0:%1], a[64:67], a[68:71], a[%0:%1]" :: "n"(4 * m), "n"(4 * m + 3) : LC_AGPR_ALL);
+    });
+  }
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float sink = 0.f;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) sink += acc[m][0];
+  if (lane == 0) out[wave] = t1 - t0;
+  if (sink == 12345.678f) out[8 + wave] = 1;
+}
+
 // Does an in-flight v_mfma_f32_32x32x16_f16 still read its A operand registers after issue?  One wave: a first MFMA
 // keeps the matrix pipe busy (QUEUED = 1) or not, then the probed MFMA is issued, then DELAY wait states, then VALU
 // (KIND 0: v_mov 0; 1: v_exp_f32; 2: an LDS load of zeros, ds_read_b128) overwrites the A operand registers; QUEUED = number

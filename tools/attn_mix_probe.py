@@ -22,3 +22,14 @@ for mix in (0, 1, 2, 3, 4):
         t = out.cpu().numpy()[:waves]
         row.append(f"{waves} waves: {t.max() / 2048 / (waves // 4):5.1f} cycles per MFMA and SIMD (per wave {t.max() / 2048:5.1f})")
     print(f"{names[mix]:72s} | " + " | ".join(row), flush=True)
+
+forms = {0: "A, B, C/D in VGPRs", 1: "A, B in AGPRs, C/D in VGPRs (Q.K^T form)", 2: "A, B in VGPRs, C/D in AGPRs (P.V form)",
+         3: "forms 1 and 2 alternating (merged phase)", 4: "A, B, C/D in AGPRs"}
+for form in range(5):
+    for _ in range(3):
+        out.zero_()
+        rc = lib.lc_probe_mfma_form(form, out.data_ptr(), None)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+    t = out.cpu().numpy()[:4]
+    print(f"MFMA operand files: {forms[form]:48s} {t.max() / 4096:5.1f} cycles per MFMA", flush=True)
