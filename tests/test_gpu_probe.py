@@ -57,3 +57,27 @@ def test_tr16_transpose_semantics():
         for i in range(16):
             want[g * 16 + i] = block[:, i]
     assert (got == want).all(), (got[:20], want[:20])
+
+
+def test_issue_probes_run_and_report_sane_cycle_counts():
+    """tools/attn_mix_probe.py's entry points (include/lc_diag.h): one wave per SIMD or two next to the softmax share of an MFMA slot,
+    and the MFMA operand register-file forms.  Sanity only — argument checks, and cycle counts between the matrix core's rate
+    (16 cycles per v_mfma_f32_16x16x32_f16) and a generous upper bound; the numbers themselves are evidence (profiles/r3ab), not a test."""
+    capi, lib = _lib()
+    out = torch.zeros(16, dtype=torch.int64, device="cuda")
+    assert lib.lc_probe_attn_mix(5, 0, out.data_ptr(), None) != 0
+    assert lib.lc_probe_attn_mix(4, 9, out.data_ptr(), None) != 0
+    assert lib.lc_probe_mfma_form(7, out.data_ptr(), None) != 0
+    for waves in (4, 8):
+        for mix in (0, 3, 4):
+            out.zero_()
+            capi.check(lib.lc_probe_attn_mix(waves, mix, out.data_ptr(), None), "probe")
+            torch.cuda.synchronize()
+            per_simd = out.cpu().numpy()[:waves].max() / 2048 / (waves // 4)
+            assert 15.5 <= per_simd <= 80.0, (waves, mix, per_simd)
+    for form in range(5):
+        out.zero_()
+        capi.check(lib.lc_probe_mfma_form(form, out.data_ptr(), None), "probe")
+        torch.cuda.synchronize()
+        per_mfma = out.cpu().numpy()[:4].max() / 4096
+        assert 15.5 <= per_mfma <= 24.0, (form, per_mfma)
