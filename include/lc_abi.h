@@ -111,6 +111,8 @@ const char* lc_build_info(int* is_diag);
  *                  query rows, one wave per SIMD (attn_w4m.hip; 260 = its A/B twin with padded Q.K^T MFMAs),
  *                  8 / 4 / 2 = lock-step kernel with that many waves (any N % (32 x waves) == 0, every D <= 128)
  *   "w4y_sched"    schedule 0..2 of LC_HGEMM_MFMA256W4Y's generated loop body (tools/gen_hgemm_w4y.py; same bits, A/B knob)
+ *   "hgemm_persist" 1 (default) = LC_HGEMM_MFMA256W4Y as one persistent workgroup per CU walking the C tiles, when their number is a
+ *                  multiple of the CU count and larger (same bits as the one-tile launch, 0: + 0.2 % at the cap, + 0.7 % zero-filled)
  *   "hgemm_stagger" K-loop stagger of LC_HGEMM_MFMA256W4Y (hgemm_w4y.hip): the workgroup starts its K walk at tile ((index & mask)
  *                  * step) mod (K / 64) and wraps, index = cx * XCD + cm * tile row + cn * tile column.  0 = auto (cx = 1, mask 7, step
  *                  K / 64 / 8: the eight XCDs start an eighth of K apart), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 |

@@ -29,6 +29,7 @@ int g_tune_attn_ablate = 0;      // attention ablation / stamp builds (diagnosis
 int g_tune_w4_abl = 0;           // hgemm_w4 ablation bits (diagnosis only, LC_DIAG)
 int g_tune_w4y_sched = 1;        // hgemm_w4y_kernel loop schedule 0..2 (lc_tune_set "w4y_sched")
 int g_tune_hgemm_stamps = 0;     // GEMM cycle-stamp builds (diagnosis only, LC_DIAG)
+int g_tune_hgemm_persist = 1;    // 1 (default) = hgemm_w4y_kernel as a persistent workgroup per CU when the tiles divide evenly (lc_tune_set "hgemm_persist")
 int g_tune_hgemm_stagger = 0;    // K-loop stagger of hgemm_w4y_kernel (lc_tune_set "hgemm_stagger"): 0 = auto (by XCD), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 | mask << 20
 int g_tune_attn_d512 = 0;        // D = 256 / 512: 0 = auto (attn_bigd2), 1 = column-split kernel, 2 = attn_bigd3 (experimental)
 }  // namespace lc
@@ -511,6 +512,11 @@ int lc_tune_set(const char* key, int value) {
     if (value < 0 || value > 2) return LC_ERR_ARG;
 #endif
     g_tune_w4y_sched = value;
+    return LC_OK;
+  }
+  if (strcmp(key, "hgemm_persist") == 0) {
+    if (value < 0 || value > 1) return LC_ERR_ARG;
+    g_tune_hgemm_persist = value;
     return LC_OK;
   }
   if (strcmp(key, "hgemm_stagger") == 0) {

@@ -39,6 +39,7 @@ int set_dyn_lds(KernelT kernel, int bytes) {
 // tuning globals (defined in lc_abi.hip, lc_tune_set)
 extern int g_tune_attn_ablate, g_tune_w4_abl, g_tune_hgemm_stamps;
 extern int g_tune_attn_d512;   // D = 256 / 512 attention kernel choice (lc_tune_set "attn_d512")
+extern int g_tune_hgemm_persist;   // 1 (default) = hgemm_w4y_kernel as a persistent workgroup per CU when the tiles divide evenly (tu_w4.hip)
 extern int g_tune_hgemm_stagger;   // K-loop stagger of hgemm_w4y_kernel: 0 = auto (by XCD, step K / 64 / 8), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 | mask << 20 (hgemm_w4y.hip)
 // the kernel argument of the K-loop stagger for a K walk of kt tiles: auto (knob 0) = by XCD, the eight start tiles spread evenly
 // over the K range (L2 sharing inside an XCD stays intact, fabric bytes unchanged: profiles/r3q_hgemm_stagger_ab.log); bit 27 = off

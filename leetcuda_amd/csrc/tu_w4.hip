@@ -13,6 +13,16 @@ int launch_w4_one(const half_t* A, const half_t* B, half_t* C, int M, int N, int
   return check_launch();
 }
 
+int w4_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    n = v;
+  }
+  return n;
+}
 int g_w4_nblk = -1;   // blocks to launch (< tiles_m * tiles_n when the ragged last wave goes to the 128-tile kernel); set per call
 
 template <bool B_KN, int Y>   // Y: -1 = hgemm_w4x_kernel, 0.. = hgemm_w4y_kernel<.., Y>
@@ -23,11 +33,17 @@ int launch_w4x_one(const half_t* A, const half_t* B, half_t* C, int M, int N, in
     else return hgemm_w4y_kernel<B_KN, Y>;
   }();
   if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
-  const dim3 grid(g_w4_nblk > 0 ? g_w4_nblk : tiles_m * tiles_n);
-  if constexpr (Y < 0)
-    hipLaunchKernelGGL(kern, grid, dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
-  else
-    hipLaunchKernelGGL(kern, grid, dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw, stagger_arg(K / BK));
+  const int nblk = g_w4_nblk > 0 ? g_w4_nblk : tiles_m * tiles_n;
+  if constexpr (Y < 0) {
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
+  } else {
+    // lc_tune_set "hgemm_persist" = 1: one workgroup per CU walks the block ids (hgemm_w4y.hip); only when every workgroup gets the
+    // same number of tiles (a ragged walk would leave CUs idle for a whole tile)
+    const int ncu = w4_cu_count();
+    const bool persist = g_tune_hgemm_persist != 0 && nblk > ncu && nblk % ncu == 0;
+    hipLaunchKernelGGL(kern, dim3(persist ? ncu : nblk), dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw,
+                       stagger_arg(K / BK), persist ? nblk : 0);
+  }
   return check_launch();
 }
 

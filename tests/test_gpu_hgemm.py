@@ -318,6 +318,31 @@ def test_k_loop_stagger_walks_every_k_tile_once(oracle, layout):
             assert ok, (M, N, K, knob, mx)
 
 
+@pytest.mark.parametrize("layout", ["nn", "tn"])
+def test_persistent_workgroup_walk_computes_the_same_bits(layout):
+    """lc_tune_set "hgemm_persist" = 1: hgemm_w4y_kernel as one persistent workgroup per CU that walks the C tiles w, w + G, ... (taken
+    when the tile count is a multiple of the CU count and larger).  The virtual block id of a tile — hence its raster position and
+    its K-loop stagger — is what the one-tile launch gives it: outputs must be IDENTICAL, with both block -> tile maps."""
+    capi = _capi()
+    lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
+    for M, N, K in ((8192, 4096, 256), (4096, 8192, 448), (8192, 8192, 128)):
+        torch.manual_seed(M + K)
+        a = torch.randn(M, K, dtype=torch.half, device="cuda")
+        b = torch.randn(K, N, dtype=torch.half, device="cuda")
+        for raster in (1, 2):
+            outs = []
+            for persist in (0, 1):
+                capi.tune("hgemm_persist", persist)
+                capi.tune("hgemm_raster", raster)
+                try:
+                    c, _ = _run(capi, a, b, lay, VARIANTS["w4y"], 2048)
+                finally:
+                    capi.tune("hgemm_persist", 0)
+                    capi.tune("hgemm_raster", 0)
+                outs.append(c)
+            assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1]), (M, N, K, raster)
+
+
 def test_auto_large_nn_b_uses_64bit_dma_addresses():
     """B of 2 GiB (NN): the buffer-descriptor DMA of the AUTO kernel (32-bit offsets) must hand over to the 64-bit
     global form; the result has to agree with the independently scheduled 8-wave kernel on every element."""

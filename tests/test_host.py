@@ -223,14 +223,14 @@ def test_steady_state_loops_keep_their_instruction_mix(built):
     import isa_count as ic
     obj = built["abi"].parent / "obj"
 
-    def mix(unit, rx):
+    def mix(unit, rx, label=None):
         name, lines = ic.kernel_lines(obj / unit, rx)
         assert lines, rx
-        body, _ = ic.loop_mix(lines)
+        body, _ = ic.loop_mix(lines, label)
         c = Counter(ic.classify(x.split()[0]) for x in body)
         return c, c["valu"] + c["valu_trans"] + c["valu_accvgpr"]
 
-    g, gv = mix("tu_w4.s", r"hgemm_w4y_kernelILb0ELi1E")
+    g, gv = mix("tu_w4.s", r"hgemm_w4y_kernelILb0ELi1E", r"w4y_loop")   # the K loop (the kernel's outer loop is the persistent tile walk)
     assert (g["mfma"], g["lds"], g["vmem"], g["s_barrier"], g["s_nop"]) == (128, 32, 16, 1, 0), g
     assert gv <= 8, g
     g64, g64v = mix("tu_attn_w4g.s", r"attn_fwd_w4g_kernelILi64")   # D = 64: one tile = 64 MFMAs for the same 64 score elements

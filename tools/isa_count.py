@@ -60,9 +60,10 @@ BRANCH = re.compile(r"s_c?branch\w*\s+(\.L[\w$]+)")
 COLD = ("ds_bpermute", "v_permlane", "global_atomic", "flat_atomic")
 
 
-def loop_mix(lines):
+def loop_mix(lines, label=None):
     """(instructions on the steady-state path of one loop iteration, number of instructions in the loop's cold blocks).
-    The loop = the largest label..backward-branch span; its header = the last label in front of the span's first s_barrier
+    The loop = the largest label..backward-branch span (label: regex — only spans whose label matches count: a persistent kernel's
+    outer tile / block walk spans the whole kernel); its header = the last label in front of the span's first s_barrier
     (hipcc lays the overflow slow path of the second phase out IN FRONT of the header).  From the header the walk follows
     the control flow; at a conditional branch it takes the side that does not run into a cross-lane reduction or an atomic
     (the overflow guard's slow path) within the next 80 instructions and stays inside the span."""
@@ -80,7 +81,7 @@ def loop_mix(lines):
     best = None
     for i, s in enumerate(ins):
         m = BRANCH.match(s)
-        if m and labels.get(m.group(1), 1 << 30) <= i:
+        if m and labels.get(m.group(1), 1 << 30) <= i and (label is None or re.search(label, m.group(1))):
             span = (labels[m.group(1)], i + 1)
             if best is None or span[1] - span[0] > best[1] - best[0]:
                 best = span
@@ -121,12 +122,12 @@ def loop_mix(lines):
     return body, (best[1] - best[0]) - len(body)
 
 
-def report(path, rx, elems):
+def report(path, rx, elems, label=None):
     name, lines = kernel_lines(path, rx)
     if not lines:
         print(f"{rx}: not found in {path}")
         return
-    body, ncold = loop_mix(lines)
+    body, ncold = loop_mix(lines, label)
     mix = Counter(classify(x.split()[0]) for x in body)
     valu = mix["valu"] + mix["valu_trans"] + mix["valu_accvgpr"]
     nops = sum(int(x.split()[1]) + 1 for x in body if x.startswith("s_nop"))
@@ -146,4 +147,4 @@ if __name__ == "__main__":
         # w4n: one loop iteration = one 64-key tile for 64 query rows per wave = 4096 scores / 64 lanes
         report(OBJ / "tu_attn_w4.s", r"attn_fwd_w4n_kernel", 64)
         report(OBJ / "tu_attn_w4.s", r"attn_fwd_w4m_kernel", 64)
-        report(OBJ / "tu_w4.s", r"hgemm_w4y_kernelILb0ELi1E", 0)
+        report(OBJ / "tu_w4.s", r"hgemm_w4y_kernelILb0ELi1E", 0, r"w4y_loop")   # (the K loop, not the persistent tile walk)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Back-to-back launches of one hot kernel for a few seconds per spec (the workload of tools/power_watch.sh; join the
 sampler log with tools/power_join.py).  usage: sustain.py [--seconds S] spec...
-   spec = hgemm | vendor | attn | attn8k | d512, optionally :nn (B stored [K][N]), :zero (zero-filled inputs), :uniform, :var=auto|w4c|w4x|pingpong2, :stg=N (hgemm K-loop stagger; stg=0 = off, no option = the default), :abl=N (hgemm only:
+   spec = hgemm | vendor | attn | attn8k | d512, optionally :nn (B stored [K][N]), :zero (zero-filled inputs), :uniform, :var=auto|w4c|w4x|pingpong2, :nopersist (hgemm: one tile per workgroup), :stg=N (hgemm K-loop stagger; stg=0 = off, no option = the default), :abl=N (hgemm only:
           lc_tune_set "w4_abl", LC_DIAG library — ablated kernels compute WRONG results), :nw=N (attention kernel choice)"""
 import sys
 import time
@@ -36,6 +36,7 @@ for spec in args:
     nw = next((int(o[3:]) for o in opts if o.startswith("nw=")), 0)
     var = next((o[4:] for o in opts if o.startswith("var=")), "auto")
     capi.tune("w4y_sched", next((int(o[6:]) for o in opts if o.startswith("sched=")), 1))
+    capi.tune("hgemm_persist", 0 if "nopersist" in opts else 1)
     capi.tune("hgemm_stagger", next((int(o[4:], 0) or 1 << 27 for o in opts if o.startswith("stg=")), 0))   # cx | cm << 4 | cn << 8 | step << 12 | mask << 20
     if what in ("hgemm", "vendor"):
         n = 8192
