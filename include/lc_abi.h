@@ -116,7 +116,8 @@ const char* lc_build_info(int* is_diag);
  *   "hgemm_stagger" K-loop stagger of LC_HGEMM_MFMA256W4Y (hgemm_w4y.hip): the workgroup starts its K walk at tile ((index & mask)
  *                  * step) mod (K / 64) and wraps, index = cx * XCD + cm * tile row + cn * tile column.  0 = auto (cx = 1, mask 7, step
  *                  K / 64 / 8: the eight XCDs start an eighth of K apart), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 |
- *                  mask << 20.  Only the fp32 accumulation order changes: results agree with the unstaggered walk to fp16 rounding
+ *                  mask << 20 with mask < 128 (bit 27 together with any other bit is refused).  Only the fp32 accumulation order changes:
+ *                  results agree with the unstaggered walk to fp16 rounding
  *   "hgemm_tail"   1 (default) = when the 256-tile grid's last wave holds at most 128 tiles, the generated-loop kernel computes the
  *                  full waves and the 128-tile kernel the four quadrants of each remaining tile; 0 = one launch
  *   "hgemm_raster" block -> C tile map of the tiled GEMM kernels: 0 = auto (2 when A + B exceed the 256 MiB Infinity Cache by half,
@@ -126,9 +127,15 @@ const char* lc_build_info(int* is_diag);
  *   "hgemm_auto"   kernel LC_HGEMM_AUTO launches on large 256-tileable shapes (a 256-tile lc_hgemm_variant value)
  *   "fp8_mx"       fp8 GEMM: 1 = MX-scaled K = 64 MFMA, 4-wave kernel (default); 2 = MX, 8-wave kernel; 0 = plain K = 16
  *   "attn_d512"    D = 256 / 512 kernel: 0 = auto (one workgroup owns all D output columns), 1 = round-1 column-split kernel,
- *                  2 = EXPERIMENTAL 32-row double-buffered tiles (attn_bigd3.hip; not validated on hardware yet)
+ *                  2 = 32-row double-buffered tiles (attn_bigd3.hip: validated on hardware in round 3, 6-8 % slower, a cross-check)
  * Diagnosis keys (include/lc_diag.h) are rejected with LC_ERR_ARG unless the library was built with LC_DIAG=1. */
 int lc_tune_set(const char* key, int value);
+/* Current and default value of a knob (either pointer may be NULL); LC_ERR_ARG for an unknown key.  lc_tune_count / lc_tune_key
+ * enumerate the keys (NULL for a diagnosis key in a production library).  The knobs are process-wide atomics: setting one while
+ * another host thread launches is well defined (that launch sees the old or the new value), but A/B benches should not rely on it. */
+int lc_tune_get(const char* key, int* value, int* default_value);
+int lc_tune_count(void);
+const char* lc_tune_key(int index);
 
 /* ---- HGEMM ------------------------------------------------------------------------------------
  * Replaces the host launchers + kernels of kernels/hgemm/mma/basic/hgemm_mma_stage.cu:644-1052,2284-2412

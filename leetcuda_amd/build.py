@@ -95,13 +95,39 @@ def _stamp_ok(stamp: Path, flags) -> bool:
         return False
 
 
-def _unit_current(obj: Path, asm, dep: Path) -> bool:
+def _unit_deps(dep: Path):
+    txt = dep.read_text().replace("\\\n", " ")
+    return [Path(d) for d in (txt.split(":", 1)[1].split() if ":" in txt else [])]
+
+
+def _unit_digest(dep: Path, flags) -> str:
+    """Content digest of everything the compiler read for one translation unit (its -MD dependency list; system headers
+    included) + the flags."""
+    import hashlib
+    h = hashlib.sha256(" ".join(_portable(flags)).encode())
+    for q in sorted(_unit_deps(dep), key=lambda x: (x.name, str(x))):
+        h.update(q.name.encode())        # names, not paths: the tree sits at another path on a GPU box
+        h.update(q.read_bytes() if q.exists() else b"<missing>")
+    return h.hexdigest()
+
+
+def _unit_current(obj: Path, asm, dep: Path, flags) -> bool:
+    """A unit is current when its object (and audit assembly) exist and the CONTENT of every file in its dependency list is
+    what it was when the object was built (stamps.json "unit:<stem>").  Not mtimes: they do not survive the snapshot to a GPU
+    box, and a stale object re-linked under a fresh library digest would never be rebuilt again (round-3 advisor finding)."""
     if not obj.exists() or not dep.exists() or (asm is not None and not asm.exists()):
         return False
-    txt = dep.read_text().replace("\\\n", " ")
-    deps = txt.split(":", 1)[1].split() if ":" in txt else []
-    t = min(obj.stat().st_mtime, asm.stat().st_mtime) if asm is not None else obj.stat().st_mtime
-    return bool(deps) and all(Path(d).exists() and Path(d).stat().st_mtime <= t for d in deps)
+    deps = _unit_deps(dep)
+    if not deps or not all(d.exists() for d in deps):
+        return False
+    have = _stamps().get("unit:" + obj.stem)
+    if have is None:   # objects of a tree built before the per-unit stamps existed: trust mtimes once, then record the digest
+        t = min(obj.stat().st_mtime, asm.stat().st_mtime) if asm is not None else obj.stat().st_mtime
+        if all(d.stat().st_mtime <= t for d in deps):
+            _mark("unit:" + obj.stem, _unit_digest(dep, flags))
+            return True
+        return False
+    return have == _unit_digest(dep, flags)
 
 
 def build_abi(force: bool = False, audit: bool = True) -> Path:
@@ -141,9 +167,12 @@ def build_abi(force: bool = False, audit: bool = True) -> Path:
         asm = objdir / (u.stem + ".s")
         dep = objdir / (u.stem + ".d")
         # per-unit staleness from the compiler's own dependency file (-MD): only units whose sources changed rebuild
-        if not force and flags_ok and _unit_current(obj, asm if audit else None, dep):
+        if not force and flags_ok and _unit_current(obj, asm if audit else None, dep, flags):
             procs.append((u, obj, None))
             continue
+        for stale in (obj, asm):         # never leave yesterday's object / assembly behind a failed compile
+            if stale.exists():
+                stale.unlink()
         cmd = [hipcc(), *flags, "-MD", "-MF", str(dep), "-c", "-o", str(obj), str(u)]
         print("[build] " + " ".join(cmd), flush=True)
         procs.append((u, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -159,6 +188,8 @@ def build_abi(force: bool = False, audit: bool = True) -> Path:
                 raise subprocess.CalledProcessError(pr.returncode, pr.args)
         if obj is not None:
             objs.append(obj)
+            if pr is not None:     # rebuilt: remember what it was built from
+                _mark("unit:" + obj.stem, _unit_digest(objdir / (obj.stem + ".d"), flags))
     if audit:
         from leetcuda_amd import isa_audit
         reps, bad = isa_audit.audit_files([objdir / (u.stem + ".s") for u in units])

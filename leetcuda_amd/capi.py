@@ -26,6 +26,9 @@ SYMBOLS = {
     "lc_device_check": (_i, [_ip]),
     "lc_build_info": (_cp, [_ip]),
     "lc_tune_set": (_i, [_cp, _i]),
+    "lc_tune_get": (_i, [_cp, _ip, _ip]),
+    "lc_tune_count": (_i, []),
+    "lc_tune_key": (_cp, [_i]),
     "lc_hgemm_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "lc_vendor_init": (_i, []),
     "lc_vendor_destroy": (_i, []),
@@ -193,6 +196,24 @@ def _need_gpu(*tensors):
 
 def tune(key: str, value: int):
     check(load().lc_tune_set(key.encode(), value), f"lc_tune_set({key})")
+
+
+def tune_get(key: str):
+    """(current, default) of a knob."""
+    v, d = C.c_int(0), C.c_int(0)
+    check(load().lc_tune_get(key.encode(), C.byref(v), C.byref(d)), f"lc_tune_get({key})")
+    return v.value, d.value
+
+
+def tune_items():
+    """{key: (current, default)} of every knob this library accepts."""
+    lib = load()
+    out = {}
+    for i in range(lib.lc_tune_count()):
+        k = lib.lc_tune_key(i)
+        if k:
+            out[k.decode()] = tune_get(k.decode())
+    return out
 
 
 def device_check() -> int:

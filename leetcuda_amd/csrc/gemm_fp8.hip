@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_w4_kernel(const uint8_t* __restr
   // K-loop stagger (hgemm_w4y.hip; lc_tune_set "hgemm_stagger"): the workgroup walks the K tiles stg, stg + 1, ..., wrapping
   int stg;
   {
-    const int cx = stagger & 15, cm = (stagger >> 4) & 15, cn = (stagger >> 8) & 15, step = (stagger >> 12) & 0xff, mask = (stagger >> 20) & 0xff;
+    const int cx = stagger & 15, cm = (stagger >> 4) & 15, cn = (stagger >> 8) & 15, step = (stagger >> 12) & 0xff, mask = (stagger >> 20) & 0x7f;
     const int idx = cx * __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7)) + cm * __builtin_amdgcn_readfirstlane(tc.tm) +
                     cn * __builtin_amdgcn_readfirstlane(tc.tn);
     stg = __builtin_amdgcn_readfirstlane((int)((unsigned)((idx & mask) * step) % (unsigned)KT));

@@ -25,24 +25,24 @@
 using namespace lc;
 
 namespace lc {
-int g_tune_attn_ablate = 0;      // attention ablation / stamp builds (diagnosis only, LC_DIAG)
-int g_tune_w4_abl = 0;           // hgemm_w4 ablation bits (diagnosis only, LC_DIAG)
-int g_tune_w4y_sched = 1;        // hgemm_w4y_kernel loop schedule 0..2 (lc_tune_set "w4y_sched")
-int g_tune_hgemm_stamps = 0;     // GEMM cycle-stamp builds (diagnosis only, LC_DIAG)
-int g_tune_hgemm_persist = 1;    // 1 (default) = hgemm_w4y_kernel as a persistent workgroup per CU when the tiles divide evenly (lc_tune_set "hgemm_persist")
-int g_tune_hgemm_stagger = 0;    // K-loop stagger of hgemm_w4y_kernel (lc_tune_set "hgemm_stagger"): 0 = auto (by XCD), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 | mask << 20
-int g_tune_attn_d512 = 0;        // D = 256 / 512: 0 = auto (attn_bigd2), 1 = column-split kernel, 2 = attn_bigd3 (experimental)
+tune_t g_tune_attn_ablate{0};      // attention ablation / stamp builds (diagnosis only, LC_DIAG)
+tune_t g_tune_w4_abl{0};           // hgemm_w4 ablation bits (diagnosis only, LC_DIAG)
+tune_t g_tune_w4y_sched{1};        // hgemm_w4y_kernel loop schedule 0..2 (lc_tune_set "w4y_sched")
+tune_t g_tune_hgemm_stamps{0};     // GEMM cycle-stamp builds (diagnosis only, LC_DIAG)
+tune_t g_tune_hgemm_persist{1};    // 1 (default) = hgemm_w4y_kernel as a persistent workgroup per CU when the tiles divide evenly (lc_tune_set "hgemm_persist")
+tune_t g_tune_hgemm_stagger{0};    // K-loop stagger of hgemm_w4y_kernel (lc_tune_set "hgemm_stagger"): 0 = auto (by XCD), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 | mask << 20
+tune_t g_tune_attn_d512{0};        // D = 256 / 512: 0 = auto (attn_bigd2), 1 = column-split kernel, 2 = attn_bigd3 (experimental)
 }  // namespace lc
 
 namespace {
 
 // run-time tuning knobs (lc_tune_set): experiments and A/B benches, never required for correctness
-int g_tune_fp8_mx = 1;                       // fp8 GEMM: 1 = MX-scaled K=64 MFMA, 4-wave kernel; 2 = MX, 8-wave kernel; 0 = plain K=16 MFMA
-int g_tune_attn_w4i_sched = 1;              // schedule of attn_fwd_w4i_kernel's generated phase statements (tools/gen_attn_w4i.py NSCHED; same bits)
-int g_tune_attn_nw = 0;                    // attention kernel for D = 128: 0 = auto, 128 / 64 / 8 / 4 / 2 (lc_abi.h)
-int g_tune_hgemm_auto = LC_HGEMM_MFMA256W4Y;   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
-int g_tune_hgemm_tail = 1;                   // 1 = hand the ragged last wave of the 256-tile kernel to the 128-tile kernel (launch_mfma256), 0 = one launch
-int g_tune_hgemm_raster = 0;                 // block -> C tile map: 0 = auto (by operand footprint, panel_tiles), 1 = the reference's block swizzle (N panels from
+tune_t g_tune_fp8_mx{1};                       // fp8 GEMM: 1 = MX-scaled K=64 MFMA, 4-wave kernel; 2 = MX, 8-wave kernel; 0 = plain K=16 MFMA
+tune_t g_tune_attn_w4i_sched{1};              // schedule of attn_fwd_w4i_kernel's generated phase statements (tools/gen_attn_w4i.py NSCHED; same bits)
+tune_t g_tune_attn_nw{0};                    // attention kernel for D = 128: 0 = auto, 128 / 64 / 8 / 4 / 2 (lc_abi.h)
+tune_t g_tune_hgemm_auto{LC_HGEMM_MFMA256W4Y};   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
+tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to the 128-tile kernel (launch_mfma256), 0 = one launch
+tune_t g_tune_hgemm_raster{0};                 // block -> C tile map: 0 = auto (by operand footprint, panel_tiles), 1 = the reference's block swizzle (N panels from
                                              // swizzle_stride, XCD-contiguous ids), 2 = XCD super-block raster (hgemm_mfma256.hip raster_xcd16)
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -187,11 +187,12 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   const dim3 grid(tiles_m * tiles_n), block(512);
   if (is_w4_variant(variant)) {
     // Ragged last wave (lc_tune_set "hgemm_tail"): T tiles on 256 CUs run ceil(T / 256) tile periods, the last one with T % 256
-    // workgroups.  When that remainder R is at most half a wave, the generated-loop kernel computes the first T − R raster
+    // workgroups (256 = the CU count of an MI355X; the rule uses the device's own).  When that remainder R is at most half a wave, the generated-loop kernel computes the first T − R raster
     // ids and the 128-tile kernel the four quadrants of each of the other R (4 R <= 512 workgroups at two per CU: ONE period of
     // a quarter-size tile) — 6144^3: 2.25 waves -> 2 + a short one instead of 3 (profiles/r3e_hgemm_tail.log).
-    const int T = tiles_m * tiles_n, R = T % 256;
-    const bool split = g_tune_hgemm_tail != 0 && T > 256 && R > 0 && R <= 128 &&
+    const int ncu = device_cu_count();   // (the same per-device figure the persistent launchers use)
+    const int T = tiles_m * tiles_n, R = T % ncu;
+    const bool split = g_tune_hgemm_tail != 0 && T > ncu && R > 0 && 2 * R <= ncu &&
                        w4_effective_variant(variant, B_KN, N, K) == LC_HGEMM_MFMA256W4Y;
     if (!split) return launch_w4_family(A, B, C, M, N, K, variant, B_KN, tiles_m, tiles_n, pw, -1, st);
     if (int rc = launch_w4_family(A, B, C, M, N, K, variant, B_KN, tiles_m, tiles_n, pw, T - R, st)) return rc;
@@ -446,7 +447,7 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
   if (is_w4_variant(v)) {
     v = w4_effective_variant(v, layout == LC_LAYOUT_NN, N, K);
     if (v == LC_HGEMM_MFMA256W4X) snprintf(buf, buflen, "hgemm_w4x_kernel<%s>", nn);
-    else if (v == LC_HGEMM_MFMA256W4Y) snprintf(buf, buflen, "hgemm_w4y_kernel<%s,%d>", nn, layout == LC_LAYOUT_NN ? 1 : g_tune_w4y_sched);
+    else if (v == LC_HGEMM_MFMA256W4Y) snprintf(buf, buflen, "hgemm_w4y_kernel<%s,%d>", nn, layout == LC_LAYOUT_NN ? 1 : g_tune_w4y_sched.load());
     else snprintf(buf, buflen, "hgemm_w4b_kernel<%s,%s,0>", nn, v == LC_HGEMM_MFMA256W4B ? "false" : "true");
   } else if (v == LC_HGEMM_MFMA256P2) snprintf(buf, buflen, "hgemm_pingpong2_kernel<%s,false>", nn);
   else if (v == LC_HGEMM_MFMA256) snprintf(buf, buflen, "hgemm_mfma256_kernel<%s>", nn);
@@ -465,7 +466,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
     if (nw == 256 || nw == 260) snprintf(buf, buflen, "attn_fwd_w4m_kernel<%d,%d>", D, nw == 260 ? 4 : 0);
     else if (nw == 512) snprintf(buf, buflen, "attn_fwd_w4n_kernel<%d>", D);
     else if (nw == 513) snprintf(buf, buflen, "attn_fwd_w4g_kernel<%d>", D);
-    else if (nw == 514) snprintf(buf, buflen, "attn_fwd_w4i_kernel<%d,%d>", D, g_tune_attn_w4i_sched);
+    else if (nw == 514) snprintf(buf, buflen, "attn_fwd_w4i_kernel<%d,%d>", D, g_tune_attn_w4i_sched.load());
     else if (nw == 515) snprintf(buf, buflen, "attn_fwd_w4p_kernel<%d>", D);
     else if (nw == 516) snprintf(buf, buflen, "attn_fwd_w8g_kernel<%d>", D);
     else snprintf(buf, buflen, "attn_fwd_kernel<%d,%d,%s,0>", D, nw, vt);
@@ -483,77 +484,81 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
   return LC_ERR_HEADDIM;
 }
 
-int lc_tune_set(const char* key, int value) {
-  if (!key) return LC_ERR_ARG;
-  if (strcmp(key, "attn_nw") == 0) {
-    if (value != 0 && value != 256 && value != 260 && value != 512 && value != 513 && value != 514 && value != 515 && value != 516 && value != 8 && value != 4 && value != 2) return LC_ERR_ARG;
-    g_tune_attn_nw = value;
-    return LC_OK;
-  }
-  if (strcmp(key, "attn_w4i_sched") == 0) {
-    if (value < 0 || value > 1) return LC_ERR_ARG;
-    g_tune_attn_w4i_sched = value;
-    return LC_OK;
-  }
-  if (strcmp(key, "fp8_mx") == 0) {
-    if (value < 0 || value > 2) return LC_ERR_ARG;
-    g_tune_fp8_mx = value;
-    return LC_OK;
-  }
-  if (strcmp(key, "attn_d512") == 0) {
-    if (value < 0 || value > 2) return LC_ERR_ARG;
-    g_tune_attn_d512 = value;
-    return LC_OK;
-  }
-  if (strcmp(key, "w4y_sched") == 0) {
+namespace {
+// the knob registry: ONE table for lc_tune_set / lc_tune_get (key, variable, default, validity of a value)
+bool ok_attn_nw(int v) {
+  return v == 0 || v == 256 || v == 260 || v == 512 || v == 513 || v == 514 || v == 515 || v == 516 || v == 8 || v == 4 || v == 2;
+}
+bool ok_01(int v) { return v == 0 || v == 1; }
+bool ok_02(int v) { return v >= 0 && v <= 2; }
+bool ok_w4y_sched(int v) {
 #ifdef LC_DIAG
-    if (value < 0 || value > 5) return LC_ERR_ARG;   // 3..5: ablations (results WRONG)
+  return v >= 0 && v <= 5;   // 3..5: ablations (results WRONG)
 #else
-    if (value < 0 || value > 2) return LC_ERR_ARG;
+  return v >= 0 && v <= 2;
 #endif
-    g_tune_w4y_sched = value;
-    return LC_OK;
-  }
-  if (strcmp(key, "hgemm_persist") == 0) {
-    if (value < 0 || value > 1) return LC_ERR_ARG;
-    g_tune_hgemm_persist = value;
-    return LC_OK;
-  }
-  if (strcmp(key, "hgemm_stagger") == 0) {
-    if (value < 0 || (value >> 28) != 0) return LC_ERR_ARG;
-    g_tune_hgemm_stagger = value;
-    return LC_OK;
-  }
-  if (strcmp(key, "hgemm_tail") == 0) {
-    if (value < 0 || value > 1) return LC_ERR_ARG;
-    g_tune_hgemm_tail = value;
-    return LC_OK;
-  }
-  if (strcmp(key, "hgemm_raster") == 0) {
-    if (value < 0 || value > 2) return LC_ERR_ARG;
-    g_tune_hgemm_raster = value;
-    return LC_OK;
-  }
-  if (strcmp(key, "hgemm_auto") == 0) {
-    if (!is_tile256_variant(value)) return LC_ERR_ARG;
-    g_tune_hgemm_auto = value;
-    return LC_OK;
-  }
-#ifdef LC_DIAG   // diagnosis keys (include/lc_diag.h): results may be WRONG; a production library rejects them
-  if (strcmp(key, "w4_abl") == 0) {
-    g_tune_w4_abl = value;
-    return LC_OK;
-  }
-  if (strcmp(key, "hgemm_stamps") == 0) {
-    g_tune_hgemm_stamps = value != 0;
-    return LC_OK;
-  }
-  if (strcmp(key, "attn_ablate") == 0) {
-    g_tune_attn_ablate = value;
-    return LC_OK;
-  }
+}
+// cx | cm << 4 | cn << 8 | step << 12 | mask << 20 with a 7-bit mask (bits 20 .. 26), or exactly STAGGER_OFF (1 << 27)
+bool ok_stagger(int v) { return v >= 0 && ((v >> 27) == 0 || v == STAGGER_OFF); }
+bool ok_auto(int v) { return is_tile256_variant(v); }
+bool ok_any(int) { return true; }
+struct Knob {
+  const char* key;
+  tune_t* var;
+  int dflt;
+  bool (*valid)(int);
+  bool diag;   // diagnosis key (include/lc_diag.h): results may be WRONG; a production library rejects it
+};
+const Knob kKnobs[] = {
+    {"attn_nw", &g_tune_attn_nw, 0, ok_attn_nw, false},
+    {"attn_w4i_sched", &g_tune_attn_w4i_sched, 1, ok_01, false},
+    {"fp8_mx", &g_tune_fp8_mx, 1, ok_02, false},
+    {"attn_d512", &g_tune_attn_d512, 0, ok_02, false},
+    {"w4y_sched", &g_tune_w4y_sched, 1, ok_w4y_sched, false},
+    {"hgemm_persist", &g_tune_hgemm_persist, 1, ok_01, false},
+    {"hgemm_stagger", &g_tune_hgemm_stagger, 0, ok_stagger, false},
+    {"hgemm_tail", &g_tune_hgemm_tail, 1, ok_01, false},
+    {"hgemm_raster", &g_tune_hgemm_raster, 0, ok_02, false},
+    {"hgemm_auto", &g_tune_hgemm_auto, LC_HGEMM_MFMA256W4Y, ok_auto, false},
+    {"w4_abl", &g_tune_w4_abl, 0, ok_any, true},
+    {"hgemm_stamps", &g_tune_hgemm_stamps, 0, ok_01, true},
+    {"attn_ablate", &g_tune_attn_ablate, 0, ok_any, true},
+};
+const Knob* find_knob(const char* key) {
+  if (!key) return nullptr;
+  for (const Knob& k : kKnobs)
+    if (strcmp(k.key, key) == 0) {
+#ifndef LC_DIAG
+      if (k.diag) return nullptr;
 #endif
-  return LC_ERR_ARG;
+      return &k;
+    }
+  return nullptr;
+}
+}  // namespace
+
+int lc_tune_set(const char* key, int value) {
+  const Knob* k = find_knob(key);
+  if (!k || !k->valid(value)) return LC_ERR_ARG;
+  k->var->store(value, std::memory_order_relaxed);
+  return LC_OK;
+}
+
+int lc_tune_get(const char* key, int* value, int* default_value) {
+  const Knob* k = find_knob(key);
+  if (!k) return LC_ERR_ARG;
+  if (value) *value = k->var->load(std::memory_order_relaxed);
+  if (default_value) *default_value = k->dflt;
+  return LC_OK;
+}
+
+int lc_tune_count(void) { return (int)(sizeof(kKnobs) / sizeof(kKnobs[0])); }
+const char* lc_tune_key(int index) {
+  if (index < 0 || index >= lc_tune_count()) return nullptr;
+#ifndef LC_DIAG
+  if (kKnobs[index].diag) return nullptr;
+#endif
+  return kKnobs[index].key;
 }
 
 int lc_device_check(int* num_cus) {

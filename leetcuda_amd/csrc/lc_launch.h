@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -36,21 +37,43 @@ int set_dyn_lds(KernelT kernel, int bytes) {
   return LC_OK;
 }
 
+// Compute units of the CURRENT device (the tail-split rule of launch_mfma256 and both persistent launchers size their grids with
+// it): looked up once per device ordinal, not once per process — a later device with another CU count gets its own figure.
+inline int device_cu_count() {
+  static std::mutex mu;
+  static int cache[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  std::lock_guard<std::mutex> g(mu);
+  if (cache[dev] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cache[dev] = v;
+  }
+  return cache[dev];
+}
+
 // tuning globals (defined in lc_abi.hip, lc_tune_set)
-extern int g_tune_attn_ablate, g_tune_w4_abl, g_tune_hgemm_stamps;
-extern int g_tune_attn_d512;   // D = 256 / 512 attention kernel choice (lc_tune_set "attn_d512")
-extern int g_tune_hgemm_persist;   // 1 (default) = hgemm_w4y_kernel as a persistent workgroup per CU when the tiles divide evenly (tu_w4.hip)
-extern int g_tune_hgemm_stagger;   // K-loop stagger of hgemm_w4y_kernel: 0 = auto (by XCD, step K / 64 / 8), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 | mask << 20 (hgemm_w4y.hip)
+// Every knob is a std::atomic<int> (relaxed loads / stores through the implicit conversions): lc_tune_set from one host thread
+// while another launches is a data race on a plain int; a launch reads each knob ONCE into a local and decides from that.
+using tune_t = std::atomic<int>;
+extern tune_t g_tune_attn_ablate, g_tune_w4_abl, g_tune_hgemm_stamps;
+extern tune_t g_tune_attn_d512;   // D = 256 / 512 attention kernel choice (lc_tune_set "attn_d512")
+extern tune_t g_tune_hgemm_persist;   // 1 (default) = hgemm_w4y_kernel as a persistent workgroup per CU when the tiles divide evenly (tu_w4.hip)
+extern tune_t g_tune_hgemm_stagger;   // K-loop stagger of hgemm_w4y_kernel: 0 = auto (by XCD, step K / 64 / 8), 1 << 27 (exactly) = off, else cx | cm << 4 | cn << 8 | step << 12 | mask << 20 with mask < 128 (hgemm_w4y.hip)
 // the kernel argument of the K-loop stagger for a K walk of kt tiles: auto (knob 0) = by XCD, the eight start tiles spread evenly
-// over the K range (L2 sharing inside an XCD stays intact, fabric bytes unchanged: profiles/r3q_hgemm_stagger_ab.log); bit 27 = off
+// over the K range (L2 sharing inside an XCD stays intact, fabric bytes unchanged: profiles/r3q_hgemm_stagger_ab.log).  The mask
+// field is 7 bits (20 .. 26); bit 27 alone is the "off" value — lc_tune_set refuses it in combination with anything else, so a
+// large mask can no longer switch the stagger off by accident (round-3 advisor finding).
+constexpr int STAGGER_OFF = 1 << 27;
 inline int stagger_arg(int kt) {
   const int knob = g_tune_hgemm_stagger;
-  if (knob & (1 << 27)) return 0;
+  if (knob == STAGGER_OFF) return 0;
   if (knob != 0) return knob;
   const int step = kt / 8;
   return 1 | (step < 1 ? 1 : step > 255 ? 255 : step) << 12 | 7 << 20;
 }
-extern int g_tune_w4y_sched;   // schedule of hgemm_w4y_kernel's generated loop body (all of them compute the same bits)
+extern tune_t g_tune_w4y_sched;   // schedule of hgemm_w4y_kernel's generated loop body (all of them compute the same bits)
 
 // launchers living in their own translation units
 // tu_w4.hip: LC_HGEMM_MFMA256W4 / W4S / W4B / W4C (M, N % 256 == 0, K % 64 == 0 checked by the caller)

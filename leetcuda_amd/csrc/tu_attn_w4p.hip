@@ -7,21 +7,11 @@
 
 namespace lc {
 namespace {
-int cu_count() {   // workgroups of the persistent grid: one per CU (each takes a CU's whole register file and > half its LDS)
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-      v = 256;
-    n = v;
-  }
-  return n;
-}
 template <int D>
 int launch_w4p_t(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, hipStream_t st) {
   const int nqb = N / 256;
   const size_t nblk = (size_t)nqb * B * H;
-  const int ncu = cu_count();
+  const int ncu = device_cu_count();   // one workgroup per CU: each takes a CU's whole register file and > half its LDS
   const dim3 grid((unsigned)(nblk < (size_t)ncu ? nblk : (size_t)ncu)), block(256);
   const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
   auto kern = attn_fwd_w4p_kernel<D>;

@@ -13,33 +13,23 @@ int launch_w4_one(const half_t* A, const half_t* B, half_t* C, int M, int N, int
   return check_launch();
 }
 
-int w4_cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-      v = 256;
-    n = v;
-  }
-  return n;
-}
-int g_w4_nblk = -1;   // blocks to launch (< tiles_m * tiles_n when the ragged last wave goes to the 128-tile kernel); set per call
-
+// nblk_arg: blocks to launch (< tiles_m * tiles_n when the ragged last wave goes to the 128-tile kernel), <= 0 = all; an explicit
+// argument of every launcher below — no per-call state lives at file scope, so concurrent host threads cannot see each other's grid
 template <bool B_KN, int Y>   // Y: -1 = hgemm_w4x_kernel, 0.. = hgemm_w4y_kernel<.., Y>
 int launch_w4x_one(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int tiles_m, int tiles_n, int pw,
-                   hipStream_t st) {
+                   int nblk_arg, hipStream_t st) {
   auto kern = [] {
     if constexpr (Y < 0) return hgemm_w4x_kernel<B_KN>;
     else return hgemm_w4y_kernel<B_KN, Y>;
   }();
   if (int rc = set_dyn_lds(kern, W4B_LDS)) return rc;
-  const int nblk = g_w4_nblk > 0 ? g_w4_nblk : tiles_m * tiles_n;
+  const int nblk = nblk_arg > 0 ? nblk_arg : tiles_m * tiles_n;
   if constexpr (Y < 0) {
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
   } else {
     // lc_tune_set "hgemm_persist" = 1: one workgroup per CU walks the block ids (hgemm_w4y.hip); only when every workgroup gets the
     // same number of tiles (a ragged walk would leave CUs idle for a whole tile)
-    const int ncu = w4_cu_count();
+    const int ncu = device_cu_count();
     const bool persist = g_tune_hgemm_persist != 0 && nblk > ncu && nblk % ncu == 0;
     hipLaunchKernelGGL(kern, dim3(persist ? ncu : nblk), dim3(256), W4B_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw,
                        stagger_arg(K / BK), persist ? nblk : 0);
@@ -49,7 +39,7 @@ int launch_w4x_one(const half_t* A, const half_t* B, half_t* C, int M, int N, in
 
 template <bool B_KN>
 int launch_w4_t(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant, int tiles_m,
-                int tiles_n, int pw, hipStream_t st) {
+                int tiles_n, int pw, int nblk, hipStream_t st) {
   variant = w4_effective_variant(variant, B_KN, N, K);
 #ifdef LC_DIAG
   if (variant == LC_HGEMM_MFMA256W4C && g_tune_hgemm_stamps)
@@ -66,19 +56,20 @@ int launch_w4_t(const half_t* A, const half_t* B, half_t* C, int M, int N, int K
   }
 #endif
   if constexpr (!B_KN) {
-    if (variant == LC_HGEMM_MFMA256W4X) return launch_w4x_one<B_KN, -1>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+    if (variant == LC_HGEMM_MFMA256W4X) return launch_w4x_one<B_KN, -1>(A, B, C, M, N, K, tiles_m, tiles_n, pw, nblk, st);
     if (variant == LC_HGEMM_MFMA256W4Y) {
-      if (g_tune_w4y_sched == 0) return launch_w4x_one<B_KN, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
-      if (g_tune_w4y_sched == 1) return launch_w4x_one<B_KN, 1>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+      const int sched = g_tune_w4y_sched;   // read once per launch
+      if (sched == 0) return launch_w4x_one<B_KN, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, nblk, st);
+      if (sched == 1) return launch_w4x_one<B_KN, 1>(A, B, C, M, N, K, tiles_m, tiles_n, pw, nblk, st);
 #ifdef LC_DIAG
-      if (g_tune_w4y_sched == 3) return launch_w4x_one<B_KN, 3>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
-      if (g_tune_w4y_sched == 4) return launch_w4x_one<B_KN, 4>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
-      if (g_tune_w4y_sched == 5) return launch_w4x_one<B_KN, 5>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+      if (sched == 3) return launch_w4x_one<B_KN, 3>(A, B, C, M, N, K, tiles_m, tiles_n, pw, nblk, st);
+      if (sched == 4) return launch_w4x_one<B_KN, 4>(A, B, C, M, N, K, tiles_m, tiles_n, pw, nblk, st);
+      if (sched == 5) return launch_w4x_one<B_KN, 5>(A, B, C, M, N, K, tiles_m, tiles_n, pw, nblk, st);
 #endif
-      return launch_w4x_one<B_KN, 2>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
+      return launch_w4x_one<B_KN, 2>(A, B, C, M, N, K, tiles_m, tiles_n, pw, nblk, st);
     }
   } else {
-    if (variant == LC_HGEMM_MFMA256W4Y) return launch_w4x_one<B_KN, 1>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);   // one NN schedule
+    if (variant == LC_HGEMM_MFMA256W4Y) return launch_w4x_one<B_KN, 1>(A, B, C, M, N, K, tiles_m, tiles_n, pw, nblk, st);   // one NN schedule
   }
   if (variant == LC_HGEMM_MFMA256W4C || variant == LC_HGEMM_MFMA256W4X || variant == LC_HGEMM_MFMA256W4Y)
     return launch_w4_one<B_KN, true, 0>(A, B, C, M, N, K, tiles_m, tiles_n, pw, st);
@@ -102,8 +93,8 @@ int w4_effective_variant(int variant, bool b_kn, int N, int K) {
 
 int launch_w4_family(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant, bool b_kn,
                      int tiles_m, int tiles_n, int panel_w, int nblk, hipStream_t st) {
-  g_w4_nblk = (nblk > 0 && nblk < tiles_m * tiles_n && w4_effective_variant(variant, b_kn, N, K) == LC_HGEMM_MFMA256W4Y) ? nblk : -1;
-  return b_kn ? launch_w4_t<true>(A, B, C, M, N, K, variant, tiles_m, tiles_n, panel_w, st)
-              : launch_w4_t<false>(A, B, C, M, N, K, variant, tiles_m, tiles_n, panel_w, st);
+  const int nb = (nblk > 0 && nblk < tiles_m * tiles_n && w4_effective_variant(variant, b_kn, N, K) == LC_HGEMM_MFMA256W4Y) ? nblk : -1;
+  return b_kn ? launch_w4_t<true>(A, B, C, M, N, K, variant, tiles_m, tiles_n, panel_w, nb, st)
+              : launch_w4_t<false>(A, B, C, M, N, K, variant, tiles_m, tiles_n, panel_w, nb, st);
 }
 }  // namespace lc

@@ -31,6 +31,22 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _knobs_stay_at_their_defaults(request):
+    """After EVERY gpu test each lc_tune_set knob must be back at its library default (round 3: a test left hgemm_persist at 0
+    and every later test of the process ran the non-default launch).  Reads the defaults from the library (lc_tune_get)."""
+    yield
+    if "gpu" not in request.keywords or not _has_gpu():
+        return
+    from leetcuda_amd import capi
+    if capi._lib is None:
+        return
+    off = {k: v for k, v in capi.tune_items().items() if v[0] != v[1]}
+    for k, (_, d) in off.items():      # restore first, so one offender does not fail every later test too
+        capi.tune(k, d)
+    assert not off, f"{request.node.name} left knobs off their defaults (current, default): {off}"
+
+
 @pytest.fixture(scope="session")
 def built():
     """Native artefacts are built in-tree; rebuild only what is missing/stale (hipcc works without a GPU)."""

@@ -48,6 +48,29 @@ def test_header_symbols_all_exported(built):
     assert lib.lc_tune_set(b"hgemm_auto", capi.HGEMM_MFMA256W4Y) == capi.LC_OK     # (back to the default)
 
 
+def test_knob_registry_reports_defaults_and_validates(built):
+    """lc_tune_get / lc_tune_count / lc_tune_key: every knob of a freshly loaded library sits at its default; the K-loop stagger's
+    mask field is 7 bits and 1 << 27 alone means "off" (round-3 advisor: a mask >= 128 used to switch the stagger off silently)."""
+    from leetcuda_amd import capi
+    items = capi.tune_items()
+    assert {"attn_nw", "attn_d512", "fp8_mx", "hgemm_persist", "hgemm_stagger", "hgemm_tail", "hgemm_raster", "hgemm_auto",
+            "w4y_sched", "attn_w4i_sched"} <= set(items)
+    assert not {"attn_ablate", "w4_abl", "hgemm_stamps"} & set(items)           # diagnosis keys: not in a production library
+    assert all(cur == dflt for cur, dflt in items.values()), items
+    assert items["hgemm_persist"] == (1, 1) and items["hgemm_tail"] == (1, 1) and items["hgemm_stagger"] == (0, 0)
+    lib = capi.load()
+    off = 1 << 27
+    assert lib.lc_tune_set(b"hgemm_stagger", off) == capi.LC_OK
+    assert capi.tune_get("hgemm_stagger") == (off, 0)
+    for bad in (off | 1, off | 7 << 20, 129 << 20, 255 << 20, 1 << 28, -1):     # (128 << 20 IS the off value)
+        assert lib.lc_tune_set(b"hgemm_stagger", bad) == capi.LC_ERR_ARG, bad
+    assert capi.tune_get("hgemm_stagger") == (off, 0)                           # a refused value changes nothing
+    assert lib.lc_tune_set(b"hgemm_stagger", 15 | 15 << 4 | 15 << 8 | 255 << 12 | 127 << 20) == capi.LC_OK
+    assert lib.lc_tune_set(b"hgemm_stagger", 0) == capi.LC_OK
+    assert lib.lc_tune_get(b"no_such_key", None, None) == capi.LC_ERR_ARG
+    assert lib.lc_tune_key(-1) is None and lib.lc_tune_key(lib.lc_tune_count()) is None
+
+
 def test_diag_library_exports_its_header(built):
     from leetcuda_amd import build, capi
     p = build.build_diag()

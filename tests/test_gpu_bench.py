@@ -48,3 +48,35 @@ def test_bench_self_spawns_two_ranks_on_one_gpu_gloo():
     assert "gloo" in out["config"]["parallelism"]
     # whole-job FLOPs / max-rank time: both ranks share one GPU here, so ~ the single-GPU rate, never above it x1.1
     assert 200 < out["value"] < 2500
+
+
+def test_bench_default_workload_at_two_ranks_headlines_config4():
+    """Round-3 verdict (structure #11): `python bench.py --gpus N` with the DEFAULT workload used to report N HGEMM replicas as
+    `value` — a scaling record of trivially linear replicas.  With N > 1 the headline is config 4 (strong scaling: 35.18 TFLOP
+    fixed, batch rows sharded), the replicas are a block, per-rank figures are in the line, and under-filled shards are skipped."""
+    out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], {"LC_DIST_BACKEND": "gloo"}, timeout=1500)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 3
+    assert "config 4" in out["config"]["workload"] and "16x32 (batch,head) problems per rank" in out["config"]["workload"]
+    assert out["n_ranks"] == 2 and out["per_rank"]["problems"] == [16, 32] and out["per_rank"]["kernel_ms_max"] > 0
+    assert out["value"] == pytest.approx(4 * 32 * 32 * 8192 ** 2 * 128 / (out["ms_per_step"] * 1e-3) * 1e-12, rel=1e-6)
+    assert "headline_note" in out
+    rep = out["hgemm_replicas"]
+    assert rep["scaling"] == "weak" and rep["roofline"]["kernel"].startswith("hgemm_w4y_kernel")
+    # 48 heads x 32 query blocks / 2 ranks = 768 workgroups per GPU: still a meaningful shard at N = 2 ...
+    assert "value" in out["attention_d64"] and "value" in out["attention_d512"]
+    assert "projected_scaling" not in out          # N = 1 only
+
+
+def test_bench_projected_scaling_block_at_one_gpu():
+    """until an 8-GPU node exists, the W-rank shard shapes of config 4 are timed one after the other on one GPU and
+    reported as PROJECTED, separately from anything measured."""
+    out = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline"], timeout=1500)
+    ps = out["projected_scaling"]
+    assert "PROJECTED" in ps["label"] and set(ps["ranks"]) == {"1", "2", "4", "8"}
+    assert ps["ranks"]["8"]["shard"] == [4, 32, 8192, 128] and ps["ranks"]["2"]["shard"] == [16, 32, 8192, 128]
+    one = ps["ranks"]["1"]["aggregate_tflops"]
+    for W in ("2", "4", "8"):
+        r = ps["ranks"][W]
+        assert r["aggregate_tflops"] == pytest.approx(35.184372088832 / (r["shard_ms"] * 1e-3), rel=1e-6)
+        assert 0.8 * int(W) * one < r["aggregate_tflops"] < 1.25 * int(W) * one     # independent units: ~linear by construction
+    assert out["attention_cfg4"]["per_rank"]["problems"] == [32, 32]

@@ -1,0 +1,214 @@
+"""Full-size GPU parity that round 3's verdict found missing (VERDICT r3 "what's weak" 1, 4 and "missing" 5):
+
+  * one KV tile perturbed at S = 8192, per kernel family: K rows of ONE 64-key tile scaled by 1.25 (the first tile, the tile
+    where the 4-slot LDS ring wraps, the last tile) — that tile's scores stand out, so a stale max, a skipped rescale or a
+    mis-addressed ring slot confined to it moves the sampled rows beyond the N-scaled bound of tests/tol.py;
+  * fp16 HGEMM at the sizes the reference publishes (kernels/hgemm/README.md:159-185: 12544 ... 16384), NN and TN, default
+    knobs: that is where the XCD super-block raster, the ragged-tail split and the non-persistent launch combine;
+  * full-size parity for D = 256 at (1,48,8192,256), a V-transposed entry at config 3, D = 1024 at N >= 2048.
+
+Reference entry points: flash_attn_mma.py:465-494 (the --check recipe), flash_attn_mma_share_qkv_swizzle_qkv.cu:961-1010 (V as
+[B,H,D,N]), flash_attn_mma_tiling_qkv.cu:881-945 (head dims up to 1024).
+"""
+import numpy as np
+import pytest
+import torch
+
+from leetcuda_amd import host
+from tests import tol
+from tests.test_gpu_configs import _rows_for, _sampled_rows_check
+
+pytestmark = pytest.mark.gpu
+
+
+def _capi():
+    from leetcuda_amd import capi
+    capi.load()
+    return capi
+
+
+# (label, D, knob key, knob value): every attention kernel family that can take an S = 8192 problem
+FAMILIES = [
+    ("d128-auto", 128, None, 0),
+    ("d128-one-block", 128, "attn_nw", 513),
+    ("d128-generated", 128, "attn_nw", 514),
+    ("d128-persistent", 128, "attn_nw", 515),
+    ("d128-lockstep8", 128, "attn_nw", 8),
+    ("d64-auto", 64, None, 0),
+    ("d64-generated", 64, "attn_nw", 514),
+    ("d64-persistent", 64, "attn_nw", 515),
+    ("d96-auto", 96, None, 0),
+    ("d32-auto", 32, None, 0),
+    ("d256-auto", 256, None, 0),
+    ("d512-auto", 512, None, 0),
+    ("d512-column-split", 512, "attn_d512", 1),
+]
+
+
+@pytest.mark.parametrize("label,D,key,val", FAMILIES, ids=[f[0] for f in FAMILIES])
+def test_one_kv_tile_perturbed_s8192(oracle, label, D, key, val):
+    capi = _capi()
+    B, H, N = 1, 2, 8192
+    T = N // 64
+    torch.manual_seed(1000 + D)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k0 = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    rows = _rows_for(N, D)
+    heads = [(0, 0), (0, 1)]
+    entry = "flash_attn_mma_stages_split_q" if D <= 128 else "flash_attn_mma_stages_split_q_tiling_qkv"
+    outs = []
+    for t in (0, 4, T - 1):           # first tile, the tile that re-uses ring slot 0, last tile
+        k = k0.clone()
+        k[:, :, 64 * t:64 * t + 64] *= 1.25
+        o = torch.full_like(q, float("nan"))
+        if key:
+            capi.tune(key, val)
+        try:
+            capi.attn_call(entry, q, k, v, o, 2)
+            torch.cuda.synchronize()
+        finally:
+            if key:
+                capi.tune(key, 0)
+        assert torch.isfinite(o).all(), (label, t)
+        _sampled_rows_check(oracle, q, k, v, o, heads, rows)
+        outs.append(o)
+    # the three perturbations are different problems: the outputs must differ (a kernel that ignored K's tile would not)
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
+
+
+@pytest.mark.parametrize("layout", ["nn", "tn"])
+@pytest.mark.parametrize("n", [12544, 15616, 16384])
+def test_hgemm_reference_published_sizes(oracle, n, layout):
+    """kernels/hgemm/README.md:159-185 publishes 12544 ... 16384 (M = N = K).  Default knobs (auto raster = XCD super-block beyond
+    the Infinity Cache, tail split when the last wave is short, persistent walk only when the tiles divide evenly), the
+    reference's primary entry names."""
+    capi = _capi()
+    lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
+    torch.manual_seed(n)
+    a = torch.randn(n, n, dtype=torch.half, device="cuda")
+    b = torch.randn(n, n, dtype=torch.half, device="cuda")
+    bb = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
+    c = torch.full((n, n), float("nan"), dtype=torch.half, device="cuda")
+    name = ("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem" if layout == "nn"
+            else "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4")
+    capi.hgemm_call(name, a, bb, c, 2, True, host.make_block_swizzle_stride(n, n))
+    torch.cuda.synchronize()
+    assert capi.hgemm_kernel_name(n, n, n, lay).startswith("hgemm_w4y_kernel")
+    assert torch.isfinite(c).all()
+    # (1) C.x == A.(B.x) in fp64 on the host (row chunks: the fp64 copies of 512 MiB operands are never materialised whole)
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n)
+
+    def matvec(t, vec):
+        out = np.empty(t.shape[0])
+        for r0 in range(0, t.shape[0], 2048):
+            out[r0:r0 + 2048] = t[r0:r0 + 2048].cpu().numpy().astype(np.float64) @ vec
+        return out
+    want = matvec(a, matvec(b, x))
+    got = matvec(c, x)
+    rel = np.abs(got - want).max() / np.abs(want).max()
+    assert rel < 2e-3, rel
+    # (2) sampled rows (first / last tile rows, a tail-split tile, mid-matrix) against the exact oracle over the full K
+    rows = [0, 255, 256, n // 2 + 1, n - 257, n - 1]
+    truth = oracle.hgemm(a[rows].contiguous(), b, len(rows), n, n, 0, "f32")
+    ok, mx, _ = tol.hgemm_close(c[rows].float().cpu().numpy(), truth, n)
+    assert ok, mx
+    # (3) the vendor comparator (hipBLASLt, fp32 compute) agrees on the same rows and to fp16 rounding everywhere
+    capi.vendor_init()
+    try:
+        cv = torch.empty_like(c)
+        capi.hgemm_vendor(a, bb, cv, lay)
+        torch.cuda.synchronize()
+        ok, mx, _ = tol.hgemm_close(cv[rows].float().cpu().numpy(), truth, n)
+        assert ok, mx
+        ulp = torch.clamp(cv.float().abs(), min=64.0) * 2.0 ** -10
+        assert ((c.float() - cv.float()).abs() <= ulp).all()
+    finally:
+        capi.vendor_destroy()
+
+
+def test_d256_full_size(oracle):
+    """(1,48,8192,256) through the tiling-QKV entry and its shared-QKV stage-1 sibling (flash_attn_mma_share_qkv.cu:872-921: d = 256
+    only with stages = 1)."""
+    capi = _capi()
+    B, H, N, D = 1, 48, 8192, 256
+    torch.manual_seed(256)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k[0, 47, 7000] = 3.0 * q[0, 47, 33]        # a late spike: forces whatever rescale path the kernel has
+    v[0, 47, 7000] = 5.0
+    o = torch.full_like(q, float("nan"))
+    capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, o, 2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o).all()
+    rows = _rows_for(N, 256, extra=[33, 127, 128])
+    _sampled_rows_check(oracle, q, k, v, o, [(0, 0), (0, 23), (0, 47)], rows)
+    o2 = torch.full_like(q, float("nan"))
+    capi.attn_call("flash_attn_mma_stages_split_q_shared_qkv", q, k, v, o2, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(o, o2)
+    vc = torch.full_like(v, 0.625)
+    capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, vc, o, 2)
+    torch.cuda.synchronize()
+    assert (o.float() - 0.625).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("entry", ["flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv",
+                                   "flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv",
+                                   "flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv"])
+def test_v_transposed_entries_config3(oracle, entry):
+    """The three *_swizzle_qkv entries take V as [B,H,D,N] (flash_attn_mma.py:441-442,716; share_qkv_swizzle_qkv.cu:961-968) —
+    at config 3's shape, against the oracle reading the same transposed tensor, and against the [B,H,N,D] sibling."""
+    capi = _capi()
+    B, H, N, D = 4, 32, 4096, 128
+    torch.manual_seed(3)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k[3, 31, 3000] = 3.0 * q[3, 31, 33]
+    v[3, 31, 3000] = 5.0
+    tv = v.transpose(-2, -1).contiguous()
+    o = torch.full_like(q, float("nan"))
+    capi.attn_call(entry, q, k, tv, o, 2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o).all()
+    rows = _rows_for(N, 3, extra=[33])
+    _sampled_rows_check(oracle, q, k, tv, o, [(0, 0), (1, 13), (2, 7), (3, 31)], rows, vt=True)
+    os_ = torch.full_like(q, float("nan"))
+    capi.attn_call(entry.replace("_swizzle_qkv", ""), q, k, v, os_, 2)
+    torch.cuda.synchronize()
+    # same products; the P.V operand order inside an MFMA may differ between the two V layouts: fp16 rounding, not more
+    assert (o.float() - os_.float()).abs().max().item() <= 2.0 ** -10 * max(1.0, os_.float().abs().max().item())
+    # V = const => O = const on every row
+    vc = torch.full_like(tv, -0.375)
+    capi.attn_call(entry, q, k, vc, o, 2)
+    torch.cuda.synchronize()
+    assert (o.float() + 0.375).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("N", [2048, 8192])
+def test_d1024_full_width(oracle, N):
+    """D = 1024 (flash_attn_mma_tiling_qkv.cu:904-910,931-937 and tiling_qk dispatch up to 1024) at N >= 2048 — round 3 tested N = 128
+    only."""
+    capi = _capi()
+    B, H, D = 1, 4 if N == 8192 else 8, 1024
+    torch.manual_seed(1024 + N)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k[0, H - 1, N - 100] = 3.0 * q[0, H - 1, 33]
+    v[0, H - 1, N - 100] = 5.0
+    rows = _rows_for(N, 1024, extra=[33, 127, 128])
+    o = torch.full_like(q, float("nan"))
+    for entry in ("flash_attn_mma_stages_split_q_tiling_qkv", "flash_attn_mma_stages_split_q_tiling_qk"):
+        o.fill_(float("nan"))
+        capi.attn_call(entry, q, k, v, o, 2)
+        torch.cuda.synchronize()
+        assert torch.isfinite(o).all()
+        _sampled_rows_check(oracle, q, k, v, o, [(0, 0), (0, H - 1)], rows)
+    vc = torch.full_like(v, 0.875)
+    capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, vc, o, 2)
+    torch.cuda.synchronize()
+    assert (o.float() - 0.875).abs().max().item() < 1e-3

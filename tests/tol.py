@@ -15,7 +15,28 @@ import math
 
 HGEMM_RTOL = 1e-2
 ATTN_ATOL = 1e-2      # the reference's --check threshold
-ATTN_MAX_ABS = 2e-3   # tighter: what fp32-accumulate kernels should hold on randn inputs
+ATTN_MAX_ABS = 2e-3   # tighter: what fp32-accumulate kernels should hold on randn inputs AT N <= 256
+ATTN_RTOL_F16 = 2.0 ** -10   # one fp16 ulp of |truth|: the final rounding of O (half an ulp) + headroom
+ATTN_RTOL_BF16 = 2.0 ** -7   # the same for bfloat16 outputs
+
+
+def attn_max_abs(N: int, bf16: bool = False) -> float:
+    """Absolute part of the long-sequence attention bound, scaled with the signal (round-3 verdict, weak #1): on randn
+    inputs |O| ~ 1/sqrt(N) and the kernel's error (fp16 rounding of P averaged over N keys) shrinks the same way — smoke
+    measures 2.4e-4 at N = 256, ~4e-5 at N = 8192 — so a fixed 2e-3 at N = 8192 would let a 25 % mis-scaling of one 64-key
+    tile (dO <= 1.5e-3) through.  ATTN_MAX_ABS * sqrt(256 / N) (3.5e-4 at N = 8192) does not; the bound a test applies is
+    |out - truth| <= attn_max_abs(N) + ATTN_RTOL * |truth| (the relative term is the output's own fp16 / bf16 rounding,
+    which matters only on rows a spike input drives to |O| >> 1/sqrt(N))."""
+    base = 1.6e-2 if bf16 else ATTN_MAX_ABS
+    return base * math.sqrt(256.0 / max(N, 256))
+
+
+def attn_close(out_f32, truth_f32, N: int, bf16: bool = False):
+    """numpy arrays -> (ok, max_abs_err, worst_excess) under the N-scaled bound."""
+    import numpy as np
+    err = np.abs(out_f32.astype(np.float64) - truth_f32.astype(np.float64))
+    bound = attn_max_abs(N, bf16) + (ATTN_RTOL_BF16 if bf16 else ATTN_RTOL_F16) * np.abs(truth_f32.astype(np.float64))
+    return bool((err <= bound).all()), float(err.max()), float((err - bound).max())
 
 
 def hgemm_atol(K: int, amp: float = 1.0) -> float:
