@@ -40,7 +40,7 @@ def _rows_for(N, seed, extra=()):
     return sorted(set(seams + rnd + list(extra)))
 
 
-def _sampled_rows_check(oracle, q, k, v, o, heads, rows, max_abs=None, bf16=False, vt=False):
+def _sampled_rows_check(oracle, q, k, v, o, heads, rows, max_abs=None, bf16=False, vt=False, rtol=None):
     """Sampled query rows x ALL keys against the exact oracle under the N-scaled bound of tests/tol.py (`max_abs` is kept for
     callers that state a fixed ceiling on top: both must hold)."""
     B, H, N, D = q.shape
@@ -57,7 +57,7 @@ def _sampled_rows_check(oracle, q, k, v, o, heads, rows, max_abs=None, bf16=Fals
     # the reference's own --check bound (flash_attn_mma.py:489) ...
     assert np.allclose(got, truth, atol=tol.ATTN_ATOL, rtol=1e-2), d.max()
     # ... and the bound that scales with the signal: ATTN_MAX_ABS * sqrt(256 / N) + one output ulp of |truth|
-    ok, mx, ex = tol.attn_close(got, truth, N, bf16)
+    ok, mx, ex = tol.attn_close(got, truth, N, bf16, rtol)
     assert ok, (mx, ex, d.mean(), tol.attn_max_abs(N, bf16))
     if max_abs is not None:
         assert d.max() < max_abs, (d.max(), d.mean())
@@ -191,8 +191,9 @@ def test_reference_published_shapes_small_head_dims(oracle, B, H, N, D):
     capi.attn_call("flash_attn_mma_stages_split_q", q, k, v, o, 2)
     torch.cuda.synchronize()
     assert torch.isfinite(o).all()
-    heads = sorted({(0, 0), (0, H // 2), (0, H - 1)})
-    _sampled_rows_check(oracle, q, k, v, o, heads, ROWS_8K + [33], tol.ATTN_MAX_ABS)
+    _sampled_rows_check(oracle, q, k, v, o, sorted({(0, 0), (0, H // 2)}), ROWS_8K + [33])
+    # the spiked head: scores of ~3 sqrt(D) against the planted key carry the fp16 rounding of Q~ and K (tests/tol.py ATTN_RTOL_SPIKE)
+    _sampled_rows_check(oracle, q, k, v, o, [(0, H - 1)], ROWS_8K + [33], rtol=tol.ATTN_RTOL_SPIKE)
     # two launches on the same inputs are bit-identical; the shared-QKV / tiling entries take the same path at D <= 128
     o2 = torch.full_like(q, float("nan"))
     capi.attn_call("flash_attn_mma_stages_split_q_shared_qkv", q, k, v, o2, 2)

@@ -31,11 +31,18 @@ def attn_max_abs(N: int, bf16: bool = False) -> float:
     return base * math.sqrt(256.0 / max(N, 256))
 
 
-def attn_close(out_f32, truth_f32, N: int, bf16: bool = False):
+ATTN_RTOL_SPIKE = 2.0 ** -8   # heads carrying a planted spike key (|score| ~ 3 sqrt(D) >> 1): Q~ = fp16(Q * scale * log2e) and K are fp16,
+                              # so a score carries a relative error ~2^-11 and a weight e^s a relative error ~|s| 2^-11 — measured 2.2e-3
+                              # at |O| = 1.5 on the D = 32 spike head (r4a); the reference's fp16-accumulated Q.K^T is coarser still
+
+
+def attn_close(out_f32, truth_f32, N: int, bf16: bool = False, rtol=None):
     """numpy arrays -> (ok, max_abs_err, worst_excess) under the N-scaled bound."""
     import numpy as np
     err = np.abs(out_f32.astype(np.float64) - truth_f32.astype(np.float64))
-    bound = attn_max_abs(N, bf16) + (ATTN_RTOL_BF16 if bf16 else ATTN_RTOL_F16) * np.abs(truth_f32.astype(np.float64))
+    if rtol is None:
+        rtol = ATTN_RTOL_BF16 if bf16 else ATTN_RTOL_F16
+    bound = attn_max_abs(N, bf16) + rtol * np.abs(truth_f32.astype(np.float64))
     return bool((err <= bound).all()), float(err.max()), float((err - bound).max())
 
 
