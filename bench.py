@@ -114,7 +114,7 @@ def timed_region(w, step, steps, warmup, prewarm=PREWARM):
 # Which launch shape each kernel was profiled on by tools/prof_kernels.py (the target of the committed --pmc passes): a
 # per-launch byte count is only comparable with the SAME shape.  New PMC summaries carry the key themselves
 # ("workload", written by tools/summarize_prof.py); the table covers the files committed before that field existed.
-LEGACY_PMC_WORKLOAD = {"hgemm_w4y_kernel": "hgemm_8192", "attn_fwd_w4n_kernel": "attn_cfg3", "attn_fwd_w4p_kernel": "attn_cfg3", "attn_fwd_w4m_kernel": "attn_cfg3",
+LEGACY_PMC_WORKLOAD = {"hgemm_w4y_kernel": "hgemm_8192", 
                        "attn_fwd_bigd2_kernel<512,false>": "attn_d512_fp16", "attn_fwd_bigd2_kernel<512,true>": "attn_d512_bf16",
                        "gemm_fp8_w4_kernel": "fp8_8192"}
 

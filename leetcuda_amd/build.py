@@ -160,6 +160,9 @@ def build_abi(force: bool = False, audit: bool = True) -> Path:
     objdir = LIBDIR / "obj"
     objdir.mkdir(exist_ok=True)
     units = [CSRC / "lc_abi.hip"] + sorted(CSRC.glob("tu_*.hip"))
+    for old in list(objdir.glob("tu_*.*")):      # objects / assembly of translation units that no longer exist
+        if old.suffix in (".o", ".s", ".d") and not (CSRC / (old.stem + ".hip")).exists():
+            old.unlink()
     flags_ok = _stamp_ok(stamp, flags)
     procs = []
     for u in units:
@@ -215,8 +218,7 @@ def build_diag(force: bool = False) -> Path:
     tools only; not part of the drop-in library).  The ablated phase statements are generated into lib/gen/ (never tracked)."""
     LIBDIR.mkdir(parents=True, exist_ok=True)
     out = LIBDIR / "liblc_diag.so"
-    srcs = sorted((CSRC / "diag").glob("*.hip")) + [CSRC / "lc_common.h", ROOT / "include" / "lc_diag.h", CSRC / "attn_w4i.hip",
-                                                     CSRC / "attn_w4g.hip", CSRC / "attn_w4n.hip", CSRC / "attn_w4m.hip",
+    srcs = sorted((CSRC / "diag").glob("*.hip")) + [CSRC / "lc_common.h", ROOT / "include" / "lc_diag.h", CSRC / "attn_w4i.hip", CSRC / "attn_mp.h", CSRC / "attn_fwd.hip",
                                                      ROOT / "tools" / "gen_attn_w4i.py"]
     dg = _digest(srcs)
     if not force and _fresh(out, "diag", dg):

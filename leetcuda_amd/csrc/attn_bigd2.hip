@@ -22,14 +22,14 @@
 //     a DMA piece has >= 32 MFMAs (>= 1000 cycles) of flight; K/V bytes per MFMA are a third of round 1's;
 //   * swizzles (LDS-DMA writes lane-linearly, so they are applied to the per-lane SOURCE address): K 16-B chunk c of row r
 //     at slot c ^ (r & 15) (conflict-free ds_read_b128 on 1-KiB rows), V 64-B unit u of row r at unit u ^ (r & 3)
-//     (transpose-read half-waves on disjoint bank quarters) — the layouts of attn_w4m.hip on longer rows;
-//   * softmax: the running max is only a SCALE (attn_w4m.hip): the fast path exponentiates against the stale max and a
+//     (transpose-read half-waves on disjoint bank quarters) — the layouts of the round-2 merged-phase kernel on longer rows;
+//   * softmax: the running max is only a SCALE (as in attn_w4u.hip): the fast path exponentiates against the stale max and a
 //     rare wave-uniform slow path (row sums >= 2^14, non-finite, or the first tile) finds the true max and rescales O, l;
 //   * O leaves through LDS as whole rows with 16-B stores.
 // Roofline: MFMA-bound (4·B·H·N²·D FLOPs, 4·B·H·N·D·2 algorithmic bytes; AI = N/2 FLOP/B per... >> 300).
 #pragma once
 #include "attn_fwd.hip"
-#include "attn_w4m.hip"   // am_acc_* / am_drain / am_xhalf_* helpers
+#include "attn_mp.h"   // am_acc_* / am_drain / am_xhalf_* helpers
 
 namespace lc {
 

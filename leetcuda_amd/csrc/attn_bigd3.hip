@@ -10,7 +10,7 @@
 //       P·V(t−1)     D/8 MFMAs from V slot 1 − PAR, softmax(t) as filler between its statements (attn_bigd2's phase B)
 //       vmcnt(0), barrier   (K(t+1), V(t) published; everybody is done with K(t), V(t−1))
 //   a DMA piece has a whole tile period (>= 2000 matrix-core cycles) of flight, the barrier cadence (one per 64 MFMAs of
-//   32 cycles) is attn_w4n's.  Same wave tile (32 query rows x all D columns, Oᵀ in the 256 AGPRs), same fragment layouts
+//   32 cycles) is attn_w4u's.  Same wave tile (32 query rows x all D columns, Oᵀ in the 256 AGPRs), same fragment layouts
 //   and swizzles as attn_bigd2 (tests/test_layouts.py), same "m is only a scale" softmax; Sᵀ is one 32 x 32 block (two
 //   accumulation chains), P 8 registers per tile, so the Q fragments all stay in registers (no LDS parking).
 // Reference: kernels/flash-attn/mma/basic/flash_attn_mma_tiling_qkv.cu:75-797, entry :881-945 (BASELINE config 5a).

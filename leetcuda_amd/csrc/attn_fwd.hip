@@ -321,7 +321,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1)) void attn_fwd_kernel(
 
 
 // (The round-1 four-cluster role-split kernel, attn_fwd_c4_kernel — 8 waves, K/V by LDS-DMA, 0.95-1.04 PFLOP/s at config 3 —
-// was retired at the end of round 2: attn_w4m.hip / attn_w4n.hip keep its K-tile swizzle (16-B chunk c of row r at slot
+// was retired at the end of round 2: attn_w4u.hip keeps its K-tile swizzle (16-B chunk c of row r at slot
 // c ^ (r & 15) on unpadded 256-B rows) and its LDS-DMA staging; git history has the kernel.)
 
 // ------------------------------------------------------------------------------------------------

@@ -1,41 +1,59 @@
-// attn_w4p.hip — FlashAttention-2 forward, D = 64 / 128: the merged-phase 4-wave kernel of attn_w4g.hip as a PERSISTENT
-// workgroup (round 3; lc_tune_set "attn_nw" = 515).
+// attn_w4u.hip — FlashAttention-2 forward, D = 64 / 128, N % 256 == 0: THE merged-phase 4-wave kernel (round 4: one templated body
+// replaces attn_w4g.hip (one block per workgroup), attn_w4p.hip (persistent workgroup), attn_w4n.hip (its D = 128 twin) and the retired
+// attn_w4m.hip / attn_w8g.hip; lc_tune_set "attn_nw" = 513 / 515 / 517 select WALK = 0 / 1 / 2).
 //
 // Same semantics / entry points as attn_fwd.hip (reference: kernels/flash-attn/mma/basic/flash_attn_mma_split_q.cu:55-699,
-// dispatcher :769-815; flash_attn_mma_share_qkv.cu:46-769).  Same arithmetic as attn_fwd_w4g_kernel, instruction for
-// instruction inside a block — the results are bit-identical (GPU test) — what changes is what happens BETWEEN two 256-row
-// query blocks.  DESIGN.md §4.13b measured the fixed cost of a block (workgroup launch, the first two K/V tiles' DMA latency,
-// the Q loads, Sᵀ(0), O through LDS) at ≈ 6 % of config 3 and ≈ 3 % at S = 8192: one wave per SIMD and one workgroup per CU
-// means nothing else runs on the CU while a workgroup starts or drains.  Here
-//   * the grid is one workgroup per CU (min(#blocks, 256)); workgroup w walks the virtual block ids w, w + G, w + 2G, … and
-//     maps each through the same XCD-aware remap as the one-block-per-workgroup launch (w + kG ≡ w mod 8: a workgroup's
-//     blocks stay on the XCD whose L2 holds their heads' K / V);
-//   * the K/V stream is continuous across the seam: the LDS-DMA of "tile T" and "tile T + 1" (issued in the tile periods
-//     T − 2 and T − 1, where the one-block kernel has nothing left to fetch) stages tiles 0 and 1 of the NEXT block into ring
-//     slots 0 and 1 — exactly where the next prologue reads them (T % 4 == 0);
-//   * the next block's Q rows are requested right after the last P·V MFMAs are issued and land during the O epilogue;
-//   * the O staging area moves behind ring slots 0 / 1 (D = 128: bytes 64 Ki … 132 Ki), so the epilogue never touches the
-//     slots that are being filled; no vmcnt wait at the epilogue (the pieces in flight do not concern it).
-// One extra barrier per block (all waves are done with the staging area before tile 2 of the next block is staged).
+// dispatcher :769-815; flash_attn_mma_share_qkv.cu:46-769; V handed over as [B,H,D,N]:
+// kernels/flash-attn/mma/swizzle/flash_attn_mma_share_qkv_swizzle_qkv.cu:961-1010, flash_attn_mma.py:441-442,716).
+//
+// template <D, VT, WALK>
+//   D     64 or 128 (geometry: attn_mp.h W4G<D>)
+//   VT    V is [B,H,D,N]: the tile image in LDS is [D rows][64 kv] (128-B rows, 16-B granule j of row d at slot j ^ ((d >> 1) & 7)),
+//         filled by LDS-DMA pieces of 8 d-rows (source stride 2 N bytes), and a Vᵀ fragment is TWO PLAIN ds_read_b64 (kv 4 g .. + 3
+//         of kv block 0 / of kv block 1 — the k-slot order the lane-local Pᵀ operand defines) where the [N][D] image needs two
+//         ds_read_b64_tr_b16: one for one, same slots, same waits -> the V-transposed entries run at their siblings' speed
+//         (round 3: the lock-step kernel, − 27 %).  Conflict-free: tests/test_layouts.py.
+//   WALK  0  one 256-row query block per workgroup (grid = #blocks; the hardware dispatches)
+//         1  persistent workgroup per CU, static walk w, w + G, w + 2 G, … (round 3's attn_w4p: the K / V / Q streams continue
+//            across block seams)
+//         2  persistent workgroup per CU, DYNAMIC queue: workgroup on XCD x claims the next id of ITS XCD (x + 8 j) with one
+//            atomic per block, one block ahead (issued behind the last P·V MFMAs of block b − 1, broadcast through LDS at block
+//            b's prologue barrier: no exposed latency); the counters reset themselves when the last workgroup leaves.
+// The arithmetic of a block is the same instruction for instruction in all three walks and for both V layouts' Q·Kᵀ / softmax
+// (VT changes only where Vᵀ fragments come from): WALK 0 / 1 / 2 are bit-identical to each other (GPU test).
+//
+// What happens BETWEEN two 256-row query blocks of a persistent workgroup: the LDS-DMA of "tile T" and "tile
+// T + 1" stages tiles 0 / 1 of the NEXT block into ring slots 0 / 1 — exactly where the next prologue reads them (T % 4 == 0);
+// the next block's Q rows are requested right after the last P·V MFMAs and land during the O epilogue; the O staging area sits
+// behind ring slots 0 / 1, so the epilogue never touches the slots being filled.  One extra barrier per block.
 #pragma once
-#include "attn_w4g.hip"
+#include "attn_mp.h"
 
 namespace lc {
 
+// claim counters of the dynamic walk: 1024 rotating slots of 16 words ([0..7] next j per XCD, [8] workgroups that left); zero at
+// module load, every launch leaves its slot zeroed again (the last workgroup out resets it).  The host picks the slot (ticket
+// mod 1024): launches in flight on different streams use different slots unless 1024 of them are outstanding at once.
+constexpr int W4U_QSLOTS = 1024;
+static __device__ unsigned int g_w4u_queue[W4U_QSLOTS][16];   // (one array per translation unit that instantiates the kernel)
+
 template <int D>
-struct W4P {
+struct W4U {
   using G = W4G<D>;
   static constexpr int EPI_OFF = 2 * G::SLOT;                                // staging behind ring slots 0, 1
   static constexpr int EPI_BYTES = 4 * 64 * G::EPI_STRIDE;
-  static constexpr int LDS = (EPI_OFF + EPI_BYTES > G::LDS) ? EPI_OFF + EPI_BYTES : G::LDS;
+  static constexpr int MBOX = (EPI_OFF + EPI_BYTES > G::LDS) ? EPI_OFF + EPI_BYTES : G::LDS;   // 16 B: the claimed next block id
+  static constexpr int LDS = MBOX + 16;
   static_assert(LDS <= 160 * 1024, "ring + staging must fit a CU's LDS");
 };
 
-template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_w4p_kernel(
+template <int D, bool VT, int WALK>
+__global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
-    half_t* __restrict__ O, int N, int nqb, float sl2, int nblk, int nwg) {
-  static_assert(D == 64 || D == 128, "w4p attention kernel: D = 64 or 128");
+    half_t* __restrict__ O, int N, int nqb, float sl2, int nblk, int nwg, int qslot) {
+  static_assert(D == 64 || D == 128, "merged-phase attention kernel: D = 64 or 128 (D = 96 / 32: attn_w4i.hip)");
+  static_assert(WALK >= 0 && WALK <= 2, "WALK: 0 one block per workgroup, 1 static persistent walk, 2 dynamic queue");
+  constexpr bool PERSIST = WALK != 0;
   using G = W4G<D>;
   constexpr int NDS = G::NDS, NDB = G::NDB, ROWB = G::ROWB, TILE = G::TILE, SLOT = G::SLOT, NS = G::NS;
   constexpr int NRV = G::NRV, NRK = G::NRK, PPW = G::PPW, KBUF = G::KBUF;
@@ -49,27 +67,43 @@ __global__ __launch_bounds__(256) void attn_fwd_w4p_kernel(
   const uint32_t smem32 = lds_addr32(smem);
   const size_t head_elems = (size_t)N * D;
 
-  // ---- LDS-DMA lane offsets (attn_w4g.hip)
+  // ---- LDS-DMA: piece p = RPP rows x ROWB bytes; this wave stages pieces wave + 4 i (i = 0 .. PPW−1) of K and of V.
+  // Lane -> row rr of the piece, 16-B slot cs of the row; the slot receives the logical chunk the read side expects there.
   unsigned k_off, v_off;
   if constexpr (D == 128) {
-    const int rr = lane >> 4, cs = lane & 15;
+    const int rr = lane >> 4, cs = lane & 15;          // row & 15 = 4 (p & 3) + rr, p & 3 = wave
     k_off = (unsigned)(rr * 256 + ((cs ^ (4 * wave + rr)) * 16));
-    v_off = (unsigned)(rr * 256 + (((((cs >> 1) ^ ((rr << 1) | (wave & 1))) << 1) | (cs & 1)) * 16));
+    v_off = (unsigned)(rr * 256 + (((((cs >> 1) ^ ((rr << 1) | (wave & 1))) << 1) | (cs & 1)) * 16));   // key: row & 3 = rr, (row >> 2) & 1 = wave & 1
   } else {
-    const int rr = lane >> 3, cs = lane & 7;
-    k_off = (unsigned)(rr * 128 + ((cs ^ (4 * (wave & 1) + (rr >> 1))) * 16));
-    v_off = (unsigned)(rr * 128 + (((((cs >> 1) ^ ((rr >> 1) & 3)) << 1) | (cs & 1)) * 16));
+    const int rr = lane >> 3, cs = lane & 7;           // row & 15 = 8 (p & 1) + rr, p & 1 = wave & 1
+    k_off = (unsigned)(rr * 128 + ((cs ^ (4 * (wave & 1) + (rr >> 1))) * 16));                          // (row >> 1) & 7
+    v_off = (unsigned)(rr * 128 + (((((cs >> 1) ^ ((rr >> 1) & 3)) << 1) | (cs & 1)) * 16));            // key = (row >> 1) & 3 = (rr >> 1) & 3
   }
-  // ---- fragment read offsets inside a ring slot (attn_w4g.hip)
+  if constexpr (VT) {
+    // V as [D][N]: piece p = d-rows 8 p .. 8 p + 7 (128 B = 64 kv each, 2 N bytes apart in memory); lane -> d-row rr = lane >> 3,
+    // LDS granule slot cs = lane & 7 <- source granule cs ^ key(row), key = (row >> 1) & 7 = 4 (p & 1) + (rr >> 1), p & 1 = wave & 1
+    const int rr = lane >> 3, cs = lane & 7;
+    v_off = (unsigned)((size_t)rr * N * 2 + ((cs ^ (4 * (wave & 1) + (rr >> 1))) * 16));
+  }
+  const unsigned v_piece_stride = VT ? (unsigned)(8u * (unsigned)N * 2u) : 1024u;   // source bytes between consecutive pieces of a V tile
+  constexpr unsigned V_TILE_STRIDE = VT ? 128u : (unsigned)TILE;                     // ... between consecutive V tiles
+  // ---- fragment read offsets inside a ring slot (attn_mp.h)
   uint32_t kx[NDS];
 #pragma unroll
   for (int ds = 0; ds < NDS; ++ds)
     kx[ds] = (uint32_t)(l16 * ROWB + (((4 * ds + g4) ^ (D == 128 ? l16 : ((l16 >> 1) & 7))) * 16));
-  constexpr int NVX = D == 128 ? 4 : NDB;
+  // Vᵀ fragment reads (8 bytes each).  [N][D] image: transpose reads — kv row 4 g4 + (l16 >> 2) (+16 x, +32 per half-tile:
+  // immediates), 8 bytes at column 4 (l16 & 3) of pair db; D = 128: vx[u] addresses pair 2 u (pair 2 u + 1 sits at ±32 B: key bit 0
+  // = g4 & 1, not an immediate); D = 64: vx[db].  VT ([D][64 kv] image, 128-B rows): d-row 16 db + l16 (16 db rows = an immediate),
+  // kv 32 H + 16 x + 4 g4 .. + 3 = half (g4 & 1) of granule 4 H + 2 x + (g4 >> 1) at slot granule ^ ((l16 >> 1) & 7): the XOR with
+  // 4 H + 2 x is not an immediate -> vx[2 H + x], four address registers like the D = 128 transposed image.
+  constexpr int NVX = (VT || D == 128) ? 4 : NDB;
   uint32_t vx[NVX];
 #pragma unroll
   for (int u = 0; u < NVX; ++u) {
-    if constexpr (D == 128)
+    if constexpr (VT)
+      vx[u] = (uint32_t)(TILE + l16 * 128 + ((((2 * u) | (g4 >> 1)) ^ ((l16 >> 1) & 7)) * 16) + 8 * (g4 & 1));
+    else if constexpr (D == 128)
       vx[u] = (uint32_t)(TILE + (4 * g4 + (l16 >> 2)) * 256 + (((2 * u) ^ (((l16 >> 2) << 1) | (g4 & 1))) * 32) + 8 * (l16 & 3));
     else
       vx[u] = (uint32_t)(TILE + (4 * g4 + (l16 >> 2)) * 128 + ((u ^ (((g4 & 1) << 1) | (l16 >> 3))) * 32) + 8 * (l16 & 3));
@@ -92,13 +126,13 @@ __global__ __launch_bounds__(256) void attn_fwd_w4p_kernel(
   buf_rsrc_t dk = make_rsrc(K + bh * head_elems), dv = make_rsrc(V + bh * head_elems);
   unsigned d_so = 0;
   char* d_slot = smem;
+  unsigned d_sov = 0;   // (V: te * V_TILE_STRIDE — 128 B per tile when V is [D][N])
   auto issue_piece = [&](int i) {   // i = 0 .. 2 PPW−1: K pieces, then V pieces
     const int p = wave + 4 * (i % PPW);
-    const unsigned so = d_so + (unsigned)p * 1024u;
     if (i < PPW)
-      blds16(dk, k_off, so, d_slot + p * 1024);
+      blds16(dk, k_off, d_so + (unsigned)p * 1024u, d_slot + p * 1024);
     else
-      blds16(dv, v_off, so, d_slot + TILE + p * 1024);
+      blds16(dv, v_off, d_sov + (unsigned)p * v_piece_stride, d_slot + TILE + p * 1024);
   };
   // Q rows of a block as raw fp16 (16 bytes per fragment): requested one block ahead
   half8_t qraw[NQ];
@@ -110,10 +144,33 @@ __global__ __launch_bounds__(256) void attn_fwd_w4p_kernel(
     });
   };
 
+  // dynamic walk: this workgroup's XCD (workgroups are dealt to the XCDs round-robin: id & 7) and its first claim — the id of the
+  // block AFTER the first one — in flight behind the first tiles' DMA
+  const int xcd = __builtin_amdgcn_readfirstlane((int)blockIdx.x & 7);
+  unsigned int* const queue = &g_w4u_queue[qslot][0];
+  unsigned claim = 0;
+  auto claim_next = [&]() {
+    if constexpr (WALK == 2) {
+      if (wave == 0 && lane == 0) claim = atomicAdd(queue + xcd, 1u);
+    }
+  };
+  claim_next();
+  // seam synchronisation: this block's tiles 0, 1 landed (own pieces; the previous block's O stores too); every wave has left the
+  // previous block's staging area.  The dynamic walk also passes the claimed id through the LDS mailbox here (wave 0 writes in
+  // front of the barrier, every wave reads behind it) and therefore synchronises at the TOP of a block, before the id is needed.
+  auto seam_sync = [&]() {
+    if constexpr (WALK == 2) {
+      if (wave == 0 && lane == 0) *(volatile unsigned*)(smem + W4U<D>::MBOX) = claim;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    raw_barrier();
+  };
+
   // first block: tiles 0, 1 and Q from scratch
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     d_so = (unsigned)t * TILE;
+    d_sov = (unsigned)t * V_TILE_STRIDE;
     d_slot = smem + t * SLOT;
 #pragma unroll
     for (int i = 0; i < 2 * PPW; ++i) issue_piece(i);
@@ -122,8 +179,15 @@ __global__ __launch_bounds__(256) void attn_fwd_w4p_kernel(
 
   for (;;) {
     // ---- the block after this one (or this one again when there is none: every address stays valid, nothing of it is used)
-    const int vbn = __builtin_amdgcn_readfirstlane(vb + nwg);   // (nwg = gridDim.x as a kernel argument: provably wave-uniform, the block walk stays in SGPRs)
-    const bool has_next = vbn < nblk;
+    int vbn_;
+    if constexpr (WALK == 2) {
+      seam_sync();
+      vbn_ = nwg + xcd + 8 * (int)*(volatile unsigned*)(smem + W4U<D>::MBOX);   // ids >= nwg with id & 7 == xcd, in claim order
+    } else {
+      vbn_ = vb + nwg;   // (nwg = gridDim.x as a kernel argument: provably wave-uniform, the block walk stays in SGPRs)
+    }
+    const int vbn = __builtin_amdgcn_readfirstlane(vbn_);
+    const bool has_next = PERSIST && vbn < nblk;
     int q0n;
     const size_t bhn = head_of(has_next ? vbn : vb, q0n);
     half_t* Ob = O + bh * head_elems;
@@ -135,6 +199,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4p_kernel(
       dv = make_rsrc(V + h * head_elems);
       const int te = own ? t2 : (has_next ? t2 - T : T - 1);
       d_so = (unsigned)__builtin_amdgcn_readfirstlane(te * TILE);   // (provably wave-uniform: no waterfall loop around the pieces)
+      d_sov = (unsigned)__builtin_amdgcn_readfirstlane(te * (int)V_TILE_STRIDE);
       d_slot = smem + (t2 & 3) * SLOT;
     };
 
@@ -190,10 +255,8 @@ __global__ __launch_bounds__(256) void attn_fwd_w4p_kernel(
       else w4g_wait_v4(vlo[first], vlo[first + 1], vhi[first], vhi[first + 1]);
     };
 
-    // ---- prologue: this block's tiles 0, 1 landed (own pieces; the previous block's O stores too); every wave has left the
-    // previous block's staging area
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    raw_barrier();
+    // ---- prologue (seam_sync: at the top of the block for the dynamic walk)
+    if constexpr (WALK != 2) seam_sync();
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using IB = std::integral_constant<int, NDB / 2>;
@@ -222,7 +285,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4p_kernel(
       }
     }
 
-    // ---- one merged phase (attn_w4g.hip; F bit 8 = issue this period's DMA pieces, target set by set_dma_tile)
+    // ---- one merged phase ( F bit 8 = issue this period's DMA pieces, target set by set_dma_tile)
     auto phase = [&](auto hc, auto fc, int t, f32x4_t (&sr)[2][4], f32x4_t (&sw)[2][4], half8_t (&pw)[4], half8_t (&pr)[4]) {
       constexpr int H = decltype(hc)::value, F = decltype(fc)::value;
       constexpr bool HAS_PV = (F & 1) != 0, HAS_QK = (F & 2) != 0, HAS_KRD = (F & 4) != 0, HAS_DMA = (F & 8) != 0;
@@ -250,23 +313,26 @@ __global__ __launch_bounds__(256) void attn_fwd_w4p_kernel(
         constexpr bool RVB = s < NRV && HAS_PV, RK = s < NRK && HAS_KRD, RVA = s >= NS / 2 && s < NS / 2 + NRV;
         constexpr int RD = ((RVB || RVA) ? 1 : 0) | (RK ? 2 : 0);
         constexpr int c = RVA ? s - NS / 2 : (s % NRV), rdb = (RVA ? 0 : NDB / 2) + (c >> 1), rx = c & 1;
-        constexpr int VOF = (RVA ? H : VB_H) * 32 * ROWB + rx * 16 * ROWB;
+        constexpr int VH = RVA ? H : VB_H;     // half-tile of the Vᵀ rows this read fetches, inside their tile
+        // [N][D] image: address register by column block, half-tile / kv block as immediates; [D][64 kv] image (VT): address register
+        // by (half-tile, kv block) — the granule XOR —, the column block's 16 d-rows (2 KiB) as the immediate
+        constexpr int VOF = VT ? rdb * 2048 : VH * 32 * ROWB + rx * 16 * ROWB;
         half4_t& vout = rx ? vhi[rdb] : vlo[rdb];
-        const uint32_t vaddr = RVA ? vaddr_of(vc, rdb) : vaddr_of(vb_a, rdb);
+        const uint32_t vaddr = VT ? (RVA ? vc : vb_a)[(2 * VH + rx) % NVX] : (RVA ? vaddr_of(vc, rdb) : vaddr_of(vb_a, rdb));
         constexpr int kc = s % NRK;
         constexpr int KR = GK + KBUF * KRB + 4 * kc, KOF = H * 32 * ROWB + (kc / NDS) * 16 * ROWB;
         if constexpr ((s & 1) == 0) {
           constexpr int ds = i >> 3, kvb = (i >> 2) & 1, qb = i & 3;
           constexpr int KIND = HAS_QK ? (ds == 0 ? 0 : 1) : 3;
           if constexpr (KIND != 3 || RD != 0)
-            an_slot<KIND, RD, KQ + 4 * (NDS * kvb + ds), GQ + 4 * (NDS * qb + ds), VOF, KR, KOF>(
+            an_slot<KIND, RD, KQ + 4 * (NDS * kvb + ds), GQ + 4 * (NDS * qb + ds), VOF, KR, KOF, VT>(
                 sw[kvb][qb], negm[qb], half8_t{}, half8_t{}, vout, vaddr, ka[kc % NDS]);
         } else {
           constexpr int db = i >> 2, qb = i & 3;
           constexpr int KIND = HAS_PV ? 2 : 3;
           if constexpr (KIND != 3 || RD != 0)
-            an_slot<KIND, RD, GO + 4 * (4 * db + qb), 0, VOF, KR, KOF>(sw[0][0], negm[0], cat4(vlo[db], vhi[db]), pr[qb], vout,
-                                                                       vaddr, ka[kc % NDS]);
+            an_slot<KIND, RD, GO + 4 * (4 * db + qb), 0, VOF, KR, KOF, VT>(sw[0][0], negm[0], cat4(vlo[db], vhi[db]), pr[qb], vout,
+                                                                           vaddr, ka[kc % NDS]);
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (s == NS / 2 - 1 && HAS_PV) wait_vset(IB{});
@@ -319,7 +385,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4p_kernel(
       pair_sum(std::integral_constant<int, 15>{}, I0{}, e0);
       pair_sum(std::integral_constant<int, 15>{}, I1{}, e1);
       pair_pack(std::integral_constant<int, 15>{}, e0, e1);
-      // ---------------- overflow guard (attn_w4g.hip)
+      // ---------------- overflow guard (attn_mp.h)
       uint32_t worst_bits = 0;
 #pragma unroll
       for (int qb = 0; qb < 4; ++qb) worst_bits = max(worst_bits, __builtin_bit_cast(uint32_t, ps[qb][0] + ps[qb][1]));
@@ -380,7 +446,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4p_kernel(
     using F_FIRST0 = std::integral_constant<int, 2 | 4 | 8>;
     using F_MID = std::integral_constant<int, 1 | 2 | 4 | 8>;
     using F_MID1 = std::integral_constant<int, 1 | 2 | 4>;
-    using F_LAST0 = std::integral_constant<int, 1 | 2 | 8>;        // j = 2T−2: stages "tile T + 1" = the next block's tile 1
+    using F_LAST0 = std::integral_constant<int, PERSIST ? (1 | 2 | 8) : (1 | 2)>;   // j = 2T−2: stages "tile T + 1" = the next block's tile 1 (one block per workgroup: nothing left to stage)
     using F_LAST1 = std::integral_constant<int, 1>;
 
     set_tile_addrs(0);
@@ -405,8 +471,13 @@ __global__ __launch_bounds__(256) void attn_fwd_w4p_kernel(
       phase(I1{}, F_LAST1{}, t, sB, sA, pB, pA);
       static_for<NRV>([&](auto cc) {
         constexpr int c = decltype(cc)::value, db = NDB / 2 + (c >> 1);
-        if constexpr ((c & 1) == 0) vlo[db] = lds_tr16_asm<32 * ROWB>(vaddr_of(vc, db));
-        else vhi[db] = lds_tr16_asm<32 * ROWB + 16 * ROWB>(vaddr_of(vc, db));
+        if constexpr (VT) {
+          if constexpr ((c & 1) == 0) vlo[db] = lds_rd64_asm<db * 2048>(vc[2 % NVX]);
+          else vhi[db] = lds_rd64_asm<db * 2048>(vc[3 % NVX]);
+        } else {
+          if constexpr ((c & 1) == 0) vlo[db] = lds_tr16_asm<32 * ROWB>(vaddr_of(vc, db));
+          else vhi[db] = lds_tr16_asm<32 * ROWB + 16 * ROWB>(vaddr_of(vc, db));
+        }
       });
       wait_vset(I0{});
       wait_vset(IB{});
@@ -416,7 +487,10 @@ __global__ __launch_bounds__(256) void attn_fwd_w4p_kernel(
       });
     }
     __builtin_amdgcn_sched_barrier(0);
-    load_q(bhn, q0n);                  // the next block's Q rows: in flight during the epilogue
+    if constexpr (PERSIST) {
+      if (has_next) claim_next();      // dynamic walk: the id of the block after next (consumed at the next block's seam)
+      load_q(bhn, q0n);                // the next block's Q rows: in flight during the epilogue
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- epilogue: O = Oᵀ / l through LDS (whole rows, 16-B stores); staging behind ring slots 0 / 1
@@ -426,7 +500,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4p_kernel(
     float inv[4];
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) inv[qb] = 1.0f / an_x4_sum(l_run[qb]);
-    char* stg = smem + W4P<D>::EPI_OFF + wave * (64 * G::EPI_STRIDE);
+    char* stg = smem + W4U<D>::EPI_OFF + wave * (64 * G::EPI_STRIDE);
     static_for<4>([&](auto qc) {
       constexpr int qb = decltype(qc)::value;
       static_for<NDB>([&](auto dc) {
@@ -453,6 +527,15 @@ __global__ __launch_bounds__(256) void attn_fwd_w4p_kernel(
     vb = vbn;
     bh = bhn;
     q0 = q0n;
+  }
+  if constexpr (WALK == 2) {
+    // the last workgroup out zeroes the slot: every workgroup has made its final claim before it gets here
+    if (wave == 0 && lane == 0) {
+      if (atomicAdd(queue + 8, 1u) == (unsigned)nwg - 1u) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) __hip_atomic_store(queue + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 

@@ -39,7 +39,8 @@ namespace {
 // run-time tuning knobs (lc_tune_set): experiments and A/B benches, never required for correctness
 tune_t g_tune_fp8_mx{1};                       // fp8 GEMM: 1 = MX-scaled K=64 MFMA, 4-wave kernel; 2 = MX, 8-wave kernel; 0 = plain K=16 MFMA
 tune_t g_tune_attn_w4i_sched{1};              // schedule of attn_fwd_w4i_kernel's generated phase statements (tools/gen_attn_w4i.py NSCHED; same bits)
-tune_t g_tune_attn_nw{0};                    // attention kernel for D = 128: 0 = auto, 128 / 64 / 8 / 4 / 2 (lc_abi.h)
+tune_t g_tune_attn_nw{0};                    // attention kernel for D <= 128: 0 = auto, 513 / 515 / 517 / 514 / 8 / 4 / 2 (choose_attn_nw, lc_abi.h)
+tune_t g_tune_attn_walk{0};                  // block walk of the merged-phase kernel under attn_nw = 0: 0 = auto by N, 1 / 2 / 3 = WALK 0 / 1 / 2
 tune_t g_tune_hgemm_auto{LC_HGEMM_MFMA256W4Y};   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
 tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to the 128-tile kernel (launch_mfma256), 0 = one launch
 tune_t g_tune_hgemm_raster{0};                 // block -> C tile map: 0 = auto (by operand footprint, panel_tiles), 1 = the reference's block swizzle (N panels from
@@ -254,26 +255,34 @@ int launch_attn(const half_t* Q, const half_t* K, const half_t* V, half_t* O, in
   return check_launch();
 }
 
-// Which kernel serves a D <= 128 problem: 513 = the merged-phase kernel generalised over D (attn_w4g.hip: default for D = 64,
-// cross-check for D = 128), 512 = merged-phase 4-wave x 64-row kernel with 16x16x32 MFMAs (attn_w4n.hip),
-// 256 = the same with 32x32x16 MFMAs (attn_w4m.hip; 260 = its padded A/B twin), 8 / 4 / 2 = lock-step kernel with that many
-// waves (the 8-wave four-cluster kernel, 64, was retired at the end of round 2).  ONE function for the launcher and lc_attn_kernel_name().  Default for D = 128,
-// N % 256 == 0: 512 (sustained, one box, config 3 / config 4's shard: 1235 / 1311 TFLOP/s at 2.08 GHz against 1220 / 1260 at
-// 1.80 GHz for 256 — both at the 1400 W cap — and 1000-1030 / 1040-1080 for the 8-wave kernels).
+// Which kernel serves a D <= 128 problem (ONE function for the launcher and lc_attn_kernel_name()).  Codes (lc_tune_set "attn_nw"):
+//   513 / 515 / 517  the merged-phase 4-wave kernel attn_fwd_w4u_kernel<D, VT, WALK> (attn_w4u.hip: D = 64 / 128, N % 256 == 0, V as
+//                    [B,H,N,D] or — the three *_swizzle_qkv entries — [B,H,D,N]) with WALK 0 (one 256-row query block per workgroup),
+//                    1 (persistent workgroup per CU, static walk), 2 (persistent, dynamic per-XCD block queue)
+//   514              the same design with each phase as one generated asm statement (attn_w4i.hip: D = 32 / 64 / 96 / 128, V as
+//                    [B,H,N,D]; the only merged-phase kernel for D = 96 / 32)
+//   8 / 4 / 2        the lock-step kernel with that many waves (attn_fwd.hip: every other shape)
+// 512 (round 2's attn_w4n) is accepted as an alias of 513: attn_w4u<128, false, 0> IS that kernel; 256 / 260 / 516 were retired in
+// round 4 with attn_w4m.hip / attn_w8g.hip.
+int attn_walk_auto(int N) {
+  // auto (measured, profiles/r3k + r4*): up to N = 4096 the persistent workgroup pays (config 3 + 1.7 %: the fixed cost of a block is
+  // ~6 % of it there); beyond, the block queue decides (lc_tune_set "attn_walk": 0 = this rule)
+  const int k = g_tune_attn_walk;
+  if (k >= 1 && k <= 3) return k - 1;
+  return N <= 4096 ? 1 : 2;
+}
 int choose_attn_nw(int D, bool vt, int N) {
-  const int want = g_tune_attn_nw;   // 0 = auto
-  if (D == 128 && !vt && N % 256 == 0) {
-    // auto: up to N = 4096 the persistent workgroup (attn_w4p.hip, 515: same arithmetic, the next block's K / V / Q fetched across
-    // the seam; config 3 +1.7 %, N = 2048 +1.0 %), beyond that the one-block-per-workgroup launch (the fixed cost of a block is < 3 %
-    // there and the hardware's dynamic dispatch balances 16+ blocks per CU better than a static walk: N = 8192 -0.5 %)
-    if (want == 0 && g_tune_attn_ablate == 0) return N <= 4096 ? 515 : 512;
-    if (want == 256 || want == 260 || want == 512 || want == 513 || want == 514 || want == 515) return want;
+  int want = g_tune_attn_nw;   // 0 = auto (read once per launch)
+  if (want == 512) want = 513;
+  const bool merged = (D == 128 || D == 64) && N % 256 == 0;
+  if (merged && g_tune_attn_ablate == 0) {
+    if (want == 0) return 513 + 2 * attn_walk_auto(N);
+    if (want == 513 || want == 515 || want == 517) return want;
+    if (want == 514 && !vt) return 514;
   }
-  // D = 64: the head-dim-generalised merged-phase kernel (attn_w4g.hip, 513) unless a lock-step kernel is asked for
-  if (D == 64 && !vt && N % 256 == 0 && (want == 0 || want >= 256)) return (want == 514 || want == 515 || want == 516) ? want : 513;
   // D = 96 / 32: only the generated kernel (attn_w4i.hip, 514) has a merged-phase instantiation (256-B / 128-B padded LDS rows)
   if ((D == 96 || D == 32) && !vt && N % 256 == 0 && (want == 0 || want >= 256)) return 514;
-  if (N % 256 == 0 && (want == 0 || want >= 8)) return 8;   // (also what 256 / 512 fall back to for D < 128)
+  if (N % 256 == 0 && (want == 0 || want >= 8)) return 8;
   if (N % 128 == 0 && (want == 0 || want >= 4)) return 4;
   return 2;
 }
@@ -282,16 +291,12 @@ template <int D, bool VT>
 int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                    hipStream_t st) {
   const int nw = choose_attn_nw(D, VT, N);
-  if constexpr (D == 128 && !VT) {
-    if (nw == 256 || nw == 260) return launch_attn_w4m_d128(Q, K, V, O, B, H, N, nw == 260, st);
-    if (nw == 512) return launch_attn_w4n_d128(Q, K, V, O, B, H, N, st);
-  }
-  if constexpr ((D == 128 || D == 64) && !VT) {
-    if (nw == 513) return launch_attn_w4g(Q, K, V, O, B, H, N, D, st);
-    if (nw == 515) return launch_attn_w4p(Q, K, V, O, B, H, N, D, st);
-  }
-  if constexpr (D == 64 && !VT) {
-    if (nw == 516) return launch_attn_w8g(Q, K, V, O, B, H, N, D, st);
+  if constexpr (D == 128 || D == 64) {
+    if (nw == 513 || nw == 515 || nw == 517) {
+      const int walk = (nw - 513) / 2;
+      if constexpr (D == 128) return VT ? launch_attn_w4u_d128t(Q, K, V, O, B, H, N, walk, st) : launch_attn_w4u_d128(Q, K, V, O, B, H, N, walk, st);
+      else return VT ? launch_attn_w4u_d64t(Q, K, V, O, B, H, N, walk, st) : launch_attn_w4u_d64(Q, K, V, O, B, H, N, walk, st);
+    }
   }
   if constexpr (!VT) {
     if (nw == 514) return launch_attn_w4i(Q, K, V, O, B, H, N, D, g_tune_attn_w4i_sched, st);
@@ -463,12 +468,9 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
   if (D == 32 || D == 64 || D == 96 || D == 128) {
     if (bf16) return LC_ERR_HEADDIM;
     const int nw = choose_attn_nw(D, v_transposed != 0, N);
-    if (nw == 256 || nw == 260) snprintf(buf, buflen, "attn_fwd_w4m_kernel<%d,%d>", D, nw == 260 ? 4 : 0);
-    else if (nw == 512) snprintf(buf, buflen, "attn_fwd_w4n_kernel<%d>", D);
-    else if (nw == 513) snprintf(buf, buflen, "attn_fwd_w4g_kernel<%d>", D);
+    // (a persistent walk with no more blocks than CUs launches WALK 0; the name reports the walk asked for at this N)
+    if (nw == 513 || nw == 515 || nw == 517) snprintf(buf, buflen, "attn_fwd_w4u_kernel<%d,%s,%d>", D, vt, (nw - 513) / 2);
     else if (nw == 514) snprintf(buf, buflen, "attn_fwd_w4i_kernel<%d,%d>", D, g_tune_attn_w4i_sched.load());
-    else if (nw == 515) snprintf(buf, buflen, "attn_fwd_w4p_kernel<%d>", D);
-    else if (nw == 516) snprintf(buf, buflen, "attn_fwd_w8g_kernel<%d>", D);
     else snprintf(buf, buflen, "attn_fwd_kernel<%d,%d,%s,0>", D, nw, vt);
     return LC_OK;
   }
@@ -487,10 +489,11 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
 namespace {
 // the knob registry: ONE table for lc_tune_set / lc_tune_get (key, variable, default, validity of a value)
 bool ok_attn_nw(int v) {
-  return v == 0 || v == 256 || v == 260 || v == 512 || v == 513 || v == 514 || v == 515 || v == 516 || v == 8 || v == 4 || v == 2;
+  return v == 0 || v == 512 || v == 513 || v == 514 || v == 515 || v == 517 || v == 8 || v == 4 || v == 2;
 }
 bool ok_01(int v) { return v == 0 || v == 1; }
 bool ok_02(int v) { return v >= 0 && v <= 2; }
+bool ok_03(int v) { return v >= 0 && v <= 3; }
 bool ok_w4y_sched(int v) {
 #ifdef LC_DIAG
   return v >= 0 && v <= 5;   // 3..5: ablations (results WRONG)
@@ -511,6 +514,7 @@ struct Knob {
 };
 const Knob kKnobs[] = {
     {"attn_nw", &g_tune_attn_nw, 0, ok_attn_nw, false},
+    {"attn_walk", &g_tune_attn_walk, 0, ok_03, false},
     {"attn_w4i_sched", &g_tune_attn_w4i_sched, 1, ok_01, false},
     {"fp8_mx", &g_tune_fp8_mx, 1, ok_02, false},
     {"attn_d512", &g_tune_attn_d512, 0, ok_02, false},
@@ -808,9 +812,10 @@ int lc_clock_probe(void* out_u64x2, void* stream) {
 }  // extern "C"
 
 extern "C" int lc_attn_slowpath_stats(unsigned* out4, int reset) {
-  if (int rc = lc::diag_attn_slowpath(out4, reset)) return rc;
   if (int rc = lc::diag_attn_slowpath_g(out4, reset)) return rc;
-  if (int rc = lc::diag_attn_slowpath_p(out4, reset)) return rc;
-  return lc::diag_attn_slowpath_8(out4, reset);
+  if (int rc = lc::diag_attn_slowpath_u_d128(out4, reset)) return rc;
+  if (int rc = lc::diag_attn_slowpath_u_d128t(out4, reset)) return rc;
+  if (int rc = lc::diag_attn_slowpath_u_d64(out4, reset)) return rc;
+  return lc::diag_attn_slowpath_u_d64t(out4, reset);
 }
 

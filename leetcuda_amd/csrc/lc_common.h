@@ -143,7 +143,7 @@ LC_DEVINL void static_for(F&& f) { static_for_impl(std::make_integer_sequence<in
 // clobber list naming every AGPR: statements that address accumulators literally (a[N:M]) carry it so that hipcc
 // never parks a value of its own in the accumulator half of the register file
 // (a translation unit whose kernels run TWO waves per SIMD defines a shorter list before including this header: a clobbered AGPR
-// counts towards the kernel's register allocation — tu_attn_w8g.hip)
+// counts towards the kernel's register allocation; round 3's eight-wave D = 64 experiment did)
 #ifndef LC_AGPR_ALL
 #define LC_AGPR_ALL \
   "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14",  \

@@ -81,27 +81,25 @@ int w4_effective_variant(int variant, bool b_kn, int N, int K);   // W4C / W4X /
 // nblk > 0: launch only the first nblk blocks (hgemm_w4y_kernel only; the caller hands the remaining raster ids to the 128-tile kernel)
 int launch_w4_family(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant, bool b_kn,
                      int tiles_m, int tiles_n, int panel_w, int nblk, hipStream_t st);
-// tu_attn_w4.hip: 4-wave x 64-row merged-phase attention kernel, D = 128, N % 256 == 0; pad = A/B knob (0 / 4 wait states)
 // tu_valu.hip: the vector-ALU ladder (hgemm_valu.hip), rung = LC_HGEMM_VALU_*
 int launch_valu_rung(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int rung, hipStream_t st);
 void valu_rung_tile(int rung, int* tm, int* tn, int* tk);
 const char* valu_rung_kernel_name(int rung);
-int launch_attn_w4m_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int pad,
-                         hipStream_t st);
-int diag_attn_slowpath(unsigned* out4, int reset);   // attn_w4n slow-path counters (host copy; resets when asked)
-// attn_w4n.hip: the same kernel with v_mfma_f32_16x16x32_f16
-int launch_attn_w4n_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, hipStream_t st);
-// tu_attn_w4g.hip: the merged-phase kernel generalised over the head dim (attn_w4g.hip): D in {64, 128}, N % 256 == 0
-int diag_attn_slowpath_g(unsigned* out4, int reset);   // + the slow-path counters of the w4g kernels
-int launch_attn_w4i(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, int sched, hipStream_t st);   // attn_w4i.hip (phase = one generated asm statement)
-int launch_attn_w4g(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, hipStream_t st);
-// tu_attn_w4p.hip: the same kernel as a persistent workgroup (attn_w4p.hip: one workgroup per CU walks the query blocks, K / V / Q
-// streams continue across block seams): D in {64, 128}, N % 256 == 0
-int launch_attn_w4p(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, hipStream_t st);
-int diag_attn_slowpath_p(unsigned* out4, int reset);   // + the slow-path counters of the w4p kernels
-// tu_attn_w8g.hip: D = 64 with eight waves of 32 query rows, two per SIMD (attn_w8g.hip), N % 256 == 0
-int launch_attn_w8g(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, hipStream_t st);
-int diag_attn_slowpath_8(unsigned* out4, int reset);   // + the slow-path counters of the w8g kernel
+// tu_attn_w4u_{d128,d128t,d64,d64t}.hip: THE merged-phase attention kernel (attn_w4u.hip), one unit per (head dim, V layout): N % 256 == 0;
+// walk 0 = one 256-row query block per workgroup, 1 = persistent workgroup per CU with a static walk, 2 = persistent with a dynamic
+// per-XCD block queue (falls back to 0 when there are no more blocks than CUs)
+int launch_attn_w4u_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int walk, hipStream_t st);
+int launch_attn_w4u_d128t(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int walk, hipStream_t st);   // V as [B,H,D,N]
+int launch_attn_w4u_d64(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int walk, hipStream_t st);
+int launch_attn_w4u_d64t(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int walk, hipStream_t st);    // V as [B,H,D,N]
+int diag_attn_slowpath_u_d128(unsigned* out4, int reset);   // slow-path counters of each unit's kernels (host copy; resets when asked)
+int diag_attn_slowpath_u_d128t(unsigned* out4, int reset);
+int diag_attn_slowpath_u_d64(unsigned* out4, int reset);
+int diag_attn_slowpath_u_d64t(unsigned* out4, int reset);
+// tu_attn_w4i.hip: the generated merged-phase kernel (attn_w4i.hip: a phase = one generated asm statement): D in {32, 64, 96, 128},
+// N % 256 == 0, V as [B,H,N,D]; the only merged-phase kernel for D = 96 / 32
+int launch_attn_w4i(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, int sched, hipStream_t st);
+int diag_attn_slowpath_g(unsigned* out4, int reset);   // + the slow-path counters of the w4i kernels
 // tu_attn_big.hip: full-width large-head-dim kernel, D in {256, 512}, N % 128 == 0, V as [B,H,N,D]; fp16 or bf16
 int launch_attn_bigd2(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, bool bf16,
                       hipStream_t st);

@@ -1,5 +1,5 @@
-// tu_attn_w4g.hip — translation unit of the head-dim-generalised merged-phase attention kernels (attn_w4g.hip: compiler-scheduled
-// fillers; attn_w4i.hip: one generated hand-ordered asm statement per phase) — see lc_launch.h
+// tu_attn_w4i.hip — translation unit of the generated merged-phase attention kernel (attn_w4i.hip: one generated hand-ordered asm
+// statement per phase) — see lc_launch.h
 #include <math.h>
 
 #include "lc_launch.h"
@@ -7,19 +7,6 @@
 #include "attn_w4i.hip"
 
 namespace lc {
-namespace {
-template <int D>
-int launch_w4g_t(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, hipStream_t st) {
-  const int nqb = N / 256;
-  const dim3 grid((unsigned)((size_t)nqb * B * H)), block(256);
-  const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
-  auto kern = attn_fwd_w4g_kernel<D>;
-  if (int rc = set_dyn_lds(kern, W4G<D>::LDS)) return rc;
-  hipLaunchKernelGGL(kern, grid, block, W4G<D>::LDS, st, Q, K, V, O, N, nqb, sl2);
-  return check_launch();
-}
-}  // namespace
-
 template <int D, int SCHED>
 int launch_w4i_t(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, hipStream_t st) {
   const int nqb = N / 256;
@@ -38,12 +25,6 @@ int launch_attn_w4i(const half_t* Q, const half_t* K, const half_t* V, half_t* O
   return LC_ERR_HEADDIM;
 }
 
-// D in {64, 128}, N % 256 == 0, V as [B,H,N,D]
-int launch_attn_w4g(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, hipStream_t st) {
-  if (D == 64) return launch_w4g_t<64>(Q, K, V, O, B, H, N, st);
-  if (D == 128) return launch_w4g_t<128>(Q, K, V, O, B, H, N, st);
-  return LC_ERR_HEADDIM;
-}
 // slow-path counters of THIS unit's kernels, added onto out4[0..2] (out4[3]: last offender, taken when this unit has one)
 int diag_attn_slowpath_g(unsigned* out4, int reset) {
   unsigned mine[4] = {0, 0, 0, 0};

@@ -45,9 +45,7 @@ from pathlib import Path
 # kernel-name regex -> AGPR ranges owned by the kernel's asm statements (inclusive)
 OWNED_AGPRS = [
     (re.compile(r"hgemm_w4b_kernel|hgemm_w4x_kernel|hgemm_w4y_kernel|gemm_fp8_w4_kernel"), [(0, 255)]),
-    (re.compile(r"attn_fwd_w4_kernel"), [(0, 127), (192, 255)]),      # a[128:191] stay with hipcc (AGPR spills)
-    (re.compile(r"attn_fwd_w4m_kernel|attn_fwd_w4n_kernel|attn_fwd_w4g_kernel|attn_fwd_w4p_kernel|attn_fwd_w4i_kernel|attn_fwd_bigd2_kernel|attn_fwd_bigd3_kernel"), [(0, 255)]),
-    (re.compile(r"attn_fwd_w8g_kernel"), [(0, 95)]),      # two waves per SIMD: the unit's clobber lists end at a95 (tu_attn_w8g.hip)
+    (re.compile(r"attn_fwd_w4u_kernel|attn_fwd_w4i_kernel|attn_fwd_bigd2_kernel|attn_fwd_bigd3_kernel|attn_fwd_bigd4_kernel"), [(0, 255)]),
 ]
 
 # kernel-name regex -> literal arch VGPR range owned by the kernel's asm (inclusive)

@@ -48,13 +48,13 @@ def test_attn_vs_oracle(oracle, D, N):
     assert (o.float() - o2.float()).abs().max().item() < 1e-3
 
 
-@pytest.mark.parametrize("nw", [256, 260, 512, 513, 514, 8, 4, 2])
+@pytest.mark.parametrize("nw", [512, 513, 515, 517, 514, 8, 4, 2])
 @pytest.mark.parametrize("D", [128, 64, 96, 32])
 def test_workgroup_shapes_agree(oracle, nw, D):
-    """The same problem through the merged-phase 4-wave kernels (512 = the D = 128 default; 256 = its 32x32x16 twin, 260 = that
-    one's padded A/B twin; 513 = the head-dim-generalised kernel, default for D = 64) and the 8-, 4-, 2-wave lock-step kernels
-    (lc_tune_set "attn_nw"; 514 = the same kernel with each phase as one generated asm statement, attn_w4i.hip); D = 96 / 32
-    always run the lock-step kernel."""
+    """The same problem through the merged-phase 4-wave kernel (attn_w4u.hip: 513 / 515 / 517 = one block per workgroup /
+    persistent static walk / persistent dynamic queue; 512 = round 2's name for 513) and the 8-, 4-, 2-wave lock-step kernels
+    (lc_tune_set "attn_nw"; 514 = the same design with each phase as one generated asm statement, attn_w4i.hip); D = 96 / 32 run
+    the generated kernel or the lock-step kernel."""
     capi = _capi()
     B, H, N = 1, 3, 768
     torch.manual_seed(77 + D)
@@ -130,7 +130,7 @@ def test_golden_fixtures(oracle, golden):
         assert d.max() < tol.ATTN_MAX_ABS, d.max()
 
 
-@pytest.mark.parametrize("nw", [0, 256, 260, 512, 513, 514, 8])
+@pytest.mark.parametrize("nw", [0, 513, 515, 517, 514, 8])
 def test_forced_rescale_spike(oracle, nw):
     """One K row matches one Q row so strongly that the running max jumps by >> 8 in the middle of the
     sequence (tile 5 of 8): every row's accumulator must be rescaled exactly once (rule 26)."""
@@ -383,7 +383,7 @@ def test_non_finite_scores_take_the_slow_path(oracle):
     k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     k[0, 1, 300] = float("inf")
-    assert capi.attn_kernel_name(N, D).startswith("attn_fwd_w4p_kernel")
+    assert capi.attn_kernel_name(N, D).startswith("attn_fwd_w4u_kernel<128,false,1>")
     capi.attn_slowpath_stats(reset=True)
     o = torch.zeros_like(q)
     capi.attn_fwd(q, k, v, o)
@@ -400,11 +400,11 @@ def test_non_finite_scores_take_the_slow_path(oracle):
 
 @pytest.mark.parametrize("D", [128, 64, 96, 32])
 def test_generalised_and_generated_kernels_reproduce_the_reference_kernel_bit_for_bit(oracle, D):
-    """attn_fwd_w4g_kernel (attn_w4g.hip: the merged-phase kernel with every D-dependent count spelled out, 513) and
-    attn_fwd_w4i_kernel (attn_w4i.hip: each phase ONE generated asm statement on reserved registers, uniform padded loop, 514)
-    must equal attn_fwd_w4n_kernel<128> (512) BIT FOR BIT at D = 128 — same MFMA order per accumulator, same exp2 / row-sum /
-    pack sequence — and each other at D = 64, on random data and on inputs that take the overflow slow path (spike rows, a
-    dominant first half-tile, a growing ramp), with the slow-path counter confirming the path was taken."""
+    """attn_fwd_w4u_kernel (attn_w4u.hip: compiler-scheduled fillers between one-MFMA asm statements, 513) and attn_fwd_w4i_kernel
+    (attn_w4i.hip: each phase ONE generated asm statement on reserved registers, uniform padded loop, 514) are two independently
+    scheduled instruction streams of one arithmetic — same MFMA order per accumulator, same exp2 / row-sum / pack sequence — and must
+    agree BIT FOR BIT at D = 128 and D = 64, on random data and on inputs that take the overflow slow path (spike rows, a dominant
+    first half-tile, a growing ramp), with the slow-path counter confirming the path was taken."""
     capi = _capi()
     B, H, N = 2, 3, 2048
     torch.manual_seed(513 + D)
@@ -417,14 +417,14 @@ def test_generalised_and_generated_kernels_reproduce_the_reference_kernel_bit_fo
     k2[:, :, :32] = 3.0 * q[:, :, :32]
     ramp = torch.linspace(0.0, 8.0, N, device="cuda").half()
     k3 = (k + ramp[None, None, :, None] * q[:, :, :1].sign()).contiguous()
-    kernels = (512, 513, 514) if D == 128 else ((513, 514) if D == 64 else (514,))   # D = 96 / 32: the two schedules of the generated kernel
+    kernels = (513, 514) if D in (128, 64) else (514,)   # D = 96 / 32: the two schedules of the generated kernel
     for ci, kk in enumerate((k, k2, k3)):
         outs = {}
         for nw, sched in [(k_, 0) for k_ in kernels] + [(514, 1)]:        # (514, 1): the generated kernel's second schedule
             capi.tune("attn_nw", nw)
             capi.tune("attn_w4i_sched", sched)
             try:
-                want = {512: "attn_fwd_w4n_kernel", 513: "attn_fwd_w4g_kernel", 514: f"attn_fwd_w4i_kernel<{D},{sched}>"}[nw]
+                want = {513: f"attn_fwd_w4u_kernel<{D},false,0>", 514: f"attn_fwd_w4i_kernel<{D},{sched}>"}[nw]
                 assert capi.attn_kernel_name(N, D).startswith(want)
                 capi.attn_slowpath_stats(reset=True)
                 o = torch.full_like(q, float("nan"))
@@ -442,33 +442,37 @@ def test_generalised_and_generated_kernels_reproduce_the_reference_kernel_bit_fo
         _check(oracle, q, kk, v, outs[(514, 1)], max_abs=8e-3)
 
 
+@pytest.mark.parametrize("vt", [False, True], ids=["v_nd", "v_dn"])
 @pytest.mark.parametrize("D", [128, 64])
-@pytest.mark.parametrize("shape", [(1, 37, 2048), (3, 43, 1024), (2, 3, 2048), (1, 130, 512)])
-def test_persistent_kernel_equals_the_one_block_kernel_bit_for_bit(oracle, D, shape):
-    """attn_fwd_w4p_kernel (attn_w4p.hip, lc_tune_set "attn_nw" = 515): one workgroup per CU walks the 256-row query blocks, the
-    K / V tiles 0 / 1 and the Q rows of the NEXT block are fetched while the current one finishes, O is staged behind ring slots
-    0 / 1.  Inside a block it is attn_fwd_w4g_kernel instruction for instruction, so the outputs must be identical — with more
-    blocks than CUs (296, 516: a workgroup runs 1-3 blocks, the last ones without a successor), fewer (48), heads that take the
-    overflow slow path right before / after a seam, and from launch to launch."""
+@pytest.mark.parametrize("shape", [(1, 37, 2048), (3, 43, 1024), (2, 3, 2048), (1, 130, 512), (2, 48, 4096)])
+def test_block_walks_compute_the_same_bits(oracle, D, shape, vt):
+    """attn_fwd_w4u_kernel<D, VT, WALK> (attn_w4u.hip): WALK 0 = one 256-row query block per workgroup (513), 1 = one persistent
+    workgroup per CU walking w, w + G, ... (515: the K / V tiles 0 / 1 and the Q rows of the NEXT block are fetched while the current
+    one finishes, O is staged behind ring slots 0 / 1), 2 = the same with a dynamic per-XCD block queue (517: one atomic per block,
+    claimed one block ahead, passed through an LDS mailbox; the claim counters reset themselves).  Inside a block the three are the
+    same instructions, so the outputs must be IDENTICAL — with more blocks than CUs (296 ... 1536: a workgroup runs 1-6 blocks), fewer
+    (48: every walk is the one-block launch), heads that take the overflow slow path right before / after a seam, from launch to launch
+    (the dynamic walk's block -> workgroup assignment differs every time), and for both V layouts."""
     capi = _capi()
     B, H, N = shape
     torch.manual_seed(515 + D + N)
     q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    vin = v.transpose(-2, -1).contiguous() if vt else v
     k2 = k.clone()
     k2[:, ::3, N - 3] = 4.0 * q[:, ::3, 300]          # last tile of every third head: slow path in the phases next to the seam
     k2[:, 1::5, :32] = 3.0 * q[:, 1::5, :32]          # dominant first half-tile: slow path right behind the seam
+    vts = "true" if vt else "false"
     for ci, kk in enumerate((k, k2)):
         outs = {}
-        for nw in (513, 515, 515):
+        for nw in (513, 515, 517, 517, 515, 517):
             capi.tune("attn_nw", nw)
             try:
-                want = {513: "attn_fwd_w4g_kernel", 515: "attn_fwd_w4p_kernel"}[nw]
-                assert capi.attn_kernel_name(N, D).startswith(want)
+                assert capi.attn_kernel_name(N, D, vt) == f"attn_fwd_w4u_kernel<{D},{vts},{(nw - 513) // 2}>"
                 capi.attn_slowpath_stats(reset=True)
                 o = torch.full_like(q, float("nan"))
-                capi.attn_fwd(q, kk, v, o)
+                capi.attn_fwd(q, kk, vin, o, v_transposed=vt)
                 torch.cuda.synchronize()
                 st = capi.attn_slowpath_stats(reset=True)
             finally:
@@ -476,59 +480,64 @@ def test_persistent_kernel_equals_the_one_block_kernel_bit_for_bit(oracle, D, sh
             assert (st[0] > 0) == (ci > 0), (nw, ci, st)
             outs.setdefault(nw, []).append((o, st[0]))
         ref, ref_slow = outs[513][0]
-        for o, slow in outs[515]:
-            assert torch.equal(ref, o), (D, shape, ci)
-            assert slow == ref_slow, (D, shape, ci, slow, ref_slow)      # the same half-tiles took the slow path
+        assert torch.isfinite(ref).all()
+        for nw in (515, 517):
+            for o, slow in outs[nw]:
+                assert torch.equal(ref, o), (D, shape, ci, nw)
+                assert slow == ref_slow, (D, shape, ci, nw, slow, ref_slow)      # the same half-tiles took the slow path
         if ci == 0 and H <= 43:
-            _check(oracle, q[:, :2].contiguous(), kk[:, :2].contiguous(), v[:, :2].contiguous(), ref[:, :2].contiguous(), max_abs=8e-3)
+            _check(oracle, q[:, :2].contiguous(), kk[:, :2].contiguous(), vin[:, :2].contiguous(), ref[:, :2].contiguous(), vt=vt,
+                   max_abs=8e-3)
 
 
-@pytest.mark.parametrize("shape", [(1, 48, 1024), (2, 3, 2048), (1, 5, 256), (3, 7, 512), (1, 48, 8192)])
-def test_eight_wave_d64_kernel_equals_the_four_wave_kernel_bit_for_bit(oracle, shape):
-    """attn_fwd_w8g_kernel<64> (attn_w8g.hip, lc_tune_set "attn_nw" = 516): eight waves of 32 query rows — two per SIMD, so that one
-    wave's softmax runs under the other's MFMAs — on the same 256-row block, ring and LDS-DMA plan as attn_fwd_w4g_kernel<64> (four waves
-    of 64 rows).  Per query row nothing changes (same MFMA k-order, same exp2 / row-sum / pack order, same overflow slow path), so the
-    outputs must be IDENTICAL on data that stays on the fast path (random inputs: T = 4 — the shortest ring walk — to the reference's
-    published shape) and from launch to launch; inputs that take the slow path in the first / a middle / the last tile agree to
-    fp16 rounding and with the oracle."""
+@pytest.mark.parametrize("D", [128, 64])
+def test_dynamic_walk_many_launches_leave_the_queue_clean(oracle, D):
+    """The dynamic walk's claim counters live in 1024 rotating slots that every launch must leave zeroed (the last workgroup out
+    resets its slot): 2100 back-to-back launches revisit every slot at least twice; every output must equal the one-block launch's and
+    no row may stay unwritten (a dirty counter would make workgroups skip blocks: NaN rows in a NaN-prefilled output)."""
     capi = _capi()
-    B, H, N = shape
-    D = 64
-    torch.manual_seed(516 + N + H)
+    B, H, N = 1, 40, 2048                        # 320 blocks on 256 CUs: most workgroups claim one more block, all claim at least once
+    torch.manual_seed(517 + D)
     q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
-    k2 = k.clone()
-    k2[:, ::3, N - 3] = 4.0 * q[:, ::3, 200]          # last tile
-    k2[:, 1::5, :32] = 3.0 * q[:, 1::5, :32]          # dominant first half-tile
-    k2[:, 2::7, N // 2 + 5] = 5.0 * q[:, 2::7, 77]    # a middle tile
-    for ci, kk in enumerate((k, k2)):
-        outs = {}
-        for nw in (513, 516, 516):
-            capi.tune("attn_nw", nw)
-            try:
-                want = {513: "attn_fwd_w4g_kernel<64>", 516: "attn_fwd_w8g_kernel<64>"}[nw]
-                assert capi.attn_kernel_name(N, D) == want
-                capi.attn_slowpath_stats(reset=True)
-                o = torch.full_like(q, float("nan"))
-                capi.attn_fwd(q, kk, v, o)
+    ref = torch.full_like(q, float("nan"))
+    capi.tune("attn_nw", 513)
+    try:
+        capi.attn_fwd(q, k, v, ref)
+    finally:
+        capi.tune("attn_nw", 0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ref).all()
+    o = torch.full_like(q, float("nan"))
+    capi.tune("attn_nw", 517)
+    try:
+        for it in range(2100):
+            if it % 300 == 0 or it >= 2096:
+                o.fill_(float("nan"))
+                capi.attn_fwd(q, k, v, o)
                 torch.cuda.synchronize()
-                st = capi.attn_slowpath_stats(reset=True)
-            finally:
-                capi.tune("attn_nw", 0)
-            assert (st[0] > 0) == (ci > 0), (nw, ci, st)
-            outs.setdefault(nw, []).append(o)
-        ref = outs[513][0]
-        assert torch.isfinite(ref).all()
-        assert torch.equal(outs[516][0], outs[516][1])                     # launch to launch
-        if ci == 0:
-            assert torch.equal(ref, outs[516][0]), (shape, (ref.float() - outs[516][0].float()).abs().max().item())
-        else:
-            # the overflow slow path rescales the rows of ONE WAVE: 64 rows there, 32 here — rows that share a wave with a spiking
-            # row only in the four-wave kernel keep the stale scale here (another valid rounding): fp16 rounding apart, not bits
-            assert (ref.float() - outs[516][0].float()).abs().max().item() < 4e-3
-        if N <= 2048:
-            _check(oracle, q, kk, v, outs[516][0], max_abs=8e-3)
+                assert torch.equal(ref, o), it
+            else:
+                capi.attn_fwd(q, k, v, o)
+    finally:
+        capi.tune("attn_nw", 0)
+    torch.cuda.synchronize()
+    assert torch.equal(ref, o)
+    # two streams at once: launches in flight together use different slots
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    o1, o2 = torch.full_like(q, float("nan")), torch.full_like(q, float("nan"))
+    capi.tune("attn_nw", 517)
+    try:
+        for _ in range(20):
+            with torch.cuda.stream(s1):
+                capi.attn_fwd(q, k, v, o1)
+            with torch.cuda.stream(s2):
+                capi.attn_fwd(q, k, v, o2)
+    finally:
+        capi.tune("attn_nw", 0)
+    torch.cuda.synchronize()
+    assert torch.equal(ref, o1) and torch.equal(ref, o2)
 
 
 @pytest.mark.parametrize("D", [64, 96, 32])

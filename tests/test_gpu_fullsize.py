@@ -32,11 +32,13 @@ FAMILIES = [
     ("d128-auto", 128, None, 0),
     ("d128-one-block", 128, "attn_nw", 513),
     ("d128-generated", 128, "attn_nw", 514),
-    ("d128-persistent", 128, "attn_nw", 515),
+    ("d128-persistent-static", 128, "attn_nw", 515),
+    ("d128-persistent-queue", 128, "attn_nw", 517),
     ("d128-lockstep8", 128, "attn_nw", 8),
     ("d64-auto", 64, None, 0),
     ("d64-generated", 64, "attn_nw", 514),
-    ("d64-persistent", 64, "attn_nw", 515),
+    ("d64-one-block", 64, "attn_nw", 513),
+    ("d64-persistent-static", 64, "attn_nw", 515),
     ("d96-auto", 96, None, 0),
     ("d32-auto", 32, None, 0),
     ("d256-auto", 256, None, 0),

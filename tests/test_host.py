@@ -182,12 +182,14 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_NN, capi.HGEMM_MFMA256P2) == "hgemm_pingpong2_kernel<true,false>"
     assert capi.hgemm_kernel_name(1024, 1024, 1024, capi.LAYOUT_NN) == "hgemm_mfma128_kernel<true>"
     assert capi.hgemm_kernel_name(1000, 1024, 1024, capi.LAYOUT_NN) == "hgemm_generic_kernel<true>"
-    assert capi.attn_kernel_name(4096, 128) == "attn_fwd_w4p_kernel<128>"                    # config 3: the persistent workgroup
-    assert capi.attn_kernel_name(8192, 128) == "attn_fwd_w4n_kernel<128>"                    # config 4: one block per workgroup
+    assert capi.attn_kernel_name(4096, 128) == "attn_fwd_w4u_kernel<128,false,1>"            # config 3: the persistent workgroup, static walk
+    assert capi.attn_kernel_name(8192, 128) == "attn_fwd_w4u_kernel<128,false,2>"            # config 4: persistent, dynamic block queue
+    assert capi.attn_kernel_name(4096, 128, True) == "attn_fwd_w4u_kernel<128,true,1>"       # V handed over as [B,H,D,N]: the same kernel
     assert capi.attn_kernel_name(4096 + 128, 128) == "attn_fwd_kernel<128,4,false,0>"      # N % 256 != 0
     assert capi.attn_kernel_name(192, 64, True) == "attn_fwd_kernel<64,2,true,0>"
-    assert capi.attn_kernel_name(8192, 64) == "attn_fwd_w4g_kernel<64>"                       # the reference's published shapes
-    assert capi.attn_kernel_name(8192, 64, True) == "attn_fwd_kernel<64,8,true,0>"            # V handed over transposed: lock-step
+    assert capi.attn_kernel_name(8192, 64) == "attn_fwd_w4u_kernel<64,false,2>"               # the reference's published shapes
+    assert capi.attn_kernel_name(8192, 64, True) == "attn_fwd_w4u_kernel<64,true,2>"
+    assert capi.attn_kernel_name(8192, 96, True) == "attn_fwd_kernel<96,8,true,0>"            # D = 96 / 32 with V transposed: lock-step
     assert capi.attn_kernel_name(8192, 96) == "attn_fwd_w4i_kernel<96,1>"                     # only the generated kernel has a D = 96 instantiation
     assert capi.attn_kernel_name(8192 + 64, 96) == "attn_fwd_kernel<96,2,false,0>"            # N % 256 != 0: lock-step
     assert capi.attn_kernel_name(8192, 32) == "attn_fwd_w4i_kernel<32,1>"
@@ -195,7 +197,7 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     assert capi.attn_kernel_name(192, 512, False, False).startswith("attn_fwd_bigd_kernel<512,")     # N % 128 != 0
     assert sump.short("_ZN2lc16hgemm_w4b_kernelILb0ELb1ELi0EEEvPKDF16_S2_PDF16_iiiiii") == \
         "hgemm_w4b_kernel<false,true,0>"
-    assert sump.short("_ZN2lc19attn_fwd_w4n_kernelILi128EEEvPKDF16_S2_S2_PDF16_iif") == "attn_fwd_w4n_kernel<128>"
+    assert sump.short("_ZN2lc19attn_fwd_w4u_kernelILi128ELb1ELi2EEEvPKDF16_S2_S2_PDF16_iifiii") == "attn_fwd_w4u_kernel<128,true,2>"
     pmc = json.loads((root / "profiles" / "latest_pmc.json").read_text())
     for key, wl, other in ((capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN), "hgemm_8192", "hgemm_4096"),
                            (capi.attn_kernel_name(4096, 128), "attn_cfg3", "attn_cfg4"),
@@ -233,14 +235,12 @@ def test_steady_state_loops_keep_their_instruction_mix(built):
     g, gv = mix("tu_w4.s", r"hgemm_w4y_kernelILb0ELi1E", r"w4y_loop")   # the K loop (the kernel's outer loop is the persistent tile walk)
     assert (g["mfma"], g["lds"], g["vmem"], g["s_barrier"], g["s_nop"]) == (128, 32, 16, 1, 0), g
     assert gv <= 8, g
-    g64, g64v = mix("tu_attn_w4g.s", r"attn_fwd_w4g_kernelILi64")   # D = 64: one tile = 64 MFMAs for the same 64 score elements
+    g64, g64v = mix("tu_attn_w4u_d64.s", r"attn_fwd_w4u_kernelILi64ELb0ELi0")   # D = 64: one tile = 64 MFMAs for the same 64 score elements
     assert g64["mfma"] == 64 and g64["valu_trans"] == 64 and g64["s_barrier"] == 1, g64
     assert g64v / 64 <= 3.0, (g64v, g64)
-    n, nv = mix("tu_attn_w4.s", r"attn_fwd_w4n_kernel")            # one 64-key tile: 64 score elements per lane
-    assert n["mfma"] == 128 and n["valu_trans"] == 64 and n["s_barrier"] == 1, n
-    assert nv / 64 <= 3.2, (nv, n)
-    m, mv = mix("tu_attn_w4.s", r"attn_fwd_w4m_kernel")
-    assert m["mfma"] == 64 and m["valu_trans"] == 64, m
-    assert mv / 64 <= 3.2, (mv, m)
+    for unit, rx in (("tu_attn_w4u_d128.s", r"attn_fwd_w4u_kernelILi128ELb0ELi0"), ("tu_attn_w4u_d128t.s", r"attn_fwd_w4u_kernelILi128ELb1ELi0")):
+        n, nv = mix(unit, rx)                                        # one 64-key tile: 64 score elements per lane, either V layout
+        assert n["mfma"] == 128 and n["valu_trans"] == 64 and n["s_barrier"] == 1 and n["lds"] == 48, n
+        assert nv / 64 <= 3.2, (nv, n)
     b, _ = mix("tu_attn_big.s", r"attn_fwd_bigd2_kernelILi512ELb0")  # two 64-key tiles per loop iteration
     assert b["mfma"] == 256 and b["s_barrier"] == 4 and b["valu_trans"] == 64, b

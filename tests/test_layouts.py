@@ -6,7 +6,7 @@ ds_read_b64_tr_b16, lane groups of one LDS cycle each:
     ds_read_b64_tr_b16  {0-31} {32-63}
 A group is conflict-free when its lanes touch pairwise different banks (or identical addresses).
 These are the formulas of hgemm_pingpong.hip / hgemm_w4.hip (st_2x8, 128-B rows) and of
-attn_fwd.hip / attn_w4m.hip / attn_bigd2.hip (K: chunk ^ (row & 15) on 256-B rows; V: 64-B unit ^ (row & 3) for the transpose reads)."""
+attn_fwd.hip / attn_w4u.hip / attn_bigd2.hip (K: chunk ^ (row & 15) on 256-B rows; V: 64-B unit ^ (row & 3) for the transpose reads)."""
 import itertools
 
 B128_GROUPS = [
@@ -103,7 +103,7 @@ def test_nn_b_image_pair_swizzle_for_transpose_reads():
 
 
 def test_attention_tiles_for_16x16x32_fragments():
-    # attn_w4n.hip.  K tile (unchanged image: chunk c of row r at slot c ^ (r & 15), 256-B rows): fragment lane -> row
+    # attn_w4u.hip (D = 128).  K tile (unchanged image: chunk c of row r at slot c ^ (r & 15), 256-B rows): fragment lane -> row
     # 16 kvb + (l & 15), chunk 4 ds + (l >> 4)
     for ds, kvb in itertools.product(range(4), range(4)):
         for grp in B128_GROUPS:
@@ -127,7 +127,7 @@ def test_attention_tiles_for_16x16x32_fragments():
                 assert a == a2
                 addrs.append(a)
             assert conflict_free(addrs, 8), (db, hh, x)
-        # (attn_w4m's 64-B-unit swizzle u ^ (r & 3) is 2-way conflicted for this read pattern)
+        # (round 2.s 64-B-unit swizzle u ^ (r & 3) is 2-way conflicted for this read pattern)
         bad = []
         for lane in TR_GROUPS[0]:
             i, g = lane & 15, lane >> 4
@@ -258,7 +258,7 @@ def test_xcd_super_block_raster_is_a_bijection_with_compact_steps():
 
 
 def test_attention_tiles_d64_for_16x16x32_fragments():
-    """attn_w4g.hip at D = 64 (128-B rows: two rows per 256-B bank row).  K: 16-B chunk c of row r at slot c ^ ((r >> 1) & 7);
+    """attn_w4u.hip at D = 64 (128-B rows: two rows per 256-B bank row).  K: 16-B chunk c of row r at slot c ^ ((r >> 1) & 7);
     fragment lane -> row 16 kvb + (l & 15), chunk 4 ds + (l >> 4).  V: 32-B pair p of row r at pair slot p ^ ((r >> 1) & 3);
     transpose read: lane i of 16-lane group g supplies row 32 H + 16 x + 4 g + (i >> 2), 8 bytes at column 4 (i & 3) of pair
     db.  DMA: a 1-KiB piece = 8 rows; wave w stages pieces w, w + 4, so row & 15 = 8 (w & 1) + rr for both of them."""
@@ -292,6 +292,48 @@ def test_attention_tiles_d64_for_16x16x32_fragments():
         assert chunk ^ ((r >> 1) & 7) == cs
         vchunk = (((cs >> 1) ^ key(r)) << 1) | (cs & 1)
         assert ((vchunk >> 1) ^ key(r)) == (cs >> 1) and (vchunk & 1) == (cs & 1)
+
+
+B64_GROUPS = [list(range(0, 32)), list(range(32, 64))]     # ds_read_b64: 2 x 32 lanes, bank (a / 4) mod 64 (MI355X_MICROARCH.md LDS table)
+
+
+def test_attention_v_transposed_image_for_plain_b64_fragment_reads():
+    """attn_w4u.hip, VT: V handed over as [D][N] (the reference's *_swizzle_qkv entries).  A tile's image is [D rows][64 kv] —
+    128-B rows whatever D is (two rows per 256-B bank row) — with 16-B granule j of row d at slot j ^ ((d >> 1) & 7).
+    The Vᵀ operand of a v_mfma_f32_16x16x32 block db, lane (l16, g4): d-row 16 db + l16, k slots 8 g4 + e <-> kv = 32 H +
+    16 (e >> 2) + 4 g4 + (e & 3) (the order the lane-local Pᵀ operand defines) = TWO plain ds_read_b64: half (g4 & 1) of granule
+    4 H + 2 x + (g4 >> 1), x = 0 / 1.  (1) conflict-free per lane group, (2) the kernel's address form, (3) the values a lane gets are
+    the right kv columns, (4) the DMA source permutation is the inverse: a piece = 8 d-rows, wave w stages pieces w, w + 4, ..."""
+    for D in (64, 128):
+        for db, H, x in itertools.product(range(D // 16), range(2), range(2)):
+            for grp in B64_GROUPS:
+                addrs = []
+                for lane in grp:
+                    l16, g4 = lane & 15, lane >> 4
+                    d = 16 * db + l16
+                    gran = 4 * H + 2 * x + (g4 >> 1)
+                    a = d * 128 + ((gran ^ ((d >> 1) & 7)) * 16) + 8 * (g4 & 1)
+                    # kernel form: vx[2 H + x] + db * 2048 with vx[u] = l16 * 128 + (((2 u) | (g4 >> 1)) ^ ((l16 >> 1) & 7)) * 16 + 8 (g4 & 1)
+                    u = 2 * H + x
+                    assert a == db * 2048 + l16 * 128 + ((((2 * u) | (g4 >> 1)) ^ ((l16 >> 1) & 7)) * 16) + 8 * (g4 & 1)
+                    addrs.append(a)
+                    # which kv columns sit there: slot s of row d holds granule s ^ key(d), i.e. kv 8 (s ^ key) .. + 7
+                    slot = (a % 128) // 16
+                    kv0 = 8 * (slot ^ ((d >> 1) & 7)) + 4 * ((a % 16) // 8)
+                    assert kv0 == 32 * H + 16 * x + 4 * g4
+                assert conflict_free(addrs, 8), (D, db, H, x)
+        for r in range(D):
+            assert sorted(j ^ ((r >> 1) & 7) for j in range(8)) == list(range(8))
+        # DMA: piece p = d-rows 8 p .. 8 p + 7; lane -> rr = lane >> 3, LDS granule slot cs = lane & 7 <- source granule cs ^ key(row)
+        for w, i, rr, cs in itertools.product(range(4), range(D // 32), range(8), range(8)):
+            p = w + 4 * i
+            row = 8 * p + rr
+            assert ((row >> 1) & 7) == 4 * (w & 1) + (rr >> 1)        # the kernel's lane-constant key (p & 1 == w & 1)
+            src = cs ^ (4 * (w & 1) + (rr >> 1))
+            assert src ^ ((row >> 1) & 7) == cs
+        # every d-row of the tile is staged exactly once
+        rows = sorted(8 * (w + 4 * i) + rr for w in range(4) for i in range(D // 32) for rr in range(8))
+        assert rows == list(range(D))
 
 
 def test_hgemm_w4y_piece_map_covers_every_row_once_and_keeps_the_image():
@@ -365,3 +407,42 @@ def test_persistent_attention_walk_visits_every_block_once_on_its_xcd():
                         assert v & 7 == w & 7        # G % 8 == 0 here: the walk stays on the workgroup's XCD
                     v += G
             assert sorted(seen) == list(range(nblk)), (ncu, nblk)
+
+
+def test_dynamic_attention_walk_claims_every_block_once_on_its_xcd():
+    """attn_w4u.hip WALK = 2: workgroup w starts on virtual block w; afterwards a workgroup on XCD x = w & 7 claims j = the next value
+    of XCD x's counter and runs virtual block G + x + 8 j (ids >= G with id & 7 == x, in claim order) until the id reaches nblk.
+    Whatever the interleaving of the claims, every real block is computed exactly once, a workgroup never leaves its XCD, and an
+    XCD's blocks are handed out in ascending real-id order (= by head: the L2 locality the one-block launch gets from the hardware
+    dispatcher).  The counters end at one failed claim per workgroup: what the last workgroup out resets."""
+    import random
+
+    def xcd_remap(b, nwg):
+        q, r, xcd, idx = nwg >> 3, nwg & 7, b & 7, b >> 3
+        base = xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q
+        return base + idx
+
+    rng = random.Random(4)
+    for G, nblk in ((256, 257), (256, 260), (256, 516), (256, 4096), (64, 1000), (8, 77)):
+        counters = [0] * 8
+        seen, per_xcd = [], {x: [] for x in range(8)}
+        live = list(range(G))
+        for w in live:
+            seen.append(xcd_remap(w, nblk))
+            per_xcd[w & 7].append(xcd_remap(w, nblk))
+        while live:                                   # workgroups finish their blocks in random order
+            w = live.pop(rng.randrange(len(live)))
+            x = w & 7
+            j = counters[x]
+            counters[x] += 1
+            v = G + x + 8 * j
+            if v < nblk:
+                assert v & 7 == x
+                seen.append(xcd_remap(v, nblk))
+                per_xcd[x].append(xcd_remap(v, nblk))
+                live.append(w)                        # it will claim again after this block
+        assert sorted(seen) == list(range(nblk)), (G, nblk)
+        for x in range(8):
+            tail = per_xcd[x][G // 8:]
+            assert tail == sorted(tail)               # claim order = ascending real ids inside the XCD's contiguous range
+        assert sum(counters) == (nblk - G) + G        # every successful claim + exactly one failed claim per workgroup

@@ -12,7 +12,7 @@ for (B, H, N, D) in ((4, 32, 4096, 128), (4, 32, 8192, 128)):
     q, k, v, o, _ = host.get_qkvo(B, H, N, D, seed=0)
     fl = host.mha_matmul_flops(B, H, N, D)
     ref = None
-    for nw in (0, 256, 8):
+    for nw in (0, 513, 515, 517, 8):
         capi.tune("attn_nw", nw)
         capi.attn_fwd(q, k, v, o)
         torch.cuda.synchronize()
@@ -21,7 +21,7 @@ for (B, H, N, D) in ((4, 32, 4096, 128), (4, 32, 8192, 128)):
         else:
             print(f"B{B} S{N} nw={nw}: max |o - o_default| = {(o.float() - ref.float()).abs().max().item():.3e}", flush=True)
     for r in range(rounds):
-        for nw in (0, 256, 8):
+        for nw in (0, 513, 515, 517, 8):
             capi.tune("attn_nw", nw)
             ms = capi.attn_time(q, k, v, o, False, capi.ATTN_SPLIT_Q, 2, warmup=2, iters=10)
             print(f"B{B} S{N} round {r} nw={nw:3d} {capi.attn_kernel_name(N, D):34s}: {ms:.4f} ms {fl / ms * 1e-9:8.1f} TFLOP/s", flush=True)

@@ -13,7 +13,7 @@ from leetcuda_amd import capi  # noqa: E402
 
 capi.load()
 mode = sys.argv[1] if len(sys.argv) > 1 else "classes"
-nws = [int(x) for x in sys.argv[2:]] or [0, 256, 8]
+nws = [int(x) for x in sys.argv[2:]] or [0, 513, 517, 8]
 
 
 def classes(outs):
@@ -42,7 +42,7 @@ if mode == "cold":
 
     torch.manual_seed(4)
     a, b, c = mk(8192, 8192), mk(8192, 8192), torch.empty(8192, 8192, dtype=torch.half, device="cuda")
-    for name, nw, shape, dt in (("w4n", 0, (4, 32, 8192, 128), torch.half), ("w4m", 256, (4, 32, 8192, 128), torch.half),
+    for name, nw, shape, dt in (("w4n", 0, (4, 32, 8192, 128), torch.half), ("w4u-queue", 517, (4, 32, 8192, 128), torch.half),
                                 ("bigd2 fp16", 0, (1, 48, 8192, 512), torch.half),
                                 ("bigd2 bf16", 0, (1, 48, 8192, 512), torch.bfloat16)):
         capi.tune("attn_nw", nw)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sustained rate of the attention forward at arbitrary shapes, interleaved A/B over tuning knobs.
 usage: attn_rate.py [--seconds S] [--rounds R] spec...
-   spec = B,H,N,D[:bf16][:zero][:nw=K][:d512=K][:sched=K]   (knobs = lc_tune_set keys attn_nw / attn_d512 / attn_w4i_sched)
+   spec = B,H,N,D[:bf16][:zero][:vt][:nw=K][:walk=K][:d512=K][:sched=K]   (vt = V handed over as [B,H,D,N]; knobs = lc_tune_set keys attn_nw / attn_walk / attn_d512 / attn_w4i_sched)
 Every spec runs >= S seconds of back-to-back launches per round; R rounds interleave the specs (within-probe A/B,
 cdna_hip_programming.md rule 24); prints the kernel name the dispatcher reports, median and best TFLOP/s (matmul FLOPs)."""
 import sys
@@ -23,7 +23,7 @@ while args and args[0].startswith("--"):
         raise SystemExit(f"unknown option {args[0]}")
     args = args[2:]
 capi.load()
-KNOBS = {"nw": "attn_nw", "d512": "attn_d512", "sched": "attn_w4i_sched"}
+KNOBS = {"nw": "attn_nw", "walk": "attn_walk", "d512": "attn_d512", "sched": "attn_w4i_sched"}
 cache = {}
 
 
@@ -42,14 +42,16 @@ def tensors(B, H, N, D, bf16, zero):
 def run(spec):
     shape, *opts = spec.split(":")
     B, H, N, D = (int(x) for x in shape.split(","))
-    bf16, zero = "bf16" in opts, "zero" in opts
+    bf16, zero, vt = "bf16" in opts, "zero" in opts, "vt" in opts
     knobs = {KNOBS[o.split("=")[0]]: int(o.split("=")[1]) for o in opts if "=" in o}
     q, k, v, o = tensors(B, H, N, D, bf16, zero)
+    if vt:
+        v = v.transpose(-2, -1).contiguous()
     for kk, vv in knobs.items():
         capi.tune(kk, vv)
     try:
-        name = capi.attn_kernel_name(N, D, False, bf16)
-        step = (lambda: capi.attn_fwd_bf16(q, k, v, o)) if bf16 else (lambda: capi.attn_fwd(q, k, v, o))
+        name = capi.attn_kernel_name(N, D, vt, bf16)
+        step = (lambda: capi.attn_fwd_bf16(q, k, v, o)) if bf16 else (lambda: capi.attn_fwd(q, k, v, o, v_transposed=vt))
         for _ in range(3):
             step()
         torch.cuda.synchronize()
