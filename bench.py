@@ -25,7 +25,8 @@ The default run reports HGEMM as `value` and carries, in the same JSON line: "ve
 NN = the reference's cuBLAS comparator), "uniform_tflops" (the same kernel on uniform[-1,1) operands, the fill the
 programming guide quotes), "sustained" (>= 2 s of back-to-back launches with the effective shader clock),
 "attention" (config 3), "attention_cfg4" (config 4, aggregate over ranks), "attention_d512" (config 5a),
-"attention_d64" (the reference's published shape (1,48,8192,64)), "fp8_gemm" (config 5b, 16384^3, roofline vs 5 PF) and, at
+"attention_d1024" ((1,48,8192,1024), the tiling dispatchers' largest head dim), "attention_d64" (the reference's published shape
+(1,48,8192,64)), "fp8_gemm" (config 5b, 16384^3, roofline vs 5 PF) and, at
 N = 1, "projected_scaling" (config 4's per-rank shard shapes for W = 2 / 4 / 8 timed one after the other on this GPU — PROJECTED,
 labelled so).  Blocks whose per-rank shard would hold fewer workgroups than a GPU has CUs are reported as skipped.
 No data-path collective exists: the only collectives are the barrier bracketing the timed region and the gather of
@@ -115,7 +116,7 @@ def timed_region(w, step, steps, warmup, prewarm=PREWARM):
 # per-launch byte count is only comparable with the SAME shape.  New PMC summaries carry the key themselves
 # ("workload", written by tools/summarize_prof.py); the table covers the files committed before that field existed.
 LEGACY_PMC_WORKLOAD = {"hgemm_w4y_kernel": "hgemm_8192", 
-                       "attn_fwd_bigd2_kernel<512,false>": "attn_d512_fp16", "attn_fwd_bigd2_kernel<512,true>": "attn_d512_bf16",
+                       "attn_fwd_bigd2_kernel<512,false": "attn_d512_fp16", "attn_fwd_bigd2_kernel<512,true": "attn_d512_bf16",
                        "gemm_fp8_w4_kernel": "fp8_8192"}
 
 
@@ -355,6 +356,29 @@ def bench_attn_d512(w, args, steps=3):
         del q, k, v, o
     out["value"] = out["fp16"]["value"]
     return out
+
+
+def bench_attn_d1024(w, args, steps=3):
+    """The largest head dim the reference's tiling-QKV / tiling-QK dispatchers take (flash_attn_mma_tiling_qkv.cu:904-910): (1,48,8192,1024)
+    fp16 through the tiling-QKV entry (attn_bigd4.hip: two waves per 32 query rows, nothing recomputed); the 48 heads are sharded."""
+    B, H, N, D = 1, 48, 8192, 1024
+    skip = too_small_to_shard("attention_d1024", B * H * (N // 64), w)
+    if skip:
+        return skip
+    lo, hi = host.shard_bounds(H, w.size, w.rank)
+    h_loc = hi - lo
+    torch.manual_seed(1024 + w.rank)
+    q, k, v, o, _ = host.get_qkvo(B, h_loc, N, D)
+    step = lambda: capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, o, 2)   # noqa: E731
+    secs = lcd.max_over_ranks(w, timed_region(w, step, steps, 1, prewarm=2))
+    ms_kernel = lcd.max_over_ranks(w, timed_region.event_ms / steps)
+    flops_total, flops_local = host.mha_matmul_flops(B, H, N, D), host.mha_matmul_flops(B, h_loc, N, D)
+    return {"value": flops_total * steps / secs * 1e-12, "ms_per_step": secs / steps * 1e3, "steps": steps,
+            "workload": f"FlashAttention-2 fwd B={B} H={H} S={N} D={D} fp16 (the tiling-QKV dispatcher's largest head dim), randn inputs, "
+                        f"{h_loc} heads per rank, entry flash_attn_mma_stages_split_q_tiling_qkv",
+            "scaling": "strong", "n_ranks": w.size,
+            "roofline": roofline(capi.attn_kernel_name(N, D), flops_local, 4.0 * B * h_loc * N * D * 2, ms_kernel,
+                                 workload=("attn_d1024" if w.size == 1 else None))}
 
 
 def bench_fp8(w, args, steps=10):
@@ -616,6 +640,7 @@ def run(args):
         if not args.no_attention and not args.quick:
             blocks["attention"] = bench_attn(w, args, cfg4=False, steps=max(5, args.steps // 5), warmup=1)
             blocks["attention_d512"] = bench_attn_d512(w, args)
+            blocks["attention_d1024"] = bench_attn_d1024(w, args)
             blocks["attention_d64"] = bench_attn_d64(w, args)
     elif args.workload == "hgemm":
         main_res = bench_hgemm(w, args)
@@ -625,6 +650,7 @@ def run(args):
                 blocks["attention_cfg4"] = bench_attn(w, args, cfg4=True, steps=3, warmup=1, prewarm=1)
                 blocks["projected_scaling"] = projected_scaling(args)
                 blocks["attention_d512"] = bench_attn_d512(w, args)
+                blocks["attention_d1024"] = bench_attn_d1024(w, args)
                 blocks["attention_d64"] = bench_attn_d64(w, args)
         if not args.quick:
             blocks["fp8_gemm"] = bench_fp8(w, args)

@@ -120,6 +120,42 @@ LC_DEVINL void bd2_rd0(half8_t& f0, half8_t& f1, half8_t& f2, half8_t& f3, const
                : "={v[240:243]}"(f0), "={v[244:247]}"(f1), "={v[248:251]}"(f2), "={v[252:255]}"(f3)
                : "v"(vx[0]), "v"(vx[1]), "v"(vx[2]), "v"(vx[3]), "n"(HOFF));
 }
+// ---- V handed over TRANSPOSED ([D][N]: the reference's *_swizzle_qkv entries): the tile image is [D rows][64 kv] and — with the K rows
+// of a 16-block fed to the MFMA in the order pi(m) = m with bits 2 and 3 swapped, so that a lane's eight k slots of P fragment g are
+// the CONTIGUOUS kv 16 g + 8 hi .. + 7 — a Vᵀ fragment is ONE ds_read_b128 (granule 2 g + hi of d-row 32 dt + l32) where the [N][D]
+// image needs two transpose reads.  Same fixed quads, same step structure; 4 reads outstanding at entry, waits 3 / 3 / 3 / 3
+// (last step 3 / 2 / 1 / 0).  A: LDS address of the NEXT step's k-step g (vxg[g1]); O0: its first d tile's byte offset (+ 4 KiB per tile).
+template <int R0, bool BF16, bool RD, int O0>
+LC_DEVINL void bd2_pv4_fix_vt(half8_t& f0, half8_t& f1, half8_t& f2, half8_t& f3, half8_t p, uint32_t a_next) {
+#define LC_BD2_STEPV(OP, W0, W1, W2, W3, R0_, R1_, R2_, R3_)                                                            \
+  asm volatile("s_nop 1\n\ts_waitcnt lgkmcnt(" #W0 ")\n\t" OP " a[%6:%7], v[240:243], %4, a[%6:%7]\n\t" R0_                          \
+               "s_waitcnt lgkmcnt(" #W1 ")\n\t" OP " a[%8:%9], v[244:247], %4, a[%8:%9]\n\t" R1_                        \
+               "s_waitcnt lgkmcnt(" #W2 ")\n\t" OP " a[%10:%11], v[248:251], %4, a[%10:%11]\n\t" R2_                        \
+               "s_waitcnt lgkmcnt(" #W3 ")\n\t" OP " a[%12:%13], v[252:255], %4, a[%12:%13]\n\t" R3_                        \
+               : "+{v[240:243]}"(f0), "+{v[244:247]}"(f1), "+{v[248:251]}"(f2), "+{v[252:255]}"(f3)                        \
+               : "v"(p), "v"(a_next), "n"(R0), "n"(R0 + 15), "n"(R0 + 16), "n"(R0 + 31), "n"(R0 + 32), "n"(R0 + 47), "n"(R0 + 48),  \
+                 "n"(R0 + 63), "n"(O0), "n"(O0 + 4096), "n"(O0 + 8192), "n"(O0 + 12288)                                     \
+               : LC_AGPR_ALL)
+  if constexpr (RD) {
+    if constexpr (BF16)
+      LC_BD2_STEPV("v_mfma_f32_32x32x16_bf16", 3, 3, 3, 3, "ds_read_b128 v[240:243], %5 offset:%14\n\t", "ds_read_b128 v[244:247], %5 offset:%15\n\t",
+                   "ds_read_b128 v[248:251], %5 offset:%16\n\t", "ds_read_b128 v[252:255], %5 offset:%17");
+    else
+      LC_BD2_STEPV("v_mfma_f32_32x32x16_f16", 3, 3, 3, 3, "ds_read_b128 v[240:243], %5 offset:%14\n\t", "ds_read_b128 v[244:247], %5 offset:%15\n\t",
+                   "ds_read_b128 v[248:251], %5 offset:%16\n\t", "ds_read_b128 v[252:255], %5 offset:%17");
+  } else {
+    if constexpr (BF16) LC_BD2_STEPV("v_mfma_f32_32x32x16_bf16", 3, 2, 1, 0, "", "", "", "");
+    else LC_BD2_STEPV("v_mfma_f32_32x32x16_f16", 3, 2, 1, 0, "", "", "", "");
+  }
+#undef LC_BD2_STEPV
+}
+// step 0's fragments (k-step 0, d tiles 0 .. 3): four ds_read_b128, in fragment order, into the fixed quads
+LC_DEVINL void bd2_rd0_vt(half8_t& f0, half8_t& f1, half8_t& f2, half8_t& f3, uint32_t a0) {
+  asm volatile("ds_read_b128 v[240:243], %4\n\tds_read_b128 v[244:247], %4 offset:4096\n\t"
+               "ds_read_b128 v[248:251], %4 offset:8192\n\tds_read_b128 v[252:255], %4 offset:12288"
+               : "={v[240:243]}"(f0), "={v[244:247]}"(f1), "={v[248:251]}"(f2), "={v[252:255]}"(f3)
+               : "v"(a0));
+}
 template <int OFF>
 LC_DEVINL half4_t bd2_tr(uint32_t addr) {   // asm transpose read (hipcc would guard the builtin with vmcnt(0) after LDS-DMA)
   half4_t r;
@@ -127,7 +163,7 @@ LC_DEVINL half4_t bd2_tr(uint32_t addr) {   // asm transpose read (hipcc would g
   return r;
 }
 
-template <int D, bool BF16>
+template <int D, bool BF16, bool VT = false>
 __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
     half_t* __restrict__ O, int N, int nqb, float sl2) {
@@ -169,11 +205,22 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = PPR ? (wave + 4 * j) : (2 * (wave + 4 * j) + rsub);
-      k_off[j] = (unsigned)(rsub * ROWB + ((cs ^ (row & 15)) * 16));
+      // VT: the K fragment of MFMA row m is read from K row pi(m) (bits 2, 3 swapped, below) with the key of the READING lane, m & 15:
+      // the row that lane m reads is pi(m), so row r is filled under key pi(r) & 15 (pi is an involution)
+      const int kkey = VT ? (((row & 3) | ((row & 4) << 1) | ((row & 8) >> 1)) & 15) : (row & 15);
+      k_off[j] = (unsigned)(rsub * ROWB + ((cs ^ kkey) * 16));
     }
     const int rowv = PPR ? wave : (2 * wave + rsub);      // (row & 3) does not depend on i
     v_off = (unsigned)(rsub * ROWB + ((cs ^ ((rowv & 3) << 2)) * 16));
+    if constexpr (VT) {
+      // V as [D][N]: piece p = d-rows 8 p .. 8 p + 7 of 128 B (64 kv), 2 N bytes apart; lane -> d-row rr = lane >> 3, LDS granule slot
+      // lane & 7 <- source granule (lane & 7) ^ key(row), key = (row >> 1) & 7 = 4 (p & 1) + (rr >> 1), p & 1 = wave & 1
+      const int rr = lane >> 3, c8 = lane & 7;
+      v_off = (unsigned)((size_t)rr * N * 2 + ((c8 ^ (4 * (wave & 1) + (rr >> 1))) * 16));
+    }
   }
+  const unsigned v_piece_stride = VT ? (unsigned)(16u * (unsigned)N) : 1024u;   // source bytes between consecutive pieces of a V tile
+  constexpr unsigned V_TILE_STRIDE = VT ? 128u : (unsigned)TILE;                 // ... between consecutive V tiles
   auto issue_k = [&](int i, int t) {   // piece i of tile t (clamped) -> K region
     const int te = t < T ? t : T - 1;
     const int p = wave + 4 * i;
@@ -182,7 +229,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
   auto issue_v = [&](int i, int t) {
     const int te = t < T ? t : T - 1;
     const int p = wave + 4 * i;
-    blds16(rv, v_off, (unsigned)te * TILE + (unsigned)p * 1024u, vsm + p * 1024);
+    blds16(rv, v_off, (unsigned)te * V_TILE_STRIDE + (unsigned)p * v_piece_stride, vsm + p * 1024);
   };
 #pragma unroll
   for (int i = 0; i < NPIECE; ++i) issue_k(i, 0);
@@ -201,12 +248,14 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
   // ---- fragment read addresses
   const char* kx[8];   // K: row l32 (+32 tt), chunk (2ks + hi): low 4 bits XOR (row & 15); + (ks >> 3) * 256 as immediate
 #pragma unroll
-  for (int k8 = 0; k8 < 8; ++k8) kx[k8] = ksm + l32 * ROWB + (((2 * k8 + hi) ^ (l32 & 15)) * 16);
+  for (int k8 = 0; k8 < 8; ++k8)
+    kx[k8] = ksm + (VT ? ((l32 & 19) | ((l32 & 4) << 1) | ((l32 & 8) >> 1)) : l32) * ROWB + (((2 * k8 + hi) ^ (l32 & 15)) * 16);
   const int vi = lane & 15, vgi = (lane >> 4) & 1;
   uint32_t vx[4];   // Vᵀ: kv row 4hi + (vi>>2) (+16g, +8), 64-B unit dt: low 2 bits XOR (row & 3); + (dt >> 2) * 256 immediate
 #pragma unroll
   for (int b = 0; b < 4; ++b)
-    vx[b] = smem32 + (uint32_t)(TILE + (4 * hi + (vi >> 2)) * ROWB + 32 * vgi + 8 * (vi & 3) + ((b ^ (vi >> 2)) << 6));
+    vx[b] = VT ? smem32 + (uint32_t)(TILE + l32 * 128 + ((((2 * b) | hi) ^ ((l32 >> 1) & 7)) * 16))     // VT: vx[g] = k-step g's granule 2 g + hi of d-row l32 (+ 4 KiB per d tile)
+               : smem32 + (uint32_t)(TILE + (4 * hi + (vi >> 2)) * ROWB + 32 * vgi + 8 * (vi & 3) + ((b ^ (vi >> 2)) << 6));
 
   float m_run = -INFINITY, l_run = 0.f;
   half8_t pfa[4], pfb[4];   // P fragments (k-step g = 16 kv rows) of the even / odd tiles
@@ -226,11 +275,15 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
   // (profiles/r3aa_attn_bigd2_span_sweep.log)
   constexpr int SP8 = D == 512 ? 6 : 4;
   constexpr int SPAN_A = SP8 * NKS / 8, SPAN_B = SP8 * NST / 8;
-  auto rd0 = [&]() { bd2_rd0<8 * ROWB>(vf0, vf1, vf2, vf3, vx); };
+  auto rd0 = [&]() {
+    if constexpr (VT) bd2_rd0_vt(vf0, vf1, vf2, vf3, vx[0]);
+    else bd2_rd0<8 * ROWB>(vf0, vf1, vf2, vf3, vx);
+  };
   auto pv_step = [&](auto stc, half8_t (&pf)[4]) {
     constexpr int st = decltype(stc)::value, g = st / NQ, dq = st % NQ;
     constexpr int g1 = (st + 1) / NQ, dq1 = (st + 1) % NQ;
-    bd2_pv4_fix<64 * dq, BF16, (st + 1 < NST), dq1 * 256 + g1 * 16 * ROWB, 8 * ROWB>(vf0, vf1, vf2, vf3, pf[g], vx);
+    if constexpr (VT) bd2_pv4_fix_vt<64 * dq, BF16, (st + 1 < NST), dq1 * 4 * 4096>(vf0, vf1, vf2, vf3, pf[g], vx[g1 & 3]);
+    else bd2_pv4_fix<64 * dq, BF16, (st + 1 < NST), dq1 * 256 + g1 * 16 * ROWB, 8 * ROWB>(vf0, vf1, vf2, vf3, pf[g], vx);
   };
 
   // ---- one tile period.  Phase A: Sᵀ(t) = K(t)·Qᵀ with the DMA of V(t−1) in its shadow; barrier; phase B: P·V(t−1) with

@@ -265,11 +265,13 @@ int launch_attn(const half_t* Q, const half_t* K, const half_t* V, half_t* O, in
 // 512 (round 2's attn_w4n) is accepted as an alias of 513: attn_w4u<128, false, 0> IS that kernel; 256 / 260 / 516 were retired in
 // round 4 with attn_w4m.hip / attn_w8g.hip.
 int attn_walk_auto(int N) {
-  // auto (measured, profiles/r3k + r4*): up to N = 4096 the persistent workgroup pays (config 3 + 1.7 %: the fixed cost of a block is
-  // ~6 % of it there); beyond, the block queue decides (lc_tune_set "attn_walk": 0 = this rule)
+  // auto (lc_tune_set "attn_walk": 0 = this rule; measured, profiles/r3k, profiles/r4c_attn_walks.log): up to N = 4096 the persistent
+  // static walk (round 3: config 3 + 1.7 %, N = 2048 + 1.0 %; round 4's box: + 0.5 % / level), beyond it one block per workgroup — with
+  // 16+ blocks per CU the hardware dispatcher balances better than either walk (N = 8192: static − 1.1 %, dynamic queue − 1.2 %; the
+  // queue is a validated alternative, never the default: a claim one block ahead buys no balance the dispatcher does not already give)
   const int k = g_tune_attn_walk;
   if (k >= 1 && k <= 3) return k - 1;
-  return N <= 4096 ? 1 : 2;
+  return N <= 4096 ? 1 : 0;
 }
 int choose_attn_nw(int D, bool vt, int N) {
   int want = g_tune_attn_nw;   // 0 = auto (read once per launch)
@@ -339,17 +341,20 @@ int launch_attn_bigd(const half_t* Q, const half_t* K, const half_t* V, half_t* 
   return check_launch();
 }
 
-// D = 256 / 512 with V as [B,H,N,D] and N % 128 == 0: the full-width kernel (attn_bigd2.hip) unless lc_tune_set
-// "attn_d512" = 1 asks for round 1's column-split kernel (kept as the independently written cross-check; it also
-// serves D = 1024, V-transposed inputs and N % 128 != 0).
+// D = 256 / 512 with N % 128 == 0: the full-width kernel (attn_bigd2.hip; V as [B,H,N,D], or — D = 256, the reach of the reference's
+// *_swizzle_qkv entries — as [B,H,D,N]) unless lc_tune_set "attn_d512" = 1 asks for round 1's column-split kernel (kept as the
+// independently written cross-check; it also serves N % 128 != 0 and D = 512 with V transposed).  D = 1024 with N % 64 == 0: the pair
+// kernel (attn_bigd4.hip); the column-split kernel under knob 1 and for ragged N.
 bool use_bigd2(int D, bool vt, int N) {
-  return (D == 256 || D == 512) && !vt && N % 128 == 0 && g_tune_attn_d512 != 1;   // (2: attn_bigd3, same launcher)
+  return (D == 256 || (D == 512 && !vt)) && N % 128 == 0 && g_tune_attn_d512 != 1;   // (2: attn_bigd3, same launcher; not for vt)
 }
+bool use_bigd4(int D, bool vt, int N) { return D == 1024 && !vt && N % 64 == 0 && g_tune_attn_d512 != 1; }
 
 template <int D, bool VT>
 int launch_attn_bigd_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                         hipStream_t st) {
-  if (use_bigd2(D, VT, N)) return launch_attn_bigd2(Q, K, V, O, B, H, N, D, false, st);
+  if (use_bigd4(D, VT, N)) return launch_attn_bigd4(Q, K, V, O, B, H, N, st);
+  if (use_bigd2(D, VT, N)) return VT ? launch_attn_bigd2_vt(Q, K, V, O, B, H, N, D, st) : launch_attn_bigd2(Q, K, V, O, B, H, N, D, false, st);
   if (N % 128 == 0) return launch_attn_bigd<D, 4, VT>(Q, K, V, O, B, H, N, st);
   return launch_attn_bigd<D, 2, VT>(Q, K, V, O, B, H, N, st);
 }
@@ -474,8 +479,14 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
     else snprintf(buf, buflen, "attn_fwd_kernel<%d,%d,%s,0>", D, nw, vt);
     return LC_OK;
   }
-  if (use_bigd2(D, v_transposed != 0, N)) {
-    snprintf(buf, buflen, "attn_fwd_bigd%d_kernel<%d,%s>", g_tune_attn_d512 == 2 ? 3 : 2, D, bf16 ? "true" : "false");
+  if (use_bigd4(D, v_transposed != 0, N) && !bf16) {
+    snprintf(buf, buflen, "attn_fwd_bigd4_kernel");
+    return LC_OK;
+  }
+  if (use_bigd2(D, v_transposed != 0, N) && !(bf16 && v_transposed)) {
+    if (v_transposed) snprintf(buf, buflen, "attn_fwd_bigd2_kernel<%d,false,true>", D);
+    else if (g_tune_attn_d512 == 2) snprintf(buf, buflen, "attn_fwd_bigd3_kernel<%d,%s>", D, bf16 ? "true" : "false");
+    else snprintf(buf, buflen, "attn_fwd_bigd2_kernel<%d,%s,false>", D, bf16 ? "true" : "false");
     return LC_OK;
   }
   if (D == 256 || D == 512 || (D == 1024 && !bf16)) {

@@ -229,7 +229,7 @@ def test_status_strings_and_argument_errors(built):
     assert lib.lc_attn_fwd_f16(one, one, one, one, 1, 1, 1 << 23, 128, 0, 0, 0, 2, None) == capi.LC_ERR_SHAPE
     assert lib.lc_attn_fwd_bf16(one, one, one, one, 1, 1, 1 << 21, 512, None) == capi.LC_ERR_SHAPE
     assert lib.lc_attn_kernel_name(1 << 23, 128, 0, 0, buf, 128) == capi.LC_ERR_SHAPE
-    assert lib.lc_attn_kernel_name((1 << 23) - 256, 128, 0, 0, buf, 128) == capi.LC_OK and buf.value.startswith(b"attn_fwd_w4u_kernel<128,false,2>")
+    assert lib.lc_attn_kernel_name((1 << 23) - 256, 128, 0, 0, buf, 128) == capi.LC_OK and buf.value.startswith(b"attn_fwd_w4u_kernel<128,false,0>")
     # head-dim limits of the reference dispatchers (split_q: 128; share_qkv stage2: 128, stage1: 256)
     assert lib.lc_attn_call(b"flash_attn_mma_stages_split_q", one, one, one, one, 1, 1, 128, 256, 2, None) \
         == capi.LC_ERR_HEADDIM

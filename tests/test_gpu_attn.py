@@ -260,7 +260,7 @@ def test_full_size_config3_properties(oracle):
     assert (o12.float() - o1.float() - o2.float()).abs().max().item() < 2e-3
 
 
-@pytest.mark.parametrize("nw", [256, 512, 514, 8])
+@pytest.mark.parametrize("nw", [513, 515, 517, 514, 8])
 def test_scale_jumps_and_extreme_scores(oracle, nw):
     """The merged-phase kernel treats the running max as a mere SCALE and only corrects it when a half-tile's row sums
     get large (attn_w4m.hip).  Inputs that force that path in many places: (a) scores that grow steadily along the

@@ -44,6 +44,11 @@ FAMILIES = [
     ("d256-auto", 256, None, 0),
     ("d512-auto", 512, None, 0),
     ("d512-column-split", 512, "attn_d512", 1),
+    ("d1024-pair", 1024, None, 0),
+    ("d1024-column-split", 1024, "attn_d512", 1),
+    ("d128-v-transposed", -128, None, 0),       # D < 0: V handed over as [B,H,D,N] through a *_swizzle_qkv entry
+    ("d64-v-transposed", -64, None, 0),
+    ("d256-v-transposed", -256, None, 0),
 ]
 
 
@@ -52,6 +57,7 @@ def test_one_kv_tile_perturbed_s8192(oracle, label, D, key, val):
     capi = _capi()
     B, H, N = 1, 2, 8192
     T = N // 64
+    vt, D = D < 0, abs(D)
     torch.manual_seed(1000 + D)
     q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     k0 = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
@@ -59,6 +65,9 @@ def test_one_kv_tile_perturbed_s8192(oracle, label, D, key, val):
     rows = _rows_for(N, D)
     heads = [(0, 0), (0, 1)]
     entry = "flash_attn_mma_stages_split_q" if D <= 128 else "flash_attn_mma_stages_split_q_tiling_qkv"
+    if vt:
+        entry = "flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv" if D <= 128 else "flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv"
+        v = v.transpose(-2, -1).contiguous()
     outs = []
     for t in (0, 4, T - 1):           # first tile, the tile that re-uses ring slot 0, last tile
         k = k0.clone()
@@ -73,7 +82,7 @@ def test_one_kv_tile_perturbed_s8192(oracle, label, D, key, val):
             if key:
                 capi.tune(key, 0)
         assert torch.isfinite(o).all(), (label, t)
-        _sampled_rows_check(oracle, q, k, v, o, heads, rows)
+        _sampled_rows_check(oracle, q, k, v, o, heads, rows, vt=vt)
         outs.append(o)
     # the three perturbations are different problems: the outputs must differ (a kernel that ignored K's tile would not)
     assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
@@ -192,6 +201,44 @@ def test_v_transposed_entries_config3(oracle, entry):
     assert (o.float() + 0.375).abs().max().item() < 1e-3
 
 
+def test_d256_v_transposed_full_size(oracle):
+    """(1,48,8192,256) with V as [B,H,D,N] — the largest head dim the reference's *_swizzle_qkv entries take
+    (flash_attn_mma_share_qkv_swizzle_qkv.cu:961-1010: d = 256 with stages = 1; tiling_qk_swizzle_qkv: d <= 256) — runs
+    attn_fwd_bigd2_kernel<256,false,true>: K rows fed in the order that makes a lane's P slots contiguous kv, Vᵀ fragments one
+    ds_read_b128 each.  Against the oracle reading the same transposed tensor and against the [B,H,N,D] sibling."""
+    capi = _capi()
+    B, H, N, D = 1, 48, 8192, 256
+    torch.manual_seed(2560)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k[0, 47, 7000] = 3.0 * q[0, 47, 33]
+    v[0, 47, 7000] = 5.0
+    tv = v.transpose(-2, -1).contiguous()
+    assert capi.attn_kernel_name(N, D, True) == "attn_fwd_bigd2_kernel<256,false,true>"
+    rows = _rows_for(N, 2560, extra=[33, 127, 128])
+    o = torch.full_like(q, float("nan"))
+    for entry, st in (("flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv", 2), ("flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv", 1)):
+        o.fill_(float("nan"))
+        capi.attn_call(entry, q, k, tv, o, st)
+        torch.cuda.synchronize()
+        assert torch.isfinite(o).all()
+        _sampled_rows_check(oracle, q, k, tv, o, [(0, 0), (0, 23)], rows, vt=True)
+        _sampled_rows_check(oracle, q, k, tv, o, [(0, 47)], rows, vt=True, rtol=tol.ATTN_RTOL_SPIKE)
+    os_ = torch.full_like(q, float("nan"))
+    capi.attn_call("flash_attn_mma_stages_split_q_tiling_qk", q, k, v, os_, 2)
+    torch.cuda.synchronize()
+    assert (o.float() - os_.float()).abs().max().item() <= 2.0 ** -10 * max(1.0, os_.float().abs().max().item())
+    o2 = torch.full_like(q, float("nan"))
+    capi.attn_call("flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv", q, k, tv, o2, 2)
+    torch.cuda.synchronize()
+    assert torch.equal(o, o2)                      # launch to launch
+    vc = torch.full_like(tv, 0.625)
+    capi.attn_call("flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv", q, k, vc, o, 2)
+    torch.cuda.synchronize()
+    assert (o.float() - 0.625).abs().max().item() < 1e-3
+
+
 @pytest.mark.parametrize("N", [2048, 8192])
 def test_d1024_full_width(oracle, N):
     """D = 1024 (flash_attn_mma_tiling_qkv.cu:904-910,931-937 and tiling_qk dispatch up to 1024) at N >= 2048 — round 3 tested N = 128
@@ -213,6 +260,20 @@ def test_d1024_full_width(oracle, N):
         assert torch.isfinite(o).all()
         _sampled_rows_check(oracle, q, k, v, o, [(0, 0)], rows)
         _sampled_rows_check(oracle, q, k, v, o, [(0, H - 1)], rows, rtol=tol.ATTN_RTOL_SPIKE)      # the spiked head
+    assert capi.attn_kernel_name(N, D) == "attn_fwd_bigd4_kernel"
+    # the pair kernel against the independently written round-1 column-split kernel: same products, other summation order
+    o1 = torch.full_like(q, float("nan"))
+    capi.tune("attn_d512", 1)
+    try:
+        capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, o1, 2)
+        torch.cuda.synchronize()
+    finally:
+        capi.tune("attn_d512", 0)
+    assert (o.float() - o1.float()).abs().max().item() <= 2.0 ** -9 * max(1.0, o1.float().abs().max().item())
+    o2 = torch.full_like(q, float("nan"))
+    capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, o2, 2)
+    torch.cuda.synchronize()
+    assert torch.equal(o, o2)                      # launch to launch (both members of a pair hold the same S: a + b == b + a)
     vc = torch.full_like(v, 0.875)
     capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, vc, o, 2)
     torch.cuda.synchronize()

@@ -183,17 +183,17 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     assert capi.hgemm_kernel_name(1024, 1024, 1024, capi.LAYOUT_NN) == "hgemm_mfma128_kernel<true>"
     assert capi.hgemm_kernel_name(1000, 1024, 1024, capi.LAYOUT_NN) == "hgemm_generic_kernel<true>"
     assert capi.attn_kernel_name(4096, 128) == "attn_fwd_w4u_kernel<128,false,1>"            # config 3: the persistent workgroup, static walk
-    assert capi.attn_kernel_name(8192, 128) == "attn_fwd_w4u_kernel<128,false,2>"            # config 4: persistent, dynamic block queue
+    assert capi.attn_kernel_name(8192, 128) == "attn_fwd_w4u_kernel<128,false,0>"            # config 4: one block per workgroup (the dispatcher balances 16+ blocks per CU best)
     assert capi.attn_kernel_name(4096, 128, True) == "attn_fwd_w4u_kernel<128,true,1>"       # V handed over as [B,H,D,N]: the same kernel
     assert capi.attn_kernel_name(4096 + 128, 128) == "attn_fwd_kernel<128,4,false,0>"      # N % 256 != 0
     assert capi.attn_kernel_name(192, 64, True) == "attn_fwd_kernel<64,2,true,0>"
-    assert capi.attn_kernel_name(8192, 64) == "attn_fwd_w4u_kernel<64,false,2>"               # the reference's published shapes
-    assert capi.attn_kernel_name(8192, 64, True) == "attn_fwd_w4u_kernel<64,true,2>"
+    assert capi.attn_kernel_name(8192, 64) == "attn_fwd_w4u_kernel<64,false,0>"               # the reference's published shapes
+    assert capi.attn_kernel_name(8192, 64, True) == "attn_fwd_w4u_kernel<64,true,0>"
     assert capi.attn_kernel_name(8192, 96, True) == "attn_fwd_kernel<96,8,true,0>"            # D = 96 / 32 with V transposed: lock-step
     assert capi.attn_kernel_name(8192, 96) == "attn_fwd_w4i_kernel<96,1>"                     # only the generated kernel has a D = 96 instantiation
     assert capi.attn_kernel_name(8192 + 64, 96) == "attn_fwd_kernel<96,2,false,0>"            # N % 256 != 0: lock-step
     assert capi.attn_kernel_name(8192, 32) == "attn_fwd_w4i_kernel<32,1>"
-    assert capi.attn_kernel_name(8192, 512, False, True) == "attn_fwd_bigd2_kernel<512,true>"
+    assert capi.attn_kernel_name(8192, 512, False, True) == "attn_fwd_bigd2_kernel<512,true,false>"
     assert capi.attn_kernel_name(192, 512, False, False).startswith("attn_fwd_bigd_kernel<512,")     # N % 128 != 0
     assert sump.short("_ZN2lc16hgemm_w4b_kernelILb0ELb1ELi0EEEvPKDF16_S2_PDF16_iiiiii") == \
         "hgemm_w4b_kernel<false,true,0>"
@@ -244,3 +244,22 @@ def test_steady_state_loops_keep_their_instruction_mix(built):
         assert nv / 64 <= 3.2, (nv, n)
     b, _ = mix("tu_attn_big.s", r"attn_fwd_bigd2_kernelILi512ELb0")  # two 64-key tiles per loop iteration
     assert b["mfma"] == 256 and b["s_barrier"] == 4 and b["valu_trans"] == 64, b
+
+
+def test_large_head_dim_kernel_names(built):
+    """Round 4: D = 1024 runs the pair kernel (attn_bigd4.hip) when N % 64 == 0, D = 256 with V as [B,H,D,N] the full-width kernel's
+    V-transposed instantiation; the round-1 column-split kernel keeps ragged N, D = 512 with V transposed and the cross-check knob."""
+    from leetcuda_amd import capi
+    capi.load()
+    assert capi.attn_kernel_name(8192, 1024) == "attn_fwd_bigd4_kernel"
+    assert capi.attn_kernel_name(64, 1024) == "attn_fwd_bigd4_kernel"
+    assert capi.attn_kernel_name(8192, 256, True) == "attn_fwd_bigd2_kernel<256,false,true>"
+    assert capi.attn_kernel_name(8192, 256) == "attn_fwd_bigd2_kernel<256,false,false>"
+    assert capi.attn_kernel_name(8192, 512, True).startswith("attn_fwd_bigd_kernel<512,")
+    assert capi.attn_kernel_name(192, 256, True).startswith("attn_fwd_bigd_kernel<256,")
+    capi.tune("attn_d512", 1)
+    try:
+        assert capi.attn_kernel_name(8192, 1024).startswith("attn_fwd_bigd_kernel<1024,")
+        assert capi.attn_kernel_name(8192, 256, True).startswith("attn_fwd_bigd_kernel<256,")
+    finally:
+        capi.tune("attn_d512", 0)

@@ -38,7 +38,7 @@ if a.what in ("all", "hgemm"):
     torch.cuda.synchronize()
 if a.what in ("all", "attn"):
     q, k, v, o, tv = host.get_qkvo(4, 32, 4096, 128, seed=0)
-    for nw in (0, 513, 514, 8):     # default (persistent merged-phase kernel), its one-block launch, the generated one-statement-per-phase twin, lock-step
+    for nw in (0, 517, 514, 8):     # default (persistent merged-phase kernel, static walk), the dynamic-queue walk, the generated one-statement-per-phase twin, lock-step
         capi.tune("attn_nw", nw)
         capi.tune("attn_w4i_sched", 1 if nw == 514 else 0)
         for _ in range(a.iters):
@@ -51,7 +51,7 @@ if a.what in ("all", "attn"):
         capi.attn_fwd(q, k, tv2, o, v_transposed=True)
     torch.cuda.synchronize()
     del q, k, v, o, tv, tv2
-    # config 4 (B32 H32 S8192 D128: 2 GiB per tensor): attn_fwd_w4u_kernel<128,false,2> — the dynamic block queue (prof_workloads: "attn_cfg4")
+    # config 4 (B32 H32 S8192 D128: 2 GiB per tensor): attn_fwd_w4u_kernel<128,false,0> — one block per workgroup (prof_workloads: "attn_cfg4")
     q, k, v, o, tv = host.get_qkvo(32, 32, 8192, 128, seed=0)
     for _ in range(2):
         capi.attn_fwd(q, k, v, o)
