@@ -35,7 +35,9 @@ constexpr int BD4_XCH = 2 * BD4_TILE;       // exchange area: 4 waves x 4 KiB
 constexpr int BD4_QPK = BD4_XCH + 4 * 4096; // parked Q: 4 waves x PARK KiB
 constexpr int BD4_LDS = BD4_QPK + 4 * BD4_PARK * 1024;
 static_assert(BD4_LDS == 160 * 1024, "bigd4 uses a CU's whole LDS");
+static_assert(2 * (512 / 32 / 4) == 8, "the softmax filler plan below is written for 8 P.V steps per tile");
 
+template <int SP8>   // the DMA pieces of a phase are spread over SP8 eighths of it (A/B knob, lc_tune_set "attn_d1024")
 __global__ __launch_bounds__(256) void attn_fwd_bigd4_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
     half_t* __restrict__ O, int N, int nqb, float sl2) {
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd4_kernel(
 
   half8_t vf0, vf1, vf2, vf3;
   constexpr int NQ = NDT / 4, NST = 2 * NQ;       // P·V steps per tile: (g, dq), g = 0, 1 (16 kv rows each), dq = quad of d tiles
-  constexpr int SPAN_A = 7 * NKS / 8, SPAN_B = 7 * NST / 8;   // DMA pieces spread over 7/8 of a phase: the texture-address unit (16 cycles per piece, four waves) is busy for the whole phase at full MFMA rate
+  constexpr int SPAN_A = SP8 * NKS / 8, SPAN_B = SP8 * NST / 8;   // DMA pieces spread over 7/8 of a phase: the texture-address unit (16 cycles per piece, four waves) is busy for the whole phase at full MFMA rate
   auto rd0 = [&]() { bd2_rd0<8 * ROWB>(vf0, vf1, vf2, vf3, vx); };
   auto pv_step = [&](auto stc, half8_t (&pf)[2]) {
     constexpr int st = decltype(stc)::value, g = st / NQ, dq = st % NQ;
@@ -182,9 +184,13 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd4_kernel(
       });
       if constexpr (HAS_PV) pv_step(stc, po);
       __builtin_amdgcn_sched_barrier(0);
-      // softmax(t) of score elements 16 st / NST .. : row sums from the unrounded P (tiling_qkv.cu keeps the same order)
-      static_for<16 / NST>([&](auto jc) {
-        constexpr int r = st * (16 / NST) + decltype(jc)::value;
+      // softmax(t): row sums from the unrounded P (tiling_qkv.cu keeps the same order).  The 16 score elements of a lane ride behind
+      // steps 2 .. 7 (3, 3, 3, 3, 2, 2): Sᵀ(t) is complete only when the partner's partial has come back from LDS, and a filler in
+      // front of steps 0 / 1 would park the in-order stream on that read — the P·V MFMAs of those steps need only the Vᵀ fragments
+      constexpr int E0 = st < 2 ? 0 : (st < 6 ? 3 * (st - 2) : 12 + 2 * (st - 6));
+      constexpr int EN = st < 2 ? 0 : (st < 6 ? 3 : 2);
+      static_for<EN>([&](auto jc) {
+        constexpr int r = E0 + decltype(jc)::value;
         const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sf[r], sl2, nm));
         if constexpr ((r & 1) != 0) ps1 += p; else ps0 += p;
         pn[r >> 3][r & 7] = cvt16<BF16>(p);

@@ -40,6 +40,7 @@ namespace {
 tune_t g_tune_fp8_mx{1};                       // fp8 GEMM: 1 = MX-scaled K=64 MFMA, 4-wave kernel; 2 = MX, 8-wave kernel; 0 = plain K=16 MFMA
 tune_t g_tune_attn_w4i_sched{1};              // schedule of attn_fwd_w4i_kernel's generated phase statements (tools/gen_attn_w4i.py NSCHED; same bits)
 tune_t g_tune_attn_nw{0};                    // attention kernel for D <= 128: 0 = auto, 513 / 515 / 517 / 514 / 8 / 4 / 2 (choose_attn_nw, lc_abi.h)
+tune_t g_tune_attn_d1024{0};                 // attn_bigd4's DMA spread in eighths of a phase: 0 = default (4), 2 / 6 / 8 (A/B knob)
 tune_t g_tune_attn_walk{0};                  // block walk of the merged-phase kernel under attn_nw = 0: 0 = auto by N, 1 / 2 / 3 = WALK 0 / 1 / 2
 tune_t g_tune_hgemm_auto{LC_HGEMM_MFMA256W4Y};   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
 tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to the 128-tile kernel (launch_mfma256), 0 = one launch
@@ -353,7 +354,7 @@ bool use_bigd4(int D, bool vt, int N) { return D == 1024 && !vt && N % 64 == 0 &
 template <int D, bool VT>
 int launch_attn_bigd_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                         hipStream_t st) {
-  if (use_bigd4(D, VT, N)) return launch_attn_bigd4(Q, K, V, O, B, H, N, st);
+  if (use_bigd4(D, VT, N)) return launch_attn_bigd4(Q, K, V, O, B, H, N, g_tune_attn_d1024, st);
   if (use_bigd2(D, VT, N)) return VT ? launch_attn_bigd2_vt(Q, K, V, O, B, H, N, D, st) : launch_attn_bigd2(Q, K, V, O, B, H, N, D, false, st);
   if (N % 128 == 0) return launch_attn_bigd<D, 4, VT>(Q, K, V, O, B, H, N, st);
   return launch_attn_bigd<D, 2, VT>(Q, K, V, O, B, H, N, st);
@@ -480,7 +481,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
     return LC_OK;
   }
   if (use_bigd4(D, v_transposed != 0, N) && !bf16) {
-    snprintf(buf, buflen, "attn_fwd_bigd4_kernel");
+    snprintf(buf, buflen, "attn_fwd_bigd4_kernel<%d>", g_tune_attn_d1024 == 0 ? 4 : g_tune_attn_d1024.load());
     return LC_OK;
   }
   if (use_bigd2(D, v_transposed != 0, N) && !(bf16 && v_transposed)) {
@@ -505,6 +506,7 @@ bool ok_attn_nw(int v) {
 bool ok_01(int v) { return v == 0 || v == 1; }
 bool ok_02(int v) { return v >= 0 && v <= 2; }
 bool ok_03(int v) { return v >= 0 && v <= 3; }
+bool ok_span8(int v) { return v == 0 || v == 2 || v == 6 || v == 8; }
 bool ok_w4y_sched(int v) {
 #ifdef LC_DIAG
   return v >= 0 && v <= 5;   // 3..5: ablations (results WRONG)
@@ -526,6 +528,7 @@ struct Knob {
 const Knob kKnobs[] = {
     {"attn_nw", &g_tune_attn_nw, 0, ok_attn_nw, false},
     {"attn_walk", &g_tune_attn_walk, 0, ok_03, false},
+    {"attn_d1024", &g_tune_attn_d1024, 0, ok_span8, false},
     {"attn_w4i_sched", &g_tune_attn_w4i_sched, 1, ok_01, false},
     {"fp8_mx", &g_tune_fp8_mx, 1, ok_02, false},
     {"attn_d512", &g_tune_attn_d512, 0, ok_02, false},

@@ -105,7 +105,7 @@ int launch_attn_bigd2(const half_t* Q, const half_t* K, const half_t* V, half_t*
                       hipStream_t st);
 // tu_attn_big4.hip: D = 1024 (attn_bigd4.hip: two waves share 32 query rows, each owns 512 columns; N % 64 == 0, V as [B,H,N,D], fp16) and
 // attn_bigd2's V-transposed instantiation (D = 256, N % 128 == 0, V as [B,H,D,N], fp16)
-int launch_attn_bigd4(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, hipStream_t st);
+int launch_attn_bigd4(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int span8, hipStream_t st);   // span8: DMA spread (eighths of a phase; 0 = default)
 int launch_attn_bigd2_vt(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, hipStream_t st);
 // tu_fp8.hip: fp8 e4m3 GEMM, mx = 1 (MX, 4 waves) / 2 (MX, 8 waves) / 0 (plain K = 16)
 int launch_gemm_fp8(const uint8_t* A, const uint8_t* B, half_t* C, int M, int N, int K, float alpha, int tiles_m,

@@ -7,14 +7,26 @@
 
 namespace lc {
 // D = 1024, N % 64 == 0, V as [B,H,N,D], fp16
-int launch_attn_bigd4(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, hipStream_t st) {
-  auto kern = attn_fwd_bigd4_kernel;
+namespace {
+template <int SP8>
+int launch_bigd4_t(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, hipStream_t st) {
+  auto kern = attn_fwd_bigd4_kernel<SP8>;
   if (int rc = set_dyn_lds(kern, BD4_LDS)) return rc;
   const int nqb = N / 64;
   const dim3 grid((unsigned)((size_t)nqb * B * H)), block(256);
   const float sl2 = (1.0f / sqrtf(1024.0f)) * 1.4426950408889634f;
   hipLaunchKernelGGL(kern, grid, block, BD4_LDS, st, Q, K, V, O, N, nqb, sl2);
   return check_launch();
+}
+}  // namespace
+int launch_attn_bigd4(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int span8, hipStream_t st) {
+  // default: the first half of a phase (profiles/r4e_bigd4_span.log: 4/8 740, 6/8 732, 7/8 725, 8/8 712 TFLOP/s — an L2 read waits ~700
+  // cycles here because the 32 workgroups of an XCD ask for the same lines at the same time; early issue hides more of it than
+  // the texture-address FIFO costs)
+  if (span8 == 2) return launch_bigd4_t<2>(Q, K, V, O, B, H, N, st);
+  if (span8 == 6) return launch_bigd4_t<6>(Q, K, V, O, B, H, N, st);
+  if (span8 == 8) return launch_bigd4_t<8>(Q, K, V, O, B, H, N, st);
+  return launch_bigd4_t<4>(Q, K, V, O, B, H, N, st);
 }
 // D = 256, N % 128 == 0, V as [B,H,D,N], fp16
 int launch_attn_bigd2_vt(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, hipStream_t st) {
