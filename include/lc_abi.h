@@ -102,14 +102,16 @@ int lc_device_check(int* num_cus);
 const char* lc_build_info(int* is_diag);
 
 /* Run-time selection knobs for A-B benches (not part of the reference surface; correctness never depends on them):
- *   "attn_nw"      attention kernel for D <= 128: 0 = auto (D = 128: 515 up to N = 4096, 512 beyond; D = 64: 513; when N % 256 == 0), 513 = the merged-phase
- *                  kernel generalised over the head dim (attn_w4g.hip: D = 64, and D = 128 as a cross-check that must equal
- *                  512 bit for bit), 515 = the same kernel as a persistent workgroup per CU (attn_w4p.hip: K / V / Q streams
- *                  continue across query-block seams; D = 64 / 128, bit-identical to 513), 516 = D = 64 with eight waves of 32 query rows, two per
- *                  SIMD (attn_w8g.hip: one wave's softmax runs under the other's MFMAs; bit-identical to 513), 512 = merged-phase kernel with 16x16x32
- *                  MFMAs (attn_w4n.hip, D = 128), 256 = the same with 32x32x16 MFMAs, 4 waves x 64
- *                  query rows, one wave per SIMD (attn_w4m.hip; 260 = its A/B twin with padded Q.K^T MFMAs),
- *                  8 / 4 / 2 = lock-step kernel with that many waves (any N % (32 x waves) == 0, every D <= 128)
+ *   "attn_nw"      attention kernel for D <= 128: 0 = auto; 513 / 515 / 517 = the merged-phase 4-wave kernel attn_fwd_w4u_kernel<D, VT, WALK>
+ *                  (attn_w4u.hip: D = 64 / 128, N % 256 == 0, V as [B,H,N,D] or [B,H,D,N]) with WALK 0 (one 256-row query block per
+ *                  workgroup), 1 (persistent workgroup per CU, static walk) or 2 (persistent, dynamic per-XCD block queue) — the three compute
+ *                  the same bits; 512 = round 2's name for 513; 514 = the same design with every phase as ONE generated asm statement
+ *                  (attn_w4i.hip: D = 32 / 64 / 96 / 128, V as [B,H,N,D]; the only merged-phase kernel for D = 96 / 32, where auto picks it);
+ *                  8 / 4 / 2 = lock-step kernel with that many waves (any N % (32 x waves) == 0, every D <= 128).  Auto: 515 up to N = 4096,
+ *                  513 beyond (D = 64 / 128, N % 256 == 0); 514 for D = 96 / 32; else the lock-step kernel
+ *   "attn_walk"    block walk of the merged-phase kernel under "attn_nw" = 0: 0 = auto by N (above), 1 / 2 / 3 = WALK 0 / 1 / 2
+ *   "attn_w4i_sched" schedule 0 / 1 (default) of attn_w4i's generated phase statements (tools/gen_attn_w4i.py; same bits, A/B knob)
+ *   "attn_d1024"   D = 1024 pair kernel (attn_bigd4.hip): its LDS-DMA pieces are spread over this many eighths of a phase: 0 = default (2), 4 / 6 / 8
  *   "w4y_sched"    schedule 0..2 of LC_HGEMM_MFMA256W4Y's generated loop body (tools/gen_hgemm_w4y.py; same bits, A/B knob)
  *   "hgemm_persist" 1 (default) = LC_HGEMM_MFMA256W4Y as one persistent workgroup per CU walking the C tiles, when their number is a
  *                  multiple of the CU count and larger (same bits as the one-tile launch, 0: + 0.2 % at the cap, + 0.7 % zero-filled)
@@ -126,7 +128,8 @@ const char* lc_build_info(int* is_diag);
  *                  swizzle_stride ignored)
  *   "hgemm_auto"   kernel LC_HGEMM_AUTO launches on large 256-tileable shapes (a 256-tile lc_hgemm_variant value)
  *   "fp8_mx"       fp8 GEMM: 1 = MX-scaled K = 64 MFMA, 4-wave kernel (default); 2 = MX, 8-wave kernel; 0 = plain K = 16
- *   "attn_d512"    D = 256 / 512 kernel: 0 = auto (one workgroup owns all D output columns), 1 = round-1 column-split kernel,
+ *   "attn_d512"    D = 256 / 512 / 1024 kernel: 0 = auto (D = 256 / 512: one workgroup owns all D output columns, attn_bigd2.hip — D = 256 also with
+ *                  V as [B,H,D,N]; D = 1024: two waves share 32 query rows and split the head dim, attn_bigd4.hip), 1 = round-1 column-split kernel,
  *                  2 = 32-row double-buffered tiles (attn_bigd3.hip: validated on hardware in round 3, 6-8 % slower, a cross-check)
  * Diagnosis keys (include/lc_diag.h) are rejected with LC_ERR_ARG unless the library was built with LC_DIAG=1. */
 int lc_tune_set(const char* key, int value);

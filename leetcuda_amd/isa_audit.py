@@ -12,8 +12,10 @@ one does not hold:
       (w4 GEMM / fp8 kernels: a0-a255; attention w4 kernels: the ranges named in their clobber lists)
   R2  no scratch: `.private_segment_fixed_size` == 0 (a spilled tuple would be reloaded around asm statements
       without the wait states the asm needs)
-  R4  kernels whose asm owns LITERAL arch VGPRs across statements or loop iterations (hgemm_w4y_kernel: v108..v255 hold the
-      fragments and read addresses of the generated K loop): no compiler-emitted instruction names one of them
+  R4  kernels whose asm owns LITERAL arch VGPRs ACROSS statements (attn_fwd_w4i_kernel: v[LB:255] are reserved registers that carry
+      the softmax state from one phase statement to the next): no compiler-emitted instruction names one of them.  (hgemm_w4y_kernel's
+      literal fragment registers live INSIDE its one K-loop statement — initialised there, all named as clobbers, nothing read by
+      another statement — so hipcc may use them between two executions of it; until round 4 the rule covered them too, vacuously.)
   R3  no compiler instruction reads or writes the destination registers of an asm-issued LDS / global load between
       the load and the next `s_waitcnt ... lgkmcnt(0)` / `vmcnt(0)` that retires it
   R5  no non-MFMA instruction names an arch VGPR written by an asm-issued MFMA before the MFMA's result latency has
@@ -50,7 +52,6 @@ OWNED_AGPRS = [
 
 # kernel-name regex -> literal arch VGPR range owned by the kernel's asm (inclusive)
 OWNED_VGPRS = [
-    (re.compile(r"hgemm_w4y_kernel"), (108, 255)),
     # attn_w4i: v[LB:255] are RESERVED registers (amdgpu_num_vgpr(LB)) holding the softmax state under literal names across
     # statements (tools/gen_attn_w4i.py register map): no compiler instruction may ever name one
     (re.compile(r"attn_fwd_w4i_kernelILi32E"), (104, 255)),

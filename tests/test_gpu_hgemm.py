@@ -426,3 +426,52 @@ def test_ragged_last_wave_goes_to_the_128_tile_kernel(oracle, layout, raster):
         truth = oracle.hgemm(a[rows].contiguous(), b, len(rows), N, K, 0, "f32")
         ok, mx, _ = tol.hgemm_close(outs[1][rows].float().cpu().numpy(), truth, K)
         assert ok, mx
+
+
+def test_concurrent_host_threads_on_two_streams():
+    """Round-3 advisor finding: the ragged-tail block count used to travel through a file-scope global, so two host threads launching
+    different shapes could pick up each other's truncated grid and leave part of C unwritten.  It is a launcher argument now: three
+    threads (ctypes releases the GIL inside the call), each with its own stream and shape — 504 tiles (last wave 248: one launch, one
+    tile per workgroup), 512 tiles (persistent walk with the cross-tile prefetch), 324 tiles (last wave 68 <= 128: the tail split,
+    256 tiles on the generated-loop kernel + 272 quadrants on the 128-tile kernel) — launch 60 GEMMs each at the same time; every
+    checked output must equal the single-threaded result bit for bit, with no unwritten (NaN-prefilled) element."""
+    import threading
+    capi = _capi()
+    shapes = [(6144, 5376, 256), (8192, 4096, 320), (4608, 4608, 256)]
+    data, want = [], []
+    for M, N, K in shapes:
+        torch.manual_seed(M + N)
+        a = torch.randn(M, K, dtype=torch.half, device="cuda")
+        b = host.as_col_major(torch.randn(K, N, dtype=torch.half, device="cuda"))
+        c = torch.full((M, N), float("nan"), dtype=torch.half, device="cuda")
+        capi.hgemm(a, b, c, layout=capi.LAYOUT_TN, variant=capi.HGEMM_AUTO, swizzle_stride=2048)
+        torch.cuda.synchronize()
+        assert torch.isfinite(c).all()
+        data.append((a, b))
+        want.append(c)
+    errs = []
+
+    def worker(idx):
+        try:
+            st = torch.cuda.Stream()
+            a, b = data[idx]
+            M, N = want[idx].shape
+            with torch.cuda.stream(st):
+                for it in range(60):
+                    c = torch.full((M, N), float("nan"), dtype=torch.half, device="cuda")
+                    capi.hgemm(a, b, c, layout=capi.LAYOUT_TN, variant=capi.HGEMM_AUTO, swizzle_stride=2048)
+                    if it % 10 == 9:
+                        st.synchronize()
+                        if not torch.equal(c, want[idx]):
+                            errs.append((idx, it))
+            st.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errs.append((idx, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(shapes))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs

@@ -446,3 +446,31 @@ def test_dynamic_attention_walk_claims_every_block_once_on_its_xcd():
             tail = per_xcd[x][G // 8:]
             assert tail == sorted(tail)               # claim order = ascending real ids inside the XCD's contiguous range
         assert sum(counters) == (nblk - G) + G        # every successful claim + exactly one failed claim per workgroup
+
+
+def test_hgemm_w4y_epilogue_staging_fits_one_ring_slot_and_is_conflict_free():
+    """hgemm_w4y.hip w4y_epilogue_b2 (round 4: the cross-tile prefetch owns A slots 0 / 1 and B slots 0 / 1, so the C tile leaves through B
+    slot 2 alone): four waves x 32 rows x 256 B = exactly 32 KiB, chunk c of row r at chunk c ^ (r & 15).  Written with 8-byte stores
+    (lane (r16, kg): row 16 ih + r16, logical chunk 2 j + (kg >> 1), half kg & 1), read back as whole rows with ds_read_b128 (lane ->
+    row 4 it + (lane >> 4), chunk slot (lane & 15) ^ (row & 15)): (1) every 8-byte cell of a pass is written once and read back as the
+    element the C row expects, (2) the b128 read groups are conflict-free."""
+    assert 4 * 32 * 256 == 32 * 1024
+    for ih_j in itertools.product(range(2), range(8)):
+        pass
+    # (1) content: simulate one pass of one wave
+    cell = {}
+    for ih, j in itertools.product(range(2), range(8)):
+        for lane in range(64):
+            r16, kg = lane & 15, lane >> 4
+            addr = (16 * ih + r16) * 256 + (((2 * j + (kg >> 1)) ^ r16) * 16) + 8 * (kg & 1)
+            assert addr not in cell
+            cell[addr] = (16 * ih + r16, 16 * j + 4 * kg)          # (row of the pass, first of 4 C columns)
+    assert len(cell) == 32 * 32
+    for it in range(8):
+        for lane in range(64):
+            row = it * 4 + (lane >> 4)
+            a = row * 256 + (((lane & 15) ^ (row & 15)) * 16)
+            assert cell[a] == (row, (lane & 15) * 8) and cell[a + 8] == (row, (lane & 15) * 8 + 4)
+        for grp in B128_GROUPS:
+            addrs = [(it * 4 + (lane >> 4)) * 256 + (((lane & 15) ^ ((it * 4 + (lane >> 4)) & 15)) * 16) for lane in grp]
+            assert conflict_free(addrs, 16), (it, grp)
