@@ -110,8 +110,6 @@ const char* lc_build_info(int* is_diag);
  *                  8 / 4 / 2 = lock-step kernel with that many waves (any N % (32 x waves) == 0, every D <= 128).  Auto: 515 up to N = 4096,
  *                  513 beyond (D = 64 / 128, N % 256 == 0); 514 for D = 96 / 32; else the lock-step kernel
  *   "attn_walk"    block walk of the merged-phase kernel under "attn_nw" = 0: 0 = auto by N (above), 1 / 2 / 3 = WALK 0 / 1 / 2
- *   "attn_lsum"    D = 64 merged-phase kernel: row sums l on the matrix core (a fifth column block against an all-ones V^T fragment: sums of the
- *                  fp16-rounded P, overflow guard on max P) instead of 32 v_add_f32 per lane and phase: 0 = auto, 1 = off, 2 = on
  *   "attn_w4i_sched" schedule 0 / 1 (default) of attn_w4i's generated phase statements (tools/gen_attn_w4i.py; same bits, A/B knob)
  *   "attn_d1024"   D = 1024 pair kernel (attn_bigd4.hip): its LDS-DMA pieces are spread over this many eighths of a phase: 0 = default (2), 4 / 6 / 8
  *   "w4y_sched"    schedule 0..2 of LC_HGEMM_MFMA256W4Y's generated loop body (tools/gen_hgemm_w4y.py; same bits, A/B knob)

@@ -47,33 +47,13 @@ struct W4U {
   static_assert(LDS <= 160 * 1024, "ring + staging must fit a CU's LDS");
 };
 
-typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
-
-// four row-sum blocks a[R0 + 4 qb ..] += ones(16 x 32) x Pᵀ(qb) in ONE statement (hipcc pads every asm boundary with a wait state)
-template <int R0>
-LC_DEVINL void an_pv4_ones(half8_t ones, half8_t p0, half8_t p1, half8_t p2, half8_t p3) {
-  asm volatile("v_mfma_f32_16x16x32_f16 a[%5:%6], %0, %1, a[%5:%6]\n\tv_mfma_f32_16x16x32_f16 a[%7:%8], %0, %2, a[%7:%8]\n\t"
-               "v_mfma_f32_16x16x32_f16 a[%9:%10], %0, %3, a[%9:%10]\n\tv_mfma_f32_16x16x32_f16 a[%11:%12], %0, %4, a[%11:%12]"
-               :: "v"(ones), "v"(p0), "v"(p1), "v"(p2), "v"(p3), "n"(R0), "n"(R0 + 3), "n"(R0 + 4), "n"(R0 + 7), "n"(R0 + 8), "n"(R0 + 11),
-                  "n"(R0 + 12), "n"(R0 + 15) : LC_AGPR_ALL);
-}
-
-template <int D, bool VT, int WALK, bool LSUM = false>
+template <int D, bool VT, int WALK>
 __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
     half_t* __restrict__ O, int N, int nqb, float sl2, int nblk, int nwg, int qslot) {
   static_assert(D == 64 || D == 128, "merged-phase attention kernel: D = 64 or 128 (D = 96 / 32: attn_w4i.hip)");
   static_assert(WALK >= 0 && WALK <= 2, "WALK: 0 one block per workgroup, 1 static persistent walk, 2 dynamic queue");
   constexpr bool PERSIST = WALK != 0;
-  // LSUM (D = 64: the kernel is bound by the vector ALU there — 3.7 fillers per 16-cycle MFMA, DESIGN.md §4.13b — while the matrix core
-  // idles > half of the time): the row sums l come off the MATRIX CORE.  A fifth "column block" of Oᵀ is accumulated against an all-ones
-  // Vᵀ fragment: block (qb) = a[GL + 4 qb ..] += 1(16 x 32) · Pᵀ(qb), every row of which is Σ_kv P[q][kv] — four MFMAs per phase (+ 12.5 %
-  // matrix work) instead of 32 v_add_f32 per lane.  The sums are then those of the fp16-ROUNDED P, the weights P·V actually uses
-  // (the reference sums the unrounded fp32 P, split_q.cu:467-468: same value to 2^-12 relative, inside every tolerance of tests/tol.py),
-  // and the overflow guard looks at max P instead of Σ P: a packed unsigned 16-bit max of the fp16 bit patterns (non-negative halves
-  // order like integers; inf / NaN sit above every finite value) — one v_pk_max_u16 per PAIR of scores.
-  static_assert(!LSUM || D == 64, "row sums on the matrix core: D = 64 only (D = 128 has no 16 AGPRs to spare)");
-  constexpr int GL = 128;   // LSUM: a[128 : 144) = the four row-sum blocks
   using G = W4G<D>;
   constexpr int NDS = G::NDS, NDB = G::NDB, ROWB = G::ROWB, TILE = G::TILE, SLOT = G::SLOT, NS = G::NS;
   constexpr int NRV = G::NRV, NRK = G::NRK, PPW = G::PPW, KBUF = G::KBUF;
@@ -129,11 +109,6 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
       vx[u] = (uint32_t)(TILE + (4 * g4 + (l16 >> 2)) * 128 + ((u ^ (((g4 & 1) << 1) | (l16 >> 3))) * 32) + 8 * (l16 & 3));
   }
   const uint32_t vodd = (uint32_t)((g4 & 1) ? -32 : 32);
-
-  half8_t vones;   // LSUM: the all-ones Vᵀ fragment (pinned: hipcc would otherwise rematerialise four v_mov per use)
-#pragma unroll
-  for (int e = 0; e < 8; ++e) vones[e] = (half_t)1.0f;
-  asm volatile("" : "+v"(vones));
 
   // ---- block walk: virtual block vb -> (head, first query row of this wave)
   int vb = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
@@ -242,7 +217,6 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
       am_acc_write<GQ + 4 * i + 3>(w[3]);
     });
     static_for<16 * NDB>([&](auto r) { am_acc_zero<decltype(r)::value>(); });
-    if constexpr (LSUM) static_for<16>([&](auto r) { am_acc_zero<GL + decltype(r)::value>(); });
 
     uint32_t ka[NDS], vc[NVX], vp[NVX];
     auto set_tile_addrs = [&](int t) {
@@ -321,14 +295,11 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
       constexpr int VB_H = H == 0 ? 1 : 0;
       wait_vset(I0{});
       float ps[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-      u16x2_t pmx[2] = {u16x2_t{0, 0}, u16x2_t{0, 0}};   // LSUM: running max of the packed P bit patterns (two chains)
       float e0 = 0.f, e1 = 0.f, c0 = 0.f, c1 = 0.f;
       auto pair_sum = [&](auto pc, auto wc, float a) {
-        if constexpr (!LSUM) {
-          constexpr int qb = (decltype(pc)::value >> 1) & 3, w = decltype(wc)::value;
-          ps[qb][w] += a;
-          asm volatile("" : "+v"(ps[qb][w]));
-        }
+        constexpr int qb = (decltype(pc)::value >> 1) & 3, w = decltype(wc)::value;
+        ps[qb][w] += a;
+        asm volatile("" : "+v"(ps[qb][w]));
       };
       auto pair_pack = [&](auto pc, float a, float b) {
         constexpr int p = decltype(pc)::value, kvb = p >> 3, qb = (p >> 1) & 3, k2 = p & 1;
@@ -336,9 +307,6 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
         asm volatile("" : "+v"(h2));
         pw[qb][4 * kvb + 2 * k2] = h2[0];
         pw[qb][4 * kvb + 2 * k2 + 1] = h2[1];
-        if constexpr (LSUM) {
-          pmx[p & 1] = __builtin_elementwise_max(pmx[p & 1], __builtin_bit_cast(u16x2_t, h2));   // (no asm pin: hipcc pads every asm boundary with an s_nop)
-        }
       };
       static_for<NS>([&](auto sc) {
         constexpr int s = decltype(sc)::value, i = s >> 1;
@@ -414,42 +382,24 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);
       });
-      if constexpr (LSUM && HAS_PV) {   // row sums of P(j−1) on the matrix core (its P·V MFMAs were the odd slots above)
-        an_pv4_ones<GL>(vones, pr[0], pr[1], pr[2], pr[3]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
       pair_sum(std::integral_constant<int, 15>{}, I0{}, e0);
       pair_sum(std::integral_constant<int, 15>{}, I1{}, e1);
       pair_pack(std::integral_constant<int, 15>{}, e0, e1);
       // ---------------- overflow guard (attn_mp.h)
       uint32_t worst_bits = 0;
-      bool ok;
-      if constexpr (LSUM) {
-        // both halves below fp16(2^14) = 0x7400 <=> adding 0x0c00 to each sets neither bit 15 (no carry between the halves:
-        // 0x7fff + 0x0c00 < 0x10000); inf (0x7c00) and NaN (>= 0x7c01) fail it
-        worst_bits = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(pmx[0], pmx[1]));
-        ok = ((worst_bits + 0x0c000c00u) & 0x80008000u) == 0u;
-      } else {
 #pragma unroll
-        for (int qb = 0; qb < 4; ++qb) worst_bits = max(worst_bits, __builtin_bit_cast(uint32_t, ps[qb][0] + ps[qb][1]));
-        ok = worst_bits < __builtin_bit_cast(uint32_t, AM_PSUM_LIMIT);
-      }
+      for (int qb = 0; qb < 4; ++qb) worst_bits = max(worst_bits, __builtin_bit_cast(uint32_t, ps[qb][0] + ps[qb][1]));
+      const bool ok = worst_bits < __builtin_bit_cast(uint32_t, AM_PSUM_LIMIT);
       if (!__all(ok)) {
         am_drain(sw);
         {
           float worst = 0.f;
           bool fin = true;
-          if constexpr (LSUM) {
-            const uint32_t hmax = max(worst_bits & 0xffffu, worst_bits >> 16);
-            fin = hmax < 0x7c00u;
-            worst = __builtin_bit_cast(float, hmax);     // (the fp16 bit pattern of the largest P, as an integer)
-          } else {
 #pragma unroll
-            for (int qb = 0; qb < 4; ++qb) {
-              const float x = ps[qb][0] + ps[qb][1];
-              fin = fin && finite_bits(x);
-              if (!psum_below(x, AM_PSUM_LIMIT)) worst = x;
-            }
+          for (int qb = 0; qb < 4; ++qb) {
+            const float x = ps[qb][0] + ps[qb][1];
+            fin = fin && finite_bits(x);
+            if (!psum_below(x, AM_PSUM_LIMIT)) worst = x;
           }
           const unsigned long long culprit = __ballot(!ok);
           if (lane == (int)__builtin_ctzll(culprit | (1ull << 63))) {
@@ -469,8 +419,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
           mx = an_x4_max(mx);
           const float delta = fmaxf(mx, 0.f);
           const float alpha = __builtin_amdgcn_exp2f(-delta);
-          if constexpr (LSUM) static_for<4>([&](auto rc) { am_acc_scale<GL + 4 * qb + decltype(rc)::value>(alpha); });
-          else l_run[qb] *= alpha;
+          l_run[qb] *= alpha;
           ps[qb][0] = 0.f;
           ps[qb][1] = 0.f;
 #pragma unroll
@@ -491,10 +440,8 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
         });
         asm volatile("s_nop 3" ::: "memory");
       }
-      if constexpr (!LSUM) {
 #pragma unroll
-        for (int qb = 0; qb < 4; ++qb) l_run[qb] += ps[qb][0] + ps[qb][1];
-      }
+      for (int qb = 0; qb < 4; ++qb) l_run[qb] += ps[qb][0] + ps[qb][1];
     };
     using F_FIRST0 = std::integral_constant<int, 2 | 4 | 8>;
     using F_MID = std::integral_constant<int, 1 | 2 | 4 | 8>;
@@ -538,7 +485,6 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
         constexpr int i = decltype(ic)::value, db = i >> 2, qb = i & 3;
         an_pv<GO + 4 * (4 * db + qb)>(cat4(vlo[db], vhi[db]), pB[qb]);
       });
-      if constexpr (LSUM) an_pv4_ones<GL>(vones, pB[0], pB[1], pB[2], pB[3]);
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (PERSIST) {
@@ -552,12 +498,8 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     raw_barrier();                     // every wave is done with ring slots 2, 3
     float inv[4];
-    if constexpr (LSUM) {   // every row of block (qb) holds the whole row sum of query 16 qb + l16: no cross-lane reduction
-      static_for<4>([&](auto qc) { inv[decltype(qc)::value] = 1.0f / am_acc_read<GL + 4 * decltype(qc)::value>(); });
-    } else {
 #pragma unroll
-      for (int qb = 0; qb < 4; ++qb) inv[qb] = 1.0f / an_x4_sum(l_run[qb]);
-    }
+    for (int qb = 0; qb < 4; ++qb) inv[qb] = 1.0f / an_x4_sum(l_run[qb]);
     char* stg = smem + W4U<D>::EPI_OFF + wave * (64 * G::EPI_STRIDE);
     static_for<4>([&](auto qc) {
       constexpr int qb = decltype(qc)::value;

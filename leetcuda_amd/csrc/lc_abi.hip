@@ -41,8 +41,6 @@ tune_t g_tune_fp8_mx{1};                       // fp8 GEMM: 1 = MX-scaled K=64 M
 tune_t g_tune_attn_w4i_sched{1};              // schedule of attn_fwd_w4i_kernel's generated phase statements (tools/gen_attn_w4i.py NSCHED; same bits)
 tune_t g_tune_attn_nw{0};                    // attention kernel for D <= 128: 0 = auto, 513 / 515 / 517 / 514 / 8 / 4 / 2 (choose_attn_nw, lc_abi.h)
 tune_t g_tune_attn_d1024{0};                 // attn_bigd4's DMA spread in eighths of a phase: 0 = default (2), 4 / 6 / 8 (A/B knob)
-tune_t g_tune_attn_lsum{0};                  // D = 64 merged-phase kernel: row sums on the matrix core — 0 = auto, 1 = off, 2 = on
-constexpr bool kAttnLsumAuto = false;        // what auto means (set from the A/B in profiles/)
 tune_t g_tune_attn_walk{0};                  // block walk of the merged-phase kernel under attn_nw = 0: 0 = auto by N, 1 / 2 / 3 = WALK 0 / 1 / 2
 tune_t g_tune_hgemm_auto{LC_HGEMM_MFMA256W4Y};   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
 tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to the 128-tile kernel (launch_mfma256), 0 = one launch
@@ -276,11 +274,6 @@ int attn_walk_auto(int N) {
   if (k >= 1 && k <= 3) return k - 1;
   return N <= 4096 ? 1 : 0;
 }
-// D = 64: row sums on the matrix core (attn_w4u.hip LSUM; lc_tune_set "attn_lsum": 0 = auto, 1 = off, 2 = on)
-int attn_lsum(int D) {
-  const int k = g_tune_attn_lsum;
-  return D == 64 && (k == 2 || (k == 0 && kAttnLsumAuto)) ? 1 : 0;
-}
 int choose_attn_nw(int D, bool vt, int N) {
   int want = g_tune_attn_nw;   // 0 = auto (read once per launch)
   if (want == 512) want = 513;
@@ -304,9 +297,8 @@ int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   if constexpr (D == 128 || D == 64) {
     if (nw == 513 || nw == 515 || nw == 517) {
       const int walk = (nw - 513) / 2;
-      const int lsum = attn_lsum(D);
-      if constexpr (D == 128) return VT ? launch_attn_w4u_d128t(Q, K, V, O, B, H, N, walk, 0, st) : launch_attn_w4u_d128(Q, K, V, O, B, H, N, walk, 0, st);
-      else return VT ? launch_attn_w4u_d64t(Q, K, V, O, B, H, N, walk, lsum, st) : launch_attn_w4u_d64(Q, K, V, O, B, H, N, walk, lsum, st);
+      if constexpr (D == 128) return VT ? launch_attn_w4u_d128t(Q, K, V, O, B, H, N, walk, st) : launch_attn_w4u_d128(Q, K, V, O, B, H, N, walk, st);
+      else return VT ? launch_attn_w4u_d64t(Q, K, V, O, B, H, N, walk, st) : launch_attn_w4u_d64(Q, K, V, O, B, H, N, walk, st);
     }
   }
   if constexpr (!VT) {
@@ -483,8 +475,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
     if (bf16) return LC_ERR_HEADDIM;
     const int nw = choose_attn_nw(D, v_transposed != 0, N);
     // (a persistent walk with no more blocks than CUs launches WALK 0; the name reports the walk asked for at this N)
-    if (nw == 513 || nw == 515 || nw == 517)
-      snprintf(buf, buflen, "attn_fwd_w4u_kernel<%d,%s,%d,%s>", D, vt, (nw - 513) / 2, attn_lsum(D) ? "true" : "false");
+    if (nw == 513 || nw == 515 || nw == 517) snprintf(buf, buflen, "attn_fwd_w4u_kernel<%d,%s,%d>", D, vt, (nw - 513) / 2);
     else if (nw == 514) snprintf(buf, buflen, "attn_fwd_w4i_kernel<%d,%d>", D, g_tune_attn_w4i_sched.load());
     else snprintf(buf, buflen, "attn_fwd_kernel<%d,%d,%s,0>", D, nw, vt);
     return LC_OK;
@@ -537,7 +528,6 @@ struct Knob {
 const Knob kKnobs[] = {
     {"attn_nw", &g_tune_attn_nw, 0, ok_attn_nw, false},
     {"attn_walk", &g_tune_attn_walk, 0, ok_03, false},
-    {"attn_lsum", &g_tune_attn_lsum, 0, ok_02, false},
     {"attn_d1024", &g_tune_attn_d1024, 0, ok_span8, false},
     {"attn_w4i_sched", &g_tune_attn_w4i_sched, 1, ok_01, false},
     {"fp8_mx", &g_tune_fp8_mx, 1, ok_02, false},

@@ -89,8 +89,8 @@ def test_isa_audit_report_is_clean(built):
     import json
     rep = json.loads((built["abi"].parent / "obj" / "isa_audit.json").read_text())
     names = " ".join(r["kernel"] for r in rep)
-    for k in ("hgemm_w4b_kernel", "hgemm_w4x_kernel", "hgemm_w4y_kernel", "gemm_fp8_w4_kernel", "attn_fwd_w4u_kernelILi128ELb0ELi0ELb0",
-              "attn_fwd_w4u_kernelILi128ELb1ELi2ELb0", "attn_fwd_w4u_kernelILi64ELb0ELi1ELb1", "attn_fwd_w4u_kernelILi64ELb1ELi0ELb0",
+    for k in ("hgemm_w4b_kernel", "hgemm_w4x_kernel", "hgemm_w4y_kernel", "gemm_fp8_w4_kernel", "attn_fwd_w4u_kernelILi128ELb0ELi0",
+              "attn_fwd_w4u_kernelILi128ELb1ELi2", "attn_fwd_w4u_kernelILi64ELb0ELi1", "attn_fwd_w4u_kernelILi64ELb1ELi0",
               "attn_fwd_w4i_kernel", "attn_fwd_bigd2_kernel", "hgemm_pingpong2_kernel"):
         assert k in names, k
     assert all(r["scratch"] == 0 and not r["violations"] for r in rep)
@@ -129,7 +129,7 @@ def test_isa_audit_detects_early_read_of_asm_mfma_result(tmp_path):
     behind the asm MFMA that writes them because the drain was a bare asm volatile.  A bare s_nop drain AFTER the read does
     not help; enough wait states BEFORE it do; MFMA -> MFMA accumulation chains are the hardware's business."""
     from leetcuda_amd import isa_audit
-    head = "\t.type\t_ZN2lc19attn_fwd_w4u_kernelILi128ELb0ELi0ELb0EEEvv,@function\n_ZN2lc19attn_fwd_w4u_kernelILi128ELb0ELi0ELb0EEEvv:\n"
+    head = "\t.type\t_ZN2lc19attn_fwd_w4u_kernelILi128ELb0ELi0EEEvv,@function\n_ZN2lc19attn_fwd_w4u_kernelILi128ELb0ELi0EEEvv:\n"
     tail = ".Lfunc_end0:\n"
     mfma = ("\t;;#ASMSTART\n\tv_mfma_f32_16x16x32_f16 v[2:5], a[0:3], a[4:7], v[2:5]\n\t;;#ASMEND\n"
             "\t;;#ASMSTART\n\tv_mfma_f32_16x16x32_f16 v[2:5], a[8:11], a[12:15], v[2:5]\n\t;;#ASMEND\n")
@@ -149,7 +149,7 @@ def test_isa_audit_replays_hazards_across_a_loop_back_edge(tmp_path):
     head reads v2 with a VALU instruction is clean in file order (the head comes first) and wrong on the back edge; with the
     wait states in front of the branch it is clean on both."""
     from leetcuda_amd import isa_audit
-    head = "\t.type\t_ZN2lc19attn_fwd_w4u_kernelILi128ELb0ELi0ELb0EEEvv,@function\n_ZN2lc19attn_fwd_w4u_kernelILi128ELb0ELi0ELb0EEEvv:\n"
+    head = "\t.type\t_ZN2lc19attn_fwd_w4u_kernelILi128ELb0ELi0EEEvv,@function\n_ZN2lc19attn_fwd_w4u_kernelILi128ELb0ELi0EEEvv:\n"
     tail = ".Lfunc_end0:\n"
     loop = (".LBB0_1:\n\tv_max_f32_e32 v1, v2, v3\n\ts_nop 7\n"
             "\t;;#ASMSTART\n\tv_mfma_f32_16x16x32_f16 v[2:5], a[0:3], a[4:7], v[2:5]\n\t;;#ASMEND\n"
@@ -229,7 +229,7 @@ def test_status_strings_and_argument_errors(built):
     assert lib.lc_attn_fwd_f16(one, one, one, one, 1, 1, 1 << 23, 128, 0, 0, 0, 2, None) == capi.LC_ERR_SHAPE
     assert lib.lc_attn_fwd_bf16(one, one, one, one, 1, 1, 1 << 21, 512, None) == capi.LC_ERR_SHAPE
     assert lib.lc_attn_kernel_name(1 << 23, 128, 0, 0, buf, 128) == capi.LC_ERR_SHAPE
-    assert lib.lc_attn_kernel_name((1 << 23) - 256, 128, 0, 0, buf, 128) == capi.LC_OK and buf.value.startswith(b"attn_fwd_w4u_kernel<128,false,0,false>")
+    assert lib.lc_attn_kernel_name((1 << 23) - 256, 128, 0, 0, buf, 128) == capi.LC_OK and buf.value.startswith(b"attn_fwd_w4u_kernel<128,false,0>")
     # head-dim limits of the reference dispatchers (split_q: 128; share_qkv stage2: 128, stage1: 256)
     assert lib.lc_attn_call(b"flash_attn_mma_stages_split_q", one, one, one, one, 1, 1, 128, 256, 2, None) \
         == capi.LC_ERR_HEADDIM

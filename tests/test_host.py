@@ -182,13 +182,13 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_NN, capi.HGEMM_MFMA256P2) == "hgemm_pingpong2_kernel<true,false>"
     assert capi.hgemm_kernel_name(1024, 1024, 1024, capi.LAYOUT_NN) == "hgemm_mfma128_kernel<true>"
     assert capi.hgemm_kernel_name(1000, 1024, 1024, capi.LAYOUT_NN) == "hgemm_generic_kernel<true>"
-    assert capi.attn_kernel_name(4096, 128) == "attn_fwd_w4u_kernel<128,false,1,false>"            # config 3: the persistent workgroup, static walk
-    assert capi.attn_kernel_name(8192, 128) == "attn_fwd_w4u_kernel<128,false,0,false>"            # config 4: one block per workgroup (the dispatcher balances 16+ blocks per CU best)
-    assert capi.attn_kernel_name(4096, 128, True) == "attn_fwd_w4u_kernel<128,true,1,false>"       # V handed over as [B,H,D,N]: the same kernel
+    assert capi.attn_kernel_name(4096, 128) == "attn_fwd_w4u_kernel<128,false,1>"            # config 3: the persistent workgroup, static walk
+    assert capi.attn_kernel_name(8192, 128) == "attn_fwd_w4u_kernel<128,false,0>"            # config 4: one block per workgroup (the dispatcher balances 16+ blocks per CU best)
+    assert capi.attn_kernel_name(4096, 128, True) == "attn_fwd_w4u_kernel<128,true,1>"       # V handed over as [B,H,D,N]: the same kernel
     assert capi.attn_kernel_name(4096 + 128, 128) == "attn_fwd_kernel<128,4,false,0>"      # N % 256 != 0
     assert capi.attn_kernel_name(192, 64, True) == "attn_fwd_kernel<64,2,true,0>"
-    assert capi.attn_kernel_name(8192, 64).startswith("attn_fwd_w4u_kernel<64,false,0,")               # the reference's published shapes
-    assert capi.attn_kernel_name(8192, 64, True).startswith("attn_fwd_w4u_kernel<64,true,0,")
+    assert capi.attn_kernel_name(8192, 64) == "attn_fwd_w4u_kernel<64,false,0>"               # the reference's published shapes
+    assert capi.attn_kernel_name(8192, 64, True) == "attn_fwd_w4u_kernel<64,true,0>"
     assert capi.attn_kernel_name(8192, 96, True) == "attn_fwd_kernel<96,8,true,0>"            # D = 96 / 32 with V transposed: lock-step
     assert capi.attn_kernel_name(8192, 96) == "attn_fwd_w4i_kernel<96,1>"                     # only the generated kernel has a D = 96 instantiation
     assert capi.attn_kernel_name(8192 + 64, 96) == "attn_fwd_kernel<96,2,false,0>"            # N % 256 != 0: lock-step
@@ -197,7 +197,7 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     assert capi.attn_kernel_name(192, 512, False, False).startswith("attn_fwd_bigd_kernel<512,")     # N % 128 != 0
     assert sump.short("_ZN2lc16hgemm_w4b_kernelILb0ELb1ELi0EEEvPKDF16_S2_PDF16_iiiiii") == \
         "hgemm_w4b_kernel<false,true,0>"
-    assert sump.short("_ZN2lc19attn_fwd_w4u_kernelILi128ELb1ELi2ELb0EEEvPKDF16_S2_S2_PDF16_iifiii") == "attn_fwd_w4u_kernel<128,true,2,false>"
+    assert sump.short("_ZN2lc19attn_fwd_w4u_kernelILi128ELb1ELi2EEEvPKDF16_S2_S2_PDF16_iifiii") == "attn_fwd_w4u_kernel<128,true,2>"
     pmc = json.loads((root / "profiles" / "latest_pmc.json").read_text())
     for key, wl, other in ((capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN), "hgemm_8192", "hgemm_4096"),
                            (capi.attn_kernel_name(4096, 128), "attn_cfg3", "attn_cfg4"),
@@ -235,10 +235,10 @@ def test_steady_state_loops_keep_their_instruction_mix(built):
     g, gv = mix("tu_w4.s", r"hgemm_w4y_kernelILb0ELi1E", r"w4y_loop")   # the K loop (the kernel's outer loop is the persistent tile walk)
     assert (g["mfma"], g["lds"], g["vmem"], g["s_barrier"], g["s_nop"]) == (128, 32, 16, 1, 0), g
     assert gv <= 8, g
-    g64, g64v = mix("tu_attn_w4u_d64.s", r"attn_fwd_w4u_kernelILi64ELb0ELi0ELb0")   # D = 64: one tile = 64 MFMAs for the same 64 score elements
+    g64, g64v = mix("tu_attn_w4u_d64.s", r"attn_fwd_w4u_kernelILi64ELb0ELi0")   # D = 64: one tile = 64 MFMAs for the same 64 score elements
     assert g64["mfma"] == 64 and g64["valu_trans"] == 64 and g64["s_barrier"] == 1, g64
     assert g64v / 64 <= 3.0, (g64v, g64)
-    for unit, rx in (("tu_attn_w4u_d128.s", r"attn_fwd_w4u_kernelILi128ELb0ELi0ELb0"), ("tu_attn_w4u_d128t.s", r"attn_fwd_w4u_kernelILi128ELb1ELi0ELb0")):
+    for unit, rx in (("tu_attn_w4u_d128.s", r"attn_fwd_w4u_kernelILi128ELb0ELi0"), ("tu_attn_w4u_d128t.s", r"attn_fwd_w4u_kernelILi128ELb1ELi0")):
         n, nv = mix(unit, rx)                                        # one 64-key tile: 64 score elements per lane, either V layout
         assert n["mfma"] == 128 and n["valu_trans"] == 64 and n["s_barrier"] == 1 and n["lds"] == 48, n
         assert nv / 64 <= 3.2, (nv, n)

@@ -23,7 +23,7 @@ while args and args[0].startswith("--"):
         raise SystemExit(f"unknown option {args[0]}")
     args = args[2:]
 capi.load()
-KNOBS = {"nw": "attn_nw", "walk": "attn_walk", "lsum": "attn_lsum", "d512": "attn_d512", "d1024": "attn_d1024", "sched": "attn_w4i_sched"}
+KNOBS = {"nw": "attn_nw", "walk": "attn_walk", "d512": "attn_d512", "d1024": "attn_d1024", "sched": "attn_w4i_sched"}
 cache = {}
 
 

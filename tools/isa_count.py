@@ -145,8 +145,7 @@ if __name__ == "__main__":
         report(sys.argv[1], sys.argv[2], float(sys.argv[3]))
     else:
         # w4u: one loop iteration = one 64-key tile for 64 query rows per wave = 4096 scores / 64 lanes
-        report(OBJ / "tu_attn_w4u_d128.s", r"attn_fwd_w4u_kernelILi128ELb0ELi0ELb0", 64)
-        report(OBJ / "tu_attn_w4u_d128t.s", r"attn_fwd_w4u_kernelILi128ELb1ELi0ELb0", 64)
-        report(OBJ / "tu_attn_w4u_d64.s", r"attn_fwd_w4u_kernelILi64ELb0ELi0ELb0", 64)
-        report(OBJ / "tu_attn_w4u_d64.s", r"attn_fwd_w4u_kernelILi64ELb0ELi0ELb1", 64)   # row sums on the matrix core
+        report(OBJ / "tu_attn_w4u_d128.s", r"attn_fwd_w4u_kernelILi128ELb0ELi0", 64)
+        report(OBJ / "tu_attn_w4u_d128t.s", r"attn_fwd_w4u_kernelILi128ELb1ELi0", 64)
+        report(OBJ / "tu_attn_w4u_d64.s", r"attn_fwd_w4u_kernelILi64ELb0ELi0", 64)
         report(OBJ / "tu_w4.s", r"hgemm_w4y_kernelILb0ELi1E", 0, r"w4y_loop")   # (the K loop, not the persistent tile walk)
