@@ -75,6 +75,12 @@ if a.what in ("all", "attn"):
         capi.attn_fwd_bf16(qb, kb, vb, ob)
     torch.cuda.synchronize()
     del q, k, v, o, qb, kb, vb, ob
+    # D = 1024 (1,48,8192,1024): the pair kernel attn_bigd4.hip (tools/prof_workloads.py: "attn_d1024")
+    q, k, v, o, tv = host.get_qkvo(1, 48, 8192, 1024, seed=0)
+    for _ in range(max(1, a.iters // 2)):
+        capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, o, 2)
+    torch.cuda.synchronize()
+    del q, k, v, o, tv
     n = 16384   # config 5b: fp8 e4m3 GEMM (tools/prof_workloads.py: "fp8_16384")
     a8 = torch.randn(n, n, device="cuda").to(torch.float8_e4m3fn)
     b8 = torch.randn(n, n, device="cuda").to(torch.float8_e4m3fn)
