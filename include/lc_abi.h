@@ -111,7 +111,7 @@ const char* lc_build_info(int* is_diag);
  *                  513 beyond (D = 64 / 128, N % 256 == 0); 514 for D = 96 / 32; else the lock-step kernel
  *   "attn_walk"    block walk of the merged-phase kernel under "attn_nw" = 0: 0 = auto by N (above), 1 / 2 / 3 = WALK 0 / 1 / 2
  *   "attn_w4i_sched" schedule 0 / 1 (default) of attn_w4i's generated phase statements (tools/gen_attn_w4i.py; same bits, A/B knob)
- *   "attn_d1024"   D = 1024 pair kernel (attn_bigd4.hip): its LDS-DMA pieces are spread over this many eighths of a phase: 0 = default (2), 4 / 6 / 8
+ *   "attn_d1024"   D = 1024 pair kernel (attn_bigd4.hip): a batch of 8 LDS-DMA pieces is spread over this many eighths of a half-phase: 0 = default (8), 2 / 4 / 6
  *   "w4y_sched"    schedule 0..2 of LC_HGEMM_MFMA256W4Y's generated loop body (tools/gen_hgemm_w4y.py; same bits, A/B knob)
  *   "hgemm_persist" 1 (default) = LC_HGEMM_MFMA256W4Y as one persistent workgroup per CU walking the C tiles, when their number is a
  *                  multiple of the CU count and larger (same bits as the one-tile launch, 0: + 0.2 % at the cap, + 0.7 % zero-filled)

@@ -10,13 +10,16 @@
 //   * a workgroup = 4 wave64 = 2 PAIRS, pair p = wave >> 1 owns query rows 32 p .. + 31 of the workgroup's 64; member h = wave & 1
 //     owns the d-half [512 h, 512 h + 512): its Q fragments (32 rows x 512 d, 128 VGPR-equivalents as in attn_bigd2<512>), its half
 //     of every Q·Kᵀ reduction and its 512 columns of Oᵀ (the 256 AGPRs);
-//   * KV tile = 32 rows: K tile 32 x 1024 and V tile 32 x 1024 single-buffered in LDS (64 KiB each), filled by LDS-DMA in the
-//     shadow of the OTHER phase exactly as in attn_bigd2.hip;
+//   * KV tile = 32 rows: K tile 32 x 1024 and V tile 32 x 1024 single-buffered in LDS (64 KiB each), filled by LDS-DMA with
+//     HALF-TILE RECYCLING: each region is split by the order in which it is consumed (K: four d-panels, V: two row halves), a barrier
+//     in the middle of each phase frees the half just read, and every batch of 8 pieces per wave is needed one and a half phases
+//     after its issue (see "LDS images and LDS-DMA" below; the first version, with attn_bigd2's one-phase DMA, was TA + latency bound:
+//     MFMA-busy 0.31, 720 - 745 TFLOP/s; this one 867);
 //   * phase A: partial Sᵀ(t) = K(t)[:, my d-half] · Qᵀ[my d-half] — 32 MFMAs in two chains — is summed and written to a 4-KiB
 //     exchange area, [barrier], read back from the partner and ADDED (a + b == b + a bit for bit: both members hold the same Sᵀ,
 //     hence the same m, P and l — the softmax is computed redundantly, 16 exps per lane and tile, as filler);
 //   * phase B: Oᵀ[my 512 columns] += Vᵀ(t−1)[my columns] · Pᵀ(t−1) — 32 MFMAs — with softmax(t) between the statements.
-//   Per wave and tile: 64 MFMAs (= 2048 matrix-core cycles), 64 KiB of K / V fragment reads + 8 KiB of exchange, two barriers.
+//   Per wave and tile: 64 MFMAs (= 2048 matrix-core cycles), 64 KiB of K / V fragment reads + 8 KiB of exchange, four barriers.
 //   Per CU and tile the LDS-DMA moves 128 KiB for 64 query rows: 64 B/clk at full MFMA rate — twice attn_bigd2's and the whole rate
 //   of the texture-address unit (one 1-KiB piece per 16 cycles).  That is what D = 1024 costs on this chip: 64 query rows per CU is
 //   all the register file holds (64 x 1024 fp32 = half of a CU's registers), so a K / V byte feeds 128 FLOPs where D = 512 gets 256.
@@ -36,6 +39,18 @@ constexpr int BD4_QPK = BD4_XCH + 4 * 4096; // parked Q: 4 waves x PARK KiB
 constexpr int BD4_LDS = BD4_QPK + 4 * BD4_PARK * 1024;
 static_assert(BD4_LDS == 160 * 1024, "bigd4 uses a CU's whole LDS");
 static_assert(2 * (512 / 32 / 4) == 8, "the softmax filler plan below is written for 8 P.V steps per tile");
+
+// the eight transpose reads of a k-step's first P·V step (d tiles 0 .. 3; kv rows at OFF, second half at OFF + HOFF), in fragment
+// order, into the fixed quads (bd2_rd0 with a row offset; a free function: clang refuses asm register constraints on lambda captures)
+template <int OFF, int HOFF>
+LC_DEVINL void bd4_rd_g(half8_t& f0, half8_t& f1, half8_t& f2, half8_t& f3, const uint32_t (&vx)[4]) {
+  asm volatile("ds_read_b64_tr_b16 v[240:241], %4 offset:%8\n\tds_read_b64_tr_b16 v[242:243], %4 offset:%9\n\t"
+               "ds_read_b64_tr_b16 v[244:245], %5 offset:%8\n\tds_read_b64_tr_b16 v[246:247], %5 offset:%9\n\t"
+               "ds_read_b64_tr_b16 v[248:249], %6 offset:%8\n\tds_read_b64_tr_b16 v[250:251], %6 offset:%9\n\t"
+               "ds_read_b64_tr_b16 v[252:253], %7 offset:%8\n\tds_read_b64_tr_b16 v[254:255], %7 offset:%9"
+               : "={v[240:243]}"(f0), "={v[244:247]}"(f1), "={v[248:251]}"(f2), "={v[252:255]}"(f3)
+               : "v"(vx[0]), "v"(vx[1]), "v"(vx[2]), "v"(vx[3]), "n"(OFF), "n"(OFF + HOFF));
+}
 
 template <int SP8>   // the DMA pieces of a phase are spread over SP8 eighths of it (A/B knob, lc_tune_set "attn_d1024")
 __global__ __launch_bounds__(256) void attn_fwd_bigd4_kernel(
@@ -67,25 +82,40 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd4_kernel(
   char* const ksm = smem;
   char* const vsm = smem + TILE;
 
-  // ---- LDS-DMA: piece i of this wave = half (i >> 3) of row wave + 4 (i & 7): 64 lanes x 16 B = 1 KiB.  Lane chunk slot cs holds
-  // source chunk cs ^ key(row) (K: row & 15 — four values over i -> k_off[i & 3]; V: (row & 3) << 2 = (wave & 3) << 2), all inside
-  // the lane's own 256-B group, so a half-row stays a half-row.
+  // ---- LDS images and LDS-DMA (round 4, second version: HALF-tile recycling).
+  // K region = four PANELS of 16 KiB, panel P = 2 (d-half of the wave that reads it) + lohi: [32 rows][512 B] = the d range
+  // [512 (P >> 1) + 256 (P & 1), + 256) of the tile's 32 rows; a DMA piece (1 KiB) = rows 2 p, 2 p + 1 of one panel (lanes 0-31 / 32-63),
+  // 16-B chunk c of row r at slot c ^ (r & 15).  "K-lo" = panels 0, 2 (what the k-steps 0 .. 15 of the two d-halves read), "K-hi" =
+  // panels 1, 3 (k-steps 16 .. 31).  V region = [32 rows][2048 B] row-major, 64-B unit u of row r at unit u ^ (r & 3); a piece = half
+  // a row; "V-lo" = rows 0 .. 15 (P·V steps of k-step g = 0), "V-hi" = rows 16 .. 31 (g = 1).
+  // Every half region is refilled as soon as ITS consumer half-phase is over (a barrier in the middle of each phase says so) and is
+  // needed again one and a half phases later: a batch of 8 pieces per wave is issued in every half-phase —
+  //     A(t) first half:  V-hi(t−1)      A(t) second half: K-lo(t+1)      B(t) first half:  K-hi(t+1)      B(t) second half: V-lo(t)
+  // — and every synchronisation point waits for vmcnt(16): the batch it needs is the OLDEST of the three in flight (loads return
+  // in order).  The first version of this kernel gave every piece one phase: the phase then lasted as long as the texture-address
+  // unit needs for a whole tile (64 pieces x 16 cycles) plus an L2 read latency of ~700 cycles, MFMA-busy 0.31.
   const buf_rsrc_t rk = make_rsrc(Kb), rv = make_rsrc(Vb);
   unsigned k_off[4], v_off;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) k_off[j] = (unsigned)(((lane & 63) ^ ((wave + 4 * j) & 15)) * 16);
+  for (int j = 0; j < 4; ++j) {   // this wave's K pieces: panel 2 (wave & 1) + lohi, row pairs p = (wave >> 1) + 2 i, i = 0 .. 7; key by i & 3
+    const int row = 2 * ((wave >> 1) + 2 * j) + (lane >> 5);
+    k_off[j] = (unsigned)((lane >> 5) * ROWB + (((lane & 31) ^ (row & 15)) * 16));
+  }
   v_off = (unsigned)(((lane & 63) ^ ((wave & 3) << 2)) * 16);
-  auto piece_off = [&](int i) { return (unsigned)((wave + 4 * (i & 7)) * ROWB + (i >> 3) * 1024); };
-  auto issue_k = [&](int i, int t) {
+  auto issue_k = [&](int i, int lohi, int t) {   // piece i (0 .. 7) of K-lo / K-hi of tile t (clamped)
     const int te = t < T ? t : T - 1;
-    blds16(rk, k_off[i & 3], (unsigned)te * TILE + piece_off(i), ksm + piece_off(i));
+    const int P = 2 * (wave & 1) + lohi, pp = (wave >> 1) + 2 * i;
+    blds16(rk, k_off[i & 3], (unsigned)te * TILE + (unsigned)(2 * pp) * ROWB + (unsigned)P * 512u, ksm + P * 16384 + pp * 1024);
   };
-  auto issue_v = [&](int i, int t) {
+  auto issue_v = [&](int i, int lohi, int t) {   // piece i (0 .. 7) of V-lo / V-hi of tile t: half (i >> 2) of row 16 lohi + wave + 4 (i & 3)
     const int te = t < T ? t : T - 1;
-    blds16(rv, v_off, (unsigned)te * TILE + piece_off(i), vsm + piece_off(i));
+    const unsigned off = (unsigned)((16 * lohi + wave + 4 * (i & 3)) * ROWB + (i >> 2) * 1024);
+    blds16(rv, v_off, (unsigned)te * TILE + off, vsm + off);
   };
 #pragma unroll
-  for (int i = 0; i < NPIECE; ++i) issue_k(i, 0);
+  for (int i = 0; i < 8; ++i) issue_k(i, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) issue_k(i, 1, 0);
 
   // ---- Q fragments of this wave's d-half -> registers (once): lane holds Q[q0 + l32][dcol + 16 ks + 8 hi .. +8]
   constexpr int PARK = BD4_PARK, NRES = NKS - PARK;
@@ -98,10 +128,10 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd4_kernel(
     *(half8_t*)(qpark + i * 1024) = *(const half8_t*)(Qb + (size_t)(q0 + l32) * D + dcol + 16 * (NRES + i) + 8 * hi);
   static_for<DH / 2>([&](auto r) { am_acc_zero<decltype(r)::value>(); });
 
-  // ---- fragment read addresses (attn_bigd2.hip's layouts on 2-KiB rows; this wave's half starts 1 KiB into every row)
-  const char* kx[8];   // K: row l32, chunk 64 half + 2 ks + hi: low 4 bits XOR (row & 15); + (ks >> 3) * 256 as immediate
+  // ---- fragment read addresses
+  const char* kx[8];   // K: panel 2 dhf (+ ks >> 4 panels), row l32, chunk 16 ((ks >> 3) & 1) + 2 (ks & 7) + hi: low 4 bits XOR (row & 15)
 #pragma unroll
-  for (int k8 = 0; k8 < 8; ++k8) kx[k8] = ksm + l32 * ROWB + dhf * 1024 + (((2 * k8 + hi) ^ (l32 & 15)) * 16);
+  for (int k8 = 0; k8 < 8; ++k8) kx[k8] = ksm + dhf * 32768 + l32 * 512 + (((2 * k8 + hi) ^ (l32 & 15)) * 16);
   const int vi = lane & 15, vgi = (lane >> 4) & 1;
   uint32_t vx[4];      // Vᵀ: kv row 4 hi + (vi >> 2) (+ 16 g, + 8), 64-B unit dt: low 2 bits XOR (row & 3); + (dt >> 2) * 256 immediate
 #pragma unroll
@@ -114,59 +144,73 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd4_kernel(
   float m_run = -INFINITY, l_run = 0.f;
   half8_t pfa[2], pfb[2];   // P fragments (k-step g = 16 kv rows) of the even / odd tiles
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  raw_barrier();   // K(0) landed; every wave's parked Q is its own (lane-private slots: no barrier needed for it)
-
   half8_t vf0, vf1, vf2, vf3;
   constexpr int NQ = NDT / 4, NST = 2 * NQ;       // P·V steps per tile: (g, dq), g = 0, 1 (16 kv rows each), dq = quad of d tiles
-  constexpr int SPAN_A = SP8 * NKS / 8, SPAN_B = SP8 * NST / 8;   // DMA pieces spread over 7/8 of a phase: the texture-address unit (16 cycles per piece, four waves) is busy for the whole phase at full MFMA rate
-  auto rd0 = [&]() { bd2_rd0<8 * ROWB>(vf0, vf1, vf2, vf3, vx); };
+  constexpr int SPAN_AH = SP8 * (NKS / 2) / 8, SPAN_BH = SP8 * NQ / 8 > 0 ? SP8 * NQ / 8 : 1;   // a batch of 8 pieces over SP8 eighths of a HALF-phase
+  // synchronisation point: the batch this half-phase reads has landed in every wave (it is the oldest of three in flight; the first
+  // two tiles — fewer batches in flight — wait for everything), every wave is done with the half region the next batch refills
+  auto sync_pt = [&](auto warmc) {
+    if constexpr (decltype(warmc)::value) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    raw_barrier();
+  };
+  // first Vᵀ fragments of k-step g (d tiles 0 .. 3) into the fixed quads
+  auto rd_g = [&](auto gc) { bd4_rd_g<decltype(gc)::value * 16 * ROWB, 8 * ROWB>(vf0, vf1, vf2, vf3, vx); };
+  // P·V step st = (g, dq): the four MFMAs of d tiles 4 dq .. + 3 and — inside a k-step — the transpose reads of the next step's
+  // fragments; the last step of a k-step reads nothing (the other half of V is only known to have landed behind the barrier)
   auto pv_step = [&](auto stc, half8_t (&pf)[2]) {
     constexpr int st = decltype(stc)::value, g = st / NQ, dq = st % NQ;
-    constexpr int g1 = (st + 1) / NQ, dq1 = (st + 1) % NQ;
-    bd2_pv4_fix<64 * dq, BF16, (st + 1 < NST), dq1 * 256 + g1 * 16 * ROWB, 8 * ROWB>(vf0, vf1, vf2, vf3, pf[g], vx);
+    bd2_pv4_fix<64 * dq, BF16, (dq + 1 < NQ), (dq + 1) * 256 + g * 16 * ROWB, 8 * ROWB>(vf0, vf1, vf2, vf3, pf[g], vx);
   };
 
-  // ---- one tile period (attn_bigd2.hip's, + the exchange).  pn = P(t) (written), po = P(t−1) (read).  HAS_PV = false: tile 0.
-  auto tile = [&](auto pvc, int t, half8_t (&pn)[2], half8_t (&po)[2]) {
+  // ---- one tile period.  pn = P(t) (written), po = P(t−1) (read).  HAS_PV = false: tile 0.  WARM: tiles 0 and 1.
+  auto tile = [&](auto pvc, auto warmc, int t, half8_t (&pn)[2], half8_t (&po)[2]) {
     constexpr bool HAS_PV = decltype(pvc)::value;
     f32x16_t s[2];   // two independent accumulation chains over the even / odd k-steps of this wave's d-half
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[c][r] = 0.f;
-    {
+    // =========================== phase A: Sᵀ(t) = K(t)[:, my d-half] · Qᵀ[my d-half]
+    sync_pt(warmc);                                     // K-lo(t) landed; every wave is out of P·V(t−2 .. ): V-hi may be refilled
+    static_for<2>([&](auto hc) {
+      constexpr int KH = decltype(hc)::value, K0 = KH * (NKS / 2);
+      if constexpr (KH == 1) sync_pt(warmc);            // K-hi(t) landed; K-lo(t) is dead
       half8_t kfr[3], qfr[3];
       auto ldk = [&](auto kc, auto rc) {
         constexpr int ks = decltype(kc)::value, r = decltype(rc)::value;
-        kfr[r] = *(const half8_t*)(kx[ks & 7] + (ks >> 3) * 256);
+        kfr[r] = *(const half8_t*)(kx[ks & 7] + (ks >> 4) * 16384 + ((ks >> 3) & 1) * 256);
         if constexpr (ks >= NRES) qfr[r] = *(const half8_t*)(qpark + (ks - NRES) * 1024);
       };
-      ldk(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-      ldk(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-      static_for<NKS>([&](auto kc) {
-        constexpr int ks = decltype(kc)::value;
-        if constexpr (ks + 2 < NKS) ldk(std::integral_constant<int, ks + 2>{}, std::integral_constant<int, (ks + 2) % 3>{});
-        if constexpr (HAS_PV)
-          static_for<NPIECE>([&](auto ic) {
-            if constexpr (decltype(ic)::value * SPAN_A / NPIECE == ks) issue_v(decltype(ic)::value, t - 1);
-          });
+      ldk(std::integral_constant<int, K0>{}, std::integral_constant<int, K0 % 3>{});
+      ldk(std::integral_constant<int, K0 + 1>{}, std::integral_constant<int, (K0 + 1) % 3>{});
+      static_for<NKS / 2>([&](auto kc) {
+        constexpr int kl = decltype(kc)::value, ks = K0 + kl;
+        if constexpr (kl + 2 < NKS / 2) ldk(std::integral_constant<int, ks + 2>{}, std::integral_constant<int, (ks + 2) % 3>{});
+        static_for<8>([&](auto ic) {
+          if constexpr (decltype(ic)::value * SPAN_AH / 8 == kl) {
+            if constexpr (KH == 0) {
+              if constexpr (HAS_PV) issue_v(decltype(ic)::value, 1, t - 1);   // V-hi(t−1)
+            } else {
+              issue_k(decltype(ic)::value, 0, t + 1);                         // K-lo(t+1)
+            }
+          }
+        });
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (ks < NRES) bd2_qk<BF16, (ks < 2)>(s[ks & 1], kfr[ks % 3], qf[ks]);
         else bd2_qk<BF16>(s[ks & 1], kfr[ks % 3], qfr[ks % 3]);
         __builtin_amdgcn_sched_barrier(0);
       });
-    }
+    });
     am_drain(s[0], s[1]);   // asm MFMAs: hipcc does not know their latency; VALU reads S next
     f32x16_t sp;            // this wave's partial Sᵀ(t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) sp[r] = s[0][r] + s[1][r];
 #pragma unroll
     for (int c = 0; c < 4; ++c) *(f32x4_t*)(xmine + c * 1024) = f32x4_t{sp[4 * c], sp[4 * c + 1], sp[4 * c + 2], sp[4 * c + 3]};
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own V(t−1) pieces landed, own K reads retired, partial written
-    raw_barrier();                                                // K(t) is dead, V(t−1) complete, both partials visible
+    sync_pt(warmc);                                     // V-lo(t−1) landed; K-hi(t) is dead; both partials visible
 
-    // =========================== phase B
+    // =========================== phase B: Oᵀ[my columns] += Vᵀ(t−1)[my columns] · Pᵀ(t−1), softmax(t) as filler
     f32x16_t sf;            // the full Sᵀ(t) = mine + the partner's (commutative: bit-identical in both members)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -176,26 +220,33 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd4_kernel(
     }
     float ps0 = 0.f, ps1 = 0.f;
     const float nm = -m_run;
-    if constexpr (HAS_PV) rd0();
-    static_for<NST>([&](auto stc) {
-      constexpr int st = decltype(stc)::value;
-      static_for<NPIECE>([&](auto ic) {
-        if constexpr (decltype(ic)::value * SPAN_B / NPIECE == st) issue_k(decltype(ic)::value, t + 1);
+    static_for<2>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (g == 1) sync_pt(warmc);             // V-hi(t−1) landed; V-lo(t−1) is dead
+      if constexpr (HAS_PV) rd_g(gc);
+      static_for<NQ>([&](auto dc) {
+        constexpr int dq = decltype(dc)::value, st = g * NQ + dq;
+        static_for<8>([&](auto ic) {
+          if constexpr (decltype(ic)::value * SPAN_BH / 8 == dq) {
+            if constexpr (g == 0) issue_k(decltype(ic)::value, 1, t + 1);     // K-hi(t+1)
+            else issue_v(decltype(ic)::value, 0, t);                          // V-lo(t)
+          }
+        });
+        if constexpr (HAS_PV) pv_step(std::integral_constant<int, st>{}, po);
+        __builtin_amdgcn_sched_barrier(0);
+        // softmax(t): row sums from the unrounded P (tiling_qkv.cu keeps the same order).  The 16 score elements of a lane ride behind
+        // steps 2 .. 7 (3, 3, 3, 3, 2, 2): Sᵀ(t) is complete only when the partner's partial has come back from LDS, and a filler in
+        // front of steps 0 / 1 would park the in-order stream on that read — the P·V MFMAs of those steps need only the Vᵀ fragments
+        constexpr int E0 = st < 2 ? 0 : (st < 6 ? 3 * (st - 2) : 12 + 2 * (st - 6));
+        constexpr int EN = st < 2 ? 0 : (st < 6 ? 3 : 2);
+        static_for<EN>([&](auto jc) {
+          constexpr int r = E0 + decltype(jc)::value;
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sf[r], sl2, nm));
+          if constexpr ((r & 1) != 0) ps1 += p; else ps0 += p;
+          pn[r >> 3][r & 7] = cvt16<BF16>(p);
+        });
+        __builtin_amdgcn_sched_barrier(0);
       });
-      if constexpr (HAS_PV) pv_step(stc, po);
-      __builtin_amdgcn_sched_barrier(0);
-      // softmax(t): row sums from the unrounded P (tiling_qkv.cu keeps the same order).  The 16 score elements of a lane ride behind
-      // steps 2 .. 7 (3, 3, 3, 3, 2, 2): Sᵀ(t) is complete only when the partner's partial has come back from LDS, and a filler in
-      // front of steps 0 / 1 would park the in-order stream on that read — the P·V MFMAs of those steps need only the Vᵀ fragments
-      constexpr int E0 = st < 2 ? 0 : (st < 6 ? 3 * (st - 2) : 12 + 2 * (st - 6));
-      constexpr int EN = st < 2 ? 0 : (st < 6 ? 3 : 2);
-      static_for<EN>([&](auto jc) {
-        constexpr int r = E0 + decltype(jc)::value;
-        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sf[r], sl2, nm));
-        if constexpr ((r & 1) != 0) ps1 += p; else ps0 += p;
-        pn[r >> 3][r & 7] = cvt16<BF16>(p);
-      });
-      __builtin_amdgcn_sched_barrier(0);
     });
     float psum = ps0 + ps1;
     if (!__all(psum_below(psum, 16384.0f)) || !HAS_PV) {        // overflow guard / first tile: establish the true max
@@ -218,29 +269,36 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd4_kernel(
       }
     }
     l_run += psum;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own K(t+1) pieces landed, own V reads retired
-    raw_barrier();                                                // V(t−1) is dead, K(t+1) complete, the exchange area is free again
   };
   using HAS = std::integral_constant<bool, true>;
   using HASNOT = std::integral_constant<bool, false>;
-  tile(HASNOT{}, 0, pfa, pfb);
-  tile(HAS{}, 1, pfb, pfa);
+  tile(HASNOT{}, HAS{}, 0, pfa, pfb);
+  tile(HAS{}, HAS{}, 1, pfb, pfa);
   for (int t = 2; t < T; t += 2) {      // T = N / 32 is even (N % 64 == 0)
-    tile(HAS{}, t, pfa, pfb);
-    tile(HAS{}, t + 1, pfb, pfa);
+    tile(HAS{}, HASNOT{}, t, pfa, pfb);
+    tile(HAS{}, HASNOT{}, t + 1, pfb, pfa);
   }
-  // ---- tail: V(T−1) -> LDS, Oᵀ += Vᵀ(T−1)·Pᵀ(T−1)   (P of the last, odd tile = pfb)
+  // ---- tail: Oᵀ += Vᵀ(T−1)·Pᵀ(T−1)   (P of the last, odd tile = pfb).  V-lo(T−1) is in flight (or landed); V-hi(T−1) has not been asked for
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  raw_barrier();                        // every wave is out of P·V(T−2): V-hi may be refilled
 #pragma unroll
-  for (int i = 0; i < NPIECE; ++i) issue_v(i, T - 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int i = 0; i < 8; ++i) issue_v(i, 1, T - 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // everything but the 8 pieces just issued: V-lo(T−1) landed
   raw_barrier();
-  rd0();
-  static_for<NST>([&](auto stc) {
-    pv_step(stc, pfb);
+  rd_g(std::integral_constant<int, 0>{});
+  static_for<NQ>([&](auto dc) {
+    pv_step(std::integral_constant<int, decltype(dc)::value>{}, pfb);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  raw_barrier();
+  rd_g(std::integral_constant<int, 1>{});
+  static_for<NQ>([&](auto dc) {
+    pv_step(std::integral_constant<int, NQ + decltype(dc)::value>{}, pfb);
     __builtin_amdgcn_sched_barrier(0);
   });
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  raw_barrier();   // every wave is done with V(T−1): the epilogue's staging aliases the tiles
+  raw_barrier();   // every wave is done with V(T−1), every DMA piece has landed: the epilogue's staging aliases the tiles
 
   // ---- epilogue: this wave's 32 rows x 512 columns of O = Oᵀ / l through LDS (whole 1-KiB half-rows, 16-B stores).  Lane holds
   // O[q = l32][d = dcol + 32 dt + 8 rq + 4 hi + (0..3)] in a[16 dt + 4 rq ..]; every wave owns a private 32 x (1024 + 16) B staging area.

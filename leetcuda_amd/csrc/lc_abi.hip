@@ -40,7 +40,7 @@ namespace {
 tune_t g_tune_fp8_mx{1};                       // fp8 GEMM: 1 = MX-scaled K=64 MFMA, 4-wave kernel; 2 = MX, 8-wave kernel; 0 = plain K=16 MFMA
 tune_t g_tune_attn_w4i_sched{1};              // schedule of attn_fwd_w4i_kernel's generated phase statements (tools/gen_attn_w4i.py NSCHED; same bits)
 tune_t g_tune_attn_nw{0};                    // attention kernel for D <= 128: 0 = auto, 513 / 515 / 517 / 514 / 8 / 4 / 2 (choose_attn_nw, lc_abi.h)
-tune_t g_tune_attn_d1024{0};                 // attn_bigd4's DMA spread in eighths of a phase: 0 = default (2), 4 / 6 / 8 (A/B knob)
+tune_t g_tune_attn_d1024{0};                 // attn_bigd4's DMA spread in eighths of a phase: 0 = default (8), 2 / 4 / 6 (A/B knob)
 tune_t g_tune_attn_walk{0};                  // block walk of the merged-phase kernel under attn_nw = 0: 0 = auto by N, 1 / 2 / 3 = WALK 0 / 1 / 2
 tune_t g_tune_hgemm_auto{LC_HGEMM_MFMA256W4Y};   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
 tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to the 128-tile kernel (launch_mfma256), 0 = one launch
@@ -481,7 +481,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
     return LC_OK;
   }
   if (use_bigd4(D, v_transposed != 0, N) && !bf16) {
-    snprintf(buf, buflen, "attn_fwd_bigd4_kernel<%d>", g_tune_attn_d1024 == 0 ? 2 : g_tune_attn_d1024.load());
+    snprintf(buf, buflen, "attn_fwd_bigd4_kernel<%d>", g_tune_attn_d1024 == 0 ? 8 : g_tune_attn_d1024.load());
     return LC_OK;
   }
   if (use_bigd2(D, v_transposed != 0, N) && !(bf16 && v_transposed)) {
@@ -506,7 +506,7 @@ bool ok_attn_nw(int v) {
 bool ok_01(int v) { return v == 0 || v == 1; }
 bool ok_02(int v) { return v >= 0 && v <= 2; }
 bool ok_03(int v) { return v >= 0 && v <= 3; }
-bool ok_span8(int v) { return v == 0 || v == 4 || v == 6 || v == 8; }
+bool ok_span8(int v) { return v == 0 || v == 2 || v == 4 || v == 6; }
 bool ok_w4y_sched(int v) {
 #ifdef LC_DIAG
   return v >= 0 && v <= 5;   // 3..5: ablations (results WRONG)

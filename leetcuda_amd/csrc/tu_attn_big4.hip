@@ -20,13 +20,14 @@ int launch_bigd4_t(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
 }
 }  // namespace
 int launch_attn_bigd4(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int span8, hipStream_t st) {
-  // default: the first QUARTER of a phase (profiles/r4e_bigd4_span.log, r4f_bigd4.log: 2/8 733, 4/8 722 - 740, 6/8 714 - 732, 7/8 725,
-  // 8/8 712 TFLOP/s — an L2 read waits ~700 cycles here because the 32 workgroups of an XCD ask for the same lines at the same
-  // time; early issue hides more of it than the texture-address FIFO costs.  attn_bigd2, whose phases are twice as long, prefers 6/8)
+  // default: a batch's 8 pieces spread over its whole half-phase — with one and a half phases between issue and need
+  // (attn_bigd4.hip: half-tile recycling) nothing is gained by issuing early, and the texture-address FIFO likes the pieces apart
+  // (profiles/r4i_bigd4_v2.log: 8/8 867, 6/8 862, 4/8 845, 2/8 842 TFLOP/s; the first version of the kernel, with one phase per
+  // piece, preferred 2/8: 733 vs 712)
+  if (span8 == 2) return launch_bigd4_t<2>(Q, K, V, O, B, H, N, st);
   if (span8 == 4) return launch_bigd4_t<4>(Q, K, V, O, B, H, N, st);
   if (span8 == 6) return launch_bigd4_t<6>(Q, K, V, O, B, H, N, st);
-  if (span8 == 8) return launch_bigd4_t<8>(Q, K, V, O, B, H, N, st);
-  return launch_bigd4_t<2>(Q, K, V, O, B, H, N, st);
+  return launch_bigd4_t<8>(Q, K, V, O, B, H, N, st);
 }
 // D = 256, N % 128 == 0, V as [B,H,D,N], fp16
 int launch_attn_bigd2_vt(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int D, hipStream_t st) {

@@ -251,8 +251,8 @@ def test_large_head_dim_kernel_names(built):
     V-transposed instantiation; the round-1 column-split kernel keeps ragged N, D = 512 with V transposed and the cross-check knob."""
     from leetcuda_amd import capi
     capi.load()
-    assert capi.attn_kernel_name(8192, 1024) == "attn_fwd_bigd4_kernel<2>"
-    assert capi.attn_kernel_name(64, 1024) == "attn_fwd_bigd4_kernel<2>"
+    assert capi.attn_kernel_name(8192, 1024) == "attn_fwd_bigd4_kernel<8>"
+    assert capi.attn_kernel_name(64, 1024) == "attn_fwd_bigd4_kernel<8>"
     assert capi.attn_kernel_name(8192, 256, True) == "attn_fwd_bigd2_kernel<256,false,true>"
     assert capi.attn_kernel_name(8192, 256) == "attn_fwd_bigd2_kernel<256,false,false>"
     assert capi.attn_kernel_name(8192, 512, True).startswith("attn_fwd_bigd_kernel<512,")
