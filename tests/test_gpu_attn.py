@@ -318,7 +318,7 @@ def test_full_width_large_head_dim_kernel(oracle, D, dtype):
         (lambda a, b, c, o: capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", a, b, c, o, 2))
     for kk in (k, k2):
         outs = []
-        for knob in (0, 1, 2):
+        for knob in (0, 1, 2) + ((3,) if D == 512 else ()):      # 3: the D = 512 kernel on the other MFMA shape (attn_bigd6 / attn_bigd2)
             capi.tune("attn_d512", knob)
             try:
                 o = torch.full_like(q, float("nan"))
@@ -331,8 +331,8 @@ def test_full_width_large_head_dim_kernel(oracle, D, dtype):
         for o in outs:
             d = np.abs(o - truth)
             assert np.isfinite(d).all() and d.max() < tol_max, d.max()
-        assert np.abs(outs[0] - outs[1]).max() < tol_max and np.abs(outs[0] - outs[2]).max() < tol_max
-    assert capi.attn_kernel_name(N, D, False, bf).startswith("attn_fwd_bigd2_kernel")
+        assert all(np.abs(outs[0] - o).max() < tol_max for o in outs[1:])
+    assert capi.attn_kernel_name(N, D, False, bf).startswith(("attn_fwd_bigd2_kernel", "attn_fwd_bigd6_kernel"))
 
 
 @pytest.mark.parametrize("D,N", [(128, 256), (256, 128)])

@@ -44,6 +44,7 @@ FAMILIES = [
     ("d256-auto", 256, None, 0),
     ("d512-auto", 512, None, 0),
     ("d512-column-split", 512, "attn_d512", 1),
+    ("d512-other-mfma-shape", 512, "attn_d512", 3),
     ("d1024-pair", 1024, None, 0),
     ("d1024-column-split", 1024, "attn_d512", 1),
     ("d128-v-transposed", -128, None, 0),       # D < 0: V handed over as [B,H,D,N] through a *_swizzle_qkv entry
