@@ -5,7 +5,11 @@
 // Why: config 5a runs at the board's 1400 W cap (attn_bigd2: 1.20 PFLOP/s on randn, 1.52 zero-filled), and at the cap an MFMA-only
 // stream of v_mfma_f32_16x16x32_f16 sustains 14 % more FLOP/s than one of 32x32x16 (1854 vs 1625 TFLOP/s, DESIGN.md §4.10: half the
 // accumulator registers moved per FLOP).  attn_bigd2 sits at 0.74 of ITS form's ceiling; with the rest of its energy per FLOP unchanged
-// the 16-wide form projects to ≈ 1.32 PFLOP/s.  Same work split (four wave64, a wave = 32 query rows x all 512 columns, Oᵀ in the 256
+// the 16-wide form projects to ≈ 1.32 PFLOP/s.  Measured (profiles/r4k_bigd6.log, same box, interleaved): fp16 1195 - 1205 vs 1142 - 1165
+// TFLOP/s (+ 3.4 ... 4.7 %), bf16 1228 - 1265 vs 1206 - 1231 (+ 1.8 ... 2.8 %); zero-filled 1382 vs 1508 — twice the MFMA statements put
+// the one-wave-per-SIMD instruction stream closer to its issue limit (≈ 720 instructions per tile period of 4096 matrix-core
+// cycles), which is what the cap hides.  Default for D = 512 since; attn_bigd2 stays for D = 256, V-transposed inputs and as the
+// cross-check on the other MFMA shape (lc_tune_set "attn_d512" = 3).  Same work split (four wave64, a wave = 32 query rows x all 512 columns, Oᵀ in the 256
 // AGPRs, Q fragments loaded once, K / V tiles of 64 rows single-buffered in 2 x 64 KiB and filled by LDS-DMA in the shadow of the other
 // phase), same K image, every fragment layout re-derived for the 16-wide shapes (they are attn_w4u's, on 1-KiB rows):
 //   * wave = 2 query blocks qb of 16 rows; KV tile = 4 kv blocks kvb of 16;
@@ -23,16 +27,21 @@
 
 namespace lc {
 
-// Sᵀ block (VGPRs) += K fragment x Q fragment.  FIRST: the first MFMA of a chain (hipcc has just zeroed the accumulator with VALU
-// moves: two wait states before an MFMA may read it, isa_audit.py rule R6)
-template <bool BF16, bool FIRST = false>
-LC_DEVINL void bd6_qk(f32x4_t& s, half8_t k, half8_t q) {
-#define LC_BD6_QK(OP)                                                                                          \
-  if constexpr (FIRST) asm volatile("s_nop 1\n\t" OP " %0, %1, %2, %0" : "+v"(s) : "v"(k), "v"(q) : LC_AGPR_ALL);  \
-  else asm volatile(OP " %0, %1, %2, %0" : "+v"(s) : "v"(k), "v"(q) : LC_AGPR_ALL)
-  if constexpr (BF16) { LC_BD6_QK("v_mfma_f32_16x16x32_bf16"); }
-  else { LC_BD6_QK("v_mfma_f32_16x16x32_f16"); }
-#undef LC_BD6_QK
+// the eight MFMAs of one d-step — Sᵀ blocks (kvb, qb) += K fragment (kvb) x Q fragment (qb), kvb = 0 .. 3, qb = 0, 1 — in ONE statement
+// (hipcc pads every asm boundary with a wait state: eight one-MFMA statements per 128 matrix-core cycles cost 7 of them).  FIRST: the
+// first d-step of a tile — hipcc has just zeroed the accumulators with VALU moves, and a VALU write needs two wait states before an
+// MFMA may read the register (isa_audit.py rule R6): the leading s_nop
+template <bool BF16, bool FIRST>
+LC_DEVINL void bd6_qk8(f32x4_t (&s)[4][2], const half8_t (&k)[4], half8_t q0, half8_t q1) {
+#define LC_BD6_QK8(OP)                                                                                                            \
+  asm volatile("s_nop %14\n\t" OP " %0, %8, %12, %0\n\t" OP " %1, %8, %13, %1\n\t" OP " %2, %9, %12, %2\n\t" OP " %3, %9, %13, %3\n\t" \
+               OP " %4, %10, %12, %4\n\t" OP " %5, %10, %13, %5\n\t" OP " %6, %11, %12, %6\n\t" OP " %7, %11, %13, %7"                  \
+               : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(s[2][0]), "+v"(s[2][1]), "+v"(s[3][0]), "+v"(s[3][1])  \
+               : "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(q0), "v"(q1), "n"(FIRST ? 1 : 0)                                     \
+               : LC_AGPR_ALL)
+  if constexpr (BF16) { LC_BD6_QK8("v_mfma_f32_16x16x32_bf16"); }
+  else { LC_BD6_QK8("v_mfma_f32_16x16x32_f16"); }
+#undef LC_BD6_QK8
 }
 // P·V step: Oᵀ blocks (db = 4 s + j, qb) += Vᵀ fragment j (fixed quad) x Pᵀ(qb), j = 0 .. 3; RD: + the two transpose reads of the NEXT
 // step's fragment j into the same quad (address A_j, offsets OFF / OFF + HOFF).  R0 = 32 s: block (db, qb) = a[R0 + 8 j + 4 qb ..].
@@ -203,16 +212,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd6_kernel(
             if constexpr (decltype(ic)::value * SPAN_A / NPIECE == ds) issue_v(decltype(ic)::value, t - 1);
           });
         __builtin_amdgcn_sched_barrier(0);
-        static_for<4>([&](auto kc) {
-          constexpr int kvb = decltype(kc)::value;
-          if constexpr (ds < NRES) {
-            bd6_qk<BF16, ds == 0>(s[kvb][0], kfr[ds & 1][kvb], qf[ds][0]);
-            bd6_qk<BF16, ds == 0>(s[kvb][1], kfr[ds & 1][kvb], qf[ds][1]);
-          } else {
-            bd6_qk<BF16>(s[kvb][0], kfr[ds & 1][kvb], qfr[ds & 1][0]);
-            bd6_qk<BF16>(s[kvb][1], kfr[ds & 1][kvb], qfr[ds & 1][1]);
-          }
-        });
+        if constexpr (ds < NRES) bd6_qk8<BF16, ds == 0>(s, kfr[ds & 1], qf[ds][0], qf[ds][1]);
+        else bd6_qk8<BF16, false>(s, kfr[ds & 1], qfr[ds & 1][0], qfr[ds & 1][1]);
         __builtin_amdgcn_sched_barrier(0);
       });
     }

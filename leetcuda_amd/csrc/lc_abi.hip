@@ -351,7 +351,7 @@ bool use_bigd2(int D, bool vt, int N) {
 }
 bool use_bigd4(int D, bool vt, int N) { return D == 1024 && !vt && N % 64 == 0 && g_tune_attn_d512 != 1; }
 // D = 512: attn_bigd6 (16x16x32 MFMAs) or attn_bigd2 (32x32x16): kBigd6Auto says which one auto means, knob 3 selects the other
-constexpr bool kBigd6Auto = false;
+constexpr bool kBigd6Auto = true;    // profiles/r4k_bigd6.log: fp16 + 3.4 ... 4.7 %, bf16 + 1.8 ... 2.8 % at the cap (zero-filled: - 8 %, the 16-wide stream is more issue-bound)
 bool use_bigd6(int D, bool vt, int N) {
   const int k = g_tune_attn_d512;
   return D == 512 && !vt && N % 128 == 0 && ((k == 0 && kBigd6Auto) || (k == 3 && !kBigd6Auto));

@@ -193,7 +193,7 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     assert capi.attn_kernel_name(8192, 96) == "attn_fwd_w4i_kernel<96,1>"                     # only the generated kernel has a D = 96 instantiation
     assert capi.attn_kernel_name(8192 + 64, 96) == "attn_fwd_kernel<96,2,false,0>"            # N % 256 != 0: lock-step
     assert capi.attn_kernel_name(8192, 32) == "attn_fwd_w4i_kernel<32,1>"
-    assert capi.attn_kernel_name(8192, 512, False, True) == "attn_fwd_bigd2_kernel<512,true,false>"
+    assert capi.attn_kernel_name(8192, 512, False, True) == "attn_fwd_bigd6_kernel<true>"             # config 5a: D = 512 on the 16x16x32 MFMA
     assert capi.attn_kernel_name(192, 512, False, False).startswith("attn_fwd_bigd_kernel<512,")     # N % 128 != 0
     assert sump.short("_ZN2lc16hgemm_w4b_kernelILb0ELb1ELi0EEEvPKDF16_S2_PDF16_iiiiii") == \
         "hgemm_w4b_kernel<false,true,0>"
@@ -257,6 +257,13 @@ def test_large_head_dim_kernel_names(built):
     assert capi.attn_kernel_name(8192, 256) == "attn_fwd_bigd2_kernel<256,false,false>"
     assert capi.attn_kernel_name(8192, 512, True).startswith("attn_fwd_bigd_kernel<512,")
     assert capi.attn_kernel_name(192, 256, True).startswith("attn_fwd_bigd_kernel<256,")
+    assert capi.attn_kernel_name(8192, 512) == "attn_fwd_bigd6_kernel<false>"
+    capi.tune("attn_d512", 3)
+    try:
+        assert capi.attn_kernel_name(8192, 512) == "attn_fwd_bigd2_kernel<512,false,false>"     # the other MFMA shape: the cross-check
+        assert capi.attn_kernel_name(8192, 256) == "attn_fwd_bigd2_kernel<256,false,false>"
+    finally:
+        capi.tune("attn_d512", 0)
     capi.tune("attn_d512", 1)
     try:
         assert capi.attn_kernel_name(8192, 1024).startswith("attn_fwd_bigd_kernel<1024,")
