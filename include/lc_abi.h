@@ -210,7 +210,7 @@ int lc_attn_entry_info(const char* entry, int* family, int* v_transposed, int* a
  * Pointers are assumed 16-byte aligned.  Returns LC_OK, LC_ERR_ARG / LC_ERR_SHAPE / LC_ERR_HEADDIM as the call would. */
 int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf, int buflen);
 int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int buflen);
-/* How often the overflow slow path of the default D = 128 attention kernel (attn_w4n.hip) ran since the last reset:
+/* How often the overflow slow path of the merged-phase attention kernels (attn_w4u.hip, attn_w4i.hip) ran since the last reset:
  * out4 = { executions, sum of their KV half-tile indices, executions that saw a non-finite row sum, bit pattern (fp32) of the
  * last offending row sum }.  Synchronises the device (hipMemcpyFromSymbol).  out4 may be NULL (reset only). */
 int lc_attn_slowpath_stats(unsigned* out4, int reset);

@@ -71,7 +71,7 @@ def test_workgroup_shapes_agree(oracle, nw, D):
     _check(oracle, q, k, v, o)
 
 
-@pytest.mark.parametrize("D,N", [(256, 128), (256, 192), (512, 256), (512, 64), (1024, 128)])
+@pytest.mark.parametrize("D,N", [(256, 128), (256, 192), (512, 256), (512, 128), (512, 64), (1024, 128), (1024, 64), (1024, 192)])   # (T = 2 tiles: (512,128) on attn_bigd6, (1024,64) on attn_bigd4)
 def test_large_head_dims_tiling_qkv(oracle, D, N):
     """D = 256 / 512 / 1024: the fine-grained Q,K,V d-slice tiling (reference: flash_attn_mma_tiling_qkv.cu,
     dispatcher cases 256, 512, 1024), through the FFPA-ancestor entry names."""
@@ -263,7 +263,7 @@ def test_full_size_config3_properties(oracle):
 @pytest.mark.parametrize("nw", [513, 515, 517, 514, 8])
 def test_scale_jumps_and_extreme_scores(oracle, nw):
     """The merged-phase kernel treats the running max as a mere SCALE and only corrects it when a half-tile's row sums
-    get large (attn_w4m.hip).  Inputs that force that path in many places: (a) scores that grow steadily along the
+    get large (attn_w4u.hip).  Inputs that force that path in many places: (a) scores that grow steadily along the
     sequence (every tile raises the max), (b) a huge uniform score level (s ~ 1000 in log2 units), (c) a first tile far
     ABOVE everything else (later P underflow harmlessly), (d) maxima that jump by > 2^14 in the LAST half-tile."""
     capi = _capi()

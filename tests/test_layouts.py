@@ -386,7 +386,7 @@ def test_k_loop_stagger_index_sequence_visits_every_tile_once():
 
 
 def test_persistent_attention_walk_visits_every_block_once_on_its_xcd():
-    """attn_w4p.hip: workgroup w of a G-workgroup grid (G = min(blocks, CUs)) walks the virtual block ids w, w + G, w + 2 G, ... and maps
+    """attn_w4u.hip WALK = 1: workgroup w of a G-workgroup grid (G = min(blocks, CUs)) walks the virtual block ids w, w + G, w + 2 G, ... and maps
     each through xcd_remap(v, nblk) (lc_common.h: virtual id v lives on XCD v & 7; an XCD owns a contiguous range of real ids).  Every
     real block is computed exactly once, and — G being a multiple of 8 whenever there is more than one round — all blocks of a
     workgroup stay on ITS XCD, whose L2 holds their heads' K / V (the GPU tests run 296 / 516 / 48 / 260 blocks)."""

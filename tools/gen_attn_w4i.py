@@ -46,7 +46,7 @@ class Cfg:
         self.D = D
         self.NDS, self.NDB = D // 32, D // 16
         self.GROWB = 2 * D                          # bytes per K / V row in global memory
-        self.ROWB = 256 if D > 64 else 128          # ... and in LDS (D = 96 / 32 keep the 256-B / 128-B rows of D = 128 / 64: attn_w4g.hip W4G)
+        self.ROWB = 256 if D > 64 else 128          # ... and in LDS (D = 96 / 32 keep the 256-B / 128-B rows of D = 128 / 64: attn_mp.h W4G.hip W4G)
         self.NS = 16 * self.NDS
         self.NRV, self.NRK = self.NDB, 2 * self.NDS
         self.TILE = KVB * self.ROWB
