@@ -325,7 +325,7 @@ def test_persistent_workgroup_walk_computes_the_same_bits(layout):
     its K-loop stagger — is what the one-tile launch gives it: outputs must be IDENTICAL, with both block -> tile maps."""
     capi = _capi()
     lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
-    for M, N, K in ((8192, 4096, 256), (4096, 8192, 448), (8192, 8192, 128)):
+    for M, N, K in ((8192, 4096, 256), (4096, 8192, 448), (8192, 8192, 128), (8192, 8192, 64)):      # K = 64: ONE K tile per C tile — the cross-tile prefetch is the whole K loop's supply
         torch.manual_seed(M + K)
         a = torch.randn(M, K, dtype=torch.half, device="cuda")
         b = torch.randn(K, N, dtype=torch.half, device="cuda")
