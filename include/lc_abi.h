@@ -127,7 +127,8 @@ const char* lc_build_info(int* is_diag);
  *                  range), 2 = XCD super-block raster (16 x 16 tile steps shared through the Infinity Cache, 4 x 8 per XCD;
  *                  swizzle_stride ignored)
  *   "hgemm_auto"   kernel LC_HGEMM_AUTO launches on large 256-tileable shapes (a 256-tile lc_hgemm_variant value)
- *   "fp8_mx"       fp8 GEMM: 1 = MX-scaled K = 64 MFMA, 4-wave kernel (default); 2 = MX, 8-wave kernel; 0 = plain K = 16
+ *   "fp8_mx"       fp8 GEMM (lc_gemm_fp8_e4m3): 3 = MX-scaled K = 128 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4), generated loop (default);
+ *                  1 = MX K = 64 MFMA, compiler-scheduled 4-wave kernel (the cross-check); 2 = MX K = 64, 8-wave kernel; 0 = plain K = 16
  *   "attn_d512"    D = 256 / 512 / 1024 kernel: 0 = auto (D = 256 / 512: one workgroup owns all D output columns, attn_bigd2.hip — D = 256 also with
  *                  V as [B,H,D,N]; D = 1024: two waves share 32 query rows and split the head dim, attn_bigd4.hip), 1 = round-1 column-split kernel,
  *                  2 = 32-row double-buffered tiles (attn_bigd3.hip: validated on hardware in round 3, 6-8 % slower, a cross-check),
@@ -167,6 +168,17 @@ int lc_hgemm_vendor_f16(const void* A, const void* B, void* C, int M, int N, int
  * stored [N,K] (the TN layout).  M, N multiples of 256, K multiple of 128, 16-byte aligned pointers. */
 int lc_gemm_fp8_e4m3(const void* A, const void* B, void* C, int M, int N, int K, float alpha,
                      int swizzle_stride, void* stream);
+
+/* EXTENSION: the same GEMM on OCP MX data — every 32 consecutive k of every row of A and of B carry an E8M0 block scale
+ * (value = e4m3 * 2^(scale - 127); scale 127 = 1.0, 255 = NaN per the MX spec):
+ *   C[m][n] = alpha * sum_k A8[m][k] 2^(SA[m][k/32] - 127) * B8[n][k] 2^(SB[n][k/32] - 127)
+ * The matrix core wants one scale byte per lane (row, k block) and instruction; lc_mxfp8_pack_scales reorders the natural
+ * [rows][K/32] byte array S into the dword array P (rows * K / 32 bytes, 8-byte aligned) that lc_gemm_mxfp8 consumes — once per weight
+ * matrix, per call for activations.  rows multiple of 256, K multiple of 128.  P's layout is an implementation detail
+ * (leetcuda_amd/csrc/gemm_fp8_w4k.hip); treat it as opaque. */
+int lc_mxfp8_pack_scales(const void* S, void* P, int rows, int K, void* stream);
+int lc_gemm_mxfp8(const void* A, const void* PA, const void* B, const void* PB, void* C, int M, int N, int K, float alpha,
+                  int swizzle_stride, void* stream);
 
 /* Dispatch by the reference's export name (hgemm.cc:126-181). 3-argument entries ignore
  * stages/swizzle/swizzle_stride. `init_cublas_handle` / `destroy_cublas_handle` take no tensors

@@ -141,14 +141,16 @@ def build_abi(force: bool = False, audit: bool = True) -> Path:
     srcs.append(PKG / "isa_audit.py")
     srcs.append(ROOT / "tools" / "gen_hgemm_w4y.py")
     srcs.append(ROOT / "tools" / "gen_attn_w4i.py")
+    srcs.append(ROOT / "tools" / "gen_gemm_fp8_w4k.py")
     flags = _flags()
     # the generated K loops (hgemm_w4y_loop*.inc) must be what tools/gen_hgemm_w4y.py emits today
     gen = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_hgemm_w4y.py"), "--check"], capture_output=True, text=True)
     if gen.returncode != 0:
         raise RuntimeError("generated sources are stale: " + gen.stderr.strip())
-    gen = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_attn_w4i.py"), "--check"], capture_output=True, text=True)
-    if gen.returncode != 0:
-        raise RuntimeError("generated sources are stale: " + gen.stderr.strip())
+    for script in ("gen_attn_w4i.py", "gen_gemm_fp8_w4k.py"):
+        gen = subprocess.run([sys.executable, str(ROOT / "tools" / script), "--check"], capture_output=True, text=True)
+        if gen.returncode != 0:
+            raise RuntimeError("generated sources are stale: " + gen.stderr.strip())
     if os.environ.get("LC_DIAG") == "1":   # the ablation loops (results WRONG by design) exist only inside a diagnosis build
         subprocess.run([sys.executable, str(ROOT / "tools" / "gen_hgemm_w4y.py"), "--diag", str(LIBDIR / "gen")], check=True)
         flags = flags + [f"-I{LIBDIR / 'gen'}"]

@@ -34,6 +34,8 @@ SYMBOLS = {
     "lc_vendor_destroy": (_i, []),
     "lc_hgemm_vendor_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "lc_gemm_fp8_e4m3": (_i, [_vp, _vp, _vp, _i, _i, _i, C.c_float, _i, _vp]),
+    "lc_mxfp8_pack_scales": (_i, [_vp, _vp, _i, _i, _vp]),
+    "lc_gemm_mxfp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.c_float, _i, _vp]),
     "lc_hgemm_call": (_i, [_cp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "lc_hgemm_entry_count": (_i, []),
     "lc_hgemm_entry_name": (_cp, [_i]),
@@ -240,6 +242,27 @@ def gemm_fp8(a8, b8_nk, c, alpha=1.0, swizzle_stride=1):
     M, N, K = _gemm_dims(a8, b8_nk, c, b_is_nk=True)
     check(load().lc_gemm_fp8_e4m3(_ptr(a8), _ptr(b8_nk), _ptr(c), M, N, K, float(alpha), swizzle_stride, _stream()),
           "lc_gemm_fp8_e4m3")
+    return c
+
+
+def mxfp8_pack_scales(s):
+    """s: uint8 [rows, K/32] E8M0 block scales -> the packed array lc_gemm_mxfp8 consumes (uint8 tensor of the same size, opaque)."""
+    import torch
+    _need_gpu(s)
+    assert s.dtype == torch.uint8 and s.dim() == 2 and s.is_contiguous()
+    rows, kb = s.shape
+    p = torch.empty(rows * kb, dtype=torch.uint8, device=s.device)
+    check(load().lc_mxfp8_pack_scales(_ptr(s), _ptr(p), rows, kb * 32, _stream()), "lc_mxfp8_pack_scales")
+    return p
+
+
+def gemm_mxfp8(a8, pa, b8_nk, pb, c, alpha=1.0, swizzle_stride=1):
+    """c[M,N] (fp16) = alpha * (a8 * 2^(sa-127)) @ (b8_nk * 2^(sb-127))^T with per-(row, 32 k) E8M0 scales; pa / pb = mxfp8_pack_scales(sa / sb)."""
+    _need_gpu(a8, b8_nk, c, pa, pb)
+    M, N, K = _gemm_dims(a8, b8_nk, c, b_is_nk=True)
+    assert pa.numel() == M * K // 32 and pb.numel() == N * K // 32
+    check(load().lc_gemm_mxfp8(_ptr(a8), _ptr(pa), _ptr(b8_nk), _ptr(pb), _ptr(c), M, N, K, float(alpha), swizzle_stride, _stream()),
+          "lc_gemm_mxfp8")
     return c
 
 

@@ -37,7 +37,7 @@ tune_t g_tune_attn_d512{0};        // D = 256 / 512 / 1024: 0 = auto, 1 = column
 namespace {
 
 // run-time tuning knobs (lc_tune_set): experiments and A/B benches, never required for correctness
-tune_t g_tune_fp8_mx{1};                       // fp8 GEMM: 1 = MX-scaled K=64 MFMA, 4-wave kernel; 2 = MX, 8-wave kernel; 0 = plain K=16 MFMA
+tune_t g_tune_fp8_mx{3};                       // fp8 GEMM: 3 = MX K=128 MFMA, generated loop (gemm_fp8_w4k.hip); 1 = MX K=64, 4-wave kernel; 2 = MX K=64, 8-wave kernel; 0 = plain K=16 MFMA
 tune_t g_tune_attn_w4i_sched{1};              // schedule of attn_fwd_w4i_kernel's generated phase statements (tools/gen_attn_w4i.py NSCHED; same bits)
 tune_t g_tune_attn_nw{0};                    // attention kernel for D <= 128: 0 = auto, 513 / 515 / 517 / 514 / 8 / 4 / 2 (choose_attn_nw, lc_abi.h)
 tune_t g_tune_attn_d1024{0};                 // attn_bigd4's DMA spread in eighths of a phase: 0 = default (8), 2 / 4 / 6 (A/B knob)
@@ -541,7 +541,7 @@ const Knob kKnobs[] = {
     {"attn_walk", &g_tune_attn_walk, 0, ok_03, false},
     {"attn_d1024", &g_tune_attn_d1024, 0, ok_span8, false},
     {"attn_w4i_sched", &g_tune_attn_w4i_sched, 1, ok_01, false},
-    {"fp8_mx", &g_tune_fp8_mx, 1, ok_02, false},
+    {"fp8_mx", &g_tune_fp8_mx, 3, ok_03, false},
     {"attn_d512", &g_tune_attn_d512, 0, ok_03, false},
     {"w4y_sched", &g_tune_w4y_sched, 1, ok_w4y_sched, false},
     {"hgemm_persist", &g_tune_hgemm_persist, 1, ok_01, false},
@@ -639,8 +639,35 @@ int lc_gemm_fp8_e4m3(const void* A, const void* B, void* C, int M, int N, int K,
   if (int rc = launch_guard()) return rc;
   const int tiles_m = M / BM, tiles_n = N / BN;
   const int pw = panel_tiles(swizzle_stride, tiles_n, BN, ((size_t)M + N) * K);   // (fp8: one byte per element)
+  const int mx = g_tune_fp8_mx;   // read once per launch
+  if (mx == 3 && gemm_fp8_w4k_fits(K))
+    return launch_gemm_fp8_w4k(static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), static_cast<half_t*>(C), M, N, K, alpha,
+                               tiles_m, tiles_n, pw, static_cast<hipStream_t>(stream));
   return launch_gemm_fp8(static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), static_cast<half_t*>(C), M, N, K,
-                         alpha, tiles_m, tiles_n, pw, g_tune_fp8_mx, static_cast<hipStream_t>(stream));
+                         alpha, tiles_m, tiles_n, pw, mx == 3 ? 1 : mx, static_cast<hipStream_t>(stream));
+}
+
+int lc_mxfp8_pack_scales(const void* S, void* P, int rows, int K, void* stream) {
+  if (!S || !P) return LC_ERR_ARG;
+  if (rows <= 0 || K <= 0) return LC_ERR_SHAPE;
+  if (rows % BM || K % 128 || ((uintptr_t)P & 7)) return LC_ERR_SHAPE;
+  if (int rc = launch_guard()) return rc;
+  return launch_mx_pack_scales(static_cast<const uint8_t*>(S), static_cast<uint32_t*>(P), rows, K, static_cast<hipStream_t>(stream));
+}
+
+int lc_gemm_mxfp8(const void* A, const void* PA, const void* B, const void* PB, void* C, int M, int N, int K, float alpha,
+                  int swizzle_stride, void* stream) {
+  if (!A || !B || !C || !PA || !PB) return LC_ERR_ARG;
+  if (M <= 0 || N <= 0 || K <= 0) return LC_ERR_SHAPE;
+  if (M % BM || N % BN || K % 128 || !aligned16(A) || !aligned16(B) || !aligned16(C) || ((uintptr_t)PA & 7) || ((uintptr_t)PB & 7))
+    return LC_ERR_SHAPE;
+  if (!gemm_fp8_w4k_fits(K)) return LC_ERR_SHAPE;   // 32-bit DMA offsets (K < 8 Mi)
+  if (int rc = launch_guard()) return rc;
+  const int tiles_m = M / BM, tiles_n = N / BN;
+  const int pw = panel_tiles(swizzle_stride, tiles_n, BN, ((size_t)M + N) * K);
+  return launch_gemm_mxfp8(static_cast<const uint8_t*>(A), static_cast<const uint32_t*>(PA), static_cast<const uint8_t*>(B),
+                           static_cast<const uint32_t*>(PB), static_cast<half_t*>(C), M, N, K, alpha, tiles_m, tiles_n, pw,
+                           static_cast<hipStream_t>(stream));
 }
 
 int lc_hgemm_entry_count(void) { return kNumHgemmEntries; }

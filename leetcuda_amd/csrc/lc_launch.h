@@ -112,5 +112,12 @@ int launch_attn_bigd6(const half_t* Q, const half_t* K, const half_t* V, half_t*
 // tu_fp8.hip: fp8 e4m3 GEMM, mx = 1 (MX, 4 waves) / 2 (MX, 8 waves) / 0 (plain K = 16)
 int launch_gemm_fp8(const uint8_t* A, const uint8_t* B, half_t* C, int M, int N, int K, float alpha, int tiles_m,
                     int tiles_n, int panel_w, int mx, hipStream_t st);
+// tu_fp8k.hip: the K = 128 MX form (gemm_fp8_w4k.hip): unit scales / real E8M0 block scales packed by launch_mx_pack_scales
+bool gemm_fp8_w4k_fits(int K);
+int launch_gemm_fp8_w4k(const uint8_t* A, const uint8_t* B, half_t* C, int M, int N, int K, float alpha, int tiles_m, int tiles_n,
+                        int panel_w, hipStream_t st);
+int launch_gemm_mxfp8(const uint8_t* A, const uint32_t* PA, const uint8_t* B, const uint32_t* PB, half_t* C, int M, int N, int K,
+                      float alpha, int tiles_m, int tiles_n, int panel_w, hipStream_t st);
+int launch_mx_pack_scales(const uint8_t* S, uint32_t* P, int rows, int K, hipStream_t st);
 
 }  // namespace lc

@@ -190,6 +190,32 @@ void lc_oracle_gemm_fp8_exact_f32(const uint8_t* A, const uint8_t* Bnk, float* C
   }
 }
 
+/* OCP MX (microscaling) fp8: every 32 consecutive k of a row carry an E8M0 block scale, value = e4m3 * 2^(scale - 127)
+ * (scale 255 = NaN).  SA [M][K/32], SB [N][K/32].  The products and the per-block partial sums are exact in fp64. */
+void lc_oracle_gemm_mxfp8_exact_f32(const uint8_t* A, const uint8_t* SA, const uint8_t* Bnk, const uint8_t* SB, float* C,
+                                    int M, int N, int K, float alpha) {
+  float lut[256];
+  double e8[256];
+  const int KB = K / 32;
+  for (int i = 0; i < 256; ++i) lut[i] = lc_e4m3_to_f32((uint8_t)i);
+  for (int i = 0; i < 255; ++i) e8[i] = ldexp(1.0, i - 127);
+  e8[255] = NAN;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int m = 0; m < M; ++m) {
+    const uint8_t* ar = A + (size_t)m * K;
+    for (int n = 0; n < N; ++n) {
+      const uint8_t* br = Bnk + (size_t)n * K;
+      double acc = 0.0;
+      for (int kb = 0; kb < KB; ++kb) {
+        double blk = 0.0;
+        for (int k = 32 * kb; k < 32 * kb + 32; ++k) blk += (double)lut[ar[k]] * (double)lut[br[k]];
+        acc += blk * e8[SA[(size_t)m * KB + kb]] * e8[SB[(size_t)n * KB + kb]];
+      }
+      C[(size_t)m * N + n] = (float)(acc * (double)alpha);
+    }
+  }
+}
+
 /* ---------------------------------------------------------------------------------------------- */
 /* attention                                                                                       */
 

@@ -42,6 +42,8 @@ class Oracle:
         _u8 = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
         lib.lc_oracle_gemm_fp8_exact_f32.restype = None
         lib.lc_oracle_gemm_fp8_exact_f32.argtypes = [_u8, _u8, _f32, _i, _i, _i, C.c_float]
+        lib.lc_oracle_gemm_mxfp8_exact_f32.restype = None
+        lib.lc_oracle_gemm_mxfp8_exact_f32.argtypes = [_u8, _u8, _u8, _u8, _f32, _i, _i, _i, C.c_float]
 
     # ---- numpy-level helpers (uint16 views of fp16 data) -------------------------------------
     @staticmethod
@@ -71,6 +73,16 @@ class Oracle:
         c = np.empty((M, N), np.float32)
         self.lib.lc_oracle_gemm_fp8_exact_f32(np.ascontiguousarray(a8), np.ascontiguousarray(b8_nk), c, M, N, K,
                                               float(alpha))
+        return c
+
+    def gemm_mxfp8(self, a8, sa, b8_nk, sb, M, N, K, alpha=1.0):
+        """a8 [M,K], b8_nk [N,K] e4m3fn (uint8 views); sa [M,K/32], sb [N,K/32] E8M0 -> fp32 exact result."""
+        def u8(x):
+            if hasattr(x, "detach"):
+                x = x.detach().cpu().contiguous().view(__import__("torch").uint8).numpy()
+            return np.ascontiguousarray(x, dtype=np.uint8)
+        c = np.empty((M, N), np.float32)
+        self.lib.lc_oracle_gemm_mxfp8_exact_f32(u8(a8), u8(sa), u8(b8_nk), u8(sb), c, M, N, K, float(alpha))
         return c
 
     def attn(self, q, k, v, B, H, N, D, vt=False, mode="exact", Bc=64, o_f32=False):

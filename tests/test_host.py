@@ -161,6 +161,141 @@ def test_generated_hgemm_loops_are_current_and_well_formed():
         assert all(not l.startswith("ds_read") for l in body[w - 2:w])
 
 
+def test_generated_fp8_k128_loop_is_current_and_consumes_the_right_tiles():
+    """gemm_fp8_w4k's K loop (tools/gen_gemm_fp8_w4k.py): committed .inc == generator output, and a replay of the generated stream as a
+    dataflow machine — LDS ring slots hold tile numbers, ds_reads copy (tile, operand, fragment, half) tags into registers, DMA pieces
+    overwrite slots, the barrier publishes — must show every MFMA of K tile t consuming exactly A fragment i / B fragment j of tile t,
+    with every register half written by a read that an s_waitcnt lgkmcnt has retired (LDS reads return in order)."""
+    import importlib.util
+    import re
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("lc_gen_w4k", root / "tools" / "gen_gemm_fp8_w4k.py")
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    for text, out in gen.outputs():
+        assert out.read_text() == text, out
+    for mx in (False, True):
+        L = gen.gen(mx)
+        for KT in (1, 2, 3, 4, 7):
+            # SGPR / VGPR state.  LDS slot addresses: A ring 0x0 / 0x8000, B ring 0x10000 / 0x18000 / 0x20000 relative to a0 = 0.
+            sg = {"kt": KT, "stg": 0, "a0": 0, "wv": 0, "blk": 0}
+            slot_tile = {0x0: 0, 0x8000: 1, 0x10000: 0, 0x18000: 1, 0x20000: None}   # what the prologue staged
+            pending_dma = []          # (slot address, tile) issued, not yet published by a vmcnt wait
+            vaddr = {}                # address VGPR -> (slot address, register half)
+            reg = {}                  # fragment register base -> {half: (tile, op, frag) or None}
+            lds_q = []                # in-flight reads: (base, half, value)
+            scale_reg, scale_q, m0 = {}, [], None
+            dirty = set()             # ring slots read since the last barrier (another wave may still be reading them)
+            mf_seen, pc, scc, steps = [], 0, 0, 0
+            labels = {l[:-1]: i for i, l in enumerate(L) if l.endswith(":")}
+            sval = lambda tok: sg[tok.strip("%[]")] if tok.startswith("%[") else int(tok, 0)
+            while pc < len(L):
+                ins = L[pc]
+                pc += 1
+                steps += 1
+                assert steps < 20000
+                if ins.endswith(":"):
+                    continue
+                op, _, rest = ins.partition(" ")
+                args = [a.strip() for a in rest.split(",")]
+                if op in ("s_mov_b32",):
+                    sg[args[0].strip("%[]")] = sval(args[1])
+                elif op in ("s_add_u32", "s_sub_u32", "s_min_u32", "s_lshl_b32"):
+                    x, y = sval(args[1]), sval(args[2])
+                    v = {"s_add_u32": x + y, "s_sub_u32": x - y, "s_min_u32": min(x, y), "s_lshl_b32": x << y}[op] & 0xffffffff
+                    if args[0] == "m0":
+                        m0 = v
+                    else:
+                        sg[args[0].strip("%[]")] = v
+                elif op == "s_cmp_ge_u32":
+                    scc = int(sval(args[0]) >= sval(args[1]))
+                elif op == "s_cmp_lt_u32":
+                    scc = int(sval(args[0]) < sval(args[1]))
+                elif op == "s_cselect_b32":
+                    sg[args[0].strip("%[]")] = sval(args[1]) if scc else sval(args[2])
+                elif op == "v_add_u32_e32":
+                    vaddr[args[0]] = (sval(args[1]), {"ar0": ("a", 0), "ar1": ("a", 1), "br0": ("b", 0), "br1": ("b", 1)}[args[2].strip("%[]")])
+                elif op == "ds_read_b128":
+                    m = re.match(r"v\[(\d+):(\d+)\]", args[0])
+                    lo = int(m.group(1))
+                    base, half = lo & ~7, (lo >> 2) & 1
+                    an, off = args[1].split(" offset:")
+                    slot, (which, h) = vaddr[an]
+                    assert h == half
+                    # the slot holds published data and no LDS-DMA into it is in flight or unpublished
+                    assert not isinstance(slot_tile[slot], tuple) and all(sl != slot for sl, _ in pending_dma), (ins, hex(slot))
+                    dirty.add(slot)
+                    lds_q.append((base, half, (slot_tile[slot], which, int(off) // 2048)))
+                    reg.setdefault(base, {})[half] = None        # in flight: unusable until retired
+                elif op == "buffer_load_dwordx4":
+                    is_a = args[1].strip("%[]") == "ra"
+                    slot = m0 & ~0x7fff
+                    assert (slot < 0x10000) == is_a, (ins, hex(m0))
+                    assert slot not in dirty, (ins, hex(slot))     # every wave is past its reads of the slot (barrier since the last one)
+                    pending_dma.append((slot, sg["soff"] >> 7))
+                elif op == "buffer_load_dwordx2":
+                    lo = int(re.match(r"v\[(\d+):", args[0]).group(1))
+                    scale_q.append((lo, sg["s1off"] >> 9))
+                elif op == "s_waitcnt":
+                    m = re.search(r"lgkmcnt\((\d+)\)", ins)
+                    if m:
+                        while len(lds_q) > int(m.group(1)):
+                            base, half, val = lds_q.pop(0)
+                            reg[base][half] = val
+                    m = re.search(r"vmcnt\((\d+)\)", ins)
+                    if m:
+                        keep = int(m.group(1))
+                        assert len(scale_q) == 0 or keep <= 8      # scale loads are older than the 8 pieces that may stay in flight
+                        for lo, t in scale_q:
+                            scale_reg[lo] = t
+                        scale_q.clear()
+                        done, pending_dma[:] = pending_dma[:len(pending_dma) - keep], pending_dma[len(pending_dma) - keep:]
+                        for slot, t in done:
+                            slot_tile[slot] = ("landed", t)
+                elif op == "s_barrier":
+                    assert not lds_q                               # reads retired before the barrier: the slots they read are free behind it
+                    dirty.clear()
+                    for k, v in slot_tile.items():
+                        if isinstance(v, tuple):
+                            slot_tile[k] = v[1]
+                elif op.startswith("v_mfma"):
+                    m = re.match(r"a\[(\d+):", args[0])
+                    blk = int(m.group(1)) // 4
+                    i, j = blk >> 3, blk & 7
+                    fb_, fa_ = int(re.match(r"v\[(\d+):", args[1]).group(1)), int(re.match(r"v\[(\d+):", args[2]).group(1))
+                    t = len(mf_seen) // 64
+                    want_t = min(t, KT - 1)
+                    assert reg[fa_] == {0: (want_t, "a", i), 1: (want_t, "a", i)}, (KT, t, i, j, reg[fa_])
+                    assert reg[fb_] == {0: (want_t, "b", j), 1: (want_t, "b", j)}, (KT, t, i, j, reg[fb_])
+                    if mx:
+                        sb_, sa_ = int(args[4][1:]), int(args[5].split()[0][1:])
+                        assert scale_reg[sa_ & ~1] == want_t and scale_reg[sb_ & ~1] == want_t
+                        assert (sa_ & 1) == (i >> 2) and (sb_ & 3) == 2 + (j >> 2)
+                        sel = re.search(r"op_sel:\[(\d),(\d),0\] op_sel_hi:\[(\d),(\d),0\]", ins)
+                        assert int(sel.group(1)) + 2 * int(sel.group(3)) == (j & 3) and int(sel.group(2)) + 2 * int(sel.group(4)) == (i & 3)
+                    mf_seen.append((i, j))
+                elif op == "s_cbranch_scc0":
+                    if not scc:
+                        pc = labels[args[0]]
+                elif op == "s_cbranch_scc1":
+                    if scc:
+                        pc = labels[args[0]]
+                else:
+                    raise AssertionError(ins)
+            assert len(mf_seen) == 64 * KT
+            for t in range(KT):
+                assert sorted(mf_seen[64 * t:64 * t + 64]) == [(i, j) for i in range(8) for j in range(8)]
+            assert not pending_dma and not lds_q
+        # stream hygiene, as for the fp16 loops
+        for a, b in zip(L, L[1:]):
+            assert not (a.startswith("s_add_u32 m0") and b.startswith("buffer_load"))
+            assert not a.startswith("s_cmp_ge_u32") or b.startswith("s_cselect_b32")
+        for k, l in enumerate(L):
+            if l.startswith("s_cmp_lt_u32"):
+                nxt = next(x for x in L[k + 1:] if not x.startswith("v_mfma") and not x.startswith("s_waitcnt"))
+                assert nxt.startswith("s_cbranch")
+
+
 def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     """bench.py labels its roofline rows with the kernel name the DISPATCHER reports (lc_*_kernel_name) and looks the
     fabric bytes of that kernel up in profiles/latest_pmc.json (tools/summarize_prof.py, separate rocprofv3 --pmc

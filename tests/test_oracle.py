@@ -158,6 +158,23 @@ def test_fp8_gemm_oracle_vs_torch(oracle):
     np.testing.assert_allclose(got, want.float().numpy(), rtol=1e-6, atol=1e-6)
 
 
+def test_mxfp8_gemm_oracle_vs_torch(oracle):
+    """The MX restatement (E8M0 block scale per row and 32 k) pinned on torch fp64 arithmetic over the dequantised operands; unit
+    scales (127) reduce it to the plain fp8 oracle."""
+    torch.manual_seed(14)
+    M, N, K = 40, 24, 160
+    a = (torch.randn(M, K) * 0.5).to(torch.float8_e4m3fn)
+    b = (torch.randn(N, K) * 0.5).to(torch.float8_e4m3fn)
+    sa = torch.randint(120, 135, (M, K // 32), dtype=torch.uint8)
+    sb = torch.randint(120, 135, (N, K // 32), dtype=torch.uint8)
+    got = oracle.gemm_mxfp8(a, sa, b, sb, M, N, K, alpha=0.5)
+    da = a.double() * torch.pow(2.0, sa.double() - 127).repeat_interleave(32, dim=1)
+    db = b.double() * torch.pow(2.0, sb.double() - 127).repeat_interleave(32, dim=1)
+    np.testing.assert_allclose(got, (0.5 * (da @ db.t())).float().numpy(), rtol=1e-6, atol=1e-6)
+    one = torch.full_like(sa, 127), torch.full_like(sb, 127)
+    np.testing.assert_array_equal(oracle.gemm_mxfp8(a, one[0], b, one[1], M, N, K, alpha=0.5), oracle.gemm_fp8(a, b, M, N, K, alpha=0.5))
+
+
 def test_bf16_attention_oracle_vs_torch(oracle):
     torch.manual_seed(13)
     B, H, N, D = 1, 2, 64, 256
