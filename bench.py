@@ -117,7 +117,7 @@ def timed_region(w, step, steps, warmup, prewarm=PREWARM):
 # ("workload", written by tools/summarize_prof.py); the table covers the files committed before that field existed.
 LEGACY_PMC_WORKLOAD = {"hgemm_w4y_kernel": "hgemm_8192", 
                        "attn_fwd_bigd2_kernel<512,false": "attn_d512_fp16", "attn_fwd_bigd2_kernel<512,true": "attn_d512_bf16",
-                       "gemm_fp8_w4_kernel": "fp8_8192"}
+                       "gemm_fp8_w4_kernel": "fp8_8192"}   # (gemm_fp8_w4k_kernel entries carry "workload" themselves)
 
 
 def pmc_traffic(kernel: str, workload: str | None = None):
@@ -383,8 +383,9 @@ def bench_attn_d1024(w, args, steps=3):
 
 def bench_fp8(w, args, steps=10):
     """Config 5b: fp8 (OCP e4m3fn) GEMM M=N=K=16384, TN, fp32 accumulate, fp16 out (lc_gemm_fp8_e4m3: MX-scaled
-    v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales = the plain e4m3 product).  Roofline: the MX fp8 rate,
-    5 PFLOP/s dense (MI355X_MICROARCH.md).  Replicas per rank, like HGEMM."""
+    v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales = the plain e4m3 product; block "block_scaled": lc_gemm_mxfp8, the same
+    kernel with a real E8M0 scale per row and 32 k).  Roofline: the MX fp8 rate, 5 PFLOP/s dense (MI355X_MICROARCH.md).  Replicas per
+    rank, like HGEMM."""
     n = 16384
     torch.manual_seed(8 + w.rank)
     a8 = torch.randn(n, n, device="cuda").to(torch.float8_e4m3fn)
@@ -397,14 +398,23 @@ def bench_fp8(w, args, steps=10):
     out = {"value": w.size * flops * steps / secs * 1e-12, "ms_per_step": secs / steps * 1e3, "steps": steps, "scaling": "weak",
            "dtype": "fp8 e4m3fn in, fp32 MFMA accumulate, f16 out",
            "workload": f"GEMM M=N=K={n} fp8 e4m3 TN (BASELINE config 5b), randn inputs cast to e4m3, alpha 1/16",
-           "roofline": roofline("gemm_fp8_w4_kernel", flops, 2.0 * n * n + 2.0 * n * n, ms_kernel, workload=f"fp8_{n}",
-                                peak=host.MI355X_FP8_MX_DENSE_PEAK_TFLOPS)}
+           "roofline": roofline("gemm_fp8_w4k_kernel<false>" if capi.tune_get("fp8_mx")[0] == 3 else "gemm_fp8_w4_kernel", flops,
+                                2.0 * n * n + 2.0 * n * n, ms_kernel, workload=f"fp8_{n}", peak=host.MI355X_FP8_MX_DENSE_PEAK_TFLOPS)}
     out["roofline"]["traffic_model"] = {
         "bytes": hgemm_traffic_model(n, n, n, in_bytes=1),
         "note": "L2-compulsory fabric bytes of 256x256 tiles with 4 x 8 tiles per XCD (12 one-byte panels per 32 tiles + C once): what the "
                 "counter reads; under the XCD super-block raster the 8 XCDs of a step share 16 + 16 panels through the Infinity Cache, "
                 "so HBM sees about a third of it (DESIGN.md 4.13c)"}
-    del a8, b8, c8
+    # the same product on OCP MX data: one E8M0 scale per row and 32 k, drawn from 2^-2 .. 2^2 (packed once, outside the timed region:
+    # weights are packed at load time)
+    sa = torch.randint(125, 130, (n, n // 32), device="cuda", dtype=torch.uint8)
+    sb = torch.randint(125, 130, (n, n // 32), device="cuda", dtype=torch.uint8)
+    pa, pb = capi.mxfp8_pack_scales(sa), capi.mxfp8_pack_scales(sb)
+    stepx = lambda: capi.gemm_mxfp8(a8, pa, b8, pb, c8, alpha=1 / 64, swizzle_stride=2048)   # noqa: E731
+    secx = lcd.max_over_ranks(w, timed_region(w, stepx, steps, 2, prewarm=3))
+    out["block_scaled"] = {"value": w.size * flops * steps / secx * 1e-12, "ms_per_step": secx / steps * 1e3,
+                           "entry": "lc_gemm_mxfp8", "scales": "E8M0 per (row, 32 k), 2^-2 .. 2^2, + 1/32 of the operand bytes"}
+    del a8, b8, c8, sa, sb, pa, pb
     return out
 
 

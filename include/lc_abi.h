@@ -120,6 +120,7 @@ const char* lc_build_info(int* is_diag);
  *                  K / 64 / 8: the eight XCDs start an eighth of K apart), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 |
  *                  mask << 20 with mask < 128 (bit 27 together with any other bit is refused).  Only the fp32 accumulation order changes:
  *                  results agree with the unstaggered walk to fp16 rounding
+ *                  (the K = 128 fp8 kernel shares the stagger and the persistent walk of "hgemm_persist")
  *   "hgemm_tail"   1 (default) = when the 256-tile grid's last wave holds at most 128 tiles, the generated-loop kernel computes the
  *                  full waves and the 128-tile kernel the four quadrants of each remaining tile; 0 = one launch
  *   "hgemm_raster" block -> C tile map of the tiled GEMM kernels: 0 = auto (2 when A + B exceed the 256 MiB Infinity Cache by half,
