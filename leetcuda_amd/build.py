@@ -142,12 +142,13 @@ def build_abi(force: bool = False, audit: bool = True) -> Path:
     srcs.append(ROOT / "tools" / "gen_hgemm_w4y.py")
     srcs.append(ROOT / "tools" / "gen_attn_w4i.py")
     srcs.append(ROOT / "tools" / "gen_gemm_fp8_w4k.py")
+    srcs.append(ROOT / "tools" / "gen_attn_bigd7.py")
     flags = _flags()
     # the generated K loops (hgemm_w4y_loop*.inc) must be what tools/gen_hgemm_w4y.py emits today
     gen = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_hgemm_w4y.py"), "--check"], capture_output=True, text=True)
     if gen.returncode != 0:
         raise RuntimeError("generated sources are stale: " + gen.stderr.strip())
-    for script in ("gen_attn_w4i.py", "gen_gemm_fp8_w4k.py"):
+    for script in ("gen_attn_w4i.py", "gen_gemm_fp8_w4k.py", "gen_attn_bigd7.py"):
         gen = subprocess.run([sys.executable, str(ROOT / "tools" / script), "--check"], capture_output=True, text=True)
         if gen.returncode != 0:
             raise RuntimeError("generated sources are stale: " + gen.stderr.strip())

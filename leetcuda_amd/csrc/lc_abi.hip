@@ -31,7 +31,7 @@ tune_t g_tune_w4y_sched{1};        // hgemm_w4y_kernel loop schedule 0..2 (lc_tu
 tune_t g_tune_hgemm_stamps{0};     // GEMM cycle-stamp builds (diagnosis only, LC_DIAG)
 tune_t g_tune_hgemm_persist{1};    // 1 (default) = hgemm_w4y_kernel as a persistent workgroup per CU when the tiles divide evenly (lc_tune_set "hgemm_persist")
 tune_t g_tune_hgemm_stagger{0};    // K-loop stagger of hgemm_w4y_kernel (lc_tune_set "hgemm_stagger"): 0 = auto (by XCD), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 | mask << 20
-tune_t g_tune_attn_d512{0};        // D = 256 / 512 / 1024: 0 = auto, 1 = column-split kernel, 2 = attn_bigd3, 3 = D = 512 on the other of attn_bigd2 / attn_bigd6 than auto
+tune_t g_tune_attn_d512{0};        // D = 256 / 512 / 1024: 0 = auto, 1 = column-split kernel, 2 = attn_bigd3, 3 = D = 256 / 512 on the other MFMA shape than auto (attn_bigd2 <-> attn_bigd7 / attn_bigd6)
 }  // namespace lc
 
 namespace {
@@ -356,12 +356,16 @@ bool use_bigd6(int D, bool vt, int N) {
   const int k = g_tune_attn_d512;
   return D == 512 && !vt && N % 128 == 0 && ((k == 0 && kBigd6Auto) || (k == 3 && !kBigd6Auto));
 }
+// D = 256 with N % 256 == 0, V as [B,H,N,D]: attn_bigd7 (64 query rows per wave, 16x16x32 MFMAs, KV rings) is auto; knob 3 selects
+// attn_bigd2 (32 rows per wave, 32x32x16: the cross-check on the other MFMA shape, and the kernel for N % 256 == 128 and V transposed)
+bool use_bigd7(int D, bool vt, int N) { return D == 256 && !vt && N % 256 == 0 && g_tune_attn_d512 == 0; }
 
 template <int D, bool VT>
 int launch_attn_bigd_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                         hipStream_t st) {
   if (use_bigd4(D, VT, N)) return launch_attn_bigd4(Q, K, V, O, B, H, N, g_tune_attn_d1024, st);
   if (use_bigd6(D, VT, N)) return launch_attn_bigd6(Q, K, V, O, B, H, N, false, st);
+  if (use_bigd7(D, VT, N)) return launch_attn_bigd7(Q, K, V, O, B, H, N, false, st);
   if (use_bigd2(D, VT, N)) return VT ? launch_attn_bigd2_vt(Q, K, V, O, B, H, N, D, st) : launch_attn_bigd2(Q, K, V, O, B, H, N, D, false, st);
   if (N % 128 == 0) return launch_attn_bigd<D, 4, VT>(Q, K, V, O, B, H, N, st);
   return launch_attn_bigd<D, 2, VT>(Q, K, V, O, B, H, N, st);
@@ -493,6 +497,10 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
   }
   if (use_bigd6(D, v_transposed != 0, N)) {
     snprintf(buf, buflen, "attn_fwd_bigd6_kernel<%s>", bf16 ? "true" : "false");
+    return LC_OK;
+  }
+  if (use_bigd7(D, v_transposed != 0, N)) {
+    snprintf(buf, buflen, "attn_fwd_bigd7_kernel<%s>", bf16 ? "true" : "false");
     return LC_OK;
   }
   if (use_bigd2(D, v_transposed != 0, N) && !(bf16 && v_transposed)) {
@@ -736,6 +744,7 @@ int lc_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, int B
   const half_t* v = static_cast<const half_t*>(V);
   half_t* o = static_cast<half_t*>(O);
   if (use_bigd6(D, false, N)) return launch_attn_bigd6(q, k, v, o, B, H, N, true, st);
+  if (use_bigd7(D, false, N)) return launch_attn_bigd7(q, k, v, o, B, H, N, true, st);
   if (use_bigd2(D, false, N)) return launch_attn_bigd2(q, k, v, o, B, H, N, D, true, st);
   const bool w4 = N % 128 == 0;
   switch (D) {

@@ -1,0 +1,25 @@
+// tu_attn_big7.hip — translation unit of attn_bigd7.hip (D = 256, 64 query rows per wave on v_mfma_f32_16x16x32, fp16 / bf16) — see lc_launch.h
+#include <math.h>
+
+#include "lc_launch.h"
+#include "attn_bigd7.hip"
+
+namespace lc {
+namespace {
+template <bool BF16>
+int launch_bigd7_t(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, hipStream_t st) {
+  auto kern = attn_fwd_bigd7_kernel<BF16>;
+  constexpr int lds = bd7_lds_bytes();
+  if (int rc = set_dyn_lds(kern, lds)) return rc;
+  const int nqb = N / 256;
+  const dim3 grid((unsigned)((size_t)nqb * B * H)), block(256);
+  const float sl2 = (1.0f / sqrtf(256.0f)) * 1.4426950408889634f;
+  hipLaunchKernelGGL(kern, grid, block, lds, st, Q, K, V, O, N, nqb, sl2);
+  return check_launch();
+}
+}  // namespace
+// D = 256, N % 256 == 0, V as [B,H,N,D]; fp16 or bf16
+int launch_attn_bigd7(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, bool bf16, hipStream_t st) {
+  return bf16 ? launch_bigd7_t<true>(Q, K, V, O, B, H, N, st) : launch_bigd7_t<false>(Q, K, V, O, B, H, N, st);
+}
+}  // namespace lc

@@ -47,7 +47,7 @@ from pathlib import Path
 # kernel-name regex -> AGPR ranges owned by the kernel's asm statements (inclusive)
 OWNED_AGPRS = [
     (re.compile(r"hgemm_w4b_kernel|hgemm_w4x_kernel|hgemm_w4y_kernel|gemm_fp8_w4_kernel|gemm_fp8_w4k_kernel"), [(0, 255)]),
-    (re.compile(r"attn_fwd_w4u_kernel|attn_fwd_w4i_kernel|attn_fwd_bigd2_kernel|attn_fwd_bigd3_kernel|attn_fwd_bigd4_kernel|attn_fwd_bigd6_kernel"), [(0, 255)]),
+    (re.compile(r"attn_fwd_w4u_kernel|attn_fwd_w4i_kernel|attn_fwd_bigd2_kernel|attn_fwd_bigd3_kernel|attn_fwd_bigd4_kernel|attn_fwd_bigd6_kernel|attn_fwd_bigd7_kernel"), [(0, 255)]),
 ]
 
 # kernel-name regex -> literal arch VGPR range owned by the kernel's asm (inclusive)

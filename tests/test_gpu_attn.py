@@ -299,9 +299,10 @@ def test_scale_jumps_and_extreme_scores(oracle, nw):
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
 @pytest.mark.parametrize("D", [256, 512])
 def test_full_width_large_head_dim_kernel(oracle, D, dtype):
-    """attn_fwd_bigd2_kernel (one workgroup owns all D columns; N % 128 == 0) against the oracle, against round 1's
-    independently written column-split kernel (lc_tune_set "attn_d512" = 1), and on inputs that force its rescale
-    path (the running max is only a scale there): a spike row late in the sequence and a dominant first tile."""
+    """The full-width kernels (one workgroup owns all D columns: attn_bigd7 for D = 256, attn_bigd6 for D = 512; attn_bigd2 on the other
+    MFMA shape under "attn_d512" = 3) against the oracle, against round 1's independently written column-split kernel (knob 1), and on
+    inputs that force their rescale paths (the running max is only a scale there): a spike row late in the sequence and a dominant
+    first tile."""
     capi = _capi()
     B, H, N = 1, 3, 1024
     bf = dtype == "bf16"
@@ -318,7 +319,7 @@ def test_full_width_large_head_dim_kernel(oracle, D, dtype):
         (lambda a, b, c, o: capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", a, b, c, o, 2))
     for kk in (k, k2):
         outs = []
-        for knob in (0, 1, 2) + ((3,) if D == 512 else ()):      # 3: the D = 512 kernel on the other MFMA shape (attn_bigd6 / attn_bigd2)
+        for knob in (0, 1, 2, 3):      # 3: the other MFMA shape (attn_bigd2 where auto is attn_bigd7 / attn_bigd6)
             capi.tune("attn_d512", knob)
             try:
                 o = torch.full_like(q, float("nan"))
@@ -332,7 +333,7 @@ def test_full_width_large_head_dim_kernel(oracle, D, dtype):
             d = np.abs(o - truth)
             assert np.isfinite(d).all() and d.max() < tol_max, d.max()
         assert all(np.abs(outs[0] - o).max() < tol_max for o in outs[1:])
-    assert capi.attn_kernel_name(N, D, False, bf).startswith(("attn_fwd_bigd2_kernel", "attn_fwd_bigd6_kernel"))
+    assert capi.attn_kernel_name(N, D, False, bf).startswith("attn_fwd_bigd7_kernel" if D == 256 else "attn_fwd_bigd6_kernel")
 
 
 @pytest.mark.parametrize("D,N", [(128, 256), (256, 128)])

@@ -42,6 +42,7 @@ FAMILIES = [
     ("d96-auto", 96, None, 0),
     ("d32-auto", 32, None, 0),
     ("d256-auto", 256, None, 0),
+    ("d256-other-mfma-shape", 256, "attn_d512", 3),
     ("d512-auto", 512, None, 0),
     ("d512-column-split", 512, "attn_d512", 1),
     ("d512-other-mfma-shape", 512, "attn_d512", 3),

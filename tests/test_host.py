@@ -389,7 +389,9 @@ def test_large_head_dim_kernel_names(built):
     assert capi.attn_kernel_name(8192, 1024) == "attn_fwd_bigd4_kernel<8>"
     assert capi.attn_kernel_name(64, 1024) == "attn_fwd_bigd4_kernel<8>"
     assert capi.attn_kernel_name(8192, 256, True) == "attn_fwd_bigd2_kernel<256,false,true>"
-    assert capi.attn_kernel_name(8192, 256) == "attn_fwd_bigd2_kernel<256,false,false>"
+    assert capi.attn_kernel_name(8192, 256) == "attn_fwd_bigd7_kernel<false>"
+    assert capi.attn_kernel_name(8192, 256, False, True) == "attn_fwd_bigd7_kernel<true>"
+    assert capi.attn_kernel_name(384, 256) == "attn_fwd_bigd2_kernel<256,false,false>"      # N % 256 == 128: the 32-rows-per-wave kernel
     assert capi.attn_kernel_name(8192, 512, True).startswith("attn_fwd_bigd_kernel<512,")
     assert capi.attn_kernel_name(192, 256, True).startswith("attn_fwd_bigd_kernel<256,")
     assert capi.attn_kernel_name(8192, 512) == "attn_fwd_bigd6_kernel<false>"

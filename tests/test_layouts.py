@@ -474,3 +474,57 @@ def test_hgemm_w4y_epilogue_staging_fits_one_ring_slot_and_is_conflict_free():
         for grp in B128_GROUPS:
             addrs = [(it * 4 + (lane >> 4)) * 256 + (((lane & 15) ^ ((it * 4 + (lane >> 4)) & 15)) * 16) for lane in grp]
             assert conflict_free(addrs, 16), (it, grp)
+
+
+def test_bigd7_rings_on_512_byte_rows():
+    """attn_bigd7.hip (D = 256, 64 query rows per wave, KV tiles of 32 rows x 512 B).  The kernel's address forms restated:
+    K read   (kvb, ds): lane (l16, g4) -> row 16 kvb + l16, chunk 4 ds + g4 at kx[ds & 3] + (ds >> 2) * 256, kx = l16 * 512 + (((4 k4 + g4) ^ l16) * 16)
+    V read   (db, x)  : lane -> kv row 16 x + 4 g4 + (l16 >> 2), 8 bytes at column 4 (l16 & 3) of pair db: vx[db & 7] + (db >> 3) * 256,
+                        vx[b] = row * 512 + 8 (l16 & 3) + ((b ^ key) * 32), key = ((l16 >> 2) << 1) | (g4 & 1)
+    DMA piece p = wave + 4 i (rows 2 p, 2 p + 1): lane -> row b = lane >> 5, chunk slot cs = lane & 31 <- source chunk (K) (cs & 16) | ((cs ^ (row & 15)) & 15),
+                        (V) pair slot ps = cs >> 1 <- source pair (ps & 8) | ((ps ^ key(row)) & 7), key(row) = ((row & 3) << 1) | ((row >> 2) & 1)
+    (1) fragment reads are bank-conflict free, (2) what the DMA writes is what the readers expect, lane offsets included."""
+    ROWB = 512
+    # ---- K: reads
+    for ds, kvb in itertools.product(range(8), range(2)):
+        for grp in B128_GROUPS:
+            addrs = []
+            for lane in grp:
+                l16, g4 = lane & 15, lane >> 4
+                a = l16 * ROWB + (((4 * (ds & 3) + g4) ^ l16) * 16) + (ds >> 2) * 256 + kvb * 16 * ROWB
+                row, c = 16 * kvb + l16, 4 * ds + g4
+                assert a == row * ROWB + ((c & 16) | ((c ^ (row & 15)) & 15)) * 16
+                addrs.append(a)
+            assert conflict_free(addrs, 16), (ds, kvb, grp)
+    # ---- V: transpose reads (two 32-lane groups)
+    vkey = lambda r: ((r & 3) << 1) | ((r >> 2) & 1)
+    for db, x in itertools.product(range(16), range(2)):
+        for grp in TR_GROUPS:
+            addrs = []
+            for lane in grp:
+                l16, g4 = lane & 15, lane >> 4
+                key = ((l16 >> 2) << 1) | (g4 & 1)
+                a = (4 * g4 + (l16 >> 2)) * ROWB + 8 * (l16 & 3) + (((db & 7) ^ key) * 32) + (db >> 3) * 256 + x * 16 * ROWB
+                row = 16 * x + 4 * g4 + (l16 >> 2)
+                assert a == row * ROWB + ((db & 8) | ((db ^ vkey(row)) & 7)) * 32 + 8 * (l16 & 3)
+                addrs.append(a)
+            assert conflict_free(addrs, 8), (db, x)
+    # ---- DMA: the kernel's lane offsets place source chunk / pair where the image wants them; the pieces tile the 32 rows
+    rows_seen = set()
+    for wave, i in itertools.product(range(4), range(4)):
+        p = wave + 4 * i
+        for lane in range(64):
+            b, cs, ps = lane >> 5, lane & 31, (lane & 31) >> 1
+            row = 2 * p + b
+            rows_seen.add(row)
+            # K: k_off[i & 1] = b * 512 + ((cs & 16) | ((cs ^ ((2 wave + 8 (i & 1) + b) & 15)) & 15)) * 16, source = piece base + k_off, LDS = piece base + lane * 16
+            ksrc = (cs & 16) | ((cs ^ ((2 * wave + 8 * (i & 1) + b) & 15)) & 15)
+            assert (ksrc & 16) | ((ksrc ^ (row & 15)) & 15) == cs                 # the image's slot of that source chunk is the lane's slot
+            kv = (((2 * wave + b) & 3) << 1) | (wave >> 1)
+            assert kv == vkey(row)
+            vsrc_pair = (ps & 8) | ((ps ^ kv) & 7)
+            assert (vsrc_pair & 8) | ((vsrc_pair ^ vkey(row)) & 7) == ps
+    assert rows_seen == set(range(32))
+    # ---- LDS budget: two rings of four 16-KiB tiles + query block 3's Q fragments (8 d-steps x 1 KiB x 4 waves) = 160 KiB; the epilogue's
+    # staging (4 waves x 64 rows x 528 B) aliases it
+    assert 2 * 4 * 32 * ROWB + 4 * 8 * 1024 == 160 * 1024 and 4 * 64 * (ROWB + 16) <= 160 * 1024

@@ -22,6 +22,9 @@ while args and args[0].startswith("--"):
     else:
         raise SystemExit(f"unknown option {args[0]}")
     args = args[2:]
+import os  # noqa: E402
+if os.environ.get("LC_AB_LIB"):    # A/B of two builds on one box: point the ctypes view at another copy of the library
+    capi.LIB_PATH = Path(os.environ["LC_AB_LIB"]).resolve()
 capi.load()
 KNOBS = {"nw": "attn_nw", "walk": "attn_walk", "d512": "attn_d512", "d1024": "attn_d1024", "sched": "attn_w4i_sched"}
 cache = {}

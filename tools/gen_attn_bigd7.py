@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Emit leetcuda_amd/csrc/attn_bigd7_stmts.inc: the asm statements of attn_fwd_bigd7_kernel (attn_bigd7.hip) that touch the score registers.
+
+Why a generator: the softmax of tile t runs as filler behind the P·V MFMAs of tile t − 1.  Written in C++ between two 8-MFMA statements
+the fillers issue AFTER the statement's MFMAs (which go out back to back, 12 of every 16 issue cycles unused) and the matrix pipe idles
+while they run: 0.53 MFMA-busy (profiles/r4n_pmc_bigd7.txt).  Here the three VALU instructions per score (v_fma_f32 s sl2 − m, v_exp_f32,
+v_add_f32 into the row sum) sit IN the gaps between the MFMAs of the statement, software-pipelined one gap apart (a transcendental's
+result may not be read by the very next VALU instruction).  That needs the scores under literal register names:
+
+  Sᵀ block (kvb, qb) = v[208 + 4 (4 kvb + qb) .. + 3]  — score element e = 16 kvb + 4 qb + r lives in v[208 + e]
+  Vᵀ quads           = v[240:255]                      — as attn_bigd6.hip
+
+Emitted (C++ function templates, BF16 selects the MFMA opcode):
+  bd7_qk8f<BF16, FIRST>(s, k0, k1, q0..q3)      the eight MFMAs of a d-step on the pinned score registers
+  bd7_pvf<X, BF16, R0, OFF, HOFF>(...)          statement X = 2 .. 7 of a tile's eight P·V statements (X >> 1 = step, X & 1 = quad pair)
+                                                 with the fillers of score elements e, e * 6 / 32 == X − 2 (two score blocks, two query
+                                                 blocks: ps / m operands A and B), the transpose reads of the NEXT step behind each
+                                                 fragment's four MFMAs (X < 6) and the counted lgkmcnt waits of attn_bigd7.hip's bd7_pv8
+Register indices inside the statements are assembler expressions on ONE "n" operand (a[%R + 4 : %R + 7]): the 30-operand limit of an asm
+statement would not hold sixteen of them.
+
+usage: tools/gen_attn_bigd7.py [--check]"""
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+OUT = ROOT / "leetcuda_amd" / "csrc" / "attn_bigd7_stmts.inc"
+S0 = 208          # first score register
+QUADS = {0: (240, 244), 1: (248, 252)}
+
+
+def elements(x):
+    return [e for e in range(32) if e * 6 // 32 == x - 2]
+
+
+def asm_lines(lines):
+    return "\n".join(f'               "{ln}\\n\\t"' for ln in lines)
+
+
+def gen_qk():
+    out = []
+    out.append("// the eight MFMAs of one d-step on the pinned score registers: Sᵀ block (kvb, qb) += K fragment (kvb) x Q fragment (qb)")
+    out.append("template <bool BF16, bool FIRST>")
+    out.append("LC_DEVINL void bd7_qk8f(f32x4_t (&s)[2][4], half8_t k0, half8_t k1, half8_t q0, half8_t q1, half8_t q2, half8_t q3) {")
+    for bf in (True, False):
+        op = "v_mfma_f32_16x16x32_bf16" if bf else "v_mfma_f32_16x16x32_f16"
+        lines = ["s_nop %14"]
+        for kvb in range(2):
+            for qb in range(4):
+                r = S0 + 4 * (4 * kvb + qb)
+                lines.append(f"{op} v[{r}:{r + 3}], %{8 + kvb}, %{10 + qb}, v[{r}:{r + 3}]")
+        cons = ", ".join(f'"+{{v[{S0 + 4 * t}:{S0 + 4 * t + 3}]}}"(s[{t >> 2}][{t & 3}])' for t in range(8))
+        out.append(f"  if constexpr ({'BF16' if bf else '!BF16'}) {{")
+        out.append("    asm volatile(\n" + asm_lines(lines) + "\n"
+                   f"               : {cons}\n"
+                   '               : "v"(k0), "v"(k1), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "n"(FIRST ? 1 : 0)\n'
+                   "               : LC_AGPR_ALL);")
+        out.append("  }")
+    out.append("}")
+    return out
+
+
+def gen_pvf(x):
+    st, hq = x >> 1, x & 1
+    rd = st + 1 < 4
+    w0, w1 = (6, 6) if rd else ((2, 0) if hq else (6, 4))
+    qx, qy = QUADS[hq]
+    es = elements(x)
+    ta, tb = sorted({e >> 2 for e in es})
+    qa, qb_ = ta & 3, tb & 3
+    # operands: %0 fx %1 fy %2 sa %3 sb %4 psa %5 psb | %6..%9 p0..p3 %10 ax %11 ay %12 sl2 %13 ma %14 mb | %15 R0 %16 OFF %17 OFF+HOFF
+    def filler(kind, e):
+        reg = f"v[{S0 + e}]"
+        first = (e >> 2) == ta
+        ps, m = ("%4", "%13") if first else ("%5", "%14")
+        if kind == "F":
+            return f"v_fma_f32 {reg}, {reg}, %12, -{m}"
+        if kind == "X":
+            return f"v_exp_f32 {reg}, {reg}"
+        return f"v_add_f32 {ps}, {ps}, {reg}"
+    gaps = [[] for _ in range(8)]
+    for i, e in enumerate(es):
+        gaps[i].append(filler("F", e))
+        gaps[i + 1].append(filler("X", e))
+        gaps[i + 2].append(filler("A", e))
+    assert len(es) + 2 <= 8
+    out = []
+    for bf in (True, False):
+        op = "v_mfma_f32_16x16x32_bf16" if bf else "v_mfma_f32_16x16x32_f16"
+        lines = ["s_nop 1", f"s_waitcnt lgkmcnt({w0})"]
+        for j, (quad, base) in enumerate(((qx, 0), (qy, 16))):
+            if j == 1:
+                lines.append(f"s_waitcnt lgkmcnt({w1})")
+            for q in range(4):
+                lines.append(f"{op} a[%15+{base + 4 * q}:%15+{base + 4 * q + 3}], v[{quad}:{quad + 3}], %{6 + q}, a[%15+{base + 4 * q}:%15+{base + 4 * q + 3}]")
+                g = 4 * j + q
+                if q == 3 and rd:
+                    ad = "%10" if j == 0 else "%11"
+                    lines.append(f"ds_read_b64_tr_b16 v[{quad}:{quad + 1}], {ad} offset:%16")
+                    lines.append(f"ds_read_b64_tr_b16 v[{quad + 2}:{quad + 3}], {ad} offset:%17")
+                lines.extend(gaps[g])
+        cons_out = (f'"+{{v[{qx}:{qx + 3}]}}"(fx), "+{{v[{qy}:{qy + 3}]}}"(fy), "+{{v[{S0 + 4 * ta}:{S0 + 4 * ta + 3}]}}"(sa), '
+                    f'"+{{v[{S0 + 4 * tb}:{S0 + 4 * tb + 3}]}}"(sb), "+v"(psa), "+v"(psb)')
+        out.append(f"    if constexpr ({'BF16' if bf else '!BF16'}) {{")
+        out.append("      asm volatile(\n" + asm_lines(lines).replace("               ", "                   ") + "\n"
+                   f"                   : {cons_out}\n"
+                   '                   : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(ax), "v"(ay), "v"(sl2), "v"(ma), "v"(mb), "n"(R0), "n"(OFF), "n"(OFF + HOFF)\n'
+                   "                   : LC_AGPR_ALL);")
+        out.append("    }")
+    return out, (ta, tb, qa, qb_)
+
+
+def render():
+    L = ["// GENERATED by tools/gen_attn_bigd7.py — do not edit.  Statements of attn_fwd_bigd7_kernel on the pinned score registers v[208:239]",
+         "// (score element e = 16 kvb + 4 qb + r in v[208 + e]) and the Vᵀ quads v[240:255]; see the generator for the schedule.", ""]
+    L += gen_qk()
+    L.append("")
+    L.append("// statement X of a tile's eight P·V statements with the softmax fillers of its score elements in the MFMA gaps.  sa / sb: the two score")
+    L.append("// blocks it touches (bd7_pvf_blocks), psa / psb and ma / mb: row sum and running maximum of their query blocks.")
+    L.append("template <int X, bool BF16, int R0, int OFF, int HOFF>")
+    L.append("LC_DEVINL void bd7_pvf(half8_t& fx, half8_t& fy, half8_t p0, half8_t p1, half8_t p2, half8_t p3, uint32_t ax, uint32_t ay,")
+    L.append("                       f32x4_t& sa, f32x4_t& sb, float& psa, float& psb, float sl2, float ma, float mb) {")
+    L.append("  static_assert(X >= 2 && X <= 7);")
+    table = {}
+    for x in range(2, 8):
+        body, info = gen_pvf(x)
+        table[x] = info
+        L.append(f"  if constexpr (X == {x}) {{")
+        L += body
+        L.append("  }")
+    L.append("}")
+    L.append("// score blocks (t = 4 kvb + qb) statement X touches, and their query blocks")
+    L.append("constexpr int bd7_pvf_ta(int x) { return " + " : ".join(f"x == {x} ? {table[x][0]}" for x in range(2, 7)) + f" : {table[7][0]}; }}")
+    L.append("constexpr int bd7_pvf_tb(int x) { return " + " : ".join(f"x == {x} ? {table[x][1]}" for x in range(2, 7)) + f" : {table[7][1]}; }}")
+    return "\n".join(L) + "\n"
+
+
+def main():
+    text = render()
+    if "--check" in sys.argv:
+        if not OUT.exists() or OUT.read_text() != text:
+            print(f"{OUT} is stale: run tools/gen_attn_bigd7.py", file=sys.stderr)
+            return 1
+        return 0
+    OUT.write_text(text)
+    print(f"wrote {OUT} ({len(text.splitlines())} lines)")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
