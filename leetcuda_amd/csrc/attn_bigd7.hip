@@ -211,10 +211,6 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd7_kernel(
     // Sᵀ(t) = K(t)·Qᵀ; DMA: with the K pieces of tile t + 3 (-> the slot K(t−1) left) behind every other d-step
     auto qk = [&](auto dmac) {
       constexpr bool DMA = decltype(dmac)::value;
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) s[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       half8_t kfr[2][2], qr[2];   // K fragments / the parked Q fragment of d-step ds in ring slot ds & 1
       if constexpr (DMA) {        // (the first pass of a period: d-step 0 was prefetched)
         kfr[0][0] = knx[0];
@@ -234,6 +230,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd7_kernel(
         if constexpr (DMA && (ds & 1) == 0) issue_k(ds >> 1, t + 3, (SL + 3) & 3);
         __builtin_amdgcn_sched_barrier(0);
         bd7_qk8f<BF16, ds == 0>(s, kfr[ds & 1][0], kfr[ds & 1][1], qf[ds][0], qf[ds][1], qf[ds][2], qr[ds & 1]);
+        // the Vᵀ fragments of the first P·V step: V(t−1) has been published for a whole period and the quads are idle during Sᵀ, so the
+        // reads go out two d-steps before they are needed
+        if constexpr (DMA && HAS_PV && ds == NDS - 3) bd6_rd<VS, 16 * ROWB>(vf0, vf1, vf2, vf3, vx[0], vx[1], vx[2], vx[3]);
         __builtin_amdgcn_sched_barrier(0);
       });
     };
@@ -291,7 +290,6 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd7_kernel(
       s_drain();
       exact();
     } else {
-      bd6_rd<VS, 16 * ROWB>(vf0, vf1, vf2, vf3, vx[0], vx[1], vx[2], vx[3]);
       pv_stmt(std::integral_constant<int, 0>{});
       pv_stmt(std::integral_constant<int, 1>{});
       // the 16 MFMAs just issued cover the latency of the Sᵀ MFMAs; this empty statement orders the VALU reads of S behind them

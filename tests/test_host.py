@@ -296,6 +296,44 @@ def test_generated_fp8_k128_loop_is_current_and_consumes_the_right_tiles():
                 assert nxt.startswith("s_cbranch")
 
 
+def test_generated_bigd7_statements_are_current_and_pipeline_the_softmax():
+    """attn_bigd7's statements on the pinned score registers (tools/gen_attn_bigd7.py): committed .inc == generator output; the six P·V
+    statements with fillers cover every score element v[208 + e], e = 0 .. 31, exactly once with v_fma -> v_exp -> v_add one MFMA gap
+    apart (a transcendental's result is never read by the next VALU instruction), on the row sum / maximum operand of the element's
+    query block; the counted lgkmcnt waits are (6, 6) while transpose reads are re-issued and (6, 4) / (2, 0) on the last step."""
+    import importlib.util
+    import re
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("lc_gen_bigd7", root / "tools" / "gen_attn_bigd7.py")
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert gen.OUT.read_text() == gen.render()
+    seen = []
+    for x in range(2, 8):
+        body, (ta, tb, qa, qb) = gen.gen_pvf(x)
+        text = "\n".join(body)
+        half = text[:text.index("if constexpr (!BF16)")]
+        ins = re.findall(r'"([^"]+?)\\n\\t"', half)
+        mf = [i for i, l in enumerate(ins) if l.startswith("v_mfma")]
+        assert len(mf) == 8
+        gap_of = lambda i: sum(1 for m in mf if m < i) - 1          # index of the MFMA an instruction follows
+        for e in gen.elements(x):
+            reg = f"v[{208 + e}]"
+            f = next(i for i, l in enumerate(ins) if l.startswith(f"v_fma_f32 {reg},"))
+            xx = next(i for i, l in enumerate(ins) if l.startswith(f"v_exp_f32 {reg},"))
+            a = next(i for i, l in enumerate(ins) if l.startswith("v_add_f32") and l.endswith(reg))
+            assert gap_of(f) + 1 == gap_of(xx) and gap_of(xx) + 1 == gap_of(a)
+            first = (e >> 2) == ta
+            assert ins[f].endswith("-%13" if first else "-%14") and ins[a].startswith("v_add_f32 %4" if first else "v_add_f32 %5")
+            assert not ins[xx + 1].endswith(reg)                      # the instruction behind the v_exp does not read its result
+            seen.append(e)
+        assert (qa, qb) == (ta & 3, tb & 3)
+        waits = [int(w) for w in re.findall(r"s_waitcnt lgkmcnt\((\d)\)", "\n".join(ins))]
+        assert waits == ([6, 6] if x < 6 else ([6, 4] if x == 6 else [2, 0]))
+        assert sum(l.startswith("ds_read_b64_tr_b16") for l in ins) == (4 if x < 6 else 0)
+    assert sorted(seen) == list(range(32))
+
+
 def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     """bench.py labels its roofline rows with the kernel name the DISPATCHER reports (lc_*_kernel_name) and looks the
     fabric bytes of that kernel up in profiles/latest_pmc.json (tools/summarize_prof.py, separate rocprofv3 --pmc

@@ -39,23 +39,26 @@ def asm_lines(lines):
 
 def gen_qk():
     out = []
-    out.append("// the eight MFMAs of one d-step on the pinned score registers: Sᵀ block (kvb, qb) += K fragment (kvb) x Q fragment (qb)")
+    out.append("// the eight MFMAs of one d-step on the pinned score registers: Sᵀ block (kvb, qb) += K fragment (kvb) x Q fragment (qb).  FIRST: the first")
+    out.append("// d-step of a tile — the accumulator input is the inline constant 0 (no VALU zeroing of the 32 score registers), outputs write-only")
     out.append("template <bool BF16, bool FIRST>")
     out.append("LC_DEVINL void bd7_qk8f(f32x4_t (&s)[2][4], half8_t k0, half8_t k1, half8_t q0, half8_t q1, half8_t q2, half8_t q3) {")
     for bf in (True, False):
-        op = "v_mfma_f32_16x16x32_bf16" if bf else "v_mfma_f32_16x16x32_f16"
-        lines = ["s_nop %14"]
-        for kvb in range(2):
-            for qb in range(4):
-                r = S0 + 4 * (4 * kvb + qb)
-                lines.append(f"{op} v[{r}:{r + 3}], %{8 + kvb}, %{10 + qb}, v[{r}:{r + 3}]")
-        cons = ", ".join(f'"+{{v[{S0 + 4 * t}:{S0 + 4 * t + 3}]}}"(s[{t >> 2}][{t & 3}])' for t in range(8))
-        out.append(f"  if constexpr ({'BF16' if bf else '!BF16'}) {{")
-        out.append("    asm volatile(\n" + asm_lines(lines) + "\n"
-                   f"               : {cons}\n"
-                   '               : "v"(k0), "v"(k1), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "n"(FIRST ? 1 : 0)\n'
-                   "               : LC_AGPR_ALL);")
-        out.append("  }")
+        for first in (True, False):
+            op = "v_mfma_f32_16x16x32_bf16" if bf else "v_mfma_f32_16x16x32_f16"
+            lines = []
+            for kvb in range(2):
+                for qb in range(4):
+                    r = S0 + 4 * (4 * kvb + qb)
+                    lines.append(f"{op} v[{r}:{r + 3}], %{8 + kvb}, %{10 + qb}, " + ("0" if first else f"v[{r}:{r + 3}]"))
+            mod = "=" if first else "+"
+            cons = ", ".join(f'"{mod}{{v[{S0 + 4 * t}:{S0 + 4 * t + 3}]}}"(s[{t >> 2}][{t & 3}])' for t in range(8))
+            out.append(f"  if constexpr ({'BF16' if bf else '!BF16'} && {'FIRST' if first else '!FIRST'}) {{")
+            out.append("    asm volatile(\n" + asm_lines(lines) + "\n"
+                       f"               : {cons}\n"
+                       '               : "v"(k0), "v"(k1), "v"(q0), "v"(q1), "v"(q2), "v"(q3)\n'
+                       "               : LC_AGPR_ALL);")
+            out.append("  }")
     out.append("}")
     return out
 
