@@ -29,18 +29,31 @@ namespace lc {
 
 // the eight MFMAs of one d-step — Sᵀ blocks (kvb, qb) += K fragment (kvb) x Q fragment (qb), kvb = 0 .. 3, qb = 0, 1 — in ONE statement
 // (hipcc pads every asm boundary with a wait state: eight one-MFMA statements per 128 matrix-core cycles cost 7 of them).  FIRST: the
-// first d-step of a tile — hipcc has just zeroed the accumulators with VALU moves, and a VALU write needs two wait states before an
-// MFMA may read the register (isa_audit.py rule R6): the leading s_nop
+// first d-step of a tile takes the inline constant 0 as its accumulator input (write-only outputs: no VALU zeroing of the 32 score
+// registers — attn_bigd7's trick, 16 v_mov_b64 per tile less)
 template <bool BF16, bool FIRST>
 LC_DEVINL void bd6_qk8(f32x4_t (&s)[4][2], const half8_t (&k)[4], half8_t q0, half8_t q1) {
 #define LC_BD6_QK8(OP)                                                                                                            \
-  asm volatile("s_nop %14\n\t" OP " %0, %8, %12, %0\n\t" OP " %1, %8, %13, %1\n\t" OP " %2, %9, %12, %2\n\t" OP " %3, %9, %13, %3\n\t" \
+  asm volatile(OP " %0, %8, %12, %0\n\t" OP " %1, %8, %13, %1\n\t" OP " %2, %9, %12, %2\n\t" OP " %3, %9, %13, %3\n\t"                   \
                OP " %4, %10, %12, %4\n\t" OP " %5, %10, %13, %5\n\t" OP " %6, %11, %12, %6\n\t" OP " %7, %11, %13, %7"                  \
                : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(s[2][0]), "+v"(s[2][1]), "+v"(s[3][0]), "+v"(s[3][1])  \
-               : "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(q0), "v"(q1), "n"(FIRST ? 1 : 0)                                     \
+               : "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(q0), "v"(q1)                                                        \
                : LC_AGPR_ALL)
-  if constexpr (BF16) { LC_BD6_QK8("v_mfma_f32_16x16x32_bf16"); }
-  else { LC_BD6_QK8("v_mfma_f32_16x16x32_f16"); }
+#define LC_BD6_QK8_FIRST(OP)                                                                                                      \
+  asm volatile(OP " %0, %8, %12, 0\n\t" OP " %1, %8, %13, 0\n\t" OP " %2, %9, %12, 0\n\t" OP " %3, %9, %13, 0\n\t"                       \
+               OP " %4, %10, %12, 0\n\t" OP " %5, %10, %13, 0\n\t" OP " %6, %11, %12, 0\n\t" OP " %7, %11, %13, 0"                      \
+               : "=&v"(s[0][0]), "=&v"(s[0][1]), "=&v"(s[1][0]), "=&v"(s[1][1]), "=&v"(s[2][0]), "=&v"(s[2][1]), "=&v"(s[3][0]),        \
+                 "=&v"(s[3][1])                                                                                                    \
+               : "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(q0), "v"(q1)                                                        \
+               : LC_AGPR_ALL)
+  if constexpr (FIRST) {
+    if constexpr (BF16) { LC_BD6_QK8_FIRST("v_mfma_f32_16x16x32_bf16"); }
+    else { LC_BD6_QK8_FIRST("v_mfma_f32_16x16x32_f16"); }
+  } else {
+    if constexpr (BF16) { LC_BD6_QK8("v_mfma_f32_16x16x32_bf16"); }
+    else { LC_BD6_QK8("v_mfma_f32_16x16x32_f16"); }
+  }
+#undef LC_BD6_QK8_FIRST
 #undef LC_BD6_QK8
 }
 // P·V step: Oᵀ blocks (db = 4 s + j, qb) += Vᵀ fragment j (fixed quad) x Pᵀ(qb), j = 0 .. 3; RD: + the two transpose reads of the NEXT
@@ -185,11 +198,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd6_kernel(
   // softmax(t) as filler and the DMA of K(t+1); barrier.  pn = P(t) (written), po = P(t−1) (read).  HAS_PV = false: tile 0.
   auto tile = [&](auto pvc, int t, half8_t (&pn)[2][2], half8_t (&po)[2][2]) {
     constexpr bool HAS_PV = decltype(pvc)::value;
-    f32x4_t s[4][2];   // [kvb][qb]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) s[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    f32x4_t s[4][2];   // [kvb][qb]; written by the first d-step (accumulator input 0)
     {
       half8_t kfr[2][4], qfr[2][2];   // K fragments / parked Q fragments of d-step ds in ring slot ds & 1
       auto ldk = [&](auto dc) {
