@@ -24,8 +24,8 @@ A "step" is one pass of the hot path over one batch of synthetic input already r
 The default run reports HGEMM as `value` and carries, in the same JSON line: "vendor_tflops" (same-run hipBLASLt TN /
 NN = the reference's cuBLAS comparator), "uniform_tflops" (the same kernel on uniform[-1,1) operands, the fill the
 programming guide quotes), "sustained" (>= 2 s of back-to-back launches with the effective shader clock),
-"attention" (config 3), "attention_cfg4" (config 4, aggregate over ranks), "attention_d512" (config 5a),
-"attention_d1024" ((1,48,8192,1024), the tiling dispatchers' largest head dim), "attention_d64" (the reference's published shape
+"attention" (config 3), "attention_cfg4" (config 4, aggregate over ranks), "attention_d512" (config 5a), "attention_d256"
+((1,48,8192,256) fp16 + bf16, the share_kv / share_qkv entries' head-dim limit), "attention_d1024" ((1,48,8192,1024), the tiling dispatchers' largest head dim), "attention_d64" (the reference's published shape
 (1,48,8192,64)), "fp8_gemm" (config 5b, 16384^3, roofline vs 5 PF) and, at
 N = 1, "projected_scaling" (config 4's per-rank shard shapes for W = 2 / 4 / 8 timed one after the other on this GPU — PROJECTED,
 labelled so).  Blocks whose per-rank shard would hold fewer workgroups than a GPU has CUs are reported as skipped.
@@ -381,6 +381,40 @@ def bench_attn_d1024(w, args, steps=3):
                                  workload=("attn_d1024" if w.size == 1 else None))}
 
 
+def bench_attn_d256(w, args, steps=5):
+    """D = 256, the head-dim limit of the reference's share_kv / share_qkv / tiling_qk_swizzle_qkv / cute entries and a row of every
+    tiling sweep (flash_attn_mma.py at (1,48,8192,256)): fp16 through the tiling-QKV entry and bf16 through lc_attn_fwd_bf16
+    (attn_bigd7.hip: 64 query rows per wave, K / V rings); the 48 heads are sharded."""
+    B, H, N, D = 1, 48, 8192, 256
+    skip = too_small_to_shard("attention_d256", B * H * (N // 256), w)
+    if skip:
+        return skip
+    lo, hi = host.shard_bounds(H, w.size, w.rank)
+    h_loc = hi - lo
+    torch.manual_seed(256 + w.rank)
+    q, k, v, o, _ = host.get_qkvo(B, h_loc, N, D)
+    flops_total, flops_local = host.mha_matmul_flops(B, H, N, D), host.mha_matmul_flops(B, h_loc, N, D)
+    out = {"workload": f"FlashAttention-2 fwd B={B} H={H} S={N} D={D} (the share_kv / share_qkv entries' head-dim limit), randn inputs, "
+                       f"{h_loc} heads per rank", "scaling": "strong", "n_ranks": w.size, "steps": steps}
+    for tag, bf in (("fp16", False), ("bf16", True)):
+        if bf:
+            qb, kb, vb = (x.float().to(torch.bfloat16) for x in (q, k, v))
+            ob = torch.zeros_like(qb)
+            step = lambda: capi.attn_fwd_bf16(qb, kb, vb, ob)   # noqa: E731
+        else:
+            step = lambda: capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, o, 2)   # noqa: E731
+        secs = lcd.max_over_ranks(w, timed_region(w, step, steps, 1, prewarm=2))
+        ms_kernel = lcd.max_over_ranks(w, timed_region.event_ms / steps)
+        blk = {"value": flops_total * steps / secs * 1e-12, "ms_per_step": secs / steps * 1e3,
+               "roofline": roofline(capi.attn_kernel_name(N, D, False, bf), flops_local, 4.0 * B * h_loc * N * D * 2, ms_kernel,
+                                    workload=(f"attn_d256_{tag}" if w.size == 1 else None))}
+        if bf:
+            out["bf16"] = blk
+        else:
+            out.update(blk)
+    return out
+
+
 def bench_fp8(w, args, steps=10):
     """Config 5b: fp8 (OCP e4m3fn) GEMM M=N=K=16384, TN, fp32 accumulate, fp16 out (lc_gemm_fp8_e4m3: MX-scaled
     v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales = the plain e4m3 product; block "block_scaled": lc_gemm_mxfp8, the same
@@ -650,6 +684,7 @@ def run(args):
         if not args.no_attention and not args.quick:
             blocks["attention"] = bench_attn(w, args, cfg4=False, steps=max(5, args.steps // 5), warmup=1)
             blocks["attention_d512"] = bench_attn_d512(w, args)
+            blocks["attention_d256"] = bench_attn_d256(w, args)
             blocks["attention_d1024"] = bench_attn_d1024(w, args)
             blocks["attention_d64"] = bench_attn_d64(w, args)
     elif args.workload == "hgemm":
@@ -660,6 +695,7 @@ def run(args):
                 blocks["attention_cfg4"] = bench_attn(w, args, cfg4=True, steps=3, warmup=1, prewarm=1)
                 blocks["projected_scaling"] = projected_scaling(args)
                 blocks["attention_d512"] = bench_attn_d512(w, args)
+                blocks["attention_d256"] = bench_attn_d256(w, args)
                 blocks["attention_d1024"] = bench_attn_d1024(w, args)
                 blocks["attention_d64"] = bench_attn_d64(w, args)
         if not args.quick:

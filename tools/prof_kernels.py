@@ -75,6 +75,15 @@ if a.what in ("all", "attn"):
         capi.attn_fwd_bf16(qb, kb, vb, ob)
     torch.cuda.synchronize()
     del q, k, v, o, qb, kb, vb, ob
+    # D = 256 (1,48,8192,256): attn_bigd7.hip, fp16 and bf16 (tools/prof_workloads.py: "attn_d256_fp16" / "attn_d256_bf16")
+    q, k, v, o, tv = host.get_qkvo(1, 48, 8192, 256, seed=0)
+    for _ in range(max(1, a.iters // 2)):
+        capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, o, 2)
+    qb, kb, vb, ob = q.bfloat16(), k.bfloat16(), v.bfloat16(), o.bfloat16()
+    for _ in range(max(1, a.iters // 2)):
+        capi.attn_fwd_bf16(qb, kb, vb, ob)
+    torch.cuda.synchronize()
+    del q, k, v, o, tv, qb, kb, vb, ob
     # D = 1024 (1,48,8192,1024): the pair kernel attn_bigd4.hip (tools/prof_workloads.py: "attn_d1024")
     q, k, v, o, tv = host.get_qkvo(1, 48, 8192, 1024, seed=0)
     for _ in range(max(1, a.iters // 2)):
