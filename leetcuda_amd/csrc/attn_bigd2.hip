@@ -54,12 +54,12 @@ LC_DEVINL void bd2_pv(half8_t v, half8_t p) {
 }
 // Sᵀ block (VGPRs) += K fragment x Q fragment.  As an asm statement with "v" operands: the builtin would let hipcc keep the
 // accumulators in AGPRs — a[0:63], on top of the literal Oᵀ accumulators (caught by leetcuda_amd/isa_audit.py rule R1).
-// FIRST: the first MFMA of a chain — hipcc has just zeroed (or copied) the accumulator with VALU moves, and a VALU write needs
-// two wait states before an MFMA may read the register; hipcc pads that for its own MFMAs only (isa_audit.py rule R6).
+// FIRST: the first MFMA of a chain takes the inline constant 0 as its accumulator input and only WRITES s (round 4: until then hipcc
+// zeroed the 16 registers with VALU moves per chain and tile, and the statement needed two wait states in front — isa_audit.py rule R6).
 template <bool BF16, bool FIRST = false>
 LC_DEVINL void bd2_qk(f32x16_t& s, half8_t k, half8_t q) {
 #define LC_BD2_QK(OP)                                                                                         \
-  if constexpr (FIRST) asm volatile("s_nop 1\n\t" OP " %0, %1, %2, %0" : "+v"(s) : "v"(k), "v"(q) : LC_AGPR_ALL); \
+  if constexpr (FIRST) asm volatile(OP " %0, %1, %2, 0" : "=&v"(s) : "v"(k), "v"(q) : LC_AGPR_ALL);             \
   else asm volatile(OP " %0, %1, %2, %0" : "+v"(s) : "v"(k), "v"(q) : LC_AGPR_ALL)
   if constexpr (BF16) { LC_BD2_QK("v_mfma_f32_32x32x16_bf16"); }
   else { LC_BD2_QK("v_mfma_f32_32x32x16_f16"); }
@@ -292,11 +292,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd2_kernel(
   // pn = P(t) (written), po = P(t−1) (read).  HAS_PV = false: tile 0.
   auto tile = [&](auto pvc, int t, half8_t (&pn)[4], half8_t (&po)[4]) {
     constexpr bool HAS_PV = decltype(pvc)::value;
-    f32x16_t s[2];   // [tt]: two independent accumulation chains (an MFMA depends on the one before the previous)
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[tt][r] = 0.f;
+    f32x16_t s[2];   // [tt]: two independent accumulation chains (an MFMA depends on the one before the previous); written by k-step 0
     // K fragments: plain LDS loads (hipcc counts their lgkmcnt), software-pipelined by hand TWO k-steps ahead through a
     // ring of three register pairs — behind opaque asm MFMAs hipcc would otherwise load and wait in the same k-step
     {

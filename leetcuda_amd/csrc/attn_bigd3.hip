@@ -137,11 +137,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd3_kernel(
   auto tile = [&](auto parc, auto pvc, int t, half8_t (&pn)[2], half8_t (&po)[2]) {
     constexpr int PAR = decltype(parc)::value;
     constexpr bool HAS_PV = decltype(pvc)::value;
-    f32x16_t s[2];   // two accumulation chains (even / odd k-steps) of the ONE 32 x 32 Sᵀ block
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[c][r] = 0.f;
+    f32x16_t s[2];   // two accumulation chains (even / odd k-steps) of the ONE 32 x 32 Sᵀ block; written by k-steps 0 / 1
     {
       half8_t kfr[3];
       auto ldk = [&](auto kc, auto rc) {

@@ -166,11 +166,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd4_kernel(
   // ---- one tile period.  pn = P(t) (written), po = P(t−1) (read).  HAS_PV = false: tile 0.  WARM: tiles 0 and 1.
   auto tile = [&](auto pvc, auto warmc, int t, half8_t (&pn)[2], half8_t (&po)[2]) {
     constexpr bool HAS_PV = decltype(pvc)::value;
-    f32x16_t s[2];   // two independent accumulation chains over the even / odd k-steps of this wave's d-half
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[c][r] = 0.f;
+    f32x16_t s[2];   // two independent accumulation chains over the even / odd k-steps of this wave's d-half; written by k-steps 0 / 1
     // =========================== phase A: Sᵀ(t) = K(t)[:, my d-half] · Qᵀ[my d-half]
     sync_pt(warmc);                                     // K-lo(t) landed; every wave is out of P·V(t−2 .. ): V-hi may be refilled
     static_for<2>([&](auto hc) {
