@@ -71,7 +71,8 @@ def test_workgroup_shapes_agree(oracle, nw, D):
     _check(oracle, q, k, v, o)
 
 
-@pytest.mark.parametrize("D,N", [(256, 128), (256, 192), (512, 256), (512, 128), (512, 64), (1024, 128), (1024, 64), (1024, 192)])   # (T = 2 tiles: (512,128) on attn_bigd6, (1024,64) on attn_bigd4)
+@pytest.mark.parametrize("D,N", [(256, 128), (256, 192), (256, 256), (256, 512), (256, 384), (512, 256), (512, 128), (512, 64), (1024, 128), (1024, 64),
+                                 (1024, 192)])   # (smallest launches: (256,256) = 8 ring periods on attn_bigd7, (512,128) on attn_bigd6, (1024,64) on attn_bigd4; (256,384): attn_bigd2)
 def test_large_head_dims_tiling_qkv(oracle, D, N):
     """D = 256 / 512 / 1024: the fine-grained Q,K,V d-slice tiling (reference: flash_attn_mma_tiling_qkv.cu,
     dispatcher cases 256, 512, 1024), through the FFPA-ancestor entry names."""
