@@ -130,8 +130,8 @@ const char* lc_build_info(int* is_diag);
  *   "hgemm_auto"   kernel LC_HGEMM_AUTO launches on large 256-tileable shapes (a 256-tile lc_hgemm_variant value)
  *   "fp8_mx"       fp8 GEMM (lc_gemm_fp8_e4m3): 3 = MX-scaled K = 128 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4), generated loop (default);
  *                  1 = MX K = 64 MFMA, compiler-scheduled 4-wave kernel (the cross-check); 2 = MX K = 64, 8-wave kernel; 0 = plain K = 16
- *   "attn_d512"    D = 256 / 512 / 1024 kernel: 0 = auto (D = 256, N % 256 == 0: 64 query rows per wave on v_mfma_f32_16x16x32 with K / V rings,
- *                  attn_bigd7.hip; D = 512: the full-width kernel on the same MFMA shape, attn_bigd6.hip; D = 256 with V as [B,H,D,N] or
+ *   "attn_d512"    D = 256 / 512 / 1024 kernel: 0 = auto (D = 256, N % 256 == 0, either V layout: 64 query rows per wave on v_mfma_f32_16x16x32 with K / V
+ *                  rings, attn_bigd7.hip; D = 512: the full-width kernel on the same MFMA shape, attn_bigd6.hip; D = 256 with
  *                  N % 256 == 128: attn_bigd2.hip; D = 1024: two waves share 32 query rows and split the head dim, attn_bigd4.hip),
  *                  1 = round-1 column-split kernel, 2 = 32-row double-buffered tiles (attn_bigd3.hip: validated on hardware in round 3,
  *                  6-8 % slower, a cross-check), 3 = D = 256 / 512 on the other MFMA shape than auto (attn_bigd2.hip: v_mfma_f32_32x32x16)

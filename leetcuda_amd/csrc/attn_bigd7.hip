@@ -37,58 +37,6 @@
 
 namespace lc {
 
-// the eight MFMAs of one d-step — Sᵀ blocks (kvb, qb) += K fragment (kvb) x Q fragment (qb), kvb = 0, 1, qb = 0 .. 3 — in ONE statement.
-// FIRST: the first d-step of a tile (hipcc has just zeroed the accumulators with VALU moves: rule R6 of isa_audit.py)
-template <bool BF16, bool FIRST>
-LC_DEVINL void bd7_qk8(f32x4_t (&s)[2][4], half8_t k0, half8_t k1, half8_t q0, half8_t q1, half8_t q2, half8_t q3) {
-#define LC_BD7_QK8(OP)                                                                                                            \
-  asm volatile("s_nop %14\n\t" OP " %0, %8, %10, %0\n\t" OP " %1, %8, %11, %1\n\t" OP " %2, %8, %12, %2\n\t" OP " %3, %8, %13, %3\n\t" \
-               OP " %4, %9, %10, %4\n\t" OP " %5, %9, %11, %5\n\t" OP " %6, %9, %12, %6\n\t" OP " %7, %9, %13, %7"                    \
-               : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[0][3]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(s[1][2]), "+v"(s[1][3])  \
-               : "v"(k0), "v"(k1), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "n"(FIRST ? 1 : 0)                                          \
-               : LC_AGPR_ALL)
-  if constexpr (BF16) { LC_BD7_QK8("v_mfma_f32_16x16x32_bf16"); }
-  else { LC_BD7_QK8("v_mfma_f32_16x16x32_f16"); }
-#undef LC_BD7_QK8
-}
-
-// half a P·V step: Oᵀ blocks (db, qb) += Vᵀ fragment (fixed quad) x Pᵀ(qb) for the TWO fragments of quad pair HQ (v[240:247] / v[248:255]) and
-// the four query blocks = 8 MFMAs in one statement; RD: each fragment's two transpose reads for the NEXT step go out right behind its
-// four MFMAs (address A, offsets OFF / OFF + HOFF).  Block (jj, qb) = a[R0 + 16 jj + 4 qb ..].  W0 / W1: the counted lgkmcnt waits — LDS
-// reads return in order and 8 are outstanding in fragment order when a step starts: (6, 6) while reads are re-issued, (6, 4) / (2, 0)
-// for the two halves of a tile's last step.  The leading s_nop 1: hipcc may pack a P fragment right in front of the statement.
-template <int R0, bool BF16, bool RD, int W0, int W1, int OFF, int HOFF, int HQ>
-LC_DEVINL void bd7_pv8(half8_t& fx, half8_t& fy, half8_t p0, half8_t p1, half8_t p2, half8_t p3, uint32_t ax, uint32_t ay) {
-#define LC_BD7_STEP(OP, X0, X1, X2, Y0, Y1, Y2, RX, RY)                                                                                        \
-  asm volatile("s_nop 1\n\ts_waitcnt lgkmcnt(%26)\n\t"                                                                                        \
-               OP " a[%8:%9], v[" X0 "], %2, a[%8:%9]\n\t" OP " a[%10:%11], v[" X0 "], %3, a[%10:%11]\n\t"                                      \
-               OP " a[%12:%13], v[" X0 "], %4, a[%12:%13]\n\t" OP " a[%14:%15], v[" X0 "], %5, a[%14:%15]\n\t" RX                                \
-               "s_waitcnt lgkmcnt(%27)\n\t"                                                                                                   \
-               OP " a[%16:%17], v[" Y0 "], %2, a[%16:%17]\n\t" OP " a[%18:%19], v[" Y0 "], %3, a[%18:%19]\n\t"                                  \
-               OP " a[%20:%21], v[" Y0 "], %4, a[%20:%21]\n\t" OP " a[%22:%23], v[" Y0 "], %5, a[%22:%23]\n\t" RY                                \
-               : "+{v[" X0 "]}"(fx), "+{v[" Y0 "]}"(fy)                                                                                        \
-               : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(ax), "v"(ay), "n"(R0), "n"(R0 + 3), "n"(R0 + 4), "n"(R0 + 7), "n"(R0 + 8), "n"(R0 + 11),    \
-                 "n"(R0 + 12), "n"(R0 + 15), "n"(R0 + 16), "n"(R0 + 19), "n"(R0 + 20), "n"(R0 + 23), "n"(R0 + 24), "n"(R0 + 27), "n"(R0 + 28),      \
-                 "n"(R0 + 31), "n"(OFF), "n"(OFF + HOFF), "n"(W0), "n"(W1)                                                                      \
-               : LC_AGPR_ALL)
-#define LC_BD7_HALF(OP, X0, X1, X2, Y0, Y1, Y2)                                                                                                 \
-  if constexpr (RD) {                                                                                                                          \
-    LC_BD7_STEP(OP, X0, X1, X2, Y0, Y1, Y2, "ds_read_b64_tr_b16 v[" X1 "], %6 offset:%24\n\tds_read_b64_tr_b16 v[" X2 "], %6 offset:%25\n\t",      \
-                "ds_read_b64_tr_b16 v[" Y1 "], %7 offset:%24\n\tds_read_b64_tr_b16 v[" Y2 "], %7 offset:%25");                                  \
-  } else {                                                                                                                                     \
-    LC_BD7_STEP(OP, X0, X1, X2, Y0, Y1, Y2, "", "");                                                                                            \
-  }
-  if constexpr (HQ == 0) {
-    if constexpr (BF16) { LC_BD7_HALF("v_mfma_f32_16x16x32_bf16", "240:243", "240:241", "242:243", "244:247", "244:245", "246:247") }
-    else { LC_BD7_HALF("v_mfma_f32_16x16x32_f16", "240:243", "240:241", "242:243", "244:247", "244:245", "246:247") }
-  } else {
-    if constexpr (BF16) { LC_BD7_HALF("v_mfma_f32_16x16x32_bf16", "248:251", "248:249", "250:251", "252:255", "252:253", "254:255") }
-    else { LC_BD7_HALF("v_mfma_f32_16x16x32_f16", "248:251", "248:249", "250:251", "252:255", "252:253", "254:255") }
-  }
-#undef LC_BD7_HALF
-#undef LC_BD7_STEP
-}
-
 #include "attn_bigd7_stmts.inc"   // bd7_qk8f / bd7_pvf: the statements on the pinned score registers (tools/gen_attn_bigd7.py)
 
 constexpr int BD7_ROWB = 512;                 // bytes per K / V row
@@ -99,7 +47,12 @@ constexpr int BD7_ESTR = BD7_ROWB + 16;       // epilogue staging row stride
 constexpr int BD7_PARK = 4 * (256 / 32) * 1024;   // the Q fragments of query block 3 (8 d-steps x 1 KiB per wave): 32 KiB
 constexpr int bd7_lds_bytes() { return 2 * BD7_RING * BD7_TILE + BD7_PARK; }   // 160 KiB; the epilogue's staging (132 KiB) aliases it
 
-template <bool BF16>
+// VT: V handed over as [B,H,D,N] (the reference's *_swizzle_qkv entries, d <= 256): the rows of that tensor already are Vᵀ.  The V tile in
+// LDS is [256 d][32 kv] (64-B rows; 16-B chunk c of row r at slot c ^ ((−(r >> 2)) & 3): conflict-free for the 4 x 16 lane groups of a
+// ds_read_b128, tests/test_layouts.py), a Vᵀ fragment is ONE ds_read_b128 — lane (l16, g4) <- row 16 db + l16, kv 8 g4 .. + 7 — and the
+// P operand must then hold kv 8 g4 + e in slot e: Sᵀ block kvb's row m stands for kv = 8 (m >> 2) + 4 kvb + (m & 3), i.e. the K fragment
+// reads K tile row 8 (l16 >> 2) + 4 kvb + (l16 & 3) (K image key (row & 3) | ((row >> 3) & 3) << 2, injective on those row sets).
+template <bool BF16, bool VT>
 __global__ __launch_bounds__(256) void attn_fwd_bigd7_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
     half_t* __restrict__ O, int N, int nqb, float sl2) {
@@ -120,7 +73,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd7_kernel(
   const int q0 = __builtin_amdgcn_readfirstlane((id - bhi * nqb) * 256 + wave * 64);
   const half_t* Qb = Q + bh * (size_t)N * D;
   const char* Kb = (const char*)(K + bh * (size_t)N * D);
-  const char* Vb = (const char*)(V + bh * (size_t)N * D);
+  const char* Vb = (const char*)(V + bh * (size_t)N * D);   // (either layout: a head is N * D elements)
   half_t* Ob = O + bh * (size_t)N * D;
   const int T = N / BD7_KVB;               // a multiple of 8 (N % 256 == 0)
   const uint32_t smem32 = lds_addr32(smem);
@@ -132,23 +85,34 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd7_kernel(
   // -> k_off[i & 1]; (V) pair slot ps = cs >> 1 holds source pair (ps & 8) | ((ps ^ key(row)) & 7), key(row) = ((row & 3) << 1) |
   // ((row >> 2) & 1) = (((2 wave + b) & 3) << 1) | (wave >> 1) for every i -> one v_off
   const buf_rsrc_t rk = make_rsrc(Kb), rv = make_rsrc(Vb);
-  unsigned k_off[2], v_off;
+  unsigned k_off[4], v_off;
   {
     const int b = lane >> 5, cs = lane & 31, ps = cs >> 1;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) k_off[j] = (unsigned)(b * ROWB + (((cs & 16) | ((cs ^ ((2 * wave + 8 * j + b) & 15)) & 15)) * 16));
-    const int key = (((2 * wave + b) & 3) << 1) | (wave >> 1);
-    v_off = (unsigned)(b * ROWB + (((((ps & 8) | ((ps ^ key) & 7)) << 1) | (cs & 1)) * 16));
+    for (int j = 0; j < 4; ++j) {
+      // row of the lane in piece wave + 4 j: 2 wave + 8 j + b; key = row & 15, or (VT) (row & 3) | ((row >> 3) & 3) << 2 = ((2 wave + b) & 3) | j << 2
+      const int key = VT ? (((2 * wave + b) & 3) | (j << 2)) : ((2 * wave + 8 * j + b) & 15);
+      k_off[j] = (unsigned)(b * ROWB + (((cs & 16) | ((cs ^ key) & 15)) * 16));
+    }
+    if constexpr (VT) {
+      // Vᵀ tile: piece p = d rows 16 p .. + 15 (64 B each): lane -> row lane >> 2, chunk slot lane & 3 <- source chunk slot ^ ((−(row >> 2)) & 3),
+      // (row >> 2) & 3 = (lane >> 4) & 3 for every piece; source row stride = 2 N bytes
+      v_off = (unsigned)(lane >> 2) * (unsigned)N * 2u + (unsigned)((((lane & 3) ^ ((0 - ((lane >> 4) & 3)) & 3))) * 16);
+    } else {
+      const int key = (((2 * wave + b) & 3) << 1) | (wave >> 1);
+      v_off = (unsigned)(b * ROWB + (((((ps & 8) | ((ps ^ key) & 7)) << 1) | (cs & 1)) * 16));
+    }
   }
   auto issue_k = [&](int i, int t, int slot) {
     const int te = t < T ? t : T - 1;
     const int p = wave + 4 * i;
-    blds16(rk, k_off[i & 1], (unsigned)te * TILE + (unsigned)p * 1024u, ksm + slot * TILE + p * 1024);
+    blds16(rk, k_off[i], (unsigned)te * TILE + (unsigned)p * 1024u, ksm + slot * TILE + p * 1024);
   };
   auto issue_v = [&](int i, int t, int slot) {
     const int te = t < 0 ? 0 : (t < T ? t : T - 1);
     const int p = wave + 4 * i;
-    blds16(rv, v_off, (unsigned)te * TILE + (unsigned)p * 1024u, vsm + slot * TILE + p * 1024);
+    if constexpr (VT) blds16(rv, v_off, (unsigned)p * 32u * (unsigned)N + (unsigned)te * 64u, vsm + slot * TILE + p * 1024);
+    else blds16(rv, v_off, (unsigned)te * TILE + (unsigned)p * 1024u, vsm + slot * TILE + p * 1024);
   };
   // virtual periods −3 .. −1: K(0..2), V(−1 (a dummy: tile 0 into slot 3), 0, 1) — every period issues 4 + 4 pieces, so that
   // "all but the youngest 8 pieces have landed" always means "everything requested before the period that just ended"
@@ -174,14 +138,21 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd7_kernel(
   static_for<256>([&](auto r) { am_acc_zero<decltype(r)::value>(); });
 
   // ---- fragment read addresses (slot, ds >> 2, kvb / db >> 3 and the second kv block go into the immediate offsets)
-  const char* kx[4];   // K: row l16 (+ 16 kvb), chunk 4 ds + g4: low 4 bits XOR (row & 15) = l16
+  // K: Sᵀ row l16 of block kvb <- K tile row 16 kvb + l16, or (VT) 8 (l16 >> 2) + 4 kvb + (l16 & 3); chunk 4 ds + g4: low 4 bits XOR key(row) = l16
+  // in both images
+  constexpr int KVB1 = (VT ? 4 : 16) * ROWB;   // from kv block 0's row to kv block 1's
+  const char* kx[4];
 #pragma unroll
-  for (int k4 = 0; k4 < 4; ++k4) kx[k4] = ksm + l16 * ROWB + (((4 * k4 + g4) ^ l16) * 16);
+  for (int k4 = 0; k4 < 4; ++k4) kx[k4] = ksm + (VT ? 8 * (l16 >> 2) + (l16 & 3) : l16) * ROWB + (((4 * k4 + g4) ^ l16) * 16);
   // Vᵀ: kv row 4 g4 + (l16 >> 2) (+ 16: second transpose read), 8 bytes at column 4 (l16 & 3) of pair db: slot ((db & 7) ^ key) + (db & 8)
+  // (VT: ONE address — row l16 of the Vᵀ tile, chunk g4 at slot g4 ^ ((−(l16 >> 2)) & 3); + 1024 per column block db as immediate)
   uint32_t vx[8];
 #pragma unroll
   for (int b = 0; b < 8; ++b)
-    vx[b] = smem32 + (uint32_t)(RING * TILE + (4 * g4 + (l16 >> 2)) * ROWB + 8 * (l16 & 3) + ((b ^ (((l16 >> 2) << 1) | (g4 & 1))) * 32));
+    vx[b] = VT ? smem32 + (uint32_t)(RING * TILE + l16 * 64 + ((g4 ^ ((0 - (l16 >> 2)) & 3)) * 16))
+               : smem32 + (uint32_t)(RING * TILE + (4 * g4 + (l16 >> 2)) * ROWB + 8 * (l16 & 3) + ((b ^ (((l16 >> 2) << 1) | (g4 & 1))) * 32));
+  // the two lane addresses and the immediates (OFF, HOFF) of the reads a P·V statement issues for step s1 (fragments db = 4 s1 + 2 hq, + 1)
+  constexpr int V_HOFF = VT ? 1024 : 16 * ROWB;
 
   float m_run[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l_run[4] = {0.f, 0.f, 0.f, 0.f};
   half8_t pf[4];   // P fragments [qb] of the previous tile
@@ -197,7 +168,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd7_kernel(
   half8_t knx[2], qnx;
   auto prefetch = [&](int kslot_bytes) {
     knx[0] = *(const half8_t*)(kx[0] + kslot_bytes);
-    knx[1] = *(const half8_t*)(kx[0] + kslot_bytes + 16 * ROWB);
+    knx[1] = *(const half8_t*)(kx[0] + kslot_bytes + KVB1);
     qnx = *(const half8_t*)(qpark);
   };
   prefetch(0);
@@ -220,7 +191,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd7_kernel(
       auto ldk = [&](auto dc) {
         constexpr int ds = decltype(dc)::value, r = ds & 1;
         kfr[r][0] = *(const half8_t*)(kx[ds & 3] + KS + (ds >> 2) * 256);
-        kfr[r][1] = *(const half8_t*)(kx[ds & 3] + KS + (ds >> 2) * 256 + 16 * ROWB);
+        kfr[r][1] = *(const half8_t*)(kx[ds & 3] + KS + (ds >> 2) * 256 + KVB1);
         qr[r] = *(const half8_t*)(qpark + ds * 1024);
       };
       if constexpr (!DMA) ldk(std::integral_constant<int, 0>{});
@@ -232,7 +203,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd7_kernel(
         bd7_qk8f<BF16, ds == 0>(s, kfr[ds & 1][0], kfr[ds & 1][1], qf[ds][0], qf[ds][1], qf[ds][2], qr[ds & 1]);
         // the Vᵀ fragments of the first P·V step: V(t−1) has been published for a whole period and the quads are idle during Sᵀ, so the
         // reads go out two d-steps before they are needed
-        if constexpr (DMA && HAS_PV && ds == NDS - 3) bd6_rd<VS, 16 * ROWB>(vf0, vf1, vf2, vf3, vx[0], vx[1], vx[2], vx[3]);
+        if constexpr (DMA && HAS_PV && ds == NDS - 3) bd7_rd<VT, VS, V_HOFF>(vf0, vf1, vf2, vf3, vx[0], vx[1], vx[2], vx[3]);
         __builtin_amdgcn_sched_barrier(0);
       });
     };
@@ -272,15 +243,12 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd7_kernel(
     // from one statement to the next); the V pieces of tile t + 2 (-> the slot V(t−2) left) behind every other statement
     auto pv_stmt = [&](auto xc) {
       constexpr int x = decltype(xc)::value, st = x >> 1, hq = x & 1, s1 = st + 1;
-      constexpr bool RD = s1 < 4;
-      constexpr int W0 = RD ? 6 : (hq ? 2 : 6), W1 = RD ? 6 : (hq ? 0 : 4);
-      constexpr int OFF = VS + (s1 >> 1) * 256;
+      constexpr int OFF = VT ? VS + (4 * s1 + 2 * hq) * 1024 : VS + (s1 >> 1) * 256;   // the reads it issues: step s1's fragments 2 hq, 2 hq + 1
       if constexpr ((x & 1) == 0) issue_v(x >> 1, t + 2, (SL + 2) & 3);
       if constexpr (HAS_PV) {
-        if constexpr (hq == 0)
-          bd7_pv8<64 * st, BF16, RD, W0, W1, OFF, 16 * ROWB, 0>(vf0, vf1, pf[0], pf[1], pf[2], pf[3], vx[4 * (s1 & 1)], vx[4 * (s1 & 1) + 1]);
-        else
-          bd7_pv8<64 * st + 32, BF16, RD, W0, W1, OFF, 16 * ROWB, 1>(vf2, vf3, pf[0], pf[1], pf[2], pf[3], vx[4 * (s1 & 1) + 2], vx[4 * (s1 & 1) + 3]);
+        const uint32_t ax = vx[VT ? 0 : 4 * (s1 & 1) + 2 * hq], ay = vx[VT ? 0 : 4 * (s1 & 1) + 2 * hq + 1];
+        if constexpr (hq == 0) bd7_pvn<x, BF16, VT, 64 * st, OFF, V_HOFF>(vf0, vf1, pf[0], pf[1], pf[2], pf[3], ax, ay);
+        else bd7_pvn<x, BF16, VT, 64 * st + 32, OFF, V_HOFF>(vf2, vf3, pf[0], pf[1], pf[2], pf[3], ax, ay);
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -307,15 +275,16 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd7_kernel(
       // if the maximum does not hold the values are garbage, possibly inf, and are thrown away below)
       static_for<6>([&](auto xc) {
         constexpr int x = decltype(xc)::value + 2, st = x >> 1, hq = x & 1, s1 = st + 1;
-        constexpr int OFF = VS + (s1 >> 1) * 256;
+        constexpr int OFF = VT ? VS + (4 * s1 + 2 * hq) * 1024 : VS + (s1 >> 1) * 256;
         constexpr int ta = bd7_pvf_ta(x), tb = bd7_pvf_tb(x);
         if constexpr ((x & 1) == 0) issue_v(x >> 1, t + 2, (SL + 2) & 3);
+        const uint32_t ax = vx[VT ? 0 : 4 * (s1 & 1) + 2 * hq], ay = vx[VT ? 0 : 4 * (s1 & 1) + 2 * hq + 1];
         if constexpr (hq == 0)
-          bd7_pvf<x, BF16, 64 * st, OFF, 16 * ROWB>(vf0, vf1, pf[0], pf[1], pf[2], pf[3], vx[4 * (s1 & 1)], vx[4 * (s1 & 1) + 1],
-                                                   s[ta >> 2][ta & 3], s[tb >> 2][tb & 3], ps[ta & 3], ps[tb & 3], sl2, m_run[ta & 3], m_run[tb & 3]);
+          bd7_pvf<x, BF16, VT, 64 * st, OFF, V_HOFF>(vf0, vf1, pf[0], pf[1], pf[2], pf[3], ax, ay, s[ta >> 2][ta & 3], s[tb >> 2][tb & 3],
+                                                     ps[ta & 3], ps[tb & 3], sl2, m_run[ta & 3], m_run[tb & 3]);
         else
-          bd7_pvf<x, BF16, 64 * st + 32, OFF, 16 * ROWB>(vf2, vf3, pf[0], pf[1], pf[2], pf[3], vx[4 * (s1 & 1) + 2], vx[4 * (s1 & 1) + 3],
-                                                        s[ta >> 2][ta & 3], s[tb >> 2][tb & 3], ps[ta & 3], ps[tb & 3], sl2, m_run[ta & 3], m_run[tb & 3]);
+          bd7_pvf<x, BF16, VT, 64 * st + 32, OFF, V_HOFF>(vf2, vf3, pf[0], pf[1], pf[2], pf[3], ax, ay, s[ta >> 2][ta & 3], s[tb >> 2][tb & 3],
+                                                          ps[ta & 3], ps[tb & 3], sl2, m_run[ta & 3], m_run[tb & 3]);
         __builtin_amdgcn_sched_barrier(0);
       });
       if (!__all(hold)) {
@@ -361,16 +330,13 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd7_kernel(
   // ---- tail: Oᵀ += Vᵀ(T−1)·Pᵀ(T−1): V(T−1) sits in slot (T − 1) & 3 = 3, published by the last barrier
   {
     constexpr int VS = 3 * TILE;
-    bd6_rd<VS, 16 * ROWB>(vf0, vf1, vf2, vf3, vx[0], vx[1], vx[2], vx[3]);
+    bd7_rd<VT, VS, V_HOFF>(vf0, vf1, vf2, vf3, vx[0], vx[1], vx[2], vx[3]);
     static_for<8>([&](auto xc) {
       constexpr int x = decltype(xc)::value, st = x >> 1, hq = x & 1, s1 = st + 1;
-      constexpr bool RD = s1 < 4;
-      constexpr int W0 = RD ? 6 : (hq ? 2 : 6), W1 = RD ? 6 : (hq ? 0 : 4);
-      constexpr int OFF = VS + (s1 >> 1) * 256;
-      if constexpr (hq == 0)
-        bd7_pv8<64 * st, BF16, RD, W0, W1, OFF, 16 * ROWB, 0>(vf0, vf1, pf[0], pf[1], pf[2], pf[3], vx[4 * (s1 & 1)], vx[4 * (s1 & 1) + 1]);
-      else
-        bd7_pv8<64 * st + 32, BF16, RD, W0, W1, OFF, 16 * ROWB, 1>(vf2, vf3, pf[0], pf[1], pf[2], pf[3], vx[4 * (s1 & 1) + 2], vx[4 * (s1 & 1) + 3]);
+      constexpr int OFF = VT ? VS + (4 * s1 + 2 * hq) * 1024 : VS + (s1 >> 1) * 256;
+      const uint32_t ax = vx[VT ? 0 : 4 * (s1 & 1) + 2 * hq], ay = vx[VT ? 0 : 4 * (s1 & 1) + 2 * hq + 1];
+      if constexpr (hq == 0) bd7_pvn<x, BF16, VT, 64 * st, OFF, V_HOFF>(vf0, vf1, pf[0], pf[1], pf[2], pf[3], ax, ay);
+      else bd7_pvn<x, BF16, VT, 64 * st + 32, OFF, V_HOFF>(vf2, vf3, pf[0], pf[1], pf[2], pf[3], ax, ay);
       __builtin_amdgcn_sched_barrier(0);
     });
   }

@@ -356,16 +356,16 @@ bool use_bigd6(int D, bool vt, int N) {
   const int k = g_tune_attn_d512;
   return D == 512 && !vt && N % 128 == 0 && ((k == 0 && kBigd6Auto) || (k == 3 && !kBigd6Auto));
 }
-// D = 256 with N % 256 == 0, V as [B,H,N,D]: attn_bigd7 (64 query rows per wave, 16x16x32 MFMAs, KV rings) is auto; knob 3 selects
-// attn_bigd2 (32 rows per wave, 32x32x16: the cross-check on the other MFMA shape, and the kernel for N % 256 == 128 and V transposed)
-bool use_bigd7(int D, bool vt, int N) { return D == 256 && !vt && N % 256 == 0 && g_tune_attn_d512 == 0; }
+// D = 256 with N % 256 == 0, either V layout: attn_bigd7 (64 query rows per wave, 16x16x32 MFMAs, KV rings) is auto; knob 3 selects
+// attn_bigd2 (32 rows per wave, 32x32x16: the cross-check on the other MFMA shape, and the kernel for N % 256 == 128)
+bool use_bigd7(int D, bool vt, int N) { return D == 256 && N % 256 == 0 && g_tune_attn_d512 == 0; }
 
 template <int D, bool VT>
 int launch_attn_bigd_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                         hipStream_t st) {
   if (use_bigd4(D, VT, N)) return launch_attn_bigd4(Q, K, V, O, B, H, N, g_tune_attn_d1024, st);
   if (use_bigd6(D, VT, N)) return launch_attn_bigd6(Q, K, V, O, B, H, N, false, st);
-  if (use_bigd7(D, VT, N)) return launch_attn_bigd7(Q, K, V, O, B, H, N, false, st);
+  if (use_bigd7(D, VT, N)) return VT ? launch_attn_bigd7_vt(Q, K, V, O, B, H, N, st) : launch_attn_bigd7(Q, K, V, O, B, H, N, false, st);
   if (use_bigd2(D, VT, N)) return VT ? launch_attn_bigd2_vt(Q, K, V, O, B, H, N, D, st) : launch_attn_bigd2(Q, K, V, O, B, H, N, D, false, st);
   if (N % 128 == 0) return launch_attn_bigd<D, 4, VT>(Q, K, V, O, B, H, N, st);
   return launch_attn_bigd<D, 2, VT>(Q, K, V, O, B, H, N, st);
@@ -499,8 +499,8 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
     snprintf(buf, buflen, "attn_fwd_bigd6_kernel<%s>", bf16 ? "true" : "false");
     return LC_OK;
   }
-  if (use_bigd7(D, v_transposed != 0, N)) {
-    snprintf(buf, buflen, "attn_fwd_bigd7_kernel<%s>", bf16 ? "true" : "false");
+  if (use_bigd7(D, v_transposed != 0, N) && !(bf16 && v_transposed)) {
+    snprintf(buf, buflen, "attn_fwd_bigd7_kernel<%s,%s>", bf16 ? "true" : "false", v_transposed ? "true" : "false");
     return LC_OK;
   }
   if (use_bigd2(D, v_transposed != 0, N) && !(bf16 && v_transposed)) {

@@ -111,6 +111,7 @@ int launch_attn_bigd2_vt(const half_t* Q, const half_t* K, const half_t* V, half
 int launch_attn_bigd6(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, bool bf16, hipStream_t st);
 // tu_attn_big7.hip: D = 256, 64 query rows per wave on v_mfma_f32_16x16x32 (attn_bigd7.hip), N % 256 == 0, V as [B,H,N,D]; fp16 or bf16
 int launch_attn_bigd7(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, bool bf16, hipStream_t st);
+int launch_attn_bigd7_vt(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, hipStream_t st);   // V as [B,H,D,N], fp16
 // tu_fp8.hip: fp8 e4m3 GEMM, mx = 1 (MX, 4 waves) / 2 (MX, 8 waves) / 0 (plain K = 16)
 int launch_gemm_fp8(const uint8_t* A, const uint8_t* B, half_t* C, int M, int N, int K, float alpha, int tiles_m,
                     int tiles_n, int panel_w, int mx, hipStream_t st);

@@ -6,9 +6,9 @@
 
 namespace lc {
 namespace {
-template <bool BF16>
+template <bool BF16, bool VT>
 int launch_bigd7_t(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, hipStream_t st) {
-  auto kern = attn_fwd_bigd7_kernel<BF16>;
+  auto kern = attn_fwd_bigd7_kernel<BF16, VT>;
   constexpr int lds = bd7_lds_bytes();
   if (int rc = set_dyn_lds(kern, lds)) return rc;
   const int nqb = N / 256;
@@ -20,6 +20,10 @@ int launch_bigd7_t(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
 }  // namespace
 // D = 256, N % 256 == 0, V as [B,H,N,D]; fp16 or bf16
 int launch_attn_bigd7(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, bool bf16, hipStream_t st) {
-  return bf16 ? launch_bigd7_t<true>(Q, K, V, O, B, H, N, st) : launch_bigd7_t<false>(Q, K, V, O, B, H, N, st);
+  return bf16 ? launch_bigd7_t<true, false>(Q, K, V, O, B, H, N, st) : launch_bigd7_t<false, false>(Q, K, V, O, B, H, N, st);
+}
+// the same with V as [B,H,D,N] (fp16: the reference's *_swizzle_qkv entries)
+int launch_attn_bigd7_vt(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, hipStream_t st) {
+  return launch_bigd7_t<false, true>(Q, K, V, O, B, H, N, st);
 }
 }  // namespace lc

@@ -64,7 +64,7 @@ def test_bench_default_workload_at_two_ranks_headlines_config4():
     assert rep["scaling"] == "weak" and rep["roofline"]["kernel"].startswith("hgemm_w4y_kernel")
     # 48 heads x 32 query blocks / 2 ranks = 768 workgroups per GPU: still a meaningful shard at N = 2 ...
     assert "value" in out["attention_d64"] and "value" in out["attention_d512"]
-    assert out["attention_d256"]["roofline"]["kernel"] == "attn_fwd_bigd7_kernel<false>" and "value" in out["attention_d256"]["bf16"]
+    assert out["attention_d256"]["roofline"]["kernel"] == "attn_fwd_bigd7_kernel<false,false>" and "value" in out["attention_d256"]["bf16"]
     assert "projected_scaling" not in out          # N = 1 only
 
 

@@ -51,6 +51,7 @@ FAMILIES = [
     ("d128-v-transposed", -128, None, 0),       # D < 0: V handed over as [B,H,D,N] through a *_swizzle_qkv entry
     ("d64-v-transposed", -64, None, 0),
     ("d256-v-transposed", -256, None, 0),
+    ("d256-v-transposed-other-mfma-shape", -256, "attn_d512", 3),
 ]
 
 
@@ -206,8 +207,8 @@ def test_v_transposed_entries_config3(oracle, entry):
 def test_d256_v_transposed_full_size(oracle):
     """(1,48,8192,256) with V as [B,H,D,N] — the largest head dim the reference's *_swizzle_qkv entries take
     (flash_attn_mma_share_qkv_swizzle_qkv.cu:961-1010: d = 256 with stages = 1; tiling_qk_swizzle_qkv: d <= 256) — runs
-    attn_fwd_bigd2_kernel<256,false,true>: K rows fed in the order that makes a lane's P slots contiguous kv, Vᵀ fragments one
-    ds_read_b128 each.  Against the oracle reading the same transposed tensor and against the [B,H,N,D] sibling."""
+    attn_fwd_bigd7_kernel<false,true> (round 3 / knob 3: attn_fwd_bigd2_kernel<256,false,true>): K rows fed in the order that makes a
+    lane's P slots contiguous kv, Vᵀ fragments one ds_read_b128 each.  Against the oracle reading the same transposed tensor and against the [B,H,N,D] sibling."""
     capi = _capi()
     B, H, N, D = 1, 48, 8192, 256
     torch.manual_seed(2560)
@@ -217,7 +218,7 @@ def test_d256_v_transposed_full_size(oracle):
     k[0, 47, 7000] = 3.0 * q[0, 47, 33]
     v[0, 47, 7000] = 5.0
     tv = v.transpose(-2, -1).contiguous()
-    assert capi.attn_kernel_name(N, D, True) == "attn_fwd_bigd2_kernel<256,false,true>"
+    assert capi.attn_kernel_name(N, D, True) == "attn_fwd_bigd7_kernel<false,true>"
     rows = _rows_for(N, 2560, extra=[33, 127, 128])
     o = torch.full_like(q, float("nan"))
     for entry, st in (("flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv", 2), ("flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv", 1)):

@@ -310,7 +310,7 @@ def test_generated_bigd7_statements_are_current_and_pipeline_the_softmax():
     assert gen.OUT.read_text() == gen.render()
     seen = []
     for x in range(2, 8):
-        body, (ta, tb, qa, qb) = gen.gen_pvf(x)
+        body, (ta, tb) = gen.gen_pv(x, True, False)
         text = "\n".join(body)
         half = text[:text.index("if constexpr (!BF16)")]
         ins = re.findall(r'"([^"]+?)\\n\\t"', half)
@@ -327,10 +327,17 @@ def test_generated_bigd7_statements_are_current_and_pipeline_the_softmax():
             assert ins[f].endswith("-%13" if first else "-%14") and ins[a].startswith("v_add_f32 %4" if first else "v_add_f32 %5")
             assert not ins[xx + 1].endswith(reg)                      # the instruction behind the v_exp does not read its result
             seen.append(e)
-        assert (qa, qb) == (ta & 3, tb & 3)
         waits = [int(w) for w in re.findall(r"s_waitcnt lgkmcnt\((\d)\)", "\n".join(ins))]
         assert waits == ([6, 6] if x < 6 else ([6, 4] if x == 6 else [2, 0]))
         assert sum(l.startswith("ds_read_b64_tr_b16") for l in ins) == (4 if x < 6 else 0)
+        # V as [B,H,D,N]: one ds_read_b128 per fragment, waits on 4 outstanding reads; same fillers
+        bodyt, _ = gen.gen_pv(x, True, True)
+        textt = "\n".join(bodyt)
+        inst = re.findall(r'"([^"]+?)\\n\\t"', textt[:textt.index("if constexpr (!BF16)")])
+        waitst = [int(w) for w in re.findall(r"s_waitcnt lgkmcnt\((\d)\)", "\n".join(inst))]
+        assert waitst == ([3, 3] if x < 6 else ([3, 2] if x == 6 else [1, 0]))
+        assert sum(l.startswith("ds_read_b128") for l in inst) == (2 if x < 6 else 0) and not any("tr_b16" in l for l in inst)
+        assert [l for l in inst if l.startswith(("v_fma", "v_exp", "v_add"))] == [l for l in ins if l.startswith(("v_fma", "v_exp", "v_add"))]
     assert sorted(seen) == list(range(32))
 
 
@@ -426,9 +433,10 @@ def test_large_head_dim_kernel_names(built):
     capi.load()
     assert capi.attn_kernel_name(8192, 1024) == "attn_fwd_bigd4_kernel<8>"
     assert capi.attn_kernel_name(64, 1024) == "attn_fwd_bigd4_kernel<8>"
-    assert capi.attn_kernel_name(8192, 256, True) == "attn_fwd_bigd2_kernel<256,false,true>"
-    assert capi.attn_kernel_name(8192, 256) == "attn_fwd_bigd7_kernel<false>"
-    assert capi.attn_kernel_name(8192, 256, False, True) == "attn_fwd_bigd7_kernel<true>"
+    assert capi.attn_kernel_name(8192, 256, True) == "attn_fwd_bigd7_kernel<false,true>"          # V as [B,H,D,N]
+    assert capi.attn_kernel_name(384, 256, True) == "attn_fwd_bigd2_kernel<256,false,true>"
+    assert capi.attn_kernel_name(8192, 256) == "attn_fwd_bigd7_kernel<false,false>"
+    assert capi.attn_kernel_name(8192, 256, False, True) == "attn_fwd_bigd7_kernel<true,false>"
     assert capi.attn_kernel_name(384, 256) == "attn_fwd_bigd2_kernel<256,false,false>"      # N % 256 == 128: the 32-rows-per-wave kernel
     assert capi.attn_kernel_name(8192, 512, True).startswith("attn_fwd_bigd_kernel<512,")
     assert capi.attn_kernel_name(192, 256, True).startswith("attn_fwd_bigd_kernel<256,")
@@ -437,6 +445,7 @@ def test_large_head_dim_kernel_names(built):
     try:
         assert capi.attn_kernel_name(8192, 512) == "attn_fwd_bigd2_kernel<512,false,false>"     # the other MFMA shape: the cross-check
         assert capi.attn_kernel_name(8192, 256) == "attn_fwd_bigd2_kernel<256,false,false>"
+        assert capi.attn_kernel_name(8192, 256, True) == "attn_fwd_bigd2_kernel<256,false,true>"
     finally:
         capi.tune("attn_d512", 0)
     capi.tune("attn_d512", 1)

@@ -528,3 +528,52 @@ def test_bigd7_rings_on_512_byte_rows():
     # ---- LDS budget: two rings of four 16-KiB tiles + query block 3's Q fragments (8 d-steps x 1 KiB x 4 waves) = 160 KiB; the epilogue's
     # staging (4 waves x 64 rows x 528 B) aliases it
     assert 2 * 4 * 32 * ROWB + 4 * 8 * 1024 == 160 * 1024 and 4 * 64 * (ROWB + 16) <= 160 * 1024
+
+
+def test_bigd7_v_transposed_tile_and_permuted_k_rows():
+    """attn_bigd7.hip with V as [B,H,D,N]: the LDS V tile is [256 d][32 kv] (64-B rows), 16-B chunk c of row r at slot c ^ ((-(r >> 2)) & 3);
+    a Vᵀ fragment (db) is ONE ds_read_b128: lane (l16, g4) <- row 16 db + l16, chunk g4.  K: Sᵀ row l16 of kv block kvb reads K tile row
+    8 (l16 >> 2) + 4 kvb + (l16 & 3) with the image key (row & 3) | ((row >> 3) & 3) << 2 — which is l16 for every such row.  Checks: both
+    reads are bank-conflict free over the 4 x 16 lane groups, the DMA lane maps write what the readers expect, and the kv order a lane's P
+    slots get (e = 4 kvb + r <-> kv 8 g4 + e) is the order of the Vᵀ fragment's chunk."""
+    ROWB = 512
+    vsw = lambda r: (-(r >> 2)) & 3
+    for db in range(16):
+        for grp in B128_GROUPS:
+            addrs = []
+            for lane in grp:
+                l16, g4 = lane & 15, lane >> 4
+                a = l16 * 64 + ((g4 ^ ((0 - (l16 >> 2)) & 3)) * 16) + db * 1024          # the kernel's form: vx[0] + db * 1024
+                row = 16 * db + l16
+                assert a == row * 64 + ((g4 ^ vsw(row)) * 16)
+                addrs.append(a)
+            assert conflict_free(addrs, 16), (db, grp)
+    kkey = lambda r: (r & 3) | (((r >> 3) & 3) << 2)
+    for ds, kvb in itertools.product(range(8), range(2)):
+        for grp in B128_GROUPS:
+            addrs = []
+            for lane in grp:
+                l16, g4 = lane & 15, lane >> 4
+                a = (8 * (l16 >> 2) + (l16 & 3)) * ROWB + (((4 * (ds & 3) + g4) ^ l16) * 16) + (ds >> 2) * 256 + kvb * 4 * ROWB
+                row, c = 8 * (l16 >> 2) + 4 * kvb + (l16 & 3), 4 * ds + g4
+                assert kkey(row) == l16 and a == row * ROWB + ((c & 16) | ((c ^ kkey(row)) & 15)) * 16
+                addrs.append(a)
+            assert conflict_free(addrs, 16), (ds, kvb, grp)
+    # the Sᵀ rows of a lane group: m = 4 g4 + r of block kvb stands for kv = 8 (m >> 2) + 4 kvb + (m & 3) = 8 g4 + 4 kvb + r: P slot e = 4 kvb + r
+    for g4, kvb, r in itertools.product(range(4), range(2), range(4)):
+        m = 4 * g4 + r
+        assert 8 * (m >> 2) + 4 * kvb + (m & 3) == 8 * g4 + (4 * kvb + r)
+    # DMA: K piece p = wave + 4 i (rows 2 p, 2 p + 1), key = ((2 wave + b) & 3) | i << 2; V piece p = d rows 16 p .. + 15, lane -> row lane >> 2,
+    # slot lane & 3 <- source chunk slot ^ ((-(lane >> 4)) & 3)
+    for wave, i in itertools.product(range(4), range(4)):
+        p = wave + 4 * i
+        for lane in range(64):
+            b, cs = lane >> 5, lane & 31
+            row = 2 * p + b
+            key = ((2 * wave + b) & 3) | (i << 2)
+            assert key == kkey(row)
+            src = (cs & 16) | ((cs ^ key) & 15)
+            assert (src & 16) | ((src ^ kkey(row)) & 15) == cs
+            vrow, slot = 16 * p + (lane >> 2), lane & 3
+            vsrc = slot ^ ((0 - ((lane >> 4) & 3)) & 3)
+            assert vsrc ^ vsw(vrow) == slot

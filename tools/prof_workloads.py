@@ -11,7 +11,7 @@ WORKLOADS = [
     ("attn_fwd_w4u_kernel<64", "attn_d64"), ("attn_fwd_w4i_kernel<64", "attn_d64"), ("attn_fwd_kernel<64", "attn_d64"),
     ("attn_fwd_bigd2_kernel<512,false", "attn_d512_fp16"), ("attn_fwd_bigd2_kernel<512,true", "attn_d512_bf16"),
     ("attn_fwd_bigd3_kernel<512,false", "attn_d512_fp16"), ("attn_fwd_bigd3_kernel<512,true", "attn_d512_bf16"),
-    ("attn_fwd_bigd7_kernel<false", "attn_d256_fp16"), ("attn_fwd_bigd7_kernel<true", "attn_d256_bf16"),
+    ("attn_fwd_bigd7_kernel<false,false", "attn_d256_fp16"), ("attn_fwd_bigd7_kernel<true", "attn_d256_bf16"), ("attn_fwd_bigd7_kernel<false,true", "attn_d256_fp16"),
     ("attn_fwd_bigd4_kernel", "attn_d1024"), ("attn_fwd_bigd6_kernel<false", "attn_d512_fp16"), ("attn_fwd_bigd6_kernel<true", "attn_d512_bf16"),
 ]
 
