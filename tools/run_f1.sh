@@ -17,5 +17,7 @@ timeout 600 $R $S/flash-attn/flash_attn_mma.py --B 4 --H 32 --N 4096 --D 128 --c
 timeout 600 $R $S/flash-attn/flash_attn_mma.py --B 1 --H 48 --N 8192 --D 64 --check --show-all --others --seed 1 > $OUT/f1_fa_1x48x8192x64_check.log 2>&1; echo "fa d64 rc=$?" | tee -a $OUT/f1_steps.log
 timeout 600 $R $S/flash-attn/flash_attn_mma.py --B 1 --H 8 --N 8192 --D 64 --check --show-all --sdpa --seed 1 > $OUT/f1_fa_1x8x8192x64_check.log 2>&1; echo "fa d64 h8 rc=$?" | tee -a $OUT/f1_steps.log
 timeout 600 $R $S/flash-attn/flash_attn_mma.py --B 1 --H 48 --N 8192 --D 512 --check --show-all --sdpa --seed 1 > $OUT/f1_fa_1x48x8192x512_check.log 2>&1; echo "fa d512 rc=$?" | tee -a $OUT/f1_steps.log
+# D = 256: the head-dim limit of the share_kv / share_qkv / *_swizzle_qkv entries (round 4: attn_bigd7, either V layout)
+timeout 600 $R $S/flash-attn/flash_attn_mma.py --B 1 --H 48 --N 8192 --D 256 --check --show-all --sdpa --seed 1 > $OUT/f1_fa_1x48x8192x256_check.log 2>&1; echo "fa d256 rc=$?" | tee -a $OUT/f1_steps.log
 ( cd _refstage && sha256sum -c SHA256SUMS ) > $OUT/f1_sha256_after.txt 2>&1
 tail -3 $OUT/f1_*.log | tail -60
