@@ -259,16 +259,14 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd7_kernel(
       exact();
     } else {
       pv_stmt(std::integral_constant<int, 0>{});
-      pv_stmt(std::integral_constant<int, 1>{});
-      // the 16 MFMAs just issued cover the latency of the Sᵀ MFMAs; this empty statement orders the VALU reads of S behind them
-      asm volatile("" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[0][3]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(s[1][2]), "+v"(s[1][3]));
-      // does the running maximum hold?  (per lane: the largest of its 8 scores of each query row against m_run + THR)
-      float over = -INFINITY;   // the largest excess of a score over its row's running maximum (log2 units)
-#pragma unroll
-      for (int qb = 0; qb < 4; ++qb) {
-        const float mxl = fmaxf(fmaxf(fmaxf(s[0][qb][0], s[0][qb][1]), fmaxf(s[0][qb][2], s[0][qb][3])),
-                                fmaxf(fmaxf(s[1][qb][0], s[1][qb][1]), fmaxf(s[1][qb][2], s[1][qb][3])));
-        over = fmaxf(over, __builtin_fmaf(mxl, sl2, -m_run[qb]));
+      // does the running maximum hold?  Per lane: the largest of its 8 raw scores of each query row against m_run + THR (log2 units) —
+      // computed in the gaps of statement 1 (generated: bd7_pvc); the 8 MFMAs of statement 0 cover the latency of the Sᵀ MFMAs
+      float over;
+      {
+        constexpr int OFF1 = VT ? VS + (4 + 2) * 1024 : VS;   // statement 1 issues step 1's fragments 2, 3
+        bd7_pvc<BF16, VT, 32, OFF1, V_HOFF>(vf2, vf3, pf[0], pf[1], pf[2], pf[3], vx[VT ? 0 : 4 + 2], vx[VT ? 0 : 4 + 3], s, over, sl2,
+                                            m_run[0], m_run[1], m_run[2], m_run[3]);
+        __builtin_amdgcn_sched_barrier(0);
       }
       const bool hold = over <= THR;
       // p = exp2(s sl2 − m_run) in place, 32 per lane IN the MFMA gaps of the remaining six statements (generated: attn_bigd7_stmts.inc;

@@ -339,6 +339,16 @@ def test_generated_bigd7_statements_are_current_and_pipeline_the_softmax():
         assert sum(l.startswith("ds_read_b128") for l in inst) == (2 if x < 6 else 0) and not any("tr_b16" in l for l in inst)
         assert [l for l in inst if l.startswith(("v_fma", "v_exp", "v_add"))] == [l for l in ins if l.startswith(("v_fma", "v_exp", "v_add"))]
     assert sorted(seen) == list(range(32))
+    # statement 1 carries the running-maximum check: every one of the 32 score registers is read exactly once, per query block through
+    # three v_max3 + one v_max, the excess against that block's maximum operand
+    for vt in (False, True):
+        text = "\n".join(gen.gen_pv_check(vt))
+        ins = re.findall(r'"([^"]+?)\\n\\t"', text[:text.index("if constexpr (!BF16)")])
+        regs = [int(r) for l in ins if l.startswith(("v_max3", "v_max_f32 %3")) for r in re.findall(r"v\[(\d+)\]", l)]
+        assert sorted(regs) == list(range(208, 240))
+        fmas = [l for l in ins if l.startswith("v_fma_f32 %3")]
+        assert [l.split("-")[-1] for l in fmas] == ["%11", "%12", "%13", "%14"]
+        assert sum(l.startswith("v_mfma") for l in ins) == 8
 
 
 def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):

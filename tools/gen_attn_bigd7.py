@@ -136,6 +136,53 @@ def gen_pv(x, fill, vt):
     return out, (ta, tb)
 
 
+def gen_pv_check(vt):
+    """Statement 1 (step 0, quad pair 1) with the running-maximum check of tile t in its MFMA gaps: per query block the largest of the lane's
+    eight raw scores (three v_max3_f32 + one v_max_f32 on the pinned score registers — final since the whole of statement 0 lies between
+    them and the Sᵀ MFMAs), its excess over the running maximum (v_fma_f32 mx sl2 − m), and the largest excess of the four into `over`."""
+    qx, qy = QUADS[1]
+    per = 1 if vt else 2
+    w0 = w1 = 3 * per
+    # operands: %0 fx %1 fy %2 over %3 tmp | %4..%7 p0..p3 %8 ax %9 ay %10 sl2 %11..%14 m0..m3 %15..%22 score blocks | %23 R0 %24 OFF %25 OFF+HOFF
+    ops = []
+    for qb in range(4):
+        r = [S0 + 4 * qb + i for i in range(4)] + [S0 + 16 + 4 * qb + i for i in range(4)]      # blocks (0, qb) and (1, qb)
+        ops.append(f"v_max3_f32 %3, v[{r[0]}], v[{r[1]}], v[{r[2]}]")
+        ops.append(f"v_max3_f32 %3, %3, v[{r[3]}], v[{r[4]}]")
+        ops.append(f"v_max3_f32 %3, %3, v[{r[5]}], v[{r[6]}]")
+        ops.append(f"v_max_f32 %3, %3, v[{r[7]}]")
+        ops.append(f"v_fma_f32 %3, %3, %10, -%{11 + qb}")
+        ops.append("v_mov_b32 %2, %3" if qb == 0 else "v_max_f32 %2, %2, %3")
+    gaps = [ops[3 * g:3 * g + 3] for g in range(8)]
+    out = []
+    for bf in (True, False):
+        op = "v_mfma_f32_16x16x32_bf16" if bf else "v_mfma_f32_16x16x32_f16"
+        lines = ["s_nop 1", f"s_waitcnt lgkmcnt({w0})"]
+        for j, (quad, base) in enumerate(((qx, 0), (qy, 16))):
+            if j == 1:
+                lines.append(f"s_waitcnt lgkmcnt({w1})")
+            for q in range(4):
+                lines.append(f"{op} a[%23+{base + 4 * q}:%23+{base + 4 * q + 3}], v[{quad}:{quad + 3}], %{4 + q}, a[%23+{base + 4 * q}:%23+{base + 4 * q + 3}]")
+                if q == 3:
+                    if vt:
+                        lines.append(f"ds_read_b128 v[{quad}:{quad + 3}], %{8 + j} offset:%{24 + j}")
+                    else:
+                        lines.append(f"ds_read_b64_tr_b16 v[{quad}:{quad + 1}], %{8 + j} offset:%24")
+                        lines.append(f"ds_read_b64_tr_b16 v[{quad + 2}:{quad + 3}], %{8 + j} offset:%25")
+                lines.extend(gaps[4 * j + q])
+        cons_out = f'"+{{v[{qx}:{qx + 3}]}}"(fx), "+{{v[{qy}:{qy + 3}]}}"(fy), "=&v"(over), "=&v"(tmp)'
+        cons_in = ('"v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(ax), "v"(ay), "v"(sl2), "v"(m0), "v"(m1), "v"(m2), "v"(m3), '
+                   + ", ".join(f'"{{v[{S0 + 4 * t}:{S0 + 4 * t + 3}]}}"(s[{t >> 2}][{t & 3}])' for t in range(8))
+                   + ', "n"(R0), "n"(OFF), "n"(OFF + HOFF)')
+        out.append(f"    if constexpr ({'BF16' if bf else '!BF16'}) {{")
+        out.append("      asm volatile(\n" + asm_lines(lines).replace("               ", "                   ") + "\n"
+                   f"                   : {cons_out}\n"
+                   f"                   : {cons_in}\n"
+                   "                   : LC_AGPR_ALL);")
+        out.append("    }")
+    return out
+
+
 def gen_rd(vt):
     """The reads of a tile's first P·V step (fragments db = 0 .. 3 into the four quads), in fragment order."""
     lines = []
@@ -179,6 +226,17 @@ def render():
             L.append(f"  if constexpr (X == {x} && {'VT' if vt else '!VT'}) {{")
             L += body
             L.append("  }")
+    L.append("}")
+    L.append("")
+    L.append("// statement 1 with the running-maximum check in its gaps: over = max over the four query blocks of (largest raw score of the lane) sl2 − m")
+    L.append("template <bool BF16, bool VT, int R0, int OFF, int HOFF>")
+    L.append("LC_DEVINL void bd7_pvc(half8_t& fx, half8_t& fy, half8_t p0, half8_t p1, half8_t p2, half8_t p3, uint32_t ax, uint32_t ay,")
+    L.append("                       const f32x4_t (&s)[2][4], float& over, float sl2, float m0, float m1, float m2, float m3) {")
+    L.append("  float tmp;")
+    for vt in (False, True):
+        L.append(f"  if constexpr ({'VT' if vt else '!VT'}) {{")
+        L += gen_pv_check(vt)
+        L.append("  }")
     L.append("}")
     L.append("")
     L.append("// statement X with the softmax fillers of its score elements in the MFMA gaps.  sa / sb: the two score blocks it touches (bd7_pvf_ta /")
