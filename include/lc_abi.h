@@ -134,7 +134,10 @@ const char* lc_build_info(int* is_diag);
  *                  rings, attn_bigd7.hip; D = 512: the full-width kernel on the same MFMA shape, attn_bigd6.hip; D = 256 with
  *                  N % 256 == 128: attn_bigd2.hip; D = 1024: two waves share 32 query rows and split the head dim, attn_bigd4.hip),
  *                  1 = round-1 column-split kernel, 2 = 32-row double-buffered tiles (attn_bigd3.hip: validated on hardware in round 3,
- *                  6-8 % slower, a cross-check), 3 = D = 256 / 512 on the other MFMA shape than auto (attn_bigd2.hip: v_mfma_f32_32x32x16)
+ *                  6-8 % slower, a cross-check), 3 = D = 256 / 512 on the other MFMA shape than auto (attn_bigd2.hip: v_mfma_f32_32x32x16),
+ *                  4 = auto, but attn_bigd7 also on grids that do not fill the GPU (auto hands D = 256 launches of fewer than about 0.75
+ *                  workgroups of 256 query rows per CU to attn_bigd2.hip, whose workgroups own 128 rows; lc_attn_kernel_name reports the
+ *                  kernel of a grid that fills the GPU)
  * Diagnosis keys (include/lc_diag.h) are rejected with LC_ERR_ARG unless the library was built with LC_DIAG=1. */
 int lc_tune_set(const char* key, int value);
 /* Current and default value of a knob (either pointer may be NULL); LC_ERR_ARG for an unknown key.  lc_tune_count / lc_tune_key

@@ -31,7 +31,7 @@ tune_t g_tune_w4y_sched{1};        // hgemm_w4y_kernel loop schedule 0..2 (lc_tu
 tune_t g_tune_hgemm_stamps{0};     // GEMM cycle-stamp builds (diagnosis only, LC_DIAG)
 tune_t g_tune_hgemm_persist{1};    // 1 (default) = hgemm_w4y_kernel as a persistent workgroup per CU when the tiles divide evenly (lc_tune_set "hgemm_persist")
 tune_t g_tune_hgemm_stagger{0};    // K-loop stagger of hgemm_w4y_kernel (lc_tune_set "hgemm_stagger"): 0 = auto (by XCD), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 | mask << 20
-tune_t g_tune_attn_d512{0};        // D = 256 / 512 / 1024: 0 = auto, 1 = column-split kernel, 2 = attn_bigd3, 3 = D = 256 / 512 on the other MFMA shape than auto (attn_bigd2 <-> attn_bigd7 / attn_bigd6)
+tune_t g_tune_attn_d512{0};        // D = 256 / 512 / 1024: 0 = auto, 1 = column-split kernel, 2 = attn_bigd3, 3 = D = 256 / 512 on the other MFMA shape than auto (attn_bigd2 <-> attn_bigd7 / attn_bigd6), 4 = auto but attn_bigd7 on any grid
 }  // namespace lc
 
 namespace {
@@ -354,18 +354,31 @@ bool use_bigd4(int D, bool vt, int N) { return D == 1024 && !vt && N % 64 == 0 &
 constexpr bool kBigd6Auto = true;    // profiles/r4k_bigd6.log: fp16 + 3.4 ... 4.7 %, bf16 + 1.8 ... 2.8 % at the cap (zero-filled: - 8 %, the 16-wide stream is more issue-bound)
 bool use_bigd6(int D, bool vt, int N) {
   const int k = g_tune_attn_d512;
-  return D == 512 && !vt && N % 128 == 0 && ((k == 0 && kBigd6Auto) || (k == 3 && !kBigd6Auto));
+  return D == 512 && !vt && N % 128 == 0 && (((k == 0 || k == 4) && kBigd6Auto) || (k == 3 && !kBigd6Auto));
 }
 // D = 256 with N % 256 == 0, either V layout: attn_bigd7 (64 query rows per wave, 16x16x32 MFMAs, KV rings) is auto; knob 3 selects
 // attn_bigd2 (32 rows per wave, 32x32x16: the cross-check on the other MFMA shape, and the kernel for N % 256 == 128)
-bool use_bigd7(int D, bool vt, int N) { return D == 256 && N % 256 == 0 && g_tune_attn_d512 == 0; }
+// attn_bigd7's workgroup owns 256 query rows, attn_bigd2's 128: on a grid that does not fill the GPU the smaller blocks win (measured,
+// profiles/r4p_bigd7_small_grids.log: (1,8,1024,256) 156 vs 272 TFLOP/s, (1,16,2048,256) 693 vs 978; from 192 workgroups up attn_bigd7 is
+// ahead).  With g7 = B H N / 256 workgroups of attn_bigd7 (1.6 time units each: twice the rows at 0.8 of the time per FLOP) against 2 g7 of
+// attn_bigd2 (1 unit each), rounds of one workgroup per CU: attn_bigd7 iff 1.6 ceil(g7 / CUs) <= ceil(2 g7 / CUs), and always from 4 rounds up.
+// bh < 0: "a grid that fills the GPU" (lc_attn_kernel_name has no batch / head count).  Knob 4 forces attn_bigd7 (tests of small shapes).
+bool use_bigd7(int D, bool vt, int N, long bh) {
+  const int k = g_tune_attn_d512;
+  if (D != 256 || N % 256 != 0 || (k != 0 && k != 4)) return false;
+  if (k == 4 || bh < 0) return true;
+  const long ncu = device_cu_count(), g7 = bh * (N / 256);
+  if (g7 >= 4 * ncu) return true;
+  const long c7 = (g7 + ncu - 1) / ncu, c2 = (2 * g7 + ncu - 1) / ncu;
+  return 16 * c7 <= 10 * c2;
+}
 
 template <int D, bool VT>
 int launch_attn_bigd_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                         hipStream_t st) {
   if (use_bigd4(D, VT, N)) return launch_attn_bigd4(Q, K, V, O, B, H, N, g_tune_attn_d1024, st);
   if (use_bigd6(D, VT, N)) return launch_attn_bigd6(Q, K, V, O, B, H, N, false, st);
-  if (use_bigd7(D, VT, N)) return VT ? launch_attn_bigd7_vt(Q, K, V, O, B, H, N, st) : launch_attn_bigd7(Q, K, V, O, B, H, N, false, st);
+  if (use_bigd7(D, VT, N, (long)B * H)) return VT ? launch_attn_bigd7_vt(Q, K, V, O, B, H, N, st) : launch_attn_bigd7(Q, K, V, O, B, H, N, false, st);
   if (use_bigd2(D, VT, N)) return VT ? launch_attn_bigd2_vt(Q, K, V, O, B, H, N, D, st) : launch_attn_bigd2(Q, K, V, O, B, H, N, D, false, st);
   if (N % 128 == 0) return launch_attn_bigd<D, 4, VT>(Q, K, V, O, B, H, N, st);
   return launch_attn_bigd<D, 2, VT>(Q, K, V, O, B, H, N, st);
@@ -499,7 +512,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
     snprintf(buf, buflen, "attn_fwd_bigd6_kernel<%s>", bf16 ? "true" : "false");
     return LC_OK;
   }
-  if (use_bigd7(D, v_transposed != 0, N) && !(bf16 && v_transposed)) {
+  if (use_bigd7(D, v_transposed != 0, N, -1) && !(bf16 && v_transposed)) {
     snprintf(buf, buflen, "attn_fwd_bigd7_kernel<%s,%s>", bf16 ? "true" : "false", v_transposed ? "true" : "false");
     return LC_OK;
   }
@@ -525,6 +538,7 @@ bool ok_attn_nw(int v) {
 bool ok_01(int v) { return v == 0 || v == 1; }
 bool ok_02(int v) { return v >= 0 && v <= 2; }
 bool ok_03(int v) { return v >= 0 && v <= 3; }
+bool ok_04(int v) { return v >= 0 && v <= 4; }
 bool ok_span8(int v) { return v == 0 || v == 2 || v == 4 || v == 6; }
 bool ok_w4y_sched(int v) {
 #ifdef LC_DIAG
@@ -550,7 +564,7 @@ const Knob kKnobs[] = {
     {"attn_d1024", &g_tune_attn_d1024, 0, ok_span8, false},
     {"attn_w4i_sched", &g_tune_attn_w4i_sched, 1, ok_01, false},
     {"fp8_mx", &g_tune_fp8_mx, 3, ok_03, false},
-    {"attn_d512", &g_tune_attn_d512, 0, ok_03, false},
+    {"attn_d512", &g_tune_attn_d512, 0, ok_04, false},
     {"w4y_sched", &g_tune_w4y_sched, 1, ok_w4y_sched, false},
     {"hgemm_persist", &g_tune_hgemm_persist, 1, ok_01, false},
     {"hgemm_stagger", &g_tune_hgemm_stagger, 0, ok_stagger, false},
@@ -744,7 +758,7 @@ int lc_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, int B
   const half_t* v = static_cast<const half_t*>(V);
   half_t* o = static_cast<half_t*>(O);
   if (use_bigd6(D, false, N)) return launch_attn_bigd6(q, k, v, o, B, H, N, true, st);
-  if (use_bigd7(D, false, N)) return launch_attn_bigd7(q, k, v, o, B, H, N, true, st);
+  if (use_bigd7(D, false, N, (long)B * H)) return launch_attn_bigd7(q, k, v, o, B, H, N, true, st);
   if (use_bigd2(D, false, N)) return launch_attn_bigd2(q, k, v, o, B, H, N, D, true, st);
   const bool w4 = N % 128 == 0;
   switch (D) {

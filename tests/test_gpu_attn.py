@@ -93,6 +93,16 @@ def test_large_head_dims_tiling_qkv(oracle, D, N):
         capi.attn_call("flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv", q, k, tv, o, 2)
         torch.cuda.synchronize()
         _check(oracle, q, k, tv, o, vt=True)
+        if N % 256 == 0:   # auto hands a grid this small to attn_bigd2 (128-row workgroups): attn_bigd7 on it, both V layouts ("attn_d512" = 4)
+            capi.tune("attn_d512", 4)
+            try:
+                for args, vt in (((q, k, v), False), ((q, k, tv), True)):
+                    o = torch.full_like(q, float("nan"))
+                    capi.attn_call("flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv" if vt else "flash_attn_mma_stages_split_q_tiling_qkv", *args, o, 2)
+                    torch.cuda.synchronize()
+                    _check(oracle, *args, o, vt=vt)
+            finally:
+                capi.tune("attn_d512", 0)
     else:
         with pytest.raises(capi.LcError) as e:   # the reference dispatcher stops at 256 for this entry
             capi.attn_call("flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv", q, k,
@@ -320,7 +330,7 @@ def test_full_width_large_head_dim_kernel(oracle, D, dtype):
         (lambda a, b, c, o: capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", a, b, c, o, 2))
     for kk in (k, k2):
         outs = []
-        for knob in (0, 1, 2, 3):      # 3: the other MFMA shape (attn_bigd2 where auto is attn_bigd7 / attn_bigd6)
+        for knob in (0, 1, 2, 3, 4):   # 3: the other MFMA shape (attn_bigd2 where auto is attn_bigd7 / attn_bigd6); 4: attn_bigd7 on this small grid too
             capi.tune("attn_d512", knob)
             try:
                 o = torch.full_like(q, float("nan"))
@@ -334,7 +344,7 @@ def test_full_width_large_head_dim_kernel(oracle, D, dtype):
             d = np.abs(o - truth)
             assert np.isfinite(d).all() and d.max() < tol_max, d.max()
         assert all(np.abs(outs[0] - o).max() < tol_max for o in outs[1:])
-    assert capi.attn_kernel_name(N, D, False, bf).startswith("attn_fwd_bigd7_kernel" if D == 256 else "attn_fwd_bigd6_kernel")
+    assert capi.attn_kernel_name(N, D, False, bf).startswith("attn_fwd_bigd7_kernel" if D == 256 else "attn_fwd_bigd6_kernel")   # (on a grid that fills the GPU)
 
 
 @pytest.mark.parametrize("D,N", [(128, 256), (256, 128)])

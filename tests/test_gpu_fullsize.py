@@ -43,6 +43,7 @@ FAMILIES = [
     ("d32-auto", 32, None, 0),
     ("d256-auto", 256, None, 0),
     ("d256-other-mfma-shape", 256, "attn_d512", 3),
+    ("d256-rings", 256, "attn_d512", 4),          # attn_bigd7 (auto hands this test's small grid — 2 heads — to attn_bigd2)
     ("d512-auto", 512, None, 0),
     ("d512-column-split", 512, "attn_d512", 1),
     ("d512-other-mfma-shape", 512, "attn_d512", 3),
@@ -52,6 +53,7 @@ FAMILIES = [
     ("d64-v-transposed", -64, None, 0),
     ("d256-v-transposed", -256, None, 0),
     ("d256-v-transposed-other-mfma-shape", -256, "attn_d512", 3),
+    ("d256-v-transposed-rings", -256, "attn_d512", 4),
 ]
 
 

@@ -458,6 +458,13 @@ def test_large_head_dim_kernel_names(built):
         assert capi.attn_kernel_name(8192, 256, True) == "attn_fwd_bigd2_kernel<256,false,true>"
     finally:
         capi.tune("attn_d512", 0)
+    capi.tune("attn_d512", 4)      # auto, but attn_bigd7 on any grid: nothing else changes
+    try:
+        assert capi.attn_kernel_name(8192, 256) == "attn_fwd_bigd7_kernel<false,false>"
+        assert capi.attn_kernel_name(8192, 512) == "attn_fwd_bigd6_kernel<false>"
+        assert capi.attn_kernel_name(8192, 1024) == "attn_fwd_bigd4_kernel<8>"
+    finally:
+        capi.tune("attn_d512", 0)
     capi.tune("attn_d512", 1)
     try:
         assert capi.attn_kernel_name(8192, 1024).startswith("attn_fwd_bigd_kernel<1024,")
