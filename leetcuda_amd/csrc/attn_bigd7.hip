@@ -19,8 +19,8 @@
 //     4 g4 + r]; the Pᵀ operand is lane-local: P(qb) = pack(S(0, qb)[0..3], S(1, qb)[0..3]) (attn_bigd6's layout with one half-tile);
 //   * ONE set of P registers: the probabilities replace the scores in place (fp32) as fillers behind the P·V MFMAs of the PREVIOUS
 //     tile and are packed to fp16 behind the last of them, when the previous tile's P is dead.  That needs the decision "does the
-//     running maximum still hold" BEFORE the scores are overwritten: a lane compares the maximum of its 8 scores per query row with
-//     m_run + 8 (log2 units; p <= 256) BEFORE the first score is overwritten; if any lane of the wave fails (rare; tile 0 takes the
+//     running maximum still hold" BEFORE the first score is overwritten: a lane compares the maximum of its 8 scores per query row with
+//     m_run + 8 (log2 units; p <= 256) — in the MFMA gaps of the second P·V statement —; if any lane of the wave fails (rare; tile 0 takes the
 //     exact path by construction), the wave recomputes Sᵀ(t) behind the P·V statements (K(t) is still in its slot) and takes the exact
 //     path — row maximum across the four lane groups, Oᵀ and l rescaled, then the probabilities.  The P·V statements stay straight-line
 //     code: the Vᵀ quads carry asm-issued reads from one statement to the next, and hipcc copies such registers around a branch
