@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Back-to-back launches of one hot kernel for a few seconds per spec (the workload of tools/power_watch.sh; join the
 sampler log with tools/power_join.py).  usage: sustain.py [--seconds S] spec...
-   spec = hgemm | vendor | attn | attn8k | d512, optionally :nn (B stored [K][N]), :zero (zero-filled inputs), :uniform, :var=auto|w4c|w4x|pingpong2, :nopersist (hgemm: one tile per workgroup), :stg=N (hgemm K-loop stagger; stg=0 = off, no option = the default), :abl=N (hgemm only:
+   spec = hgemm | vendor | attn | attn8k | d512 | d256 (:bf16, :d512=K = lc_tune_set "attn_d512") | fp8 (16384^3; :k64 = the K = 64 kernel, :mx = lc_gemm_mxfp8 with block scales 2^-2 .. 2^2), optionally :nn (B stored [K][N]), :zero (zero-filled inputs), :uniform, :var=auto|w4c|w4x|pingpong2, :nopersist (hgemm: one tile per workgroup), :stg=N (hgemm K-loop stagger; stg=0 = off, no option = the default), :abl=N (hgemm only:
           lc_tune_set "w4_abl", LC_DIAG library — ablated kernels compute WRONG results), :nw=N (attention kernel choice)"""
 import sys
 import time
@@ -72,6 +72,29 @@ for spec in args:
         o = torch.zeros_like(q)
         step = lambda: capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, o, 2)  # noqa: E731
         flops = host.mha_matmul_flops(1, 48, 8192, 512)
+    elif what == "d256":
+        dt = torch.bfloat16 if "bf16" in opts else torch.half
+        q = fill(torch.randn(1, 48, 8192, 256, device="cuda").to(dt), opts)
+        k = fill(torch.randn(1, 48, 8192, 256, device="cuda").to(dt), opts)
+        v = fill(torch.randn(1, 48, 8192, 256, device="cuda").to(dt), opts)
+        o = torch.zeros_like(q)
+        capi.tune("attn_d512", next((int(x[5:]) for x in opts if x.startswith("d512=")), 0))
+        step = (lambda: capi.attn_fwd_bf16(q, k, v, o)) if "bf16" in opts else \
+            (lambda: capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, o, 2))  # noqa: E731
+        flops = host.mha_matmul_flops(1, 48, 8192, 256)
+    elif what == "fp8":
+        n = 16384
+        a8 = fill(torch.randn(n, n, device="cuda"), opts).to(torch.float8_e4m3fn)
+        b8 = fill(torch.randn(n, n, device="cuda"), opts).to(torch.float8_e4m3fn)
+        c8 = torch.empty(n, n, dtype=torch.half, device="cuda")
+        capi.tune("fp8_mx", 1 if "k64" in opts else 3)
+        if "mx" in opts:
+            pa = capi.mxfp8_pack_scales(torch.randint(125, 130, (n, n // 32), device="cuda", dtype=torch.uint8))
+            pb = capi.mxfp8_pack_scales(torch.randint(125, 130, (n, n // 32), device="cuda", dtype=torch.uint8))
+            step = lambda: capi.gemm_mxfp8(a8, pa, b8, pb, c8, alpha=1 / 64, swizzle_stride=2048)  # noqa: E731
+        else:
+            step = lambda: capi.gemm_fp8(a8, b8, c8, alpha=1 / 16, swizzle_stride=2048)  # noqa: E731
+        flops = 2.0 * n ** 3
     else:
         raise SystemExit(f"unknown spec {spec}")
     for _ in range(5):
@@ -95,3 +118,5 @@ for spec in args:
         capi.tune("w4_abl", 0)
     if nw:
         capi.tune("attn_nw", 0)
+    capi.tune("attn_d512", 0)
+    capi.tune("fp8_mx", 3)
