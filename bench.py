@@ -406,7 +406,7 @@ def bench_attn_d256(w, args, steps=5):
         secs = lcd.max_over_ranks(w, timed_region(w, step, steps, 1, prewarm=2))
         ms_kernel = lcd.max_over_ranks(w, timed_region.event_ms / steps)
         blk = {"value": flops_total * steps / secs * 1e-12, "ms_per_step": secs / steps * 1e3,
-               "roofline": roofline(capi.attn_kernel_name(N, D, False, bf), flops_local, 4.0 * B * h_loc * N * D * 2, ms_kernel,
+               "roofline": roofline(capi.attn_kernel_name(N, D, False, bf, bh=B * h_loc), flops_local, 4.0 * B * h_loc * N * D * 2, ms_kernel,
                                     workload=(f"attn_d256_{tag}" if w.size == 1 else None))}
         if bf:
             out["bf16"] = blk

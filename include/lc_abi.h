@@ -137,7 +137,7 @@ const char* lc_build_info(int* is_diag);
  *                  6-8 % slower, a cross-check), 3 = D = 256 / 512 on the other MFMA shape than auto (attn_bigd2.hip: v_mfma_f32_32x32x16),
  *                  4 = auto, but attn_bigd7 also on grids that do not fill the GPU (auto hands D = 256 launches of fewer than about 0.75
  *                  workgroups of 256 query rows per CU to attn_bigd2.hip, whose workgroups own 128 rows; lc_attn_kernel_name reports the
- *                  kernel of a grid that fills the GPU)
+ *                  kernel of a grid that fills the GPU, lc_attn_kernel_name_bh the one a launch of BH problems runs)
  * Diagnosis keys (include/lc_diag.h) are rejected with LC_ERR_ARG unless the library was built with LC_DIAG=1. */
 int lc_tune_set(const char* key, int value);
 /* Current and default value of a knob (either pointer may be NULL); LC_ERR_ARG for an unknown key.  lc_tune_count / lc_tune_key
@@ -227,6 +227,9 @@ int lc_attn_entry_info(const char* entry, int* family, int* v_transposed, int* a
  * Pointers are assumed 16-byte aligned.  Returns LC_OK, LC_ERR_ARG / LC_ERR_SHAPE / LC_ERR_HEADDIM as the call would. */
 int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf, int buflen);
 int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int buflen);
+/* the same for a launch of BH = batch x heads problems: where the choice depends on how far the grid fills the GPU (D = 256, "attn_d512"
+ * above) the name is the kernel THAT launch runs; BH <= 0 = lc_attn_kernel_name (a grid that fills the GPU) */
+int lc_attn_kernel_name_bh(int BH, int N, int D, int v_transposed, int bf16, char* buf, int buflen);
 /* How often the overflow slow path of the merged-phase attention kernels (attn_w4u.hip, attn_w4i.hip) ran since the last reset:
  * out4 = { executions, sum of their KV half-tile indices, executions that saw a non-finite row sum, bit pattern (fp32) of the
  * last offending row sum }.  Synchronises the device (hipMemcpyFromSymbol).  out4 may be NULL (reset only). */

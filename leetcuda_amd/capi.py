@@ -50,6 +50,7 @@ SYMBOLS = {
     "lc_attn_time": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _fp]),
     "lc_hgemm_kernel_name": (_i, [_i, _i, _i, _i, _i, _cp, _i]),
     "lc_attn_kernel_name": (_i, [_i, _i, _i, _i, _cp, _i]),
+    "lc_attn_kernel_name_bh": (_i, [_i, _i, _i, _i, _i, _cp, _i]),
     "lc_attn_slowpath_stats": (_i, [C.POINTER(C.c_uint), _i]),
     "lc_timer_start": (_i, [_vp, C.POINTER(_vp)]),
     "lc_timer_stop": (_i, [_vp, _fp]),
@@ -398,9 +399,11 @@ def attn_slowpath_stats(reset=True):
     return [out[0], out[1], out[2], struct.unpack("f", struct.pack("I", out[3]))[0]]
 
 
-def attn_kernel_name(N, D, v_transposed=False, bf16=False) -> str:
+def attn_kernel_name(N, D, v_transposed=False, bf16=False, bh=None) -> str:
+    """The kernel the dispatcher picks for sequence length N and head dim D; bh = batch x heads of the launch (None: a grid that fills
+    the GPU — the choice depends on it for D = 256 only)."""
     buf = C.create_string_buffer(128)
-    check(load().lc_attn_kernel_name(N, D, int(v_transposed), int(bf16), buf, 128), "lc_attn_kernel_name")
+    check(load().lc_attn_kernel_name_bh(int(bh) if bh else -1, N, D, int(v_transposed), int(bf16), buf, 128), "lc_attn_kernel_name_bh")
     return buf.value.decode()
 
 

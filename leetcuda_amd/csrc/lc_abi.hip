@@ -362,7 +362,7 @@ bool use_bigd6(int D, bool vt, int N) {
 // profiles/r4p_bigd7_small_grids.log: (1,8,1024,256) 156 vs 272 TFLOP/s, (1,16,2048,256) 693 vs 978; from 192 workgroups up attn_bigd7 is
 // ahead).  With g7 = B H N / 256 workgroups of attn_bigd7 (1.6 time units each: twice the rows at 0.8 of the time per FLOP) against 2 g7 of
 // attn_bigd2 (1 unit each), rounds of one workgroup per CU: attn_bigd7 iff 1.6 ceil(g7 / CUs) <= ceil(2 g7 / CUs), and always from 4 rounds up.
-// bh < 0: "a grid that fills the GPU" (lc_attn_kernel_name has no batch / head count).  Knob 4 forces attn_bigd7 (tests of small shapes).
+// bh < 0: "a grid that fills the GPU" (lc_attn_kernel_name has no batch / head count; lc_attn_kernel_name_bh has).  Knob 4 forces attn_bigd7 (tests of small shapes).
 bool use_bigd7(int D, bool vt, int N, long bh) {
   const int k = g_tune_attn_d512;
   if (D != 256 || N % 256 != 0 || (k != 0 && k != 4)) return false;
@@ -492,6 +492,10 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
 }
 
 int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int buflen) {
+  return lc_attn_kernel_name_bh(-1, N, D, v_transposed, bf16, buf, buflen);
+}
+
+int lc_attn_kernel_name_bh(int BH, int N, int D, int v_transposed, int bf16, char* buf, int buflen) {
   if (!buf || buflen < 8 || N <= 0 || N % KVB != 0) return LC_ERR_ARG;
   if (D > 0 && (size_t)N * (size_t)D * 2 >= 0x80000000ull) return LC_ERR_SHAPE;   // (mirrors lc_attn_fwd_f16)
   const char* vt = v_transposed ? "true" : "false";
@@ -512,7 +516,7 @@ int lc_attn_kernel_name(int N, int D, int v_transposed, int bf16, char* buf, int
     snprintf(buf, buflen, "attn_fwd_bigd6_kernel<%s>", bf16 ? "true" : "false");
     return LC_OK;
   }
-  if (use_bigd7(D, v_transposed != 0, N, -1) && !(bf16 && v_transposed)) {
+  if (use_bigd7(D, v_transposed != 0, N, BH > 0 ? (long)BH : -1) && !(bf16 && v_transposed)) {
     snprintf(buf, buflen, "attn_fwd_bigd7_kernel<%s,%s>", bf16 ? "true" : "false", v_transposed ? "true" : "false");
     return LC_OK;
   }

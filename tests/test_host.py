@@ -448,6 +448,14 @@ def test_large_head_dim_kernel_names(built):
     assert capi.attn_kernel_name(8192, 256) == "attn_fwd_bigd7_kernel<false,false>"
     assert capi.attn_kernel_name(8192, 256, False, True) == "attn_fwd_bigd7_kernel<true,false>"
     assert capi.attn_kernel_name(384, 256) == "attn_fwd_bigd2_kernel<256,false,false>"      # N % 256 == 128: the 32-rows-per-wave kernel
+    # D = 256 by grid size (lc_attn_kernel_name_bh; the rounds rule of use_bigd7 on the 256 CUs this test assumes when no GPU is present):
+    # 8 heads x 4 blocks = 32 workgroups and 16 x 8 = 128 go to the 128-row kernel, 96 x 2 = 192 and everything from 256 up to the ring kernel
+    if capi.attn_kernel_name(1024, 256, bh=64) == "attn_fwd_bigd7_kernel<false,false>":     # (a 256-CU device or the no-device default)
+        assert capi.attn_kernel_name(1024, 256, bh=8) == "attn_fwd_bigd2_kernel<256,false,false>"
+        assert capi.attn_kernel_name(2048, 256, bh=16) == "attn_fwd_bigd2_kernel<256,false,false>"
+        assert capi.attn_kernel_name(1024, 256, True, bh=8) == "attn_fwd_bigd2_kernel<256,false,true>"
+        assert capi.attn_kernel_name(512, 256, bh=96) == "attn_fwd_bigd7_kernel<false,false>"
+        assert capi.attn_kernel_name(8192, 256, bh=48) == "attn_fwd_bigd7_kernel<false,false>"
     assert capi.attn_kernel_name(8192, 512, True).startswith("attn_fwd_bigd_kernel<512,")
     assert capi.attn_kernel_name(192, 256, True).startswith("attn_fwd_bigd_kernel<256,")
     assert capi.attn_kernel_name(8192, 512) == "attn_fwd_bigd6_kernel<false>"

@@ -53,7 +53,7 @@ def run(spec):
     for kk, vv in knobs.items():
         capi.tune(kk, vv)
     try:
-        name = capi.attn_kernel_name(N, D, vt, bf16)
+        name = capi.attn_kernel_name(N, D, vt, bf16, bh=B * H)
         step = (lambda: capi.attn_fwd_bf16(q, k, v, o)) if bf16 else (lambda: capi.attn_fwd(q, k, v, o, v_transposed=vt))
         for _ in range(3):
             step()
