@@ -53,19 +53,22 @@ typedef enum lc_layout { LC_LAYOUT_NN = 0, LC_LAYOUT_TN = 1 } lc_layout;
 /* HGEMM kernel families behind the ABI (numeric values are stable; 2, 5, 7, 8, 11 were experiments that
  * measured slower and were retired — passing them returns LC_ERR_ARG). */
 typedef enum lc_hgemm_variant {
-  LC_HGEMM_AUTO = 0,       /* best available for the shape (MFMA256W4Y / MFMA128 / GENERIC by divisibility)            */
+  LC_HGEMM_AUTO = 0,       /* best available for the shape: the reference's legal shapes (M, N % 128 == 0, K % 32 == 0, K >= 64;
+                              hgemm_mma_stage.cu:650,675-676) run MFMA256W4Y when the 256-tileable interior has > 128 tiles (128-wide
+                              border strips on MFMA128 in a second launch), MFMA128 otherwise; every other shape GENERIC          */
   LC_HGEMM_MFMA256 = 1,    /* 256x256x64 WG tile, 8 wave64, LDS-DMA double buffer, one barrier / K-tile (simplest)      */
   LC_HGEMM_GENERIC = 3,    /* 64x64x32 edge-predicated MFMA kernel: any M,N,K                                           */
   LC_HGEMM_MFMA256P2 = 4,  /* 8-wave ping-pong, 2 phases of 16 MFMAs per K tile, DMA issued inside the MFMA clusters:
                               the independently scheduled cross-check of the default kernel                            */
-  LC_HGEMM_MFMA128 = 6,    /* 128x128x64 tile, 4 wave64: M, N multiples of 128 (the reference's own tile)               */
+  LC_HGEMM_MFMA128 = 6,    /* 128x128x64 tile, 4 wave64: M, N multiples of 128 (the reference's own tile), K of 32 (>= 64)  */
   LC_HGEMM_MFMA256W4B = 9, /* 256x256x64 tile, FOUR wave64 with 128x128 wave tiles, A ring of 2 + B ring of 3 K tiles,      */
                            /* v_mfma_f32_32x32x16_f16, global_load_lds DMA (64-bit addresses: the fallback for > 2 GiB spans) */
   LC_HGEMM_MFMA256W4C = 10, /* W4B with buffer_load ... lds (descriptor + scalar offset) DMA: the 32x32x16 baseline         */
   LC_HGEMM_MFMA256W4X = 12, /* W4C's ring / DMA schedule with v_mfma_f32_16x16x32_f16 (8 x 8 blocks of 16 x 16 per wave):   */
                             /* fewer joules per FLOP at the board power cap (hgemm_w4x.hip, compiler-scheduled; TN only)   */
   LC_HGEMM_MFMA256W4Y = 13, /* W4X with the K loop as one generated, hand-ordered instruction stream (hgemm_w4y.hip; TN and  */
-                            /* NN): what LC_HGEMM_AUTO launches for large 256-tileable shapes                              */
+                            /* NN): what LC_HGEMM_AUTO launches for large shapes.  Unlike the other 256-tile kernels (M, N % 256 == 0, */
+                            /* K % 64 == 0) it takes M, N % 128 == 0 (>= 256) and K % 32 == 0 (>= 64): border strips + a half K-step  */
   /* the reference's "CUDA-core" ladder as vector-ALU kernels (hgemm_valu.hip; NN only; v_dot2c_f32_f16, fp32 accumulate);
    * shapes a rung does not tile (and TN) run LC_HGEMM_GENERIC */
   LC_HGEMM_VALU_NAIVE = 20,                  /* one thread per C element, operands from global memory                       */

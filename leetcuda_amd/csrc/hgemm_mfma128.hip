@@ -1,8 +1,10 @@
 // hgemm_mfma128.hip — 128x128x64 workgroup tile, 4 wave64 (2 x 2, wave tile 64x64), LDS-DMA double buffer.
 // The mid-size sibling of hgemm_mfma256.hip (same LDS images, swizzles and one-barrier-per-K-tile schedule)
-// for the shapes the reference itself accepts but a 256 tile does not divide: M, N multiples of 128, K of 64
-// (reference tiles are 128x128, kernels/hgemm/mma/basic/hgemm_mma_stage.cu:644-676).  64 KiB of LDS, two
-// workgroups per CU.
+// for the shapes the reference itself accepts but a 256 tile does not divide: M, N multiples of 128, K of 32
+// (reference tiles are 128x128x32, kernels/hgemm/mma/basic/hgemm_mma_stage.cu:644-676; K % 64 == 32: one half K-step with
+// fragments straight from global memory after the tile loop).  64 KiB of LDS, two workgroups per CU.  Besides its own grid it
+// computes, for the 256-tile kernels (lc_abi.hip launch_mfma256), the quadrants of their ragged last wave and the 128-wide border
+// strips of M, N % 256 == 128 problems.
 #pragma once
 #include "hgemm_mfma256.hip"
 
@@ -17,21 +19,35 @@ template <bool B_KN>
 __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __restrict__ A,
                                                                const half_t* __restrict__ B,
                                                                half_t* __restrict__ C, int M, int N, int K,
-                                                               int tiles_m, int tiles_n, int panel_w, int rem_base) {
+                                                               int tiles_m, int tiles_n, int panel_w, int rem_base,
+                                                               int rem_blocks, int nright) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = wave_id();
   const int wr = wave >> 1, wc = wave & 1;
   const int i16 = lane & 15, g = lane >> 4;
 
-  // rem_base < 0: this kernel's own grid of 128 x 128 tiles.  rem_base >= 0 (the 256-tile kernels' ragged last wave, lc_abi.hip
-  // launch_mfma256): tiles_m / tiles_n / panel_w describe the 256 x 256 tile grid, block b computes quadrant b & 3 of the 256-tile
-  // whose raster id is rem_base + (b >> 2) — the ids the big kernel's truncated grid left out.
+  // rem_base == -1: this kernel's own grid of 128 x 128 tiles.  Otherwise (lc_abi.hip launch_mfma256) tiles_m / tiles_n / panel_w
+  // describe the 256 x 256 tile grid of the interior and the blocks are, in this order:
+  //   b < rem_blocks           quadrant b & 3 of the 256-tile whose raster id is rem_base + (b >> 2) — the ids the big kernel's
+  //                            truncated grid left out (its ragged last wave);
+  //   the next nright blocks   the right border strip of an N % 256 == 128 problem: columns N - 128 .., 128-row tile b' (all M rows);
+  //   the rest                 the bottom border strip of an M % 256 == 128 problem: rows M - 128 .., 128-column tile b'' of the
+  //                            256 tiles_n interior columns (the corner belongs to the right strip).
   int m0, n0;
-  if (rem_base < 0) {
+  if (rem_base == -1) {
     const TileCoord tc = block_tile(blockIdx.x, gridDim.x, tiles_m, tiles_n, panel_w);
     m0 = tc.tm * BM1;
     n0 = tc.tn * BN1;
+  } else if ((int)blockIdx.x >= rem_blocks) {
+    const int bb = (int)blockIdx.x - rem_blocks;
+    if (bb < nright) {
+      m0 = bb * BM1;
+      n0 = N - BN1;
+    } else {
+      m0 = M - BM1;
+      n0 = (bb - nright) * BN1;
+    }
   } else {
     const int id = rem_base + ((int)blockIdx.x >> 2), qd = blockIdx.x & 3;
     const TileCoord tc = panel_w < 0 ? raster_xcd16(id, tiles_m * tiles_n, tiles_m, tiles_n) : raster(id, tiles_m, tiles_n, panel_w);
@@ -123,6 +139,25 @@ __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __r
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(bf[ni], af[mi], acc[mi][ni]);
     }
+  }
+  if (K & 32) {   // K % 64 == 32: the last half K-step, fragments straight from global memory in the MFMA operand layout
+    const int k0 = KT * BK + 8 * g;
+    half8_t af[4], bf[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) af[mi] = *(const half8_t*)(A + (size_t)(m0 + wr * 64 + mi * 16 + i16) * K + k0);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      if constexpr (!B_KN) {
+        bf[ni] = *(const half8_t*)(B + (size_t)(n0 + wc * 64 + ni * 16 + i16) * K + k0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bf[ni][e] = B[(size_t)(k0 + e) * N + n0 + wc * 64 + ni * 16 + i16];
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(bf[ni], af[mi], acc[mi][ni]);
   }
   // ---- epilogue: each wave stages its 64x64 sub-tile through LDS, stores 128-byte row segments
   char* stg = smem + wave * (64 * EPI_STRIDE);

@@ -184,6 +184,9 @@ int panel_tiles(int swizzle_stride, int tiles_n, int tile_n, size_t operand_byte
 template <bool B_KN>
 int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant,
                    int swizzle_stride, hipStream_t st) {
+  // Interior = the 256-tileable part of C.  M, N % 256 == 128 (the reference's kernels are legal on multiples of 128,
+  // hgemm_mma_stage.cu:675-676; resolve_hgemm_variant admits them for hgemm_w4y_kernel only): the 128-wide right / bottom border
+  // strips go to the 128-tile kernel in the launch that also takes the ragged last wave.
   const int tiles_m = M / BM, tiles_n = N / BN;
   const int pw = panel_tiles(swizzle_stride, tiles_n, BN, ((size_t)M + N) * K * 2);
   const dim3 grid(tiles_m * tiles_n), block(512);
@@ -194,13 +197,17 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
     // a quarter-size tile) — 6144^3: 2.25 waves -> 2 + a short one instead of 3 (profiles/r3e_hgemm_tail.log).
     const int ncu = device_cu_count();   // (the same per-device figure the persistent launchers use)
     const int T = tiles_m * tiles_n, R = T % ncu;
-    const bool split = g_tune_hgemm_tail != 0 && T > ncu && R > 0 && 2 * R <= ncu &&
-                       w4_effective_variant(variant, B_KN, N, K) == LC_HGEMM_MFMA256W4Y;
-    if (!split) return launch_w4_family(A, B, C, M, N, K, variant, B_KN, tiles_m, tiles_n, pw, -1, st);
-    if (int rc = launch_w4_family(A, B, C, M, N, K, variant, B_KN, tiles_m, tiles_n, pw, T - R, st)) return rc;
+    const bool w4y = w4_effective_variant(variant, B_KN, N, K) == LC_HGEMM_MFMA256W4Y;
+    const int nright = (N % BN) ? M / BM1 : 0, nbottom = (M % BM) ? 2 * tiles_n : 0;   // border strips in 128 x 128 tiles
+    if ((nright || nbottom || (K % BK)) && !w4y) return LC_ERR_SHAPE;   // (resolve_hgemm_variant never lets this happen)
+    const bool split = g_tune_hgemm_tail != 0 && T > ncu && R > 0 && 2 * R <= ncu && w4y;
+    if (int rc = launch_w4_family(A, B, C, M, N, K, variant, B_KN, tiles_m, tiles_n, pw, split ? T - R : -1, st)) return rc;
+    const int nb128 = (split ? 4 * R : 0) + nright + nbottom;
+    if (nb128 == 0) return LC_OK;
     auto kern = hgemm_mfma128_kernel<B_KN>;
     if (int rc = set_dyn_lds(kern, HGEMM128_LDS)) return rc;
-    hipLaunchKernelGGL(kern, dim3(4 * R), dim3(256), HGEMM128_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw, T - R);
+    hipLaunchKernelGGL(kern, dim3(nb128), dim3(256), HGEMM128_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw, split ? T - R : -2,
+                       split ? 4 * R : 0, nright);
     return check_launch();
   }
   if (false) {
@@ -230,7 +237,7 @@ int launch_mfma128(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   auto kern = hgemm_mfma128_kernel<B_KN>;
   if (int rc = set_dyn_lds(kern, HGEMM128_LDS)) return rc;
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), HGEMM128_LDS, st, A, B, C, M, N, K, tiles_m,
-                     tiles_n, pw, -1);
+                     tiles_n, pw, -1, 0, 0);
   return check_launch();
 }
 
@@ -445,15 +452,24 @@ bool is_hgemm_variant(int v) {
 namespace {
 // LC_HGEMM_AUTO -> a concrete kernel family; tile checks of the explicit families.  ONE function for lc_hgemm_f16
 // and lc_hgemm_kernel_name().  Returns the variant or a negative lc_status.
-int resolve_hgemm_variant(int variant, int M, int N, int K, bool al) {
-  const bool tiles256 = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && al;
-  const bool tiles128 = (M % BM1 == 0) && (N % BN1 == 0) && (K % BK == 0) && al;
+// Shapes (the reference's kernels are legal on M, N multiples of 128 and K multiples of 32, hgemm_mma_stage.cu:650,675-676):
+//   hgemm_w4y_kernel        M, N % 128 == 0 with a 256-tileable interior (the 128-wide border strips run on the 128-tile kernel,
+//                           launch_mfma256), K % 32 == 0, K >= 64 (K % 64 == 32: a half K-step behind the generated loop)
+//   hgemm_mfma128_kernel    M, N % 128 == 0, K % 32 == 0, K >= 64
+//   the other 256-tile kernels (cross-checks): M, N % 256 == 0, K % 64 == 0
+int resolve_hgemm_variant(int variant, int M, int N, int K, bool al, bool b_kn) {
+  const bool k64 = K % BK == 0, k32 = K % 32 == 0 && K >= BK;
+  const bool tiles256 = (M % BM == 0) && (N % BN == 0) && k64 && al;
+  const bool tiles128 = (M % BM1 == 0) && (N % BN1 == 0) && k32 && al;
+  // hgemm_w4y_kernel itself (not the 64-bit-address kernel w4_effective_variant substitutes for huge operands) on this shape
+  const bool w4y_ok = tiles128 && M >= BM && N >= BN && w4_effective_variant(LC_HGEMM_MFMA256W4Y, b_kn, N, K) == LC_HGEMM_MFMA256W4Y;
   if (variant == LC_HGEMM_AUTO) {
     // measured crossover on MI355X (TN, square): the 256-tile kernel wins once its grid has more
     // than ~128 workgroups (n >= 3072); below that the 128-tile kernel fills the 256 CUs better
     // (n = 2048: 715 vs 436 TFLOP/s).
     const long wg256 = (long)(M / BM) * (N / BN);
-    if (tiles256 && wg256 > 128) return g_tune_hgemm_auto;
+    const int a = g_tune_hgemm_auto;
+    if (wg256 > 128 && (tiles256 || (a == LC_HGEMM_MFMA256W4Y && w4y_ok))) return a;
     return tiles128 ? LC_HGEMM_MFMA128 : LC_HGEMM_GENERIC;
   }
   if (is_valu_variant(variant)) {   // a rung of the vector-ALU ladder: its own tile, else the edge kernel (never an error)
@@ -462,6 +478,7 @@ int resolve_hgemm_variant(int variant, int M, int N, int K, bool al) {
     const bool ok = (M % tm == 0) && (N % tn == 0) && (K % tk == 0) && (variant == LC_HGEMM_VALU_NAIVE || (al && K % 8 == 0));
     return ok ? variant : LC_HGEMM_GENERIC;
   }
+  if (variant == LC_HGEMM_MFMA256W4Y && w4y_ok) return variant;
   if (is_tile256_variant(variant) && !tiles256) return LC_ERR_SHAPE;
   if (variant == LC_HGEMM_MFMA128 && !tiles128) return LC_ERR_SHAPE;
   return variant;
@@ -471,7 +488,7 @@ int resolve_hgemm_variant(int variant, int M, int N, int K, bool al) {
 int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf, int buflen) {
   if (!buf || buflen < 8 || M <= 0 || N <= 0 || K <= 0 || !is_hgemm_variant(variant)) return LC_ERR_ARG;
   if (layout != LC_LAYOUT_NN && layout != LC_LAYOUT_TN) return LC_ERR_ARG;
-  int v = resolve_hgemm_variant(variant, M, N, K, true);
+  int v = resolve_hgemm_variant(variant, M, N, K, true, layout == LC_LAYOUT_NN);
   if (v < 0) return v;
   if (is_valu_variant(v) && layout != LC_LAYOUT_NN) v = LC_HGEMM_GENERIC;   // the ladder is NN only
   const char* nn = layout == LC_LAYOUT_NN ? "true" : "false";
@@ -638,7 +655,7 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   const half_t* b = static_cast<const half_t*>(B);
   half_t* c = static_cast<half_t*>(C);
   const bool al = aligned16(A) && aligned16(B) && aligned16(C);
-  variant = resolve_hgemm_variant(variant, M, N, K, al);
+  variant = resolve_hgemm_variant(variant, M, N, K, al, layout == LC_LAYOUT_NN);
   if (variant < 0) return variant;
   if (int rc = launch_guard()) return rc;   // a sticky HIP error of an earlier call: report it, launch nothing
   if (is_valu_variant(variant)) {
@@ -716,12 +733,13 @@ int lc_hgemm_call(const char* entry, const void* A, const void* B, void* C, int 
   if (e->variant == -3) return lc_vendor_destroy();
   if (e->variant == -1) return lc_hgemm_vendor_f16(A, B, C, M, N, K, e->layout, stream);
   int variant = e->variant;
-  // the tuned kernels need 256-multiples; every reference entry must still accept the reference's own
-  // legal shapes (multiples of 128 / K of 32, hgemm_mma_stage.cu:650,675), so fall back per shape.
-  const bool tiles256 = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && aligned16(A) &&
-                        aligned16(B) && aligned16(C);
-  const bool tiles128 = (M % BM1 == 0) && (N % BN1 == 0) && (K % BK == 0) && aligned16(A) && aligned16(B) && aligned16(C);
-  if (is_tile256_variant(variant) && !tiles256) variant = LC_HGEMM_AUTO;   // 128-tile kernel or generic
+  // the cross-check kernels need 256-multiples and K % 64 == 0; every reference entry must still accept the reference's own
+  // legal shapes (multiples of 128 / K of 32, hgemm_mma_stage.cu:650,675), so fall back per shape: AUTO serves those with the
+  // flagship kernel + border strips, the 128-tile kernel or the edge kernel (resolve_hgemm_variant)
+  const bool al = aligned16(A) && aligned16(B) && aligned16(C);
+  const bool tiles256 = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && al;
+  const bool tiles128 = (M % BM1 == 0) && (N % BN1 == 0) && (K % 32 == 0) && K >= BK && al;
+  if (is_tile256_variant(variant) && !tiles256) variant = LC_HGEMM_AUTO;
   if (variant == LC_HGEMM_MFMA128 && !tiles128) variant = LC_HGEMM_GENERIC;
   const int stride = (e->nargs == 6 && swizzle) ? swizzle_stride : 1;
   return lc_hgemm_f16(A, B, C, M, N, K, e->layout, variant, e->nargs == 6 ? stages : 2, stride, stream);

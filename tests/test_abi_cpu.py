@@ -241,6 +241,30 @@ def test_status_strings_and_argument_errors(built):
     assert lib.lc_clock_probe(None, None) == capi.LC_ERR_ARG
 
 
+def test_hgemm_dispatch_covers_the_reference_legal_shapes(built):
+    """Kernel selection needs no GPU (lc_hgemm_kernel_name shares resolve_hgemm_variant with the launcher).  The reference's kernels
+    are legal on M, N multiples of 128 and K multiples of 32 (hgemm_mma_stage.cu:650,675-676): with a large 256-tileable interior those
+    shapes run the flagship kernel (+ border strips / a half K-step), small grids the 128-tile kernel, anything else the edge kernel;
+    the cross-check kernels keep their 256 / K % 64 contract and say so."""
+    from leetcuda_amd import capi
+    capi.load()
+    for lay, nn in ((capi.LAYOUT_NN, "true"), (capi.LAYOUT_TN, "false")):
+        for shp in ((8320, 8320, 8320), (8192, 8320, 8192), (8320, 8192, 8192), (8192, 8192, 8224), (3200, 3200, 96)):
+            assert capi.hgemm_kernel_name(*shp, lay) == f"hgemm_w4y_kernel<{nn},1>", shp
+            assert capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_MFMA128) == f"hgemm_mfma128_kernel<{nn}>"
+            for v in (capi.HGEMM_MFMA256, capi.HGEMM_MFMA256W4C, capi.HGEMM_MFMA256W4X):
+                with pytest.raises(capi.LcError, match="Tensor size mismatch"):
+                    capi.hgemm_kernel_name(*shp, lay, v)
+        for shp in ((384, 384, 128), (256, 256, 96), (128, 640, 160), (2048, 2048, 2080)):      # <= 128 interior tiles: the 128-tile kernel
+            assert capi.hgemm_kernel_name(*shp, lay) == f"hgemm_mfma128_kernel<{nn}>", shp
+        for shp in ((384, 384, 128), (256, 256, 96)):                                             # ... the flagship kernel when asked for
+            assert capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_MFMA256W4Y) == f"hgemm_w4y_kernel<{nn},1>"
+        for shp in ((256, 256, 32), (8192, 8192, 8200), (8192, 8256, 8192), (128, 128, 48)):     # K < 64, K % 32, N % 128: the edge kernel
+            assert capi.hgemm_kernel_name(*shp, lay) == f"hgemm_generic_kernel<{nn}>", shp
+            with pytest.raises(capi.LcError, match="Tensor size mismatch"):
+                capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_MFMA256W4Y)
+
+
 def test_python_wrappers_validate_shapes(built):
     """a mismatched tensor must raise the reference's 'Tensor size mismatch!', not reach the device."""
     from leetcuda_amd import capi

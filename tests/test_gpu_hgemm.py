@@ -76,6 +76,69 @@ def test_mfma128_reference_tile_shapes(oracle, layout, shape):
 
 
 @pytest.mark.parametrize("layout", ["nn", "tn"])
+@pytest.mark.parametrize("shape", [(256, 256, 96), (512, 256, 160), (256, 512, 1056),           # K % 64 == 32 on the 256 tile
+                                   (384, 384, 128), (640, 256, 64), (256, 896, 192),             # 128-wide border strips
+                                   (384, 640, 96), (896, 1152, 544)])                            # both
+def test_flagship_kernel_on_the_reference_legal_shapes(oracle, layout, shape):
+    """Round-4 verdict (missing #1): the reference's kernels are legal on M, N multiples of 128 and K multiples of 32
+    (hgemm_mma_stage.cu:650,675-676).  hgemm_w4y_kernel now takes them: a half K-step behind its generated loop (fragments straight
+    from global memory) and the 128-wide right / bottom border strips on the 128-tile kernel in a second launch."""
+    capi = _capi()
+    M, N, K = shape
+    torch.manual_seed(M * 11 + N * 3 + K)
+    a = torch.randn(M, K, dtype=torch.half, device="cuda")
+    b = torch.randn(K, N, dtype=torch.half, device="cuda")
+    lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
+    assert capi.hgemm_kernel_name(M, N, K, lay, capi.HGEMM_MFMA256W4Y).startswith("hgemm_w4y_kernel")
+    for stride in (1, 256):
+        c, _ = _run(capi, a, b, lay, capi.HGEMM_MFMA256W4Y, stride)
+        _check(oracle, capi, a, b, c, lay)
+    # the other 256-tile kernels keep their own contract (256-multiples, K % 64 == 0): a clean error, never a wrong answer
+    c = torch.zeros(M, N, dtype=torch.half, device="cuda")
+    bb = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
+    with pytest.raises(capi.LcError, match="Tensor size mismatch"):
+        capi.hgemm(a, bb, c, layout=lay, variant=VARIANTS["w4x"] if layout == "tn" else VARIANTS["w4c"])
+
+
+@pytest.mark.parametrize("layout", ["nn", "tn"])
+@pytest.mark.parametrize("shape", [(128, 128, 96), (384, 128, 160), (256, 384, 224), (128, 256, 1056)])
+def test_mfma128_half_k_step(oracle, layout, shape):
+    """K % 64 == 32 on the 128-tile kernel (explicitly and as LC_HGEMM_AUTO's choice for small grids)."""
+    capi = _capi()
+    M, N, K = shape
+    torch.manual_seed(M * 13 + N + K)
+    a = torch.randn(M, K, dtype=torch.half, device="cuda")
+    b = torch.randn(K, N, dtype=torch.half, device="cuda")
+    lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
+    assert capi.hgemm_kernel_name(M, N, K, lay).startswith("hgemm_mfma128_kernel")
+    for var in (capi.HGEMM_MFMA128, capi.HGEMM_AUTO):
+        c, _ = _run(capi, a, b, lay, var, 256)
+        _check(oracle, capi, a, b, c, lay)
+
+
+@pytest.mark.parametrize("layout", ["nn", "tn"])
+@pytest.mark.parametrize("shape", [(3200, 3200, 96), (3072, 3456, 160), (3456, 3072, 128)])
+def test_auto_routes_128_multiples_with_a_large_interior_to_the_flagship_kernel(oracle, layout, shape):
+    """LC_HGEMM_AUTO and the reference's entry names: > 128 interior tiles of 256 x 256 -> hgemm_w4y_kernel + border strips (round 4:
+    the whole problem fell to the 128-tile kernel, - 32 % at 8192-class sizes).  Rows of the bottom strip, columns of the right strip
+    and the corner are all inside the full comparison."""
+    capi = _capi()
+    M, N, K = shape
+    torch.manual_seed(M + 7 * N + K)
+    a = torch.randn(M, K, dtype=torch.half, device="cuda")
+    b = torch.randn(K, N, dtype=torch.half, device="cuda")
+    lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
+    assert capi.hgemm_kernel_name(M, N, K, lay).startswith("hgemm_w4y_kernel")
+    c, bb = _run(capi, a, b, lay, capi.HGEMM_AUTO, 1024)
+    _check(oracle, capi, a, b, c, lay)
+    name = ("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem" if layout == "nn" else "hgemm_mma_stages_block_swizzle_tn_cute")
+    c2 = torch.full_like(c, float("nan"))
+    capi.hgemm_call(name, a, bb, c2, 2, True, 1024)
+    torch.cuda.synchronize()
+    assert torch.equal(c, c2)
+
+
+@pytest.mark.parametrize("layout", ["nn", "tn"])
 @pytest.mark.parametrize("shape", [(64, 64, 64), (128, 128, 32), (100, 72, 50), (1, 1, 1), (257, 129, 65),
                                    (384, 640, 96)])
 def test_generic_kernel_ragged_shapes(oracle, layout, shape):
