@@ -84,7 +84,11 @@ typedef enum lc_hgemm_variant {
   LC_HGEMM_VALU_T16X8_K32 = 30               /* 256x128 tile, 16x8 per thread                                               */
 } lc_hgemm_variant;
 
-/* FlashAttention-2 forward families (resource policies of kernels/flash-attn/mma/basic/ .cu files). */
+/* FlashAttention-2 forward families: the reference's resource policies (kernels/flash-attn/mma/basic/ .cu files), kept as an enum
+ * for signature parity ONLY.  `family`, `acc_f32` and `stages` of lc_attn_fwd_f16 are validated and then SELECT NOTHING: the kernel is
+ * chosen from (D, N, V layout, B x H and the device's CU count) alone (lc_attn_kernel_name_bh reports it), every kernel accumulates
+ * in fp32, and the LDS ring depth is fixed per kernel.  What a family name still decides is the head-dim limit of its ENTRY
+ * (lc_attn_call / lc_attn_entry_info: the reference wrappers' switch(d)). */
 typedef enum lc_attn_family {
   LC_ATTN_SPLIT_Q = 0,     /* flash_attn_mma_split_q.cu:55      K,V tiles staged in LDS, Q in regs   */
   LC_ATTN_SHARED_QKV = 1,  /* flash_attn_mma_share_qkv.cu:70    one LDS arena time-shared by K and V */
@@ -204,7 +208,10 @@ int lc_hgemm_entry_info(const char* entry, int* layout, int* nargs);
  * Q,K,O: [B,H,N,D] fp16 contiguous.  V: [B,H,N,D], or [B,H,D,N] when v_transposed != 0
  * (the reference's *_swizzle_qkv share_kv/share_qkv/tiling_qk entries, flash_attn_mma.py:441-442).
  * Non-causal, scale = 1/sqrt(D), no dropout / mask / LSE output.  fp32 softmax, fp32 MFMA accumulate
- * (acc_f32 is accepted for signature parity; CDNA4 MFMA has no fp16-accumulate form).
+ * (family / acc_f32 / stages are accepted for signature parity and select nothing; CDNA4 MFMA has no fp16-accumulate form).
+ * Batch variance: the kernel — and with it the fp32 summation order, i.e. the low bits of O — depends on B x H and the CU count
+ * for shapes whose grid would not fill the GPU (small grids run 128-row workgroups or the split-KV path); one (B, H, N, D) on one
+ * device is bit-reproducible from launch to launch.
  * N must be a multiple of 64; D in {32, 64, 96, 128, 256, 512, 1024} — the head dims of the reference dispatchers. */
 int lc_attn_fwd_f16(const void* Q, const void* K, const void* V, void* O, int B, int H, int N, int D,
                     int v_transposed, int family, int acc_f32, int stages, void* stream);

@@ -12,17 +12,25 @@ void attn_dispatch(const char* entry, torch::Tensor Q, torch::Tensor K, torch::T
   LC_CHECK_DTYPE(K, torch::kHalf)  // K [B,H,N,D]
   LC_CHECK_DTYPE(V, torch::kHalf)  // V [B,H,N,D] ([B,H,D,N] for the *_swizzle_qkv share/tiling_qk entries)
   LC_CHECK_DTYPE(O, torch::kHalf)  // O [B,H,N,D]
+  LC_CHECK_CONTIGUOUS(Q)
+  LC_CHECK_CONTIGUOUS(K)
+  LC_CHECK_CONTIGUOUS(V)
+  LC_CHECK_CONTIGUOUS(O)
   LC_CHECK_DEVICE(Q)
   LC_CHECK_DEVICE(K)
   LC_CHECK_DEVICE(V)
   LC_CHECK_DEVICE(O)
+  LC_CHECK_SAME_DEVICE(K, Q)
+  LC_CHECK_SAME_DEVICE(V, Q)
+  LC_CHECK_SAME_DEVICE(O, Q)
   if (Q.dim() != 4 || K.dim() != 4 || V.dim() != 4 || O.dim() != 4)
     throw std::runtime_error("Tensor size mismatch!");
   const int B = Q.size(0), H = Q.size(1), N = Q.size(2), D = Q.size(3);
   if (K.numel() != Q.numel() || V.numel() != Q.numel() || O.numel() != Q.numel())
     throw std::runtime_error("Tensor size mismatch!");
+  const LcDeviceScope dev(Q);
   const int rc = lc_attn_call(entry, Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, N, D,
-                              stages, lc_current_stream());
+                              stages, dev.stream());
   lc_throw_on_error(rc, entry);
 }
 

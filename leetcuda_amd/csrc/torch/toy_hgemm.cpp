@@ -10,16 +10,22 @@ void hgemm_dispatch(const char* entry, torch::Tensor a, torch::Tensor b, torch::
   LC_CHECK_DTYPE(a, torch::kHalf)
   LC_CHECK_DTYPE(b, torch::kHalf)
   LC_CHECK_DTYPE(c, torch::kHalf)
+  LC_CHECK_CONTIGUOUS(a)
+  LC_CHECK_CONTIGUOUS(b)   // (a TN operand is the CONTIGUOUS tensor utils.py:152-156 as_col_major returns, not a .t() view)
+  LC_CHECK_CONTIGUOUS(c)
   LC_CHECK_DEVICE(a)
   LC_CHECK_DEVICE(b)
   LC_CHECK_DEVICE(c)
+  LC_CHECK_SAME_DEVICE(b, a)
+  LC_CHECK_SAME_DEVICE(c, a)
   if (a.dim() != 2 || b.dim() != 2 || c.dim() != 2) throw std::runtime_error("Tensor size mismatch!");
   const int M = a.size(0);
   const int K = a.size(1);
   const int N = b.size(1);  // TN entries still present B as a [K,N]-shaped tensor (utils.py:152-156)
   if (b.size(0) != K || c.size(0) != M || c.size(1) != N) throw std::runtime_error("Tensor size mismatch!");
+  const LcDeviceScope dev(a);
   const int rc = lc_hgemm_call(entry, a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, stages,
-                               swizzle ? 1 : 0, swizzle_stride, lc_current_stream());
+                               swizzle ? 1 : 0, swizzle_stride, dev.stream());
   lc_throw_on_error(rc, entry);
 }
 

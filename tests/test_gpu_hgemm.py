@@ -278,6 +278,17 @@ def test_torch_extension_module_drop_in(oracle):
     assert tol.hgemm_close(c.float().cpu().numpy(), truth, K)[0]
     with pytest.raises(RuntimeError, match="Tensor size mismatch!"):
         toy_hgemm.hgemm_naive_f16(a, b[:256], c)
+    # boundary hardening (round-4 verdict, structure #11 / #12): views are refused, the launch follows the tensors' device and ITS
+    # current stream (here: a side stream of device 0 entered without touching the current device)
+    with pytest.raises(RuntimeError, match="must be contiguous"):
+        toy_hgemm.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4(a, b.t(), c, 2, True, 256)
+    side = torch.cuda.Stream(device=0)
+    c.zero_()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        toy_hgemm.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem(a, b, c, 2, True, 256)
+    side.synchronize()               # ONLY the side stream: the result must be there
+    assert tol.hgemm_close(c.float().cpu().numpy(), truth, K)[0]
 
 
 @pytest.mark.parametrize("layout", ["nn", "tn"])
