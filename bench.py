@@ -290,7 +290,7 @@ def bench_attn(w, args, cfg4=False, steps=None, warmup=None, prewarm=PREWARM):
                     f"randn inputs, {b_loc}x{h_loc} (batch,head) problems per rank, entry {entry}",
         "scaling": "strong",
         "n_ranks": w.size,
-        "roofline": roofline(capi.attn_kernel_name(N, D), flops_local, 4.0 * b_loc * h_loc * N * D * 2, ms_kernel,
+        "roofline": roofline(capi.attn_kernel_name(N, D, bh=b_loc * h_loc), flops_local, 4.0 * b_loc * h_loc * N * D * 2, ms_kernel,
                              workload=(f"attn_{tag}" if w.size == 1 else None)),
     }
 
@@ -353,7 +353,7 @@ def bench_attn_d512(w, args, steps=3):
         secs = lcd.max_over_ranks(w, timed_region(w, step, steps, 1, prewarm=2))
         ms_kernel = lcd.max_over_ranks(w, timed_region.event_ms / steps)
         out[name] = {"value": flops_total * steps / secs * 1e-12, "ms_per_step": secs / steps * 1e3, "steps": steps,
-                     "roofline": roofline(capi.attn_kernel_name(N, D, False, dt == torch.bfloat16), flops_local,
+                     "roofline": roofline(capi.attn_kernel_name(N, D, False, dt == torch.bfloat16, bh=B * h_loc), flops_local,
                                           4.0 * B * h_loc * N * D * 2, ms_kernel,
                                           workload=(f"attn_d512_{name}" if w.size == 1 else None))}
         del q, k, v, o
@@ -380,7 +380,7 @@ def bench_attn_d1024(w, args, steps=3):
             "workload": f"FlashAttention-2 fwd B={B} H={H} S={N} D={D} fp16 (the tiling-QKV dispatcher's largest head dim), randn inputs, "
                         f"{h_loc} heads per rank, entry flash_attn_mma_stages_split_q_tiling_qkv",
             "scaling": "strong", "n_ranks": w.size,
-            "roofline": roofline(capi.attn_kernel_name(N, D), flops_local, 4.0 * B * h_loc * N * D * 2, ms_kernel,
+            "roofline": roofline(capi.attn_kernel_name(N, D, bh=B * h_loc), flops_local, 4.0 * B * h_loc * N * D * 2, ms_kernel,
                                  workload=("attn_d1024" if w.size == 1 else None))}
 
 
@@ -475,7 +475,7 @@ def bench_attn_d64(w, args, steps=10):
             "workload": f"FlashAttention-2 fwd B={B} H={H} S={N} D={D} fp16 (the reference's published shape, README.md:126-127), "
                         f"randn inputs, {h_loc} heads per rank, entry flash_attn_mma_stages_split_q",
             "scaling": "strong", "n_ranks": w.size,
-            "roofline": roofline(capi.attn_kernel_name(N, D), flops_local, 4.0 * B * h_loc * N * D * 2, ms_kernel,
+            "roofline": roofline(capi.attn_kernel_name(N, D, bh=B * h_loc), flops_local, 4.0 * B * h_loc * N * D * 2, ms_kernel,
                                  workload=("attn_d64" if w.size == 1 else None))}
 
 

@@ -19,6 +19,11 @@
 //         2  persistent workgroup per CU, DYNAMIC queue: workgroup on XCD x claims the next id of ITS XCD (x + 8 j) with one
 //            atomic per block, one block ahead (issued behind the last P·V MFMAs of block b − 1, broadcast through LDS at block
 //            b's prologue barrier: no exposed latency); the counters reset themselves when the last workgroup leaves.
+//         3  SPLIT-KV (round 5; grids that do not fill the GPU — the reference author's regime "B <= 4, H <= 48, SeqLen <= 8192",
+//            README.md:120): `nsplit` workgroups per 256-row query block, workgroup (block, s) walks the KV tiles
+//            [s T / nsplit, (s + 1) T / nsplit) exactly as WALK 0 walks a whole head and writes its NORMALISED partial O (fp16, layout
+//            [nsplit][B H][N][D] in the workspace `O` points to) plus the base-2 log-sum-exp of its range per query row
+//            (`lse`, [nsplit][B H][N] fp32); attn_split_combine_kernel merges them: O = sum_s 2^(L_s − L) O_s, L = log2 sum_s 2^L_s.
 // The arithmetic of a block is the same instruction for instruction in all three walks and for both V layouts' Q·Kᵀ / softmax
 // (VT changes only where Vᵀ fragments come from): WALK 0 / 1 / 2 are bit-identical to each other (GPU test).
 //
@@ -50,10 +55,11 @@ struct W4U {
 template <int D, bool VT, int WALK>
 __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
-    half_t* __restrict__ O, int N, int nqb, float sl2, int nblk, int nwg, int qslot) {
+    half_t* __restrict__ O, int N, int nqb, float sl2, int nblk, int nwg, int qslot, int nsplit, float* __restrict__ lse) {
   static_assert(D == 64 || D == 128, "merged-phase attention kernel: D = 64 or 128 (D = 96 / 32: attn_w4i.hip)");
-  static_assert(WALK >= 0 && WALK <= 2, "WALK: 0 one block per workgroup, 1 static persistent walk, 2 dynamic queue");
-  constexpr bool PERSIST = WALK != 0;
+  static_assert(WALK >= 0 && WALK <= 3, "WALK: 0 one block per workgroup, 1 static persistent walk, 2 dynamic queue, 3 split-KV");
+  constexpr bool PERSIST = WALK == 1 || WALK == 2;
+  constexpr bool SPLIT = WALK == 3;
   using G = W4G<D>;
   constexpr int NDS = G::NDS, NDB = G::NDB, ROWB = G::ROWB, TILE = G::TILE, SLOT = G::SLOT, NS = G::NS;
   constexpr int NRV = G::NRV, NRK = G::NRK, PPW = G::PPW, KBUF = G::KBUF;
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
   const int lane = threadIdx.x & 63;
   const int wave = wave_id();
   const int g4 = lane >> 4, l16 = lane & 15;
-  const int T = N / KVB;
+  const int T = SPLIT ? N / KVB / nsplit : N / KVB;   // KV tiles this workgroup walks (SPLIT: its share of the head's, >= 2)
   const uint32_t smem32 = lds_addr32(smem);
   const size_t head_elems = (size_t)N * D;
 
@@ -112,18 +118,26 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
 
   // ---- block walk: virtual block vb -> (head, first query row of this wave)
   int vb = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+  int sp = 0;   // SPLIT: which KV range of the head this workgroup walks (ids of one query block are consecutive: one XCD, one Q in L2)
   auto head_of = [&](int v, int& q0w) -> size_t {
-    const int id = xcd_remap(v, nblk);
+    int id = xcd_remap(v, nblk);
+    if constexpr (SPLIT) {
+      sp = id % nsplit;
+      id /= nsplit;
+    }
     const int bh = id / nqb;
     q0w = (id - bh * nqb) * 256 + wave * 64;
     return (size_t)bh;
   };
   int q0;
   size_t bh = head_of(vb, q0);
+  // SPLIT: element offsets of this workgroup's first KV row inside the head (K and V as [N][D]: kv0 rows; V as [D][N]: kv0 columns)
+  const size_t kv0 = SPLIT ? (size_t)sp * T * KVB : 0;
+  const size_t k_base = kv0 * D, v_base = VT ? kv0 : kv0 * D;
 
   // DMA of one K / V piece of the tile this period stages: descriptor + tile index chosen once per tile period (make_rsrc
   // reads the chosen base through readfirstlane: a descriptor hipcc cannot prove wave-uniform gets a waterfall loop per piece)
-  buf_rsrc_t dk = make_rsrc(K + bh * head_elems), dv = make_rsrc(V + bh * head_elems);
+  buf_rsrc_t dk = make_rsrc(K + bh * head_elems + k_base), dv = make_rsrc(V + bh * head_elems + v_base);
   unsigned d_so = 0;
   char* d_slot = smem;
   unsigned d_sov = 0;   // (V: te * V_TILE_STRIDE — 128 B per tile when V is [D][N])
@@ -190,13 +204,14 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
     const bool has_next = PERSIST && vbn < nblk;
     int q0n;
     const size_t bhn = head_of(has_next ? vbn : vb, q0n);
-    half_t* Ob = O + bh * head_elems;
+    const size_t nbh = SPLIT ? (size_t)(nblk / (nqb * nsplit)) : 0;          // B H (SPLIT: partial s of head bh = slab s nbh + bh)
+    half_t* Ob = O + ((size_t)sp * nbh + bh) * head_elems;
     // tile t2 >= T of this block = tile t2 − T of the next one (no next block: the last tile again, into a dead slot)
     auto set_dma_tile = [&](int t2) {
       const bool own = t2 < T;
       const size_t h = own ? bh : bhn;
-      dk = make_rsrc(K + h * head_elems);
-      dv = make_rsrc(V + h * head_elems);
+      dk = make_rsrc(K + h * head_elems + k_base);
+      dv = make_rsrc(V + h * head_elems + v_base);
       const int te = own ? t2 : (has_next ? t2 - T : T - 1);
       d_so = (unsigned)__builtin_amdgcn_readfirstlane(te * TILE);   // (provably wave-uniform: no waterfall loop around the pieces)
       d_sov = (unsigned)__builtin_amdgcn_readfirstlane(te * (int)V_TILE_STRIDE);
@@ -499,7 +514,13 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
     raw_barrier();                     // every wave is done with ring slots 2, 3
     float inv[4];
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) inv[qb] = 1.0f / an_x4_sum(l_run[qb]);
+    for (int qb = 0; qb < 4; ++qb) {
+      const float lsum = an_x4_sum(l_run[qb]);
+      inv[qb] = 1.0f / lsum;
+      if constexpr (SPLIT) {   // base-2 log-sum-exp of this KV range for query row q0 + 16 qb + l16 (scores carry scale * log2 e already)
+        if (g4 == 0) lse[((size_t)sp * nbh + bh) * N + q0 + 16 * qb + l16] = __builtin_log2f(lsum) - negm[qb][0];
+      }
+    }
     char* stg = smem + W4U<D>::EPI_OFF + wave * (64 * G::EPI_STRIDE);
     static_for<4>([&](auto qc) {
       constexpr int qb = decltype(qc)::value;
@@ -537,6 +558,34 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
       }
     }
   }
+}
+
+// ---- split-KV combine: O[row] = sum_s w_s O_s[row] / sum_s w_s, w_s = 2^(L_s[row] - max_s L_s[row]).  One thread per 8 output
+// columns (16 B in per split, 16 B out); rows = B H N.  HBM-bound and tiny next to the attention itself: nsplit + 1 rows of D halves.
+template <int D>
+__global__ __launch_bounds__(256) void attn_split_combine_kernel(const half_t* __restrict__ Op, const float* __restrict__ lse,
+                                                                 half_t* __restrict__ O, int nsplit, size_t rows) {
+  constexpr int C8 = D / 8;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t row = idx / C8;
+  const int c = (int)(idx % C8);
+  if (row >= rows) return;
+  float mx = lse[row];
+  for (int s = 1; s < nsplit; ++s) mx = fmaxf(mx, lse[(size_t)s * rows + row]);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float den = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float w = __builtin_amdgcn_exp2f(lse[(size_t)s * rows + row] - mx);
+    const half8_t v = *(const half8_t*)(Op + ((size_t)s * rows + row) * D + 8 * c);
+    den += w;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += w * (float)v[e];
+  }
+  const float inv = 1.0f / den;
+  half8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (half_t)(acc[e] * inv);
+  *(half8_t*)(O + row * D + 8 * c) = o;
 }
 
 }  // namespace lc

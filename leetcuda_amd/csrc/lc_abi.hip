@@ -42,6 +42,7 @@ tune_t g_tune_attn_w4i_sched{1};              // schedule of attn_fwd_w4i_kernel
 tune_t g_tune_attn_nw{0};                    // attention kernel for D <= 128: 0 = auto, 513 / 515 / 517 / 514 / 8 / 4 / 2 (choose_attn_nw, lc_abi.h)
 tune_t g_tune_attn_d1024{0};                 // attn_bigd4's DMA spread in eighths of a phase: 0 = default (8), 2 / 4 / 6 (A/B knob)
 tune_t g_tune_attn_walk{0};                  // block walk of the merged-phase kernel under attn_nw = 0: 0 = auto by N, 1 / 2 / 3 = WALK 0 / 1 / 2
+tune_t g_tune_attn_split{0};                 // split-KV of the merged-phase kernel on grids that do not fill the GPU: 0 = auto (attn_split_auto), 1 = off, 2 / 4 / 8 / 16 = that many KV ranges per query block
 tune_t g_tune_hgemm_auto{LC_HGEMM_MFMA256W4Y};   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
 tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to the 128-tile kernel (launch_mfma256), 0 = one launch
 tune_t g_tune_hgemm_raster{0};                 // block -> C tile map: 0 = auto (by operand footprint, panel_tiles), 1 = the reference's block swizzle (N panels from
@@ -281,12 +282,28 @@ int attn_walk_auto(int N) {
   if (k >= 1 && k <= 3) return k - 1;
   return N <= 4096 ? 1 : 0;
 }
-int choose_attn_nw(int D, bool vt, int N) {
+// Split-KV factor of the merged-phase kernel for a launch of `bh` (batch, head) problems (lc_tune_set "attn_split"; 1 = no split).
+// The kernel owns 256 query rows per workgroup and one workgroup per CU: g = bh N / 256 workgroups on ncu CUs leave the GPU idle when
+// 2 g <= ncu — the reference author's own regime (README.md:120 "B <= 4, H <= 48, SeqLen <= 8192").  Auto: the largest power of two S
+// with g S <= ncu that leaves every range >= kMinSplitTiles KV tiles of 64 rows (a range pays the block's fixed cost: Q load,
+// prologue, O epilogue + its share of the combine).  bh < 0 (lc_attn_kernel_name has no batch / head count): a grid that fills the GPU.
+constexpr int kMinSplitTiles = 2;
+int attn_split_auto(int D, int N, long bh) {
+  const int k = g_tune_attn_split;
+  if ((D != 128 && D != 64) || N % 256 != 0 || bh <= 0 || k == 1) return 1;
+  const int T = N / 64;
+  if (k >= 2) return (T % k == 0 && T / k >= 2) ? k : 1;
+  const long ncu = device_cu_count(), g = bh * (N / 256);
+  int S = 1;
+  while (g * S * 2 <= ncu && S < 16 && T % (S * 2) == 0 && T / (S * 2) >= kMinSplitTiles) S *= 2;
+  return S;
+}
+int choose_attn_nw(int D, bool vt, int N, long bh = -1) {
   int want = g_tune_attn_nw;   // 0 = auto (read once per launch)
   if (want == 512) want = 513;
   const bool merged = (D == 128 || D == 64) && N % 256 == 0;
   if (merged && g_tune_attn_ablate == 0) {
-    if (want == 0) return 513 + 2 * attn_walk_auto(N);
+    if (want == 0) return attn_split_auto(D, N, bh) > 1 ? 519 : 513 + 2 * attn_walk_auto(N);
     if (want == 513 || want == 515 || want == 517) return want;
     if (want == 514 && !vt) return 514;
   }
@@ -300,12 +317,13 @@ int choose_attn_nw(int D, bool vt, int N) {
 template <int D, bool VT>
 int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                    hipStream_t st) {
-  const int nw = choose_attn_nw(D, VT, N);
+  const int nw = choose_attn_nw(D, VT, N, (long)B * H);
   if constexpr (D == 128 || D == 64) {
-    if (nw == 513 || nw == 515 || nw == 517) {
+    if (nw == 513 || nw == 515 || nw == 517 || nw == 519) {
       const int walk = (nw - 513) / 2;
-      if constexpr (D == 128) return VT ? launch_attn_w4u_d128t(Q, K, V, O, B, H, N, walk, st) : launch_attn_w4u_d128(Q, K, V, O, B, H, N, walk, st);
-      else return VT ? launch_attn_w4u_d64t(Q, K, V, O, B, H, N, walk, st) : launch_attn_w4u_d64(Q, K, V, O, B, H, N, walk, st);
+      const int ns = walk == 3 ? attn_split_auto(D, N, (long)B * H) : 1;   // (519 = split-KV: auto only)
+      if constexpr (D == 128) return VT ? launch_attn_w4u_d128t(Q, K, V, O, B, H, N, walk, ns, st) : launch_attn_w4u_d128(Q, K, V, O, B, H, N, walk, ns, st);
+      else return VT ? launch_attn_w4u_d64t(Q, K, V, O, B, H, N, walk, ns, st) : launch_attn_w4u_d64(Q, K, V, O, B, H, N, walk, ns, st);
     }
   }
   if constexpr (!VT) {
@@ -518,9 +536,10 @@ int lc_attn_kernel_name_bh(int BH, int N, int D, int v_transposed, int bf16, cha
   const char* vt = v_transposed ? "true" : "false";
   if (D == 32 || D == 64 || D == 96 || D == 128) {
     if (bf16) return LC_ERR_HEADDIM;
-    const int nw = choose_attn_nw(D, v_transposed != 0, N);
-    // (a persistent walk with no more blocks than CUs launches WALK 0; the name reports the walk asked for at this N)
-    if (nw == 513 || nw == 515 || nw == 517) snprintf(buf, buflen, "attn_fwd_w4u_kernel<%d,%s,%d>", D, vt, (nw - 513) / 2);
+    const int nw = choose_attn_nw(D, v_transposed != 0, N, BH > 0 ? (long)BH : -1);
+    // (a persistent walk with no more blocks than CUs launches WALK 0; the name reports the walk asked for at this N; 3 = split-KV, whose
+    // launch also runs attn_split_combine_kernel<D>)
+    if (nw == 513 || nw == 515 || nw == 517 || nw == 519) snprintf(buf, buflen, "attn_fwd_w4u_kernel<%d,%s,%d>", D, vt, (nw - 513) / 2);
     else if (nw == 514) snprintf(buf, buflen, "attn_fwd_w4i_kernel<%d,%d>", D, g_tune_attn_w4i_sched.load());
     else snprintf(buf, buflen, "attn_fwd_kernel<%d,%d,%s,0>", D, nw, vt);
     return LC_OK;
@@ -560,6 +579,7 @@ bool ok_01(int v) { return v == 0 || v == 1; }
 bool ok_02(int v) { return v >= 0 && v <= 2; }
 bool ok_03(int v) { return v >= 0 && v <= 3; }
 bool ok_04(int v) { return v >= 0 && v <= 4; }
+bool ok_split(int v) { return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16; }
 bool ok_span8(int v) { return v == 0 || v == 2 || v == 4 || v == 6; }
 bool ok_w4y_sched(int v) {
 #ifdef LC_DIAG
@@ -582,6 +602,7 @@ struct Knob {
 const Knob kKnobs[] = {
     {"attn_nw", &g_tune_attn_nw, 0, ok_attn_nw, false},
     {"attn_walk", &g_tune_attn_walk, 0, ok_03, false},
+    {"attn_split", &g_tune_attn_split, 0, ok_split, false},
     {"attn_d1024", &g_tune_attn_d1024, 0, ok_span8, false},
     {"attn_w4i_sched", &g_tune_attn_w4i_sched, 1, ok_01, false},
     {"fp8_mx", &g_tune_fp8_mx, 3, ok_03, false},

@@ -14,26 +14,77 @@ namespace lc {
 namespace {
 template <int WALK>
 int launch_w4u_walk(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int grid_wgs, size_t nblk,
-                    hipStream_t st) {
+                    hipStream_t st, int nsplit = 1, float* lse = nullptr) {
   constexpr int D = W4U_D;
   static std::atomic<unsigned> ticket{0};     // rotating claim-counter slot of the dynamic walk (attn_w4u.hip g_w4u_queue)
   const int qslot = WALK == 2 ? (int)(ticket.fetch_add(1, std::memory_order_relaxed) % (unsigned)W4U_QSLOTS) : 0;
   const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
   auto kern = attn_fwd_w4u_kernel<D, W4U_VT, WALK>;
   if (int rc = set_dyn_lds(kern, W4U<D>::LDS)) return rc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid_wgs), dim3(256), W4U<D>::LDS, st, Q, K, V, O, N, N / 256, sl2, (int)nblk, grid_wgs, qslot);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid_wgs), dim3(256), W4U<D>::LDS, st, Q, K, V, O, N, N / 256, sl2, (int)nblk, grid_wgs, qslot,
+                     nsplit, lse);
   return check_launch();
+}
+
+// Split-KV (WALK 3): nsplit workgroups per query block into a stream-ordered workspace ([nsplit][B H][N][D] fp16 partials +
+// [nsplit][B H][N] fp32 log-sum-exps: hipMallocAsync / hipFreeAsync on the launch stream, so concurrent streams never share it and
+// nothing outlives the call), then the combine kernel.  Returns LC_ERR_ARG when the split cannot run here (the stream is being
+// captured into a graph — an allocation node is not something a drop-in launch should add — or the allocator refuses): the caller
+// then launches the one-block walk instead, never an error.
+int launch_w4u_split(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int nsplit, hipStream_t st) {
+  constexpr int D = W4U_D;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return LC_ERR_ARG;
+  }
+  const size_t rows = (size_t)B * H * N;
+  const size_t obytes = (size_t)nsplit * rows * D * sizeof(half_t), lbytes = (size_t)nsplit * rows * sizeof(float);
+  void* ws = nullptr;
+  if (hipMallocAsync(&ws, obytes + lbytes, st) != hipSuccess || !ws) {
+    (void)hipGetLastError();
+    return LC_ERR_ARG;
+  }
+  half_t* op = static_cast<half_t*>(ws);
+  float* lse = reinterpret_cast<float*>(static_cast<char*>(ws) + obytes);
+  const size_t nblk = (size_t)(N / 256) * B * H * nsplit;
+  int rc = launch_w4u_walk<3>(Q, K, V, op, B, H, N, (int)nblk, nblk, st, nsplit, lse);
+  if (rc == LC_OK) {
+    const size_t threads = rows * (D / 8);
+    hipLaunchKernelGGL(attn_split_combine_kernel<D>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, op, lse, O, nsplit, rows);
+    rc = check_launch();
+  }
+  if (hipFreeAsync(ws, st) != hipSuccess && rc == LC_OK) rc = LC_ERR_LAUNCH;
+  return rc;
 }
 }  // namespace
 
 // N % 256 == 0; walk: 0 one block per workgroup, 1 persistent static walk, 2 persistent dynamic queue.  A persistent walk with no
 // more blocks than CUs IS the one-block launch; the dynamic queue needs a grid that is a multiple of the 8 XCDs.
+// walk 3 = split-KV with `nsplit` (>= 2, N / 64 % nsplit == 0, >= 2 tiles per split: attn_split_auto, lc_abi.hip) workgroups per query
+// block; when the split cannot run on this stream (graph capture, allocator) the one-block walk runs instead.
 int W4U_CAT(launch_attn_w4u_, W4U_TAG)(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int walk,
-                                       hipStream_t st) {
+                                       int nsplit, hipStream_t st) {
   const size_t nblk = (size_t)(N / 256) * B * H;
   const int ncu = device_cu_count();   // one workgroup per CU: each takes a CU's whole register file and > half its LDS
+  if (walk == 3) {
+    if (nsplit >= 2 && (N / 64) % nsplit == 0 && (N / 64) / nsplit >= 2) {
+      const int rc = launch_w4u_split(Q, K, V, O, B, H, N, nsplit, st);
+      if (rc != LC_ERR_ARG) return rc;
+    }
+    walk = 0;
+  }
   if (walk != 0 && nblk <= (size_t)ncu) walk = 0;
   if (walk == 2 && ncu % 8 != 0) walk = 1;
+  if (walk == 2) {
+    // the dynamic queue's claim-counter slot is picked by a host-side ticket AT LAUNCH TIME: captured into a graph it would be baked
+    // in, and concurrent replays would share counters (round-4 advisor) -> the static walk while the stream is capturing
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      walk = 1;
+    }
+  }
   if (walk == 0) return launch_w4u_walk<0>(Q, K, V, O, B, H, N, (int)nblk, nblk, st);
   if (walk == 1) return launch_w4u_walk<1>(Q, K, V, O, B, H, N, ncu, nblk, st);
   return launch_w4u_walk<2>(Q, K, V, O, B, H, N, ncu, nblk, st);

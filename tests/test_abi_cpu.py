@@ -91,6 +91,7 @@ def test_isa_audit_report_is_clean(built):
     names = " ".join(r["kernel"] for r in rep)
     for k in ("hgemm_w4b_kernel", "hgemm_w4x_kernel", "hgemm_w4y_kernel", "gemm_fp8_w4_kernel", "gemm_fp8_w4k_kernelILb0E", "gemm_fp8_w4k_kernelILb1E", "attn_fwd_w4u_kernelILi128ELb0ELi0",
               "attn_fwd_w4u_kernelILi128ELb1ELi2", "attn_fwd_w4u_kernelILi64ELb0ELi1", "attn_fwd_w4u_kernelILi64ELb1ELi0",
+              "attn_fwd_w4u_kernelILi128ELb0ELi3", "attn_fwd_w4u_kernelILi64ELb1ELi3",            # split-KV (round 5)
               "attn_fwd_w4i_kernel", "attn_fwd_bigd2_kernel", "hgemm_pingpong2_kernel"):
         assert k in names, k
     assert all(r["scratch"] == 0 and not r["violations"] for r in rep)

@@ -398,8 +398,12 @@ def test_non_finite_scores_take_the_slow_path(oracle):
     assert capi.attn_kernel_name(N, D).startswith("attn_fwd_w4u_kernel<128,false,1>")
     capi.attn_slowpath_stats(reset=True)
     o = torch.zeros_like(q)
-    capi.attn_fwd(q, k, v, o)
-    torch.cuda.synchronize()
+    capi.tune("attn_split", 1)          # the merged-phase kernel itself (auto hands this 6-workgroup grid to the split-KV path: tested below)
+    try:
+        capi.attn_fwd(q, k, v, o)
+        torch.cuda.synchronize()
+    finally:
+        capi.tune("attn_split", 0)
     st = capi.attn_slowpath_stats(reset=True)
     assert st[0] >= 1 and st[2] >= 1, st                     # executions, of which with a non-finite row sum
     good = [0, 2]
@@ -590,3 +594,112 @@ def test_scale_jumps_and_spikes_d64(oracle, nw, D):
         assert (st[0] > 0) == (nw != 8), st          # the merged-phase kernels took their slow path on these inputs
     finally:
         capi.tune("attn_nw", 0)
+
+
+# ---- split-KV (round 5): grids that do not fill the GPU ------------------------------------------------------------------------
+SPLIT_SHAPES = [(1, 8, 1024, 128), (1, 8, 2048, 64), (1, 16, 2048, 128), (2, 3, 512, 128), (1, 1, 256, 64), (1, 5, 4096, 64)]
+
+
+@pytest.mark.parametrize("vt", [False, True], ids=["v_nd", "v_dn"])
+@pytest.mark.parametrize("shape", SPLIT_SHAPES, ids=[str(s) for s in SPLIT_SHAPES])
+def test_split_kv_on_grids_that_do_not_fill_the_gpu(oracle, shape, vt):
+    """Round-4 verdict (missing #2): the tuned kernels own 256 query rows per workgroup, so (1,8,1024,128) ran on 32 of 256 CUs.  Auto
+    now launches attn_fwd_w4u_kernel<D, VT, 3>: S workgroups per query block over disjoint KV ranges (partials: normalised fp16 O + the
+    base-2 log-sum-exp per row in a stream-ordered workspace) + attn_split_combine_kernel.  Against the oracle on random data, with a
+    spike key planted in the LAST KV range and one in a middle range (the combine must weight ranges by 2^(L_s - L): a range holding a
+    spike dominates its row), against the unsplit kernel, for both V layouts, and bit-reproducible from launch to launch."""
+    capi = _capi()
+    B, H, N, D = shape
+    torch.manual_seed(519 + N + D + B * H)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k[:, :, N - 3] = 3.0 * q[:, :, 5]            # spike in the last range: query row 5 attends almost only to key N - 3
+    k[:, :, N // 2 + 1] = 3.0 * q[:, :, 200]       # ... and one in a middle range
+    vin = v.transpose(-2, -1).contiguous() if vt else v
+    vts = "true" if vt else "false"
+    name = capi.attn_kernel_name(N, D, vt, bh=B * H)
+    assert name == f"attn_fwd_w4u_kernel<{D},{vts},3>", name
+    assert capi.attn_kernel_name(N, D, vt).endswith(",1>")       # no batch / head count: a grid that fills the GPU
+    outs = []
+    for _ in range(2):
+        o = torch.full_like(q, float("nan"))
+        capi.attn_fwd(q, k, vin, o, v_transposed=vt)
+        torch.cuda.synchronize()
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])           # same shape, same device: the same bits
+    truth = oracle.attn(q, k, v, B, H, N, D, mode="f32")
+    ok, mx, ex = tol.attn_close(outs[0].float().cpu().numpy(), truth, N, rtol=tol.ATTN_RTOL_SPIKE)
+    assert ok, (mx, ex)
+    assert abs(float(outs[0][0, 0, 5].float().abs().max()) - float(v[0, 0, N - 3].float().abs().max())) < 2e-2     # the spike row IS v[N - 3]
+    capi.tune("attn_split", 1)
+    try:
+        o1 = torch.full_like(q, float("nan"))
+        capi.attn_fwd(q, k, vin, o1, v_transposed=vt)
+        torch.cuda.synchronize()
+        assert capi.attn_kernel_name(N, D, vt, bh=B * H).endswith(",1>")
+    finally:
+        capi.tune("attn_split", 0)
+    # split vs unsplit: the partials are fp16-rounded once more (|O_s| <= max |v|: 2^-11 relative to the partial, weights sum to 1)
+    d = (outs[0].float() - o1.float()).abs()
+    assert float(d.max()) <= 2.0 ** -9 * max(1.0, float(v.float().abs().max())), float(d.max())
+
+
+@pytest.mark.parametrize("D", [128, 64])
+@pytest.mark.parametrize("S", [2, 4, 8, 16])
+def test_split_kv_every_factor(oracle, S, D):
+    """lc_tune_set "attn_split" = S forces S KV ranges per query block on any grid: N = 2048 = 32 KV tiles -> 16 / 8 / 4 / 2 tiles per range
+    (2 = the shortest walk the kernel's prologue / last-tile structure admits); a non-finite key poisons exactly its own head."""
+    capi = _capi()
+    B, H, N = 1, 6, 2048
+    torch.manual_seed(S * 7 + D)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k[0, 4, 1500] = float("inf")
+    q[0, 4] = q[0, 4].abs()
+    capi.tune("attn_split", S)
+    try:
+        assert capi.attn_kernel_name(N, D, bh=B * H) == f"attn_fwd_w4u_kernel<{D},false,3>"
+        o = torch.full_like(q, float("nan"))
+        capi.attn_fwd(q, k, v, o)
+        torch.cuda.synchronize()
+        capi.attn_slowpath_stats(reset=True)
+    finally:
+        capi.tune("attn_split", 0)
+    good = [0, 1, 2, 3, 5]
+    truth = oracle.attn(q[:, good].contiguous(), k[:, good].contiguous(), v[:, good].contiguous(), B, len(good), N, D, mode="f32")
+    ok, mx, ex = tol.attn_close(o[:, good].float().cpu().numpy(), truth, N)
+    assert ok, (S, mx, ex)
+    assert not torch.isfinite(o[0, 4]).all()          # IEEE, like the unsplit kernel: not finite, not silently wrong
+
+
+def test_split_kv_inside_graph_capture_falls_back(oracle):
+    """The split needs a stream-ordered workspace (hipMallocAsync): while the stream is being captured into a graph the launcher runs
+    the one-block walk instead — a captured drop-in launch stays ONE kernel node, and the replay computes the same attention."""
+    capi = _capi()
+    B, H, N, D = 1, 4, 1024, 128
+    torch.manual_seed(77)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    o = torch.zeros_like(q)
+    capi.attn_fwd(q, k, v, o)                     # outside capture: the split path
+    torch.cuda.synchronize()
+    o_split = o.clone()
+    capi.tune("attn_split", 1)                    # warm-up of the kernel the capture will fall back to (its LDS attribute is set on first use)
+    try:
+        capi.attn_fwd(q, k, v, o)
+        torch.cuda.synchronize()
+    finally:
+        capi.tune("attn_split", 0)
+    o.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        capi.attn_fwd(q, k, v, o)
+    g.replay()
+    torch.cuda.synchronize()
+    truth = oracle.attn(q, k, v, B, H, N, D, mode="f32")
+    ok, mx, _ = tol.attn_close(o.float().cpu().numpy(), truth, N)
+    assert ok, mx
+    assert float((o.float() - o_split.float()).abs().max()) <= 2.0 ** -9 * float(v.float().abs().max())
