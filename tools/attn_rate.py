@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sustained rate of the attention forward at arbitrary shapes, interleaved A/B over tuning knobs.
 usage: attn_rate.py [--seconds S] [--rounds R] spec...
-   spec = B,H,N,D[:bf16][:zero][:vt][:nw=K][:walk=K][:d512=K][:sched=K]   (vt = V handed over as [B,H,D,N]; knobs = lc_tune_set keys attn_nw / attn_walk / attn_d512 / attn_w4i_sched)
+   spec = B,H,N,D[:bf16][:zero][:vt][:nw=K][:walk=K][:split=K][:d512=K][:sched=K]   (vt = V handed over as [B,H,D,N]; knobs = lc_tune_set keys attn_nw / attn_walk / attn_split / attn_d512 / attn_w4i_sched)
 Every spec runs >= S seconds of back-to-back launches per round; R rounds interleave the specs (within-probe A/B,
 cdna_hip_programming.md rule 24); prints the kernel name the dispatcher reports, median and best TFLOP/s (matmul FLOPs)."""
 import sys
@@ -26,7 +26,7 @@ import os  # noqa: E402
 if os.environ.get("LC_AB_LIB"):    # A/B of two builds on one box: point the ctypes view at another copy of the library
     capi.LIB_PATH = Path(os.environ["LC_AB_LIB"]).resolve()
 capi.load()
-KNOBS = {"nw": "attn_nw", "walk": "attn_walk", "d512": "attn_d512", "d1024": "attn_d1024", "sched": "attn_w4i_sched"}
+KNOBS = {"nw": "attn_nw", "walk": "attn_walk", "d512": "attn_d512", "d1024": "attn_d1024", "sched": "attn_w4i_sched", "split": "attn_split"}
 cache = {}
 
 
