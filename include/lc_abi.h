@@ -128,6 +128,13 @@ const char* lc_build_info(int* is_diag);
  *                  mask << 20 with mask < 128 (bit 27 together with any other bit is refused).  Only the fp32 accumulation order changes:
  *                  results agree with the unstaggered walk to fp16 rounding
  *                  (the K = 128 fp8 kernel shares the stagger and the persistent walk of "hgemm_persist")
+ *   "attn_split"   split-KV of the merged-phase kernel (attn_w4u.hip WALK 3) for grids that do not fill the GPU: 0 = auto (a cost model
+ *                  over B x H, N, D and the CU count picks 1 / 2 / 4 / 8 / 16 KV ranges per 256-row query block, lc_abi.hip attn_split_auto),
+ *                  1 = off, 2 / 4 / 8 / 16 = that factor on any grid (N / 64 divisible by it, >= 2 tiles per range).  Partials live in a
+ *                  cached per-stream workspace (a few MiB, never freed); while a stream is being captured the unsplit kernel runs
+ *   "hgemm_splitk" split-K of the 128-tile blocks that serve the border strips (M, N % 256 == 128) / the ragged last wave of
+ *                  LC_HGEMM_MFMA256W4Y: 0 = auto (2 CUs' worth of blocks per tile when the launch holds fewer blocks than CUs, every K
+ *                  range >= 8 tiles), 1 = off, 2 .. 8 = that factor; fp32 partials in the same workspace + a reduce kernel
  *   "hgemm_tail"   1 (default) = when the 256-tile grid's last wave holds at most 128 tiles, the generated-loop kernel computes the
  *                  full waves and the 128-tile kernel the four quadrants of each remaining tile; 0 = one launch
  *   "hgemm_raster" block -> C tile map of the tiled GEMM kernels: 0 = auto (2 when A + B exceed the 256 MiB Infinity Cache by half,

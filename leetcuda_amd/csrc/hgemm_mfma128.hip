@@ -15,45 +15,61 @@ constexpr int TILE1_BYTES = BM1 * BK * 2;        // 16 KiB (A) == BK * BN1 * 2 (
 constexpr int SLOT1_BYTES = 2 * TILE1_BYTES;
 constexpr int HGEMM128_LDS = 2 * SLOT1_BYTES;    // 64 KiB
 
+// Block -> origin of its 128 x 128 C tile.  rem_base == -1: this kernel's own grid of 128 x 128 tiles.  Otherwise (lc_abi.hip
+// launch_mfma256) tiles_m / tiles_n / panel_w describe the 256 x 256 tile grid of the interior and the blocks are, in this order:
+//   b < rem_blocks           quadrant b & 3 of the 256-tile whose raster id is rem_base + (b >> 2) — the ids the big kernel's
+//                            truncated grid left out (its ragged last wave);
+//   the next nright blocks   the right border strip of an N % 256 == 128 problem: columns N - 128 .., 128-row tile b' (all M rows);
+//   the rest                 the bottom border strip of an M % 256 == 128 problem: rows M - 128 .., 128-column tile b'' of the
+//                            256 tiles_n interior columns (the corner belongs to the right strip).
+struct Tile128 {
+  int m0, n0;
+};
+LC_DEVINL Tile128 mfma128_tile(int b, int nblocks, int M, int N, int tiles_m, int tiles_n, int panel_w, int rem_base, int rem_blocks,
+                               int nright) {
+  Tile128 t;
+  if (rem_base == -1) {
+    const TileCoord tc = block_tile(b, nblocks, tiles_m, tiles_n, panel_w);
+    t.m0 = tc.tm * 128;
+    t.n0 = tc.tn * 128;
+  } else if (b >= rem_blocks) {
+    const int bb = b - rem_blocks;
+    if (bb < nright) {
+      t.m0 = bb * 128;
+      t.n0 = N - 128;
+    } else {
+      t.m0 = M - 128;
+      t.n0 = (bb - nright) * 128;
+    }
+  } else {
+    const int id = rem_base + (b >> 2), qd = b & 3;
+    const TileCoord tc = panel_w < 0 ? raster_xcd16(id, tiles_m * tiles_n, tiles_m, tiles_n) : raster(id, tiles_m, tiles_n, panel_w);
+    t.m0 = tc.tm * 256 + (qd >> 1) * 128;
+    t.n0 = tc.tn * 256 + (qd & 1) * 128;
+  }
+  return t;
+}
+
+// ksplit > 1 (border strips / ragged-tail quadrants only: few tiles with a long K walk, profiles/r5a_hgemm_shapes.log): the grid holds
+// ksplit consecutive blocks per tile, block (tile, s) walks the K tiles [s KT / ksplit, (s + 1) KT / ksplit) (the last one also the
+// K % 64 == 32 half-step) and writes its fp32 accumulators in the MFMA lane order — 16 coalesced float4 rows per wave — to
+// ws[(tile ksplit + s)][wave][16][64]; hgemm_splitk_reduce_kernel adds the ksplit partials and stores C.
 template <bool B_KN>
 __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __restrict__ A,
                                                                const half_t* __restrict__ B,
                                                                half_t* __restrict__ C, int M, int N, int K,
                                                                int tiles_m, int tiles_n, int panel_w, int rem_base,
-                                                               int rem_blocks, int nright) {
+                                                               int rem_blocks, int nright, int ksplit, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = wave_id();
   const int wr = wave >> 1, wc = wave & 1;
   const int i16 = lane & 15, g = lane >> 4;
 
-  // rem_base == -1: this kernel's own grid of 128 x 128 tiles.  Otherwise (lc_abi.hip launch_mfma256) tiles_m / tiles_n / panel_w
-  // describe the 256 x 256 tile grid of the interior and the blocks are, in this order:
-  //   b < rem_blocks           quadrant b & 3 of the 256-tile whose raster id is rem_base + (b >> 2) — the ids the big kernel's
-  //                            truncated grid left out (its ragged last wave);
-  //   the next nright blocks   the right border strip of an N % 256 == 128 problem: columns N - 128 .., 128-row tile b' (all M rows);
-  //   the rest                 the bottom border strip of an M % 256 == 128 problem: rows M - 128 .., 128-column tile b'' of the
-  //                            256 tiles_n interior columns (the corner belongs to the right strip).
-  int m0, n0;
-  if (rem_base == -1) {
-    const TileCoord tc = block_tile(blockIdx.x, gridDim.x, tiles_m, tiles_n, panel_w);
-    m0 = tc.tm * BM1;
-    n0 = tc.tn * BN1;
-  } else if ((int)blockIdx.x >= rem_blocks) {
-    const int bb = (int)blockIdx.x - rem_blocks;
-    if (bb < nright) {
-      m0 = bb * BM1;
-      n0 = N - BN1;
-    } else {
-      m0 = M - BM1;
-      n0 = (bb - nright) * BN1;
-    }
-  } else {
-    const int id = rem_base + ((int)blockIdx.x >> 2), qd = blockIdx.x & 3;
-    const TileCoord tc = panel_w < 0 ? raster_xcd16(id, tiles_m * tiles_n, tiles_m, tiles_n) : raster(id, tiles_m, tiles_n, panel_w);
-    m0 = tc.tm * 256 + (qd >> 1) * BM1;
-    n0 = tc.tn * 256 + (qd & 1) * BN1;
-  }
+  const int tb = ksplit > 1 ? (int)blockIdx.x / ksplit : (int)blockIdx.x, ks = ksplit > 1 ? (int)blockIdx.x % ksplit : 0;
+  const Tile128 tl = mfma128_tile(tb, ksplit > 1 ? (int)gridDim.x / ksplit : (int)gridDim.x, M, N, tiles_m, tiles_n, panel_w, rem_base,
+                                  rem_blocks, nright);
+  const int m0 = tl.m0, n0 = tl.n0;
 
   // ---- LDS-DMA sources: 16 + 16 pieces of 1 KiB per K tile, 4 + 4 per wave
   const half_t* sa[4];
@@ -96,6 +112,7 @@ __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __r
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int KT = K / BK;
+  const int kt0 = ksplit > 1 ? (int)((long)ks * KT / ksplit) : 0, kt1 = ksplit > 1 ? (int)((long)(ks + 1) * KT / ksplit) : KT;
   const size_t bstep = B_KN ? (size_t)BK * N : (size_t)BK;
   auto issue = [&](int t, char* slot) {
 #pragma unroll
@@ -103,13 +120,13 @@ __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __r
 #pragma unroll
     for (int i = 0; i < 4; ++i) glds16(sb[i] + (size_t)t * bstep, slot + TILE1_BYTES + (B_KN ? wave * 4 + i : 4 * i + wave) * 1024);
   };
-  issue(0, smem);
-  for (int kt = 0; kt < KT; ++kt) {
-    const char* cur = smem + (kt & 1) * SLOT1_BYTES;
-    char* nxt = smem + ((kt & 1) ^ 1) * SLOT1_BYTES;
+  issue(kt0, smem);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const char* cur = smem + ((kt - kt0) & 1) * SLOT1_BYTES;
+    char* nxt = smem + (((kt - kt0) & 1) ^ 1) * SLOT1_BYTES;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < KT) issue(kt + 1, nxt);
+    if (kt + 1 < kt1) issue(kt + 1, nxt);
     const char* la = cur;
     const char* lb = cur + TILE1_BYTES;
 #pragma unroll
@@ -140,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __r
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(bf[ni], af[mi], acc[mi][ni]);
     }
   }
-  if (K & 32) {   // K % 64 == 32: the last half K-step, fragments straight from global memory in the MFMA operand layout
+  if ((K & 32) && (ksplit <= 1 || ks == ksplit - 1)) {   // K % 64 == 32: the last half K-step (split-K: of the last range), fragments straight from global memory in the MFMA operand layout
     const int k0 = KT * BK + 8 * g;
     half8_t af[4], bf[4];
 #pragma unroll
@@ -158,6 +175,14 @@ __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __r
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(bf[ni], af[mi], acc[mi][ni]);
+  }
+  if (ksplit > 1) {   // split-K: the fp32 partial of this K range, lane order (hgemm_splitk_reduce_kernel reads it back the same way)
+    f32x4_t* wp = reinterpret_cast<f32x4_t*>(ws) + ((size_t)blockIdx.x * 4 + wave) * (16 * 64) + lane;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) wp[(mi * 4 + ni) * 64] = acc[mi][ni];
+    return;
   }
   // ---- epilogue: each wave stages its 64x64 sub-tile through LDS, stores 128-byte row segments
   char* stg = smem + wave * (64 * EPI_STRIDE);
@@ -180,6 +205,30 @@ __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __r
     half_t* dst = C + (size_t)(m0 + wr * 64 + row) * N + n0 + wc * 64 + (lane & 7) * 8;
     *(u32x4_t*)dst = v;
   }
+}
+
+// Second half of a split-K border launch: block t adds the ksplit fp32 partials of tile t (written by hgemm_mfma128_kernel in MFMA lane
+// order) and stores the 128 x 128 fp16 tile: lane (i16, g) of wave (wr, wc) holds C[m0 + 64 wr + 16 mi + i16][n0 + 64 wc + 16 ni + 4 g ..+3].
+__global__ __launch_bounds__(256) void hgemm_splitk_reduce_kernel(const float* __restrict__ ws, half_t* __restrict__ C, int M, int N,
+                                                                  int tiles_m, int tiles_n, int panel_w, int rem_base, int rem_blocks,
+                                                                  int nright, int ksplit) {
+  const int lane = threadIdx.x & 63, wave = wave_id();
+  const int wr = wave >> 1, wc = wave & 1, i16 = lane & 15, g = lane >> 4;
+  const Tile128 tl = mfma128_tile((int)blockIdx.x, (int)gridDim.x, M, N, tiles_m, tiles_n, panel_w, rem_base, rem_blocks, nright);
+  const f32x4_t* wp = reinterpret_cast<const f32x4_t*>(ws) + ((size_t)blockIdx.x * ksplit * 4 + wave) * (16 * 64) + lane;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      f32x4_t v = wp[(mi * 4 + ni) * 64];
+      for (int s = 1; s < ksplit; ++s) {
+        const f32x4_t x = wp[(size_t)s * 4 * (16 * 64) + (mi * 4 + ni) * 64];
+        v[0] += x[0]; v[1] += x[1]; v[2] += x[2]; v[3] += x[3];
+      }
+      half4_t h;
+      h[0] = (half_t)v[0]; h[1] = (half_t)v[1]; h[2] = (half_t)v[2]; h[3] = (half_t)v[3];
+      *(half4_t*)(C + (size_t)(tl.m0 + wr * 64 + mi * 16 + i16) * N + tl.n0 + wc * 64 + ni * 16 + g * 4) = h;
+    }
 }
 
 }  // namespace lc

@@ -44,6 +44,7 @@ tune_t g_tune_attn_d1024{0};                 // attn_bigd4's DMA spread in eight
 tune_t g_tune_attn_walk{0};                  // block walk of the merged-phase kernel under attn_nw = 0: 0 = auto by N, 1 / 2 / 3 = WALK 0 / 1 / 2
 tune_t g_tune_attn_split{0};                 // split-KV of the merged-phase kernel on grids that do not fill the GPU: 0 = auto (attn_split_auto), 1 = off, 2 / 4 / 8 / 16 = that many KV ranges per query block
 tune_t g_tune_hgemm_auto{LC_HGEMM_MFMA256W4Y};   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
+tune_t g_tune_hgemm_splitk{0};                 // split-K of the 128-tile blocks that serve border strips / the ragged last wave: 0 = auto (launch_mfma256), 1 = off, 2 .. 8 = that factor
 tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to the 128-tile kernel (launch_mfma256), 0 = one launch
 tune_t g_tune_hgemm_raster{0};                 // block -> C tile map: 0 = auto (by operand footprint, panel_tiles), 1 = the reference's block swizzle (N panels from
                                              // swizzle_stride, XCD-contiguous ids), 2 = XCD super-block raster (hgemm_mfma256.hip raster_xcd16)
@@ -207,9 +208,29 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
     if (nb128 == 0) return LC_OK;
     auto kern = hgemm_mfma128_kernel<B_KN>;
     if (int rc = set_dyn_lds(kern, HGEMM128_LDS)) return rc;
-    hipLaunchKernelGGL(kern, dim3(nb128), dim3(256), HGEMM128_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw, split ? T - R : -2,
-                       split ? 4 * R : 0, nright);
-    return check_launch();
+    // Split-K of these blocks (lc_tune_set "hgemm_splitk"): a lone 128-tile block walks its K range at a quarter of a CU's MFMA rate
+    // (one barrier per K tile, nothing to overlap with), and the launch holds few of them — 8192 x 8320 x 8192: 64 blocks, 107 us
+    // for 1.5 % of the FLOPs (profiles/r5a_hgemm_shapes.log).  ks blocks per tile (two per CU fill the GPU: ks = 2 ncu / nb128, each
+    // range >= 8 K tiles) write fp32 partials into this stream's cached workspace, a second kernel adds them and stores C.  Not while
+    // the stream is being captured (no allocation, no pool pointer inside a graph): one block per tile then.
+    int ks = 1;
+    const int knob = g_tune_hgemm_splitk, KT = K / BK;
+    if (knob >= 2) ks = knob;
+    else if (knob == 0 && nb128 < ncu) ks = 2 * ncu / nb128;
+    if (ks > 8) ks = 8;
+    while (ks > 1 && KT / ks < 8) --ks;
+    WorkspaceLease lease;
+    if (ks > 1 && !stream_is_capturing(st)) lease = stream_workspace(st, (size_t)nb128 * ks * (128 * 128 * sizeof(float)));
+    if (!lease.ptr) ks = 1;
+    hipLaunchKernelGGL(kern, dim3(nb128 * ks), dim3(256), HGEMM128_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw, split ? T - R : -2,
+                       split ? 4 * R : 0, nright, ks, static_cast<float*>(lease.ptr));
+    if (int rc = check_launch()) return rc;
+    if (ks > 1) {
+      hipLaunchKernelGGL(hgemm_splitk_reduce_kernel, dim3(nb128), dim3(256), 0, st, static_cast<const float*>(lease.ptr), C, M, N, tiles_m,
+                         tiles_n, pw, split ? T - R : -2, split ? 4 * R : 0, nright, ks);
+      return check_launch();
+    }
+    return LC_OK;
   }
   if (false) {
 #ifdef LC_DIAG
@@ -238,7 +259,7 @@ int launch_mfma128(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   auto kern = hgemm_mfma128_kernel<B_KN>;
   if (int rc = set_dyn_lds(kern, HGEMM128_LDS)) return rc;
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), HGEMM128_LDS, st, A, B, C, M, N, K, tiles_m,
-                     tiles_n, pw, -1, 0, 0);
+                     tiles_n, pw, -1, 0, 0, 1, (float*)nullptr);
   return check_launch();
 }
 
@@ -284,19 +305,33 @@ int attn_walk_auto(int N) {
 }
 // Split-KV factor of the merged-phase kernel for a launch of `bh` (batch, head) problems (lc_tune_set "attn_split"; 1 = no split).
 // The kernel owns 256 query rows per workgroup and one workgroup per CU: g = bh N / 256 workgroups on ncu CUs leave the GPU idle when
-// 2 g <= ncu — the reference author's own regime (README.md:120 "B <= 4, H <= 48, SeqLen <= 8192").  Auto: the largest power of two S
-// with g S <= ncu that leaves every range >= kMinSplitTiles KV tiles of 64 rows (a range pays the block's fixed cost: Q load,
-// prologue, O epilogue + its share of the combine).  bh < 0 (lc_attn_kernel_name has no batch / head count): a grid that fills the GPU.
-constexpr int kMinSplitTiles = 2;
+// 2 g <= ncu — the reference author's own regime (README.md:120 "B <= 4, H <= 48, SeqLen <= 8192").  Auto picks, among the powers of
+// two S with g S <= ncu that divide the T = N / 64 KV tiles into ranges of >= kMinSplitTiles, the S that minimises the cost model
+//     t(S) = (T / S) tau_D + [S > 1] (x0 + S * 4 bh N D bytes / bw)          (microseconds)
+// fitted to profiles/r5a_attn_split.log: tau_128 = 1.3, tau_64 = 0.8 us per 64-key tile of a 256-row block on an under-filled GPU
+// (no power cap: 2.4 GHz), x0 = the second launch + the partial epilogue, bw = the rate at which a split's fp16 partial is written and
+// read back (small transfers: a third of HBM speed).  Examples (256 CUs): (1,8,1024,128) -> 4, (1,8,2048,64) -> 4, (1,16,2048,128) -> 2,
+// (1,4,4096,128) -> 4, (1,32,1024,128) -> 1 (a half-full GPU and 16 tiles: the combine costs more than half the walk saves).
+// bh < 0 (lc_attn_kernel_name has no batch / head count): a grid that fills the GPU.
+constexpr int kMinSplitTiles = 4;
+constexpr double kSplitFixedUs = 5.0, kSplitBytesPerUs = 2.6e6;
 int attn_split_auto(int D, int N, long bh) {
   const int k = g_tune_attn_split;
   if ((D != 128 && D != 64) || N % 256 != 0 || bh <= 0 || k == 1) return 1;
   const int T = N / 64;
   if (k >= 2) return (T % k == 0 && T / k >= 2) ? k : 1;
   const long ncu = device_cu_count(), g = bh * (N / 256);
-  int S = 1;
-  while (g * S * 2 <= ncu && S < 16 && T % (S * 2) == 0 && T / (S * 2) >= kMinSplitTiles) S *= 2;
-  return S;
+  const double tau = D == 128 ? 1.3 : 0.8, unit = 4.0 * (double)bh * N * D / kSplitBytesPerUs;
+  int best = 1;
+  double tbest = T * tau;
+  for (int S = 2; S <= 16 && g * S <= ncu && T % S == 0 && T / S >= kMinSplitTiles; S *= 2) {
+    const double t = (T / S) * tau + kSplitFixedUs + S * unit;
+    if (t < tbest) {
+      tbest = t;
+      best = S;
+    }
+  }
+  return best;
 }
 int choose_attn_nw(int D, bool vt, int N, long bh = -1) {
   int want = g_tune_attn_nw;   // 0 = auto (read once per launch)
@@ -579,6 +614,7 @@ bool ok_01(int v) { return v == 0 || v == 1; }
 bool ok_02(int v) { return v >= 0 && v <= 2; }
 bool ok_03(int v) { return v >= 0 && v <= 3; }
 bool ok_04(int v) { return v >= 0 && v <= 4; }
+bool ok_08(int v) { return v >= 0 && v <= 8; }
 bool ok_split(int v) { return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16; }
 bool ok_span8(int v) { return v == 0 || v == 2 || v == 4 || v == 6; }
 bool ok_w4y_sched(int v) {
@@ -611,6 +647,7 @@ const Knob kKnobs[] = {
     {"hgemm_persist", &g_tune_hgemm_persist, 1, ok_01, false},
     {"hgemm_stagger", &g_tune_hgemm_stagger, 0, ok_stagger, false},
     {"hgemm_tail", &g_tune_hgemm_tail, 1, ok_01, false},
+    {"hgemm_splitk", &g_tune_hgemm_splitk, 0, ok_08, false},
     {"hgemm_raster", &g_tune_hgemm_raster, 0, ok_02, false},
     {"hgemm_auto", &g_tune_hgemm_auto, LC_HGEMM_MFMA256W4Y, ok_auto, false},
     {"w4_abl", &g_tune_w4_abl, 0, ok_any, true},

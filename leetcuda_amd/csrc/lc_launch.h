@@ -53,6 +53,75 @@ inline int device_cu_count() {
   return cache[dev];
 }
 
+// Scratch workspace for the two launch sequences that need partial results in HBM (split-KV attention: attn_w4u.hip WALK 3;
+// split-K border strips of the GEMM: hgemm_mfma128.hip): one cached buffer per (device, stream), grown on demand, at most 16 of them
+// (least recently used evicted).  Why not hipMallocAsync per call: measured (profiles/r5a_attn_split.log) the allocation + free pair
+// costs about as much as the whole attention of a (1,8,1024,128) problem.  Safety: successive users on ONE stream are ordered by the
+// stream; different streams never share a buffer; the lease holds a process-wide mutex until the caller has enqueued its last kernel,
+// so two host threads enqueueing on the same stream cannot interleave their sequences.  hipMalloc / hipFree are illegal while a stream
+// is being captured — callers check hipStreamIsCapturing first and take their workspace-free path.  Nothing is freed at exit.
+struct WorkspaceLease {
+  std::unique_lock<std::mutex> lock;
+  void* ptr = nullptr;
+};
+inline WorkspaceLease stream_workspace(hipStream_t st, size_t bytes) {
+  struct Entry { int dev; hipStream_t st; void* p; size_t bytes; unsigned long long tick; };
+  static std::mutex mu;
+  static std::vector<Entry> pool;
+  static unsigned long long tick = 0;
+  WorkspaceLease lease;
+  lease.lock = std::unique_lock<std::mutex>(mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return lease;
+  bytes = (bytes + ((size_t)1 << 22) - 1) & ~(((size_t)1 << 22) - 1);   // 4 MiB granules: a slightly larger next shape re-uses the buffer
+  Entry* e = nullptr;
+  for (auto& x : pool)
+    if (x.dev == dev && x.st == st) e = &x;
+  if (e && e->bytes >= bytes) {
+    e->tick = ++tick;
+    lease.ptr = e->p;
+    return lease;
+  }
+  if (!e && pool.size() >= 16) {   // evict the least recently used buffer (hipFree waits for the device: no kernel still reads it)
+    size_t lru = 0;
+    for (size_t i = 1; i < pool.size(); ++i)
+      if (pool[i].tick < pool[lru].tick) lru = i;
+    int cur = dev;
+    (void)hipSetDevice(pool[lru].dev);
+    (void)hipFree(pool[lru].p);
+    (void)hipSetDevice(cur);
+    pool.erase(pool.begin() + lru);
+  }
+  if (e) {
+    (void)hipFree(e->p);   // (device-synchronising: the stream's earlier users are done with it)
+    e->p = nullptr;
+    e->bytes = 0;
+  }
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess || !p) {
+    (void)hipGetLastError();
+    if (e) pool.erase(pool.begin() + (e - pool.data()));
+    return lease;
+  }
+  if (e) {
+    e->p = p;
+    e->bytes = bytes;
+    e->tick = ++tick;
+  } else {
+    pool.push_back(Entry{dev, st, p, bytes, ++tick});
+  }
+  lease.ptr = p;
+  return lease;
+}
+inline bool stream_is_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) {
+    (void)hipGetLastError();
+    return true;   // cannot tell: behave as if it were
+  }
+  return cap != hipStreamCaptureStatusNone;
+}
+
 // tuning globals (defined in lc_abi.hip, lc_tune_set)
 // Every knob is a std::atomic<int> (relaxed loads / stores through the implicit conversions): lc_tune_set from one host thread
 // while another launches is a data race on a plain int; a launch reads each knob ONCE into a local and decides from that.

@@ -26,36 +26,24 @@ int launch_w4u_walk(const half_t* Q, const half_t* K, const half_t* V, half_t* O
   return check_launch();
 }
 
-// Split-KV (WALK 3): nsplit workgroups per query block into a stream-ordered workspace ([nsplit][B H][N][D] fp16 partials +
-// [nsplit][B H][N] fp32 log-sum-exps: hipMallocAsync / hipFreeAsync on the launch stream, so concurrent streams never share it and
-// nothing outlives the call), then the combine kernel.  Returns LC_ERR_ARG when the split cannot run here (the stream is being
-// captured into a graph — an allocation node is not something a drop-in launch should add — or the allocator refuses): the caller
-// then launches the one-block walk instead, never an error.
+// Split-KV (WALK 3): nsplit workgroups per query block write [nsplit][B H][N][D] fp16 partials + [nsplit][B H][N] fp32 log-sum-exps
+// into this stream's cached workspace (lc_launch.h stream_workspace), then the combine kernel.  Returns LC_ERR_ARG when the split
+// cannot run here (the stream is being captured into a graph — no allocation may happen, and a graph must not keep a pointer into a
+// pool that can be regrown — or the allocator refuses): the caller then launches the one-block walk instead, never an error.
 int launch_w4u_split(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int nsplit, hipStream_t st) {
   constexpr int D = W4U_D;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-    (void)hipGetLastError();
-    return LC_ERR_ARG;
-  }
+  if (stream_is_capturing(st)) return LC_ERR_ARG;
   const size_t rows = (size_t)B * H * N;
   const size_t obytes = (size_t)nsplit * rows * D * sizeof(half_t), lbytes = (size_t)nsplit * rows * sizeof(float);
-  void* ws = nullptr;
-  if (hipMallocAsync(&ws, obytes + lbytes, st) != hipSuccess || !ws) {
-    (void)hipGetLastError();
-    return LC_ERR_ARG;
-  }
-  half_t* op = static_cast<half_t*>(ws);
-  float* lse = reinterpret_cast<float*>(static_cast<char*>(ws) + obytes);
+  WorkspaceLease ws = stream_workspace(st, obytes + lbytes);   // (held until both kernels are enqueued)
+  if (!ws.ptr) return LC_ERR_ARG;
+  half_t* op = static_cast<half_t*>(ws.ptr);
+  float* lse = reinterpret_cast<float*>(static_cast<char*>(ws.ptr) + obytes);
   const size_t nblk = (size_t)(N / 256) * B * H * nsplit;
-  int rc = launch_w4u_walk<3>(Q, K, V, op, B, H, N, (int)nblk, nblk, st, nsplit, lse);
-  if (rc == LC_OK) {
-    const size_t threads = rows * (D / 8);
-    hipLaunchKernelGGL(attn_split_combine_kernel<D>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, op, lse, O, nsplit, rows);
-    rc = check_launch();
-  }
-  if (hipFreeAsync(ws, st) != hipSuccess && rc == LC_OK) rc = LC_ERR_LAUNCH;
-  return rc;
+  if (int rc = launch_w4u_walk<3>(Q, K, V, op, B, H, N, (int)nblk, nblk, st, nsplit, lse)) return rc;
+  const size_t threads = rows * (D / 8);
+  hipLaunchKernelGGL(attn_split_combine_kernel<D>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, op, lse, O, nsplit, rows);
+  return check_launch();
 }
 }  // namespace
 
@@ -79,11 +67,7 @@ int W4U_CAT(launch_attn_w4u_, W4U_TAG)(const half_t* Q, const half_t* K, const h
   if (walk == 2) {
     // the dynamic queue's claim-counter slot is picked by a host-side ticket AT LAUNCH TIME: captured into a graph it would be baked
     // in, and concurrent replays would share counters (round-4 advisor) -> the static walk while the stream is capturing
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-      (void)hipGetLastError();
-      walk = 1;
-    }
+    if (stream_is_capturing(st)) walk = 1;
   }
   if (walk == 0) return launch_w4u_walk<0>(Q, K, V, O, B, H, N, (int)nblk, nblk, st);
   if (walk == 1) return launch_w4u_walk<1>(Q, K, V, O, B, H, N, ncu, nblk, st);
