@@ -210,13 +210,13 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
     if (int rc = set_dyn_lds(kern, HGEMM128_LDS)) return rc;
     // Split-K of these blocks (lc_tune_set "hgemm_splitk"): a lone 128-tile block walks its K range at a quarter of a CU's MFMA rate
     // (one barrier per K tile, nothing to overlap with), and the launch holds few of them — 8192 x 8320 x 8192: 64 blocks, 107 us
-    // for 1.5 % of the FLOPs (profiles/r5a_hgemm_shapes.log).  ks blocks per tile (two per CU fill the GPU: ks = 2 ncu / nb128, each
+    // for 1.5 % of the FLOPs (profiles/r5a_hgemm_shapes.log).  ks blocks per tile (about 1.5 per CU, each
     // range >= 8 K tiles) write fp32 partials into this stream's cached workspace, a second kernel adds them and stores C.  Not while
     // the stream is being captured (no allocation, no pool pointer inside a graph): one block per tile then.
     int ks = 1;
     const int knob = g_tune_hgemm_splitk, KT = K / BK;
     if (knob >= 2) ks = knob;
-    else if (knob == 0 && nb128 < ncu) ks = 2 * ncu / nb128;
+    else if (knob == 0 && nb128 < ncu) ks = (3 * ncu / 2 + nb128 / 2) / nb128;   // ~1.5 blocks per CU (profiles/r5b_hgemm_splitk_sweep.log: 64 blocks: 4 best, 129 blocks: 3 best)
     if (ks > 8) ks = 8;
     while (ks > 1 && KT / ks < 8) --ks;
     WorkspaceLease lease;
