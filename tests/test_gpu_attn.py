@@ -609,7 +609,8 @@ def test_split_kv_on_grids_that_do_not_fill_the_gpu(oracle, shape, vt):
     now launches attn_fwd_w4u_kernel<D, VT, 3>: S workgroups per query block over disjoint KV ranges (partials: normalised fp16 O + the
     base-2 log-sum-exp per row in a stream-ordered workspace) + attn_split_combine_kernel.  Against the oracle on random data, with a
     spike key planted in the LAST KV range and one in a middle range (the combine must weight ranges by 2^(L_s - L): a range holding a
-    spike dominates its row), against the unsplit kernel, for both V layouts, and bit-reproducible from launch to launch."""
+    spike dominates its row), against the unsplit kernel, for both V layouts, bit-reproducible from launch to launch — although WHICH
+    workgroup arrives last at a query block and merges it differs from launch to launch — and identical to the two-launch form."""
     capi = _capi()
     B, H, N, D, S = shape
     if S > 0 and capi.device_check() != 256:
@@ -635,9 +636,17 @@ def test_split_kv_on_grids_that_do_not_fill_the_gpu(oracle, shape, vt):
             capi.attn_fwd(q, k, vin, o, v_transposed=vt)
             torch.cuda.synchronize()
             outs.append(o)
+        capi.tune("attn_split_fuse", 0)           # the two-launch form (attn_split_combine_kernel): the same arithmetic, the same bits
+        try:
+            o2 = torch.full_like(q, float("nan"))
+            capi.attn_fwd(q, k, vin, o2, v_transposed=vt)
+            torch.cuda.synchronize()
+        finally:
+            capi.tune("attn_split_fuse", 1)
     finally:
         capi.tune("attn_split", 0)
     assert torch.equal(outs[0], outs[1])           # same shape, same device: the same bits
+    assert torch.equal(outs[0], o2)                # merged by the last arrival of each query block == merged by the combine kernel
     truth = oracle.attn(q, k, v, B, H, N, D, mode="f32")
     ok, mx, ex = tol.attn_close(outs[0].float().cpu().numpy(), truth, N, rtol=tol.ATTN_RTOL_SPIKE)
     assert ok, (mx, ex)
@@ -713,3 +722,36 @@ def test_split_kv_inside_graph_capture_falls_back(oracle):
     ok, mx, _ = tol.attn_close(o.float().cpu().numpy(), truth, N)
     assert ok, mx
     assert float((o.float() - o_split.float()).abs().max()) <= 2.0 ** -9 * float(v.float().abs().max())
+
+
+def test_split_kv_many_launches_leave_the_counters_clean(oracle):
+    """The fused combine keeps one arrival counter per query block in the workspace header; the last arrival resets it.  200 back-to-back
+    launches of two alternating shapes on one stream (the second re-uses the first one's counters), every output identical to the first."""
+    capi = _capi()
+    torch.manual_seed(2024)
+    shapes = [(1, 8, 1024, 128), (1, 4, 2048, 64)]
+    data = []
+    for B, H, N, D in shapes:
+        q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+        k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+        v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+        data.append((q, k, v, torch.zeros_like(q)))
+    capi.tune("attn_split", 4)
+    try:
+        first = []
+        for q, k, v, o in data:
+            capi.attn_fwd(q, k, v, o)
+            torch.cuda.synchronize()
+            first.append(o.clone())
+            truth = oracle.attn(q, k, v, *q.shape, mode="f32")
+            assert tol.attn_close(o.float().cpu().numpy(), truth, q.shape[2])[0]
+        for it in range(100):
+            for i, (q, k, v, o) in enumerate(data):
+                o.fill_(float("nan"))
+                capi.attn_fwd(q, k, v, o)
+            if it % 25 == 24:
+                torch.cuda.synchronize()
+                for i, (_, _, _, o) in enumerate(data):
+                    assert torch.equal(o, first[i]), (it, i)
+    finally:
+        capi.tune("attn_split", 0)
