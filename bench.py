@@ -148,6 +148,18 @@ def hgemm_traffic_model(M, N, K, tile=256, xcds=8, cus_per_xcd=32, panel_w=8, in
     return waves * panels * tile * K * in_bytes + M * N * out_bytes
 
 
+def attn_traffic_model(BH, N, D, rows_per_wg, elt=2, cus_per_xcd=32):
+    """L2-compulsory fabric bytes of a FlashAttention forward whose workgroups own `rows_per_wg` query rows: the xcd_remap block order
+    gives every XCD consecutive query blocks of one head, its cus_per_xcd CUs walk that head's K / V tiles together, so ONE pass over the
+    head's K and V (2 N D elements) serves cus_per_xcd x rows_per_wg query rows; a head needs ceil(N / rows_per_wg / cus_per_xcd) passes per
+    XCD-resident group (a head's K + V — 32 MiB at D = 1024 — does not survive in a 4 MiB L2 from one pass to the next), plus Q and O
+    once.  (1,48,8192,1024) with 64-row workgroups: 4 passes -> 8.05 GB; (1,48,8192,512) with 128-row workgroups: 2 passes -> 2.42 GB — the
+    PMC figures (8.05 / 2.417 GB): no wasted re-reads; fewer bytes would need more query rows per CU (the register file is full at 64
+    rows x D = 1024) or a second group trailing the first inside L2's reach."""
+    passes = -(-(N // rows_per_wg) // cus_per_xcd)
+    return BH * (passes * 2 * N * D + 2 * N * D) * elt
+
+
 def roofline(kernel, flops, nbytes, ms_kernel, workload=None, peak=PEAK):
     """workload: key of the launch shape (hgemm_8192, attn_cfg3, attn_d512_fp16, ...); `traffic` is printed when the committed
     --pmc passes hold a counter for this kernel ON THAT SHAPE, with traffic_ratio = traffic / algorithmic bytes (1.0 = every
@@ -356,6 +368,7 @@ def bench_attn_d512(w, args, steps=3):
                      "roofline": roofline(capi.attn_kernel_name(N, D, False, dt == torch.bfloat16, bh=B * h_loc), flops_local,
                                           4.0 * B * h_loc * N * D * 2, ms_kernel,
                                           workload=(f"attn_d512_{name}" if w.size == 1 else None))}
+        out[name]["roofline"]["traffic_model"] = {"bytes": attn_traffic_model(B * h_loc, N, D, 128), "note": "128-row workgroups, 32 CUs per XCD share one pass over a head's K / V: 2 passes per head + Q, O once (attn_traffic_model)"}
         del q, k, v, o
     out["value"] = out["fp16"]["value"]
     return out
@@ -376,12 +389,14 @@ def bench_attn_d1024(w, args, steps=3):
     secs = lcd.max_over_ranks(w, timed_region(w, step, steps, 1, prewarm=2))
     ms_kernel = lcd.max_over_ranks(w, timed_region.event_ms / steps)
     flops_total, flops_local = host.mha_matmul_flops(B, H, N, D), host.mha_matmul_flops(B, h_loc, N, D)
+    rl = roofline(capi.attn_kernel_name(N, D, bh=B * h_loc), flops_local, 4.0 * B * h_loc * N * D * 2, ms_kernel,
+                  workload=("attn_d1024" if w.size == 1 else None))
+    rl["traffic_model"] = {"bytes": attn_traffic_model(B * h_loc, N, D, 64), "note": "64-row workgroups (the register file is full), 32 CUs per XCD share one pass over a head's K / V: 4 passes per head + Q, O once (attn_traffic_model) = the counter to 3 digits: L2-compulsory, not re-reads"}
     return {"value": flops_total * steps / secs * 1e-12, "ms_per_step": secs / steps * 1e3, "steps": steps,
             "workload": f"FlashAttention-2 fwd B={B} H={H} S={N} D={D} fp16 (the tiling-QKV dispatcher's largest head dim), randn inputs, "
                         f"{h_loc} heads per rank, entry flash_attn_mma_stages_split_q_tiling_qkv",
             "scaling": "strong", "n_ranks": w.size,
-            "roofline": roofline(capi.attn_kernel_name(N, D, bh=B * h_loc), flops_local, 4.0 * B * h_loc * N * D * 2, ms_kernel,
-                                 workload=("attn_d1024" if w.size == 1 else None))}
+            "roofline": rl}
 
 
 def bench_attn_d256(w, args, steps=5):

@@ -26,7 +26,7 @@ import os  # noqa: E402
 if os.environ.get("LC_AB_LIB"):    # A/B of two builds on one box: point the ctypes view at another copy of the library
     capi.LIB_PATH = Path(os.environ["LC_AB_LIB"]).resolve()
 capi.load()
-KNOBS = {"nw": "attn_nw", "walk": "attn_walk", "d512": "attn_d512", "d1024": "attn_d1024", "sched": "attn_w4i_sched", "split": "attn_split"}
+KNOBS = {"split_fuse": "attn_split_fuse", "nw": "attn_nw", "walk": "attn_walk", "d512": "attn_d512", "d1024": "attn_d1024", "sched": "attn_w4i_sched", "split": "attn_split"}
 cache = {}
 
 
@@ -73,7 +73,7 @@ def run(spec):
         ms = e0.elapsed_time(e1) / n
     finally:
         for kk in knobs:
-            capi.tune(kk, 1 if kk == "attn_w4i_sched" else 0)      # back to the defaults
+            capi.tune(kk, capi.tune_items()[kk][1])      # back to the library default
     return name, host.mha_matmul_flops(B, H, N, D) / ms * 1e-9, ms
 
 
