@@ -1,4 +1,4 @@
-// attn_w4u.hip — FlashAttention-2 forward, D = 64 / 128, N % 256 == 0: THE merged-phase 4-wave kernel (round 4: one templated body
+// attn_w4u.hip — FlashAttention-2 forward, D = 64 / 128, N % 256 == 0 (one block per workgroup: also N % 256 == 128): THE merged-phase 4-wave kernel (round 4: one templated body
 // replaces attn_w4g.hip (one block per workgroup), attn_w4p.hip (persistent workgroup), attn_w4n.hip (its D = 128 twin) and the retired
 // attn_w4m.hip / attn_w8g.hip; lc_tune_set "attn_nw" = 513 / 515 / 517 select WALK = 0 / 1 / 2).
 //
@@ -159,7 +159,9 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
     const half_t* Qb = Q + h * head_elems;
     static_for<NQ>([&](auto ic) {
       constexpr int i = decltype(ic)::value, qb = i / NDS, ds = i % NDS;
-      qraw[i] = *(const half8_t*)(Qb + (size_t)(q0w + 16 * qb + l16) * D + 32 * ds + 8 * g4);
+      // (row clamp: N % 256 == 128 — legal in the reference, flash_attn_mma_share_qkv.cu:839 — gives the head's last query block 128 real
+      // rows; its waves 2 / 3 walk the KV tiles on a copy of row N − 1 and store nothing)
+      qraw[i] = *(const half8_t*)(Qb + (size_t)min(q0w + 16 * qb + l16, N - 1) * D + 32 * ds + 8 * g4);
     });
   };
 
@@ -543,11 +545,13 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     half_t* ow = Ob + (size_t)q0 * D;
     constexpr int LPR = ROWB / 16, RPI = 64 / LPR;
+    if (q0 < N) {   // (wave-uniform; false only for waves 2 / 3 of the last query block when N % 256 == 128)
 #pragma unroll
-    for (int it = 0; it < 64 / RPI; ++it) {
-      const int row = it * RPI + lane / LPR;
-      const u32x4_t v = *(const u32x4_t*)(stg + row * G::EPI_STRIDE + (lane % LPR) * 16);
-      *(u32x4_t*)(ow + (size_t)row * D + (lane % LPR) * 8) = v;
+      for (int it = 0; it < 64 / RPI; ++it) {
+        const int row = it * RPI + lane / LPR;
+        const u32x4_t v = *(const u32x4_t*)(stg + row * G::EPI_STRIDE + (lane % LPR) * 16);
+        *(u32x4_t*)(ow + (size_t)row * D + (lane % LPR) * 8) = v;
+      }
     }
     if constexpr (SPLIT) {
       if (counters != nullptr) {

@@ -31,7 +31,7 @@ tune_t g_tune_w4y_sched{1};        // hgemm_w4y_kernel loop schedule 0..2 (lc_tu
 tune_t g_tune_hgemm_stamps{0};     // GEMM cycle-stamp builds (diagnosis only, LC_DIAG)
 tune_t g_tune_hgemm_persist{1};    // 1 (default) = hgemm_w4y_kernel as a persistent workgroup per CU when the tiles divide evenly (lc_tune_set "hgemm_persist")
 tune_t g_tune_hgemm_stagger{0};    // K-loop stagger of hgemm_w4y_kernel (lc_tune_set "hgemm_stagger"): 0 = auto (by XCD), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 | mask << 20
-tune_t g_tune_attn_split_fuse{1};  // split-KV: 1 = the last workgroup to arrive at a query block merges the partials (one launch), 0 = a second kernel (lc_tune_set "attn_split_fuse")
+tune_t g_tune_attn_split_fuse{0};  // split-KV: 0 (default) = attn_split_combine_kernel merges the partials, 1 = the last workgroup to arrive at a query block does, in the same launch (measured slower: profiles/r5c_attn_split_fused.log)
 tune_t g_tune_attn_d512{0};        // D = 256 / 512 / 1024: 0 = auto, 1 = column-split kernel, 2 = attn_bigd3, 3 = D = 256 / 512 on the other MFMA shape than auto (attn_bigd2 <-> attn_bigd7 / attn_bigd6), 4 = auto but attn_bigd7 on any grid
 }  // namespace lc
 
@@ -343,6 +343,10 @@ int choose_attn_nw(int D, bool vt, int N, long bh = -1) {
     if (want == 513 || want == 515 || want == 517) return want;
     if (want == 514 && !vt) return 514;
   }
+  // N % 256 == 128 (legal in the reference: flash_attn_mma_share_qkv.cu:839 asserts N % max(Br, Bc) = 128): the merged-phase kernel with
+  // one block per workgroup, the head's last 256-row block half real (its waves 2 / 3 compute on a copy of the last row and store
+  // nothing: 128 / (N + 128) of the work wasted) — from N = 896 on that is cheaper than the lock-step kernel's MFMA-busy 0.46 vs 0.58
+  if ((D == 128 || D == 64) && N % 256 == 128 && N >= 896 && g_tune_attn_ablate == 0 && (want == 0 || want == 513)) return 513;
   // D = 96 / 32: only the generated kernel (attn_w4i.hip, 514) has a merged-phase instantiation (256-B / 128-B padded LDS rows)
   if ((D == 96 || D == 32) && !vt && N % 256 == 0 && (want == 0 || want >= 256)) return 514;
   if (N % 256 == 0 && (want == 0 || want >= 8)) return 8;
@@ -640,7 +644,7 @@ const Knob kKnobs[] = {
     {"attn_nw", &g_tune_attn_nw, 0, ok_attn_nw, false},
     {"attn_walk", &g_tune_attn_walk, 0, ok_03, false},
     {"attn_split", &g_tune_attn_split, 0, ok_split, false},
-    {"attn_split_fuse", &g_tune_attn_split_fuse, 1, ok_01, false},
+    {"attn_split_fuse", &g_tune_attn_split_fuse, 0, ok_01, false},
     {"attn_d1024", &g_tune_attn_d1024, 0, ok_span8, false},
     {"attn_w4i_sched", &g_tune_attn_w4i_sched, 1, ok_01, false},
     {"fp8_mx", &g_tune_fp8_mx, 3, ok_03, false},

