@@ -135,6 +135,9 @@ const char* lc_build_info(int* is_diag);
  *   "attn_split_fuse" 0 (default) = a second kernel merges the partials of a split; 1 = the last workgroup to arrive at a query block does,
  *                  in the same launch (an arrival counter per block, agent-scope release / acquire: the cross-check — measured 2 x slower,
  *                  one workgroup merging 256 rows is a serial tail)
+ *   "attn_bigd_map" block -> query block map of the D = 1024 / D = 512 kernels: 0 (default) = every XCD owns consecutive query blocks of a head
+ *                  (its 32 CUs share one pass over the head's K / V), 1 = round-robin over the XCDs (A/B knob: every XCD streams every head's
+ *                  K / V — twice the fabric bytes, same bits; used to show that fabric traffic is not what bounds these kernels)
  *   "hgemm_splitk" split-K of the 128-tile blocks that serve the border strips (M, N % 256 == 128) / the ragged last wave of
  *                  LC_HGEMM_MFMA256W4Y: 0 = auto (2 CUs' worth of blocks per tile when the launch holds fewer blocks than CUs, every K
  *                  range >= 8 tiles), 1 = off, 2 .. 8 = that factor; fp32 partials in the same workspace + a reduce kernel

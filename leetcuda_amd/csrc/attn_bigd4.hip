@@ -55,7 +55,7 @@ LC_DEVINL void bd4_rd_g(half8_t& f0, half8_t& f1, half8_t& f2, half8_t& f3, cons
 template <int SP8>   // the DMA pieces of a phase are spread over SP8 eighths of it (A/B knob, lc_tune_set "attn_d1024")
 __global__ __launch_bounds__(256) void attn_fwd_bigd4_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
-    half_t* __restrict__ O, int N, int nqb, float sl2) {
+    half_t* __restrict__ O, int N, int nqb_arg, float sl2) {
   constexpr int D = 1024, DH = 512;        // head dim, the half a wave owns
   constexpr int ROWB = BD4_ROWB, TILE = BD4_TILE;
   constexpr int NKS = DH / 16;             // k-steps of this wave's half of Q·Kᵀ (32)
@@ -68,7 +68,11 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd4_kernel(
   const int hi = lane >> 5, l32 = lane & 31;
   const int pair = wave >> 1, dhf = wave & 1;   // pair of the workgroup, member of the pair (= which d-half)
 
-  const int id = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x));
+  // nqb_arg < 0 (lc_tune_set "attn_bigd_map" = 1, an A/B knob): block b is query block b of the launch — consecutive blocks of a head go
+  // round-robin over the 8 XCDs, so EVERY XCD streams the head's K / V for its share of the blocks (2 x the fabric bytes of the default
+  // map, where one XCD owns consecutive blocks: bench.py attn_traffic_model); same bits either way
+  const int nqb = nqb_arg < 0 ? -nqb_arg : nqb_arg;
+  const int id = __builtin_amdgcn_readfirstlane(nqb_arg < 0 ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x));
   const int bhi = __builtin_amdgcn_readfirstlane(id / nqb);
   const size_t bh = (size_t)bhi;
   const int q0 = __builtin_amdgcn_readfirstlane((id - bhi * nqb) * 64 + pair * 32);

@@ -101,7 +101,7 @@ LC_DEVINL void bd6_rd(half8_t& f0, half8_t& f1, half8_t& f2, half8_t& f3, uint32
 template <bool BF16>
 __global__ __launch_bounds__(256) void attn_fwd_bigd6_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
-    half_t* __restrict__ O, int N, int nqb, float sl2) {
+    half_t* __restrict__ O, int N, int nqb_arg, float sl2) {
   constexpr int D = 512;
   constexpr int ROWB = D * 2;              // bytes per K / V row (1 KiB)
   constexpr int TILE = KVB * ROWB;         // one K or V tile (64 KiB)
@@ -113,7 +113,11 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd6_kernel(
   const int wave = wave_id();
   const int g4 = lane >> 4, l16 = lane & 15;
 
-  const int id = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x));
+  // nqb_arg < 0 (lc_tune_set "attn_bigd_map" = 1, an A/B knob): block b is query block b of the launch — consecutive blocks of a head go
+  // round-robin over the 8 XCDs, so EVERY XCD streams the head's K / V for its share of the blocks (2 x the fabric bytes of the default
+  // map, where one XCD owns consecutive blocks: bench.py attn_traffic_model); same bits either way
+  const int nqb = nqb_arg < 0 ? -nqb_arg : nqb_arg;
+  const int id = __builtin_amdgcn_readfirstlane(nqb_arg < 0 ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x));
   const int bhi = __builtin_amdgcn_readfirstlane(id / nqb);
   const size_t bh = (size_t)bhi;
   const int q0 = __builtin_amdgcn_readfirstlane((id - bhi * nqb) * 128 + wave * 32);

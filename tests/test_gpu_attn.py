@@ -793,3 +793,27 @@ def test_n_multiple_of_128_runs_the_merged_phase_kernel(oracle, N, D, vt):
     finally:
         capi.tune("attn_nw", 0)
     assert float((o.float() - o2.float()).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("D,N", [(1024, 512), (512, 1024)])
+def test_bigd_block_map_knob_computes_the_same_bits(oracle, D, N):
+    """lc_tune_set "attn_bigd_map" = 1 deals a head's query blocks round-robin over the XCDs instead of giving every XCD consecutive ones:
+    an A/B knob for the fabric-traffic question (the counters equal the tile model) — the arithmetic of a block does not change."""
+    capi = _capi()
+    B, H = 1, 5
+    torch.manual_seed(D + N)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+    outs = []
+    for m in (0, 1):
+        capi.tune("attn_bigd_map", m)
+        try:
+            o = torch.full_like(q, float("nan"))
+            capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, o, 2)
+            torch.cuda.synchronize()
+            outs.append(o)
+        finally:
+            capi.tune("attn_bigd_map", 0)
+    assert torch.equal(outs[0], outs[1])
+    _check(oracle, q, k, v, outs[1])
