@@ -132,12 +132,10 @@ const char* lc_build_info(int* is_diag);
  *                  over B x H, N, D and the CU count picks 1 / 2 / 4 / 8 / 16 KV ranges per 256-row query block, lc_abi.hip attn_split_auto),
  *                  1 = off, 2 / 4 / 8 / 16 = that factor on any grid (N / 64 divisible by it, >= 2 tiles per range).  Partials live in a
  *                  cached per-stream workspace (a few MiB, never freed); while a stream is being captured the unsplit kernel runs
- *   "attn_split_fuse" 0 (default) = a second kernel merges the partials of a split; 1 = the last workgroup to arrive at a query block does,
- *                  in the same launch (an arrival counter per block, agent-scope release / acquire: the cross-check — measured 2 x slower,
- *                  one workgroup merging 256 rows is a serial tail)
- *   "attn_bigd_map" block -> query block map of the D = 1024 / D = 512 kernels: 0 (default) = every XCD owns consecutive query blocks of a head
- *                  (its 32 CUs share one pass over the head's K / V), 1 = round-robin over the XCDs (A/B knob: every XCD streams every head's
- *                  K / V — twice the fabric bytes, same bits; used to show that fabric traffic is not what bounds these kernels)
+ *   "attn_bigd_map" block -> query block map of the D = 1024 / D = 512 kernels: 1 = every XCD owns consecutive query blocks of a head (its 32
+ *                  CUs share one pass over the head's K / V: the fewest fabric bytes), 2 = round-robin over the XCDs (every XCD streams every
+ *                  head: ~2 x the fabric bytes, but the 8 XCDs walk the same heads out of the Infinity Cache); 0 = auto: 2 for D = 1024
+ *                  (+ 3.7 %), 1 for D = 512 (2: - 2 %).  Same bits
  *   "hgemm_splitk" split-K of the 128-tile blocks that serve the border strips (M, N % 256 == 128) / the ragged last wave of
  *                  LC_HGEMM_MFMA256W4Y: 0 = auto (2 CUs' worth of blocks per tile when the launch holds fewer blocks than CUs, every K
  *                  range >= 8 tiles), 1 = off, 2 .. 8 = that factor; fp32 partials in the same workspace + a reduce kernel

@@ -113,9 +113,11 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd6_kernel(
   const int wave = wave_id();
   const int g4 = lane >> 4, l16 = lane & 15;
 
-  // nqb_arg < 0 (lc_tune_set "attn_bigd_map" = 1, an A/B knob): block b is query block b of the launch — consecutive blocks of a head go
-  // round-robin over the 8 XCDs, so EVERY XCD streams the head's K / V for its share of the blocks (2 x the fabric bytes of the default
-  // map, where one XCD owns consecutive blocks: bench.py attn_traffic_model); same bits either way
+  // nqb_arg < 0 (lc_tune_set "attn_bigd_map"): block b is query block b of the launch — consecutive blocks of a head go round-robin
+  // over the 8 XCDs, so EVERY XCD streams the head's K / V for its share of the blocks: about twice the fabric bytes of the XCD-contiguous
+  // map (nqb_arg > 0: one XCD owns consecutive blocks, bench.py attn_traffic_model), but all XCDs walk the same two heads, whose K / V
+  // then live in the Infinity Cache.  Measured (profiles/r5f_bigd_map.log, r5f_bigd_map_pmc.log): D = 1024 + 3.7 % at 13.7 vs 7.2 GB
+  // fetched, D = 512 - 2 % at 6.8 vs 2.0 GB — fabric bytes are not what bounds these kernels.  Same bits either way.
   const int nqb = nqb_arg < 0 ? -nqb_arg : nqb_arg;
   const int id = __builtin_amdgcn_readfirstlane(nqb_arg < 0 ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x));
   const int bhi = __builtin_amdgcn_readfirstlane(id / nqb);

@@ -23,11 +23,10 @@
 //            README.md:120): `nsplit` workgroups per 256-row query block, workgroup (block, s) walks the KV tiles
 //            [s T / nsplit, (s + 1) T / nsplit) exactly as WALK 0 walks a whole head and writes its NORMALISED partial O (fp16, layout
 //            [nsplit][B H][N][D] in the workspace `O` points to) plus the base-2 log-sum-exp of its range per query row
-//            (`lse`, [nsplit][B H][N] fp32).  The merge O = sum_s 2^(L_s − L) O_s, L = log2 sum_s 2^L_s runs in the SAME launch when
-//            `counters` is given: every workgroup publishes its partial (agent-scope release), bumps its query block's arrival counter,
-//            and the LAST of the nsplit arrivals (agent-scope acquire) combines the block's 256 rows into `Ofinal` and zeroes the counter
-//            (flash-decoding's semaphore; one launch instead of two — at (1,8,1024,128) a launch is a fifth of the job).  Without
-//            counters the partials stay and attn_split_combine_kernel merges them in a second launch (lc_tune_set "attn_split_fuse" = 0).
+//            (`lse`, [nsplit][B H][N] fp32); attn_split_combine_kernel merges them: O = sum_s 2^(L_s − L) O_s, L = log2 sum_s 2^L_s.
+//            (A one-launch form — the last of a query block's nsplit workgroups to arrive merges it, flash-decoding's semaphore — was
+//            built and measured in round 5: bit-identical and 2 x slower, one workgroup merging 256 rows is a serial tail of dependent
+//            loads against a 4.9 us combine kernel: profiles/r5c_attn_split_fused.log, r5f_small_split_kernel_durations.log; removed.)
 // The arithmetic of a block is the same instruction for instruction in all three walks and for both V layouts' Q·Kᵀ / softmax
 // (VT changes only where Vᵀ fragments come from): WALK 0 / 1 / 2 are bit-identical to each other (GPU test).
 //
@@ -59,8 +58,7 @@ struct W4U {
 template <int D, bool VT, int WALK>
 __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
-    half_t* __restrict__ O, int N, int nqb, float sl2, int nblk, int nwg, int qslot, int nsplit, float* __restrict__ lse,
-    unsigned int* __restrict__ counters, half_t* __restrict__ Ofinal) {
+    half_t* __restrict__ O, int N, int nqb, float sl2, int nblk, int nwg, int qslot, int nsplit, float* __restrict__ lse) {
   static_assert(D == 64 || D == 128, "merged-phase attention kernel: D = 64 or 128 (D = 96 / 32: attn_w4i.hip)");
   static_assert(WALK >= 0 && WALK <= 3, "WALK: 0 one block per workgroup, 1 static persistent walk, 2 dynamic queue, 3 split-KV");
   constexpr bool PERSIST = WALK == 1 || WALK == 2;
@@ -551,46 +549,6 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
         const int row = it * RPI + lane / LPR;
         const u32x4_t v = *(const u32x4_t*)(stg + row * G::EPI_STRIDE + (lane % LPR) * 16);
         *(u32x4_t*)(ow + (size_t)row * D + (lane % LPR) * 8) = v;
-      }
-    }
-    if constexpr (SPLIT) {
-      if (counters != nullptr) {
-        // ---- fused combine.  Publish: each wave's partial O / log-sum-exp stores, released at agent scope (the nsplit workgroups of a
-        // query block may sit on different XCDs: the release writes this XCD's L2 back), then the workgroup's arrival.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        raw_barrier();
-        const int qblk = (int)bh * nqb + (q0 - wave * 64) / 256;      // this query block among the launch's B H N / 256
-        if (wave == 0 && lane == 0)
-          *(volatile unsigned*)(smem + W4U<D>::MBOX) = __hip_atomic_fetch_add(counters + qblk, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        raw_barrier();
-        const unsigned arrived = *(volatile unsigned*)(smem + W4U<D>::MBOX);
-        if (arrived == (unsigned)nsplit - 1u) {      // the last arrival: every other partial of this block is published
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          constexpr int C8 = D / 8;
-          const size_t rows = nbh * (size_t)N, row0 = bh * (size_t)N + (size_t)(q0 - wave * 64);
-          for (int c = (int)threadIdx.x; c < 256 * C8; c += 256) {
-            const size_t row = row0 + c / C8;
-            const int col = (c % C8) * 8;
-            float mx = lse[row];
-            for (int s2 = 1; s2 < nsplit; ++s2) mx = fmaxf(mx, lse[(size_t)s2 * rows + row]);
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            float den = 0.f;
-            for (int s2 = 0; s2 < nsplit; ++s2) {
-              const float w = __builtin_amdgcn_exp2f(lse[(size_t)s2 * rows + row] - mx);
-              const half8_t pv = *(const half8_t*)(O + ((size_t)s2 * rows + row) * D + col);
-              den += w;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) acc[e] += w * (float)pv[e];
-            }
-            const float rden = 1.0f / den;
-            half8_t ov;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ov[e] = (half_t)(acc[e] * rden);
-            *(half8_t*)(Ofinal + row * D + col) = ov;
-          }
-          if (wave == 0 && lane == 0) __hip_atomic_store(counters + qblk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch finds it zero
-        }
       }
     }
     if (!has_next) break;

@@ -31,8 +31,7 @@ tune_t g_tune_w4y_sched{1};        // hgemm_w4y_kernel loop schedule 0..2 (lc_tu
 tune_t g_tune_hgemm_stamps{0};     // GEMM cycle-stamp builds (diagnosis only, LC_DIAG)
 tune_t g_tune_hgemm_persist{1};    // 1 (default) = hgemm_w4y_kernel as a persistent workgroup per CU when the tiles divide evenly (lc_tune_set "hgemm_persist")
 tune_t g_tune_hgemm_stagger{0};    // K-loop stagger of hgemm_w4y_kernel (lc_tune_set "hgemm_stagger"): 0 = auto (by XCD), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 | mask << 20
-tune_t g_tune_attn_bigd_map{0};    // block -> query block map of attn_bigd4 / attn_bigd6: 0 = XCD-contiguous (default), 1 = round-robin over the XCDs (A/B knob: twice the fabric bytes, same bits)
-tune_t g_tune_attn_split_fuse{0};  // split-KV: 0 (default) = attn_split_combine_kernel merges the partials, 1 = the last workgroup to arrive at a query block does, in the same launch (measured slower: profiles/r5c_attn_split_fused.log)
+tune_t g_tune_attn_bigd_map{0};    // block -> query block map of attn_bigd4 / attn_bigd6: 0 = auto (D = 1024: round-robin over the XCDs, D = 512: XCD-contiguous), 1 = XCD-contiguous, 2 = round-robin (same bits; profiles/r5f_bigd_map.log)
 tune_t g_tune_attn_d512{0};        // D = 256 / 512 / 1024: 0 = auto, 1 = column-split kernel, 2 = attn_bigd3, 3 = D = 256 / 512 on the other MFMA shape than auto (attn_bigd2 <-> attn_bigd7 / attn_bigd6), 4 = auto but attn_bigd7 on any grid
 }  // namespace lc
 
@@ -306,15 +305,18 @@ int attn_walk_auto(int N) {
   return N <= 4096 ? 1 : 0;
 }
 // Split-KV factor of the merged-phase kernel for a launch of `bh` (batch, head) problems (lc_tune_set "attn_split"; 1 = no split).
-// The kernel owns 256 query rows per workgroup and one workgroup per CU: g = bh N / 256 workgroups on ncu CUs leave the GPU idle when
-// 2 g <= ncu — the reference author's own regime (README.md:120 "B <= 4, H <= 48, SeqLen <= 8192").  Auto picks, among the powers of
-// two S with g S <= ncu that divide the T = N / 64 KV tiles into ranges of >= kMinSplitTiles, the S that minimises the cost model
-//     t(S) = (T / S) tau_D + [S > 1] (x0 + S * 4 bh N D bytes / bw)          (microseconds)
-// fitted to profiles/r5a_attn_split.log: tau_128 = 1.3, tau_64 = 0.8 us per 64-key tile of a 256-row block on an under-filled GPU
-// (no power cap: 2.4 GHz), x0 = the second launch + the partial epilogue, bw = the rate at which a split's fp16 partial is written and
-// read back (small transfers: a third of HBM speed).  Examples (256 CUs): (1,8,1024,128) -> 4, (1,8,2048,64) -> 4, (1,16,2048,128) -> 2,
-// (1,4,4096,128) -> 4, (1,32,1024,128) -> 1 (a half-full GPU and 16 tiles: the combine costs more than half the walk saves).
-// bh < 0 (lc_attn_kernel_name has no batch / head count): a grid that fills the GPU.
+// The kernel owns 256 query rows per workgroup and one workgroup per CU, so g = bh N / 256 workgroups on ncu CUs run ceil(g / ncu)
+// rounds of T = N / 64 KV tiles: a grid that does not fill the GPU (the reference author's own regime, README.md:120 "B <= 4, H <= 48,
+// SeqLen <= 8192") leaves CUs idle for the whole launch, and a grid of 1.25 rounds pays for 2.  With S KV ranges per query block the
+// launch runs ceil(g S / ncu) rounds of T / S tiles + the combine.  Auto picks, among S = 2, 4, 8, 16 (T divisible, >= kMinSplitTiles
+// tiles per range, partials <= 256 MiB), the S that minimises the cost model
+//     t(S) = ceil(g S / ncu) (T / S) tau_D + [S > 1] (x0 + S * 4 bh N D bytes / bw)          (microseconds)
+// and splits when that is 5 % below t(1).  Fitted to profiles/r5b_attn_split.log, r5f_attn_split_quant.log, r5f_small_split_kernel_
+// durations.log: tau_128 = 1.35, tau_64 = 0.85 us per 64-key tile of a 256-row block, x0 = 5 us (the combine kernel: 4.9 us), bw = the rate
+// at which a range's fp16 partial is written and read back (2.6 TB/s: small transfers).  Examples (256 CUs): (1,8,1024,128) -> 4 (+ 34 %),
+// (1,8,2048,64) -> 4 (+ 61 %), (1,4,4096,128) -> 4 (2.1 x), (1,2,8192,128) -> 8 (2.6 x), (1,16,2048,128) -> 2 (+ 20 %), (1,10,8192,128) -> 4
+// (1.25 rounds: + 22 %), (1,12,8192,64) -> 2 (+ 18 %), (1,32,1024,128) -> 1 (a half-full GPU and 16 tiles: the combine costs more than
+// half the walk saves), (1,6,8192,128) -> 1, config 3 / 4 -> 1.  bh < 0 (lc_attn_kernel_name has no batch / head count): no split.
 constexpr int kMinSplitTiles = 4;
 constexpr double kSplitFixedUs = 5.0, kSplitBytesPerUs = 2.6e6;
 int attn_split_auto(int D, int N, long bh) {
@@ -323,11 +325,12 @@ int attn_split_auto(int D, int N, long bh) {
   const int T = N / 64;
   if (k >= 2) return (T % k == 0 && T / k >= 2) ? k : 1;
   const long ncu = device_cu_count(), g = bh * (N / 256);
-  const double tau = D == 128 ? 1.3 : 0.8, unit = 4.0 * (double)bh * N * D / kSplitBytesPerUs;
+  const double tau = D == 128 ? 1.35 : 0.85, part = 4.0 * (double)bh * N * D;   // bytes of one range's partial O, written + read
   int best = 1;
-  double tbest = T * tau;
-  for (int S = 2; S <= 16 && g * S <= ncu && T % S == 0 && T / S >= kMinSplitTiles; S *= 2) {
-    const double t = (T / S) * tau + kSplitFixedUs + S * unit;
+  const double t1 = (double)((g + ncu - 1) / ncu) * T * tau;
+  double tbest = 0.95 * t1;
+  for (int S = 2; S <= 16 && T % S == 0 && T / S >= kMinSplitTiles && S * part <= 2.0 * ((size_t)256 << 20); S *= 2) {
+    const double t = (double)((g * S + ncu - 1) / ncu) * (T / S) * tau + kSplitFixedUs + S * part / kSplitBytesPerUs;
     if (t < tbest) {
       tbest = t;
       best = S;
@@ -645,8 +648,7 @@ const Knob kKnobs[] = {
     {"attn_nw", &g_tune_attn_nw, 0, ok_attn_nw, false},
     {"attn_walk", &g_tune_attn_walk, 0, ok_03, false},
     {"attn_split", &g_tune_attn_split, 0, ok_split, false},
-    {"attn_split_fuse", &g_tune_attn_split_fuse, 0, ok_01, false},
-    {"attn_bigd_map", &g_tune_attn_bigd_map, 0, ok_01, false},
+    {"attn_bigd_map", &g_tune_attn_bigd_map, 0, ok_02, false},
     {"attn_d1024", &g_tune_attn_d1024, 0, ok_span8, false},
     {"attn_w4i_sched", &g_tune_attn_w4i_sched, 1, ok_01, false},
     {"fp8_mx", &g_tune_fp8_mx, 3, ok_03, false},

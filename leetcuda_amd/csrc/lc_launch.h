@@ -60,11 +60,9 @@ inline int device_cu_count() {
 // stream; different streams never share a buffer; the lease holds a process-wide mutex until the caller has enqueued its last kernel,
 // so two host threads enqueueing on the same stream cannot interleave their sequences.  hipMalloc / hipFree are illegal while a stream
 // is being captured — callers check hipStreamIsCapturing first and take their workspace-free path.  Nothing is freed at exit.
-constexpr size_t WS_HEADER_BYTES = 16384;   // 4096 arrival counters in front of every pool buffer: zero at allocation, every user leaves them zero
 struct WorkspaceLease {
   std::unique_lock<std::mutex> lock;
-  void* ptr = nullptr;            // `bytes` of scratch
-  unsigned int* counters = nullptr;   // WS_HEADER_BYTES / 4 zeroed counters (split-KV attention: one per query block; self-resetting)
+  void* ptr = nullptr;
 };
 inline WorkspaceLease stream_workspace(hipStream_t st, size_t bytes) {
   struct Entry { int dev; hipStream_t st; void* p; size_t bytes; unsigned long long tick; };
@@ -81,8 +79,7 @@ inline WorkspaceLease stream_workspace(hipStream_t st, size_t bytes) {
     if (x.dev == dev && x.st == st) e = &x;
   if (e && e->bytes >= bytes) {
     e->tick = ++tick;
-    lease.counters = static_cast<unsigned int*>(e->p);
-    lease.ptr = static_cast<char*>(e->p) + WS_HEADER_BYTES;
+    lease.ptr = e->p;
     return lease;
   }
   if (!e && pool.size() >= 16) {   // evict the least recently used buffer (hipFree waits for the device: no kernel still reads it)
@@ -101,9 +98,8 @@ inline WorkspaceLease stream_workspace(hipStream_t st, size_t bytes) {
     e->bytes = 0;
   }
   void* p = nullptr;
-  if (hipMalloc(&p, bytes + WS_HEADER_BYTES) != hipSuccess || !p || hipMemset(p, 0, WS_HEADER_BYTES) != hipSuccess) {
+  if (hipMalloc(&p, bytes) != hipSuccess || !p) {
     (void)hipGetLastError();
-    if (p) (void)hipFree(p);
     if (e) pool.erase(pool.begin() + (e - pool.data()));
     return lease;
   }
@@ -114,8 +110,7 @@ inline WorkspaceLease stream_workspace(hipStream_t st, size_t bytes) {
   } else {
     pool.push_back(Entry{dev, st, p, bytes, ++tick});
   }
-  lease.counters = static_cast<unsigned int*>(p);
-  lease.ptr = static_cast<char*>(p) + WS_HEADER_BYTES;
+  lease.ptr = p;
   return lease;
 }
 inline bool stream_is_capturing(hipStream_t st) {
@@ -133,8 +128,7 @@ inline bool stream_is_capturing(hipStream_t st) {
 using tune_t = std::atomic<int>;
 extern tune_t g_tune_attn_ablate, g_tune_w4_abl, g_tune_hgemm_stamps;
 extern tune_t g_tune_attn_d512;   // D = 256 / 512 attention kernel choice (lc_tune_set "attn_d512")
-extern tune_t g_tune_attn_bigd_map;     // 0 (default) = XCD-contiguous query blocks (attn_bigd4 / attn_bigd6), 1 = round-robin over the XCDs (A/B: twice the fabric bytes)
-extern tune_t g_tune_attn_split_fuse;   // 0 (default) = attn_split_combine_kernel merges a split's partials, 1 = the last arrival per query block does, in the same launch
+extern tune_t g_tune_attn_bigd_map;     // query-block map of attn_bigd4 / attn_bigd6: 0 = auto (D = 1024 round-robin over the XCDs, D = 512 XCD-contiguous), 1 = contiguous, 2 = round-robin
 extern tune_t g_tune_hgemm_persist;   // 1 (default) = hgemm_w4y_kernel as a persistent workgroup per CU when the tiles divide evenly (tu_w4.hip)
 extern tune_t g_tune_hgemm_stagger;   // K-loop stagger of hgemm_w4y_kernel: 0 = auto (by XCD, step K / 64 / 8), 1 << 27 (exactly) = off, else cx | cm << 4 | cn << 8 | step << 12 | mask << 20 with mask < 128 (hgemm_w4y.hip)
 // the kernel argument of the K-loop stagger for a K walk of kt tiles: auto (knob 0) = by XCD, the eight start tiles spread evenly

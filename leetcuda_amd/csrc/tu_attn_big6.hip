@@ -14,7 +14,7 @@ int launch_bigd6_t(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   const int nqb = N / 128;
   const dim3 grid((unsigned)((size_t)nqb * B * H)), block(256);
   const float sl2 = (1.0f / sqrtf(512.0f)) * 1.4426950408889634f;
-  hipLaunchKernelGGL(kern, grid, block, lds, st, Q, K, V, O, N, g_tune_attn_bigd_map != 0 ? -nqb : nqb, sl2);
+  hipLaunchKernelGGL(kern, grid, block, lds, st, Q, K, V, O, N, (g_tune_attn_bigd_map == 2 ? -nqb : nqb)   /* auto = XCD-contiguous: round-robin measured - 2 % here, profiles/r5f_bigd_map.log */, sl2);
   return check_launch();
 }
 }  // namespace

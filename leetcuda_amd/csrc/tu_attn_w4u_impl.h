@@ -14,7 +14,7 @@ namespace lc {
 namespace {
 template <int WALK>
 int launch_w4u_walk(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int grid_wgs, size_t nblk,
-                    hipStream_t st, int nsplit = 1, float* lse = nullptr, unsigned int* counters = nullptr, half_t* Ofinal = nullptr) {
+                    hipStream_t st, int nsplit = 1, float* lse = nullptr) {
   constexpr int D = W4U_D;
   static std::atomic<unsigned> ticket{0};     // rotating claim-counter slot of the dynamic walk (attn_w4u.hip g_w4u_queue)
   const int qslot = WALK == 2 ? (int)(ticket.fetch_add(1, std::memory_order_relaxed) % (unsigned)W4U_QSLOTS) : 0;
@@ -22,7 +22,7 @@ int launch_w4u_walk(const half_t* Q, const half_t* K, const half_t* V, half_t* O
   auto kern = attn_fwd_w4u_kernel<D, W4U_VT, WALK>;
   if (int rc = set_dyn_lds(kern, W4U<D>::LDS)) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid_wgs), dim3(256), W4U<D>::LDS, st, Q, K, V, O, N, (N + 255) / 256, sl2, (int)nblk, grid_wgs, qslot,
-                     nsplit, lse, counters, Ofinal);
+                     nsplit, lse);
   return check_launch();
 }
 
@@ -30,7 +30,7 @@ int launch_w4u_walk(const half_t* Q, const half_t* K, const half_t* V, half_t* O
 // into this stream's cached workspace (lc_launch.h stream_workspace), then the combine kernel.  Returns LC_ERR_ARG when the split
 // cannot run here (the stream is being captured into a graph — no allocation may happen, and a graph must not keep a pointer into a
 // pool that can be regrown — or the allocator refuses): the caller then launches the one-block walk instead, never an error.
-int launch_w4u_split(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int nsplit, bool fuse, hipStream_t st) {
+int launch_w4u_split(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int nsplit, hipStream_t st) {
   constexpr int D = W4U_D;
   if (stream_is_capturing(st)) return LC_ERR_ARG;
   const size_t rows = (size_t)B * H * N;
@@ -40,10 +40,6 @@ int launch_w4u_split(const half_t* Q, const half_t* K, const half_t* V, half_t* 
   half_t* op = static_cast<half_t*>(ws.ptr);
   float* lse = reinterpret_cast<float*>(static_cast<char*>(ws.ptr) + obytes);
   const size_t nblk = (size_t)(N / 256) * B * H * nsplit;
-  // one launch: the last workgroup to arrive at a query block merges its partials (one self-resetting counter per block in the
-  // workspace header); more query blocks than counters, or lc_tune_set "attn_split_fuse" = 0: the combine kernel
-  if (fuse && nblk / nsplit <= WS_HEADER_BYTES / sizeof(unsigned int))
-    return launch_w4u_walk<3>(Q, K, V, op, B, H, N, (int)nblk, nblk, st, nsplit, lse, ws.counters, O);
   if (int rc = launch_w4u_walk<3>(Q, K, V, op, B, H, N, (int)nblk, nblk, st, nsplit, lse)) return rc;
   const size_t threads = rows * (D / 8);
   hipLaunchKernelGGL(attn_split_combine_kernel<D>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, op, lse, O, nsplit, rows);
@@ -62,7 +58,7 @@ int W4U_CAT(launch_attn_w4u_, W4U_TAG)(const half_t* Q, const half_t* K, const h
   if (N % 256 != 0) walk = 0;          // the persistent walks stage the NEXT block's tiles into ring slots T % 4 == 0 expects; split-KV needs whole blocks
   if (walk == 3) {
     if (nsplit >= 2 && (N / 64) % nsplit == 0 && (N / 64) / nsplit >= 2) {
-      const int rc = launch_w4u_split(Q, K, V, O, B, H, N, nsplit, g_tune_attn_split_fuse != 0, st);
+      const int rc = launch_w4u_split(Q, K, V, O, B, H, N, nsplit, st);
       if (rc != LC_ERR_ARG) return rc;
     }
     walk = 0;
