@@ -148,15 +148,20 @@ def hgemm_traffic_model(M, N, K, tile=256, xcds=8, cus_per_xcd=32, panel_w=8, in
     return waves * panels * tile * K * in_bytes + M * N * out_bytes
 
 
-def attn_traffic_model(BH, N, D, rows_per_wg, elt=2, cus_per_xcd=32):
-    """L2-compulsory fabric bytes of a FlashAttention forward whose workgroups own `rows_per_wg` query rows: the xcd_remap block order
-    gives every XCD consecutive query blocks of one head, its cus_per_xcd CUs walk that head's K / V tiles together, so ONE pass over the
-    head's K and V (2 N D elements) serves cus_per_xcd x rows_per_wg query rows; a head needs ceil(N / rows_per_wg / cus_per_xcd) passes per
-    XCD-resident group (a head's K + V — 32 MiB at D = 1024 — does not survive in a 4 MiB L2 from one pass to the next), plus Q and O
-    once.  (1,48,8192,1024) with 64-row workgroups: 4 passes -> 8.05 GB; (1,48,8192,512) with 128-row workgroups: 2 passes -> 2.42 GB — the
-    PMC figures (8.05 / 2.417 GB): no wasted re-reads; fewer bytes would need more query rows per CU (the register file is full at 64
-    rows x D = 1024) or a second group trailing the first inside L2's reach."""
-    passes = -(-(N // rows_per_wg) // cus_per_xcd)
+def attn_traffic_model(BH, N, D, rows_per_wg, elt=2, cus_per_xcd=32, xcds=8, round_robin=False):
+    """L2-compulsory fabric bytes of a FlashAttention forward whose workgroups own `rows_per_wg` query rows.
+    XCD-contiguous block order (xcd_remap; attn_bigd6 / attn_bigd7 / attn_w4u): every XCD gets consecutive query blocks of one head, its
+    cus_per_xcd CUs walk that head's K / V tiles together, so ONE pass over the head's K and V (2 N D elements) serves cus_per_xcd x
+    rows_per_wg query rows; a head needs ceil(N / rows_per_wg / cus_per_xcd) passes (its K + V — 32 MiB at D = 1024 — does not survive in
+    a 4 MiB L2 from one pass to the next), plus Q and O once.  (1,48,8192,1024) with 64-row workgroups: 4 passes -> 8.05 GB;
+    (1,48,8192,512) with 128-row workgroups: 2 passes -> 2.42 GB — the PMC figures of round 4 (8.05 / 2.417 GB): no wasted re-reads.
+    Round-robin order (round_robin=True; attn_bigd4 since round 5): a head's query blocks are dealt over all `xcds` XCDs, each XCD
+    streams the head's K / V once for its share -> xcds passes per head: 14.5 GB at D = 1024 (PMC: 13.69 fetched + 0.81 written) — and
+    3.7 % FASTER than the 8.05 GB order (profiles/r5f_bigd_map.log): the XCDs then walk the same two heads out of the Infinity Cache.
+    Fabric bytes are not what bounds these kernels; fewer of them would need more query rows per CU (the register file is full at 64
+    rows x D = 1024)."""
+    nqb = N // rows_per_wg
+    passes = xcds * (-(-(nqb // xcds) // cus_per_xcd) if nqb >= xcds else 1) if round_robin else -(-nqb // cus_per_xcd)
     return BH * (passes * 2 * N * D + 2 * N * D) * elt
 
 
@@ -391,7 +396,11 @@ def bench_attn_d1024(w, args, steps=3):
     flops_total, flops_local = host.mha_matmul_flops(B, H, N, D), host.mha_matmul_flops(B, h_loc, N, D)
     rl = roofline(capi.attn_kernel_name(N, D, bh=B * h_loc), flops_local, 4.0 * B * h_loc * N * D * 2, ms_kernel,
                   workload=("attn_d1024" if w.size == 1 else None))
-    rl["traffic_model"] = {"bytes": attn_traffic_model(B * h_loc, N, D, 64), "note": "64-row workgroups (the register file is full), 32 CUs per XCD share one pass over a head's K / V: 4 passes per head + Q, O once (attn_traffic_model) = the counter to 3 digits: L2-compulsory, not re-reads"}
+    rr = capi.tune_get("attn_bigd_map")[0] != 1
+    rl["traffic_model"] = {"bytes": attn_traffic_model(B * h_loc, N, D, 64, round_robin=rr),
+                           "note": "64-row workgroups (the register file is full); query blocks dealt round-robin over the 8 XCDs (auto since round 5): every XCD streams "
+                                   "a head's K / V once = 8 passes per head + Q, O once = 14.5 GB (PMC 13.69 + 0.81), + 3.7 % over the XCD-contiguous order's 4 passes = "
+                                   "8.05 GB (attn_traffic_model, profiles/r5f_bigd_map*.log): L2-compulsory bytes, and not what bounds the kernel"}
     return {"value": flops_total * steps / secs * 1e-12, "ms_per_step": secs / steps * 1e3, "steps": steps,
             "workload": f"FlashAttention-2 fwd B={B} H={H} S={N} D={D} fp16 (the tiling-QKV dispatcher's largest head dim), randn inputs, "
                         f"{h_loc} heads per rank, entry flash_attn_mma_stages_split_q_tiling_qkv",

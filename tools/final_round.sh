@@ -1,6 +1,6 @@
 #!/bin/bash
 # final validation + profile of a round: full GPU suite, smoke, default bench, then tools/profile_round.sh <tag>
-TAG=${1:-r4Z}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+TAG=${1:-final}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 python -m pytest tests -m gpu -q 2>&1 | tail -12 > $OUT/pytest.log; tail -4 $OUT/pytest.log
 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
