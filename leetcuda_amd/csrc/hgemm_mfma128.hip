@@ -54,16 +54,26 @@ LC_DEVINL Tile128 mfma128_tile(int b, int nblocks, int M, int N, int tiles_m, in
 // ksplit consecutive blocks per tile, block (tile, s) walks the K tiles [s KT / ksplit, (s + 1) KT / ksplit) (the last one also the
 // K % 64 == 32 half-step) and writes its fp32 accumulators in the MFMA lane order — 16 coalesced float4 rows per wave — to
 // ws[(tile ksplit + s)][wave][16][64]; hgemm_splitk_reduce_kernel adds the ksplit partials and stores C.
-template <bool B_KN>
-__global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __restrict__ A,
+// KSW = 2 (round 5): EIGHT waves on the same 128 x 128 tile — waves 4 .. 7 repeat the 2 x 2 wave grid and each group of four takes ONE of
+// the two 32-wide k-steps of every K tile (intra-workgroup split-K: half the MFMAs per wave, the same LDS tile, half the DMA pieces per
+// wave); at the end group 1 hands its fp32 accumulators over through LDS (4 x 16 KiB = the whole allocation) and group 0 adds and runs
+// the epilogue.  Why: a LONE 4-wave block walks K at a quarter of a CU's MFMA rate — one wave per SIMD, one barrier per K tile, nothing
+// to overlap with (two co-resident blocks reach 937 TFLOP/s at 8192-class sizes, one per CU 715 at 2048^3) — and grids of <= 1.5 blocks
+// per CU are exactly what LC_HGEMM_AUTO sends here (2048^3: 256 blocks on 256 CUs).  Two waves per SIMD inside ONE block give the same
+// overlap without a second tile.  Not combined with the workspace split-K (ksplit must be 1).
+template <bool B_KN, int KSW>
+__global__ __launch_bounds__(256 * KSW, KSW == 1 ? 2 : 1) void hgemm_mfma128_kernel(const half_t* __restrict__ A,
                                                                const half_t* __restrict__ B,
                                                                half_t* __restrict__ C, int M, int N, int K,
                                                                int tiles_m, int tiles_n, int panel_w, int rem_base,
                                                                int rem_blocks, int nright, int ksplit, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(KSW == 1 || KSW == 2, "KSW: 1 = four waves, 2 = eight waves (one k-step of every K tile per group of four)");
+  constexpr int NWAVES = 4 * KSW, NPW = 4 / KSW;   // waves per workgroup, LDS-DMA pieces per wave, operand and K tile
   const int lane = threadIdx.x & 63;
   const int wave = wave_id();
-  const int wr = wave >> 1, wc = wave & 1;
+  const int kgrp = wave >> 2;                      // which k-step of a K tile this wave computes (KSW == 2)
+  const int wr = (wave >> 1) & 1, wc = wave & 1;
   const int i16 = lane & 15, g = lane >> 4;
 
   const int tb = ksplit > 1 ? (int)blockIdx.x / ksplit : (int)blockIdx.x, ks = ksplit > 1 ? (int)blockIdx.x % ksplit : 0;
@@ -71,14 +81,14 @@ __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __r
                                   rem_blocks, nright);
   const int m0 = tl.m0, n0 = tl.n0;
 
-  // ---- LDS-DMA sources: 16 + 16 pieces of 1 KiB per K tile, 4 + 4 per wave
-  const half_t* sa[4];
-  const half_t* sb[4];
+  // ---- LDS-DMA sources: 16 + 16 pieces of 1 KiB per K tile, NPW + NPW per wave
+  const half_t* sa[NPW];
+  const half_t* sb[NPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    // piece i of this wave = 8-row block 4 i + wave (K-contiguous operands): the four waves' concurrent requests cover 32 consecutive
-    // rows (hgemm_w4y.hip's piece map); NN B pieces (4 k rows of 256 B) keep one band per wave
-    const int p = wave * 4 + i, pk = 4 * i + wave;
+  for (int i = 0; i < NPW; ++i) {
+    // piece i of this wave = 8-row block NWAVES i + wave (K-contiguous operands): the waves' concurrent requests cover 32 / 64 consecutive
+    // rows (hgemm_w4y.hip's piece map, docs/HISTORY.md 4.14d); NN B pieces (4 k rows of 256 B) keep one band per wave
+    const int p = wave * NPW + i, pk = NWAVES * i + wave;
     const int row = pk * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     sa[i] = A + (size_t)(m0 + row) * K + c * 8;
@@ -116,9 +126,9 @@ __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __r
   const size_t bstep = B_KN ? (size_t)BK * N : (size_t)BK;
   auto issue = [&](int t, char* slot) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(sa[i] + (size_t)t * BK, slot + (4 * i + wave) * 1024);
+    for (int i = 0; i < NPW; ++i) glds16(sa[i] + (size_t)t * BK, slot + (NWAVES * i + wave) * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(sb[i] + (size_t)t * bstep, slot + TILE1_BYTES + (B_KN ? wave * 4 + i : 4 * i + wave) * 1024);
+    for (int i = 0; i < NPW; ++i) glds16(sb[i] + (size_t)t * bstep, slot + TILE1_BYTES + (B_KN ? wave * NPW + i : NWAVES * i + wave) * 1024);
   };
   issue(kt0, smem);
   for (int kt = kt0; kt < kt1; ++kt) {
@@ -131,6 +141,7 @@ __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __r
     const char* lb = cur + TILE1_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      if (KSW == 2 && ks != kgrp) continue;   // (wave-uniform: this group's k-step only)
       half8_t af[4], bf[4];
       half4_t braw[8];   // NN: asm transpose reads (the builtin form is guarded by s_waitcnt vmcnt(0) after an LDS-DMA,
                          // which here would serialise the DMA of tile kt+1 with the MFMAs of tile kt)
@@ -157,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __r
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(bf[ni], af[mi], acc[mi][ni]);
     }
   }
-  if ((K & 32) && (ksplit <= 1 || ks == ksplit - 1)) {   // K % 64 == 32: the last half K-step (split-K: of the last range), fragments straight from global memory in the MFMA operand layout
+  if ((K & 32) && (ksplit <= 1 || ks == ksplit - 1) && kgrp == 0) {   // K % 64 == 32: the last half K-step (split-K: of the last range), fragments straight from global memory in the MFMA operand layout
     const int k0 = KT * BK + 8 * g;
     half8_t af[4], bf[4];
 #pragma unroll
@@ -176,7 +187,29 @@ __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __r
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(bf[ni], af[mi], acc[mi][ni]);
   }
+  if constexpr (KSW == 2) {
+    // group 1 -> LDS -> group 0: lane-order float4 rows (16 per wave, conflict-free), 16 KiB per wave pair
+    __syncthreads();                                  // every wave is done with the last K tile
+    f32x4_t* xp = reinterpret_cast<f32x4_t*>(smem) + (wave & 3) * (16 * 64) + lane;
+    if (kgrp == 1) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) xp[(mi * 4 + ni) * 64] = acc[mi][ni];
+    }
+    __syncthreads();
+    if (kgrp == 0) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const f32x4_t x = xp[(mi * 4 + ni) * 64];
+          acc[mi][ni][0] += x[0]; acc[mi][ni][1] += x[1]; acc[mi][ni][2] += x[2]; acc[mi][ni][3] += x[3];
+        }
+    }
+  }
   if (ksplit > 1) {   // split-K: the fp32 partial of this K range, lane order (hgemm_splitk_reduce_kernel reads it back the same way)
+    if (kgrp != 0) return;   // (KSW == 2 is never launched with ksplit > 1)
     f32x4_t* wp = reinterpret_cast<f32x4_t*>(ws) + ((size_t)blockIdx.x * 4 + wave) * (16 * 64) + lane;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -185,25 +218,29 @@ __global__ __launch_bounds__(256, 2) void hgemm_mfma128_kernel(const half_t* __r
     return;
   }
   // ---- epilogue: each wave stages its 64x64 sub-tile through LDS, stores 128-byte row segments
-  char* stg = smem + wave * (64 * EPI_STRIDE);
-  __syncthreads();
+  char* stg = smem + (wave & 3) * (64 * EPI_STRIDE);
+  __syncthreads();                                    // (KSW == 2: group 0 has read every partial)
+  if (kgrp == 0) {
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const f32x4_t v = acc[mi][ni];
-      half4_t h;
-      h[0] = (half_t)v[0]; h[1] = (half_t)v[1]; h[2] = (half_t)v[2]; h[3] = (half_t)v[3];
-      *(half4_t*)(stg + (mi * 16 + i16) * EPI_STRIDE + (ni * 16 + g * 4) * 2) = h;
+      for (int ni = 0; ni < 4; ++ni) {
+        const f32x4_t v = acc[mi][ni];
+        half4_t h;
+        h[0] = (half_t)v[0]; h[1] = (half_t)v[1]; h[2] = (half_t)v[2]; h[3] = (half_t)v[3];
+        *(half4_t*)(stg + (mi * 16 + i16) * EPI_STRIDE + (ni * 16 + g * 4) * 2) = h;
+      }
     }
   }
   __syncthreads();
+  if (kgrp == 0) {
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int row = it * 8 + (lane >> 3);
-    const u32x4_t v = *(const u32x4_t*)(stg + row * EPI_STRIDE + (lane & 7) * 16);
-    half_t* dst = C + (size_t)(m0 + wr * 64 + row) * N + n0 + wc * 64 + (lane & 7) * 8;
-    *(u32x4_t*)dst = v;
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + (lane >> 3);
+      const u32x4_t v = *(const u32x4_t*)(stg + row * EPI_STRIDE + (lane & 7) * 16);
+      half_t* dst = C + (size_t)(m0 + wr * 64 + row) * N + n0 + wc * 64 + (lane & 7) * 8;
+      *(u32x4_t*)dst = v;
+    }
   }
 }
 

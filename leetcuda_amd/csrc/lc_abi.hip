@@ -46,6 +46,7 @@ tune_t g_tune_attn_walk{0};                  // block walk of the merged-phase k
 tune_t g_tune_attn_split{0};                 // split-KV of the merged-phase kernel on grids that do not fill the GPU: 0 = auto (attn_split_auto), 1 = off, 2 / 4 / 8 / 16 = that many KV ranges per query block
 tune_t g_tune_hgemm_auto{LC_HGEMM_MFMA256W4Y};   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
 tune_t g_tune_hgemm_splitk{0};                 // split-K of the 128-tile blocks that serve border strips / the ragged last wave: 0 = auto (launch_mfma256), 1 = off, 2 .. 8 = that factor
+tune_t g_tune_hgemm_128w{0};                   // waves of the 128-tile kernel: 0 = auto (eight — intra-workgroup split-K — on grids of <= 1.5 blocks per CU), 1 = always four, 2 = always eight
 tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to the 128-tile kernel (launch_mfma256), 0 = one launch
 tune_t g_tune_hgemm_raster{0};                 // block -> C tile map: 0 = auto (by operand footprint, panel_tiles), 1 = the reference's block swizzle (N panels from
                                              // swizzle_stride, XCD-contiguous ids), 2 = XCD super-block raster (hgemm_mfma256.hip raster_xcd16)
@@ -184,6 +185,30 @@ int panel_tiles(int swizzle_stride, int tiles_n, int tile_n, size_t operand_byte
   return w;
 }
 
+// Waves of hgemm_mfma128_kernel for a launch of `blocks` 128 x 128 tiles (lc_tune_set "hgemm_128w"): eight (KSW = 2, two waves per SIMD
+// inside one block) when the grid cannot put two blocks on a CU anyway, four (two co-resident blocks overlap each other) otherwise.
+int mfma128_ksw(long blocks) {
+  const int k = g_tune_hgemm_128w;
+  if (k == 1 || k == 2) return k;
+  return 2 * blocks <= 3 * (long)device_cu_count() ? 2 : 1;
+}
+template <bool B_KN>
+int launch_mfma128_blocks(int ksw, int nblocks, const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int tiles_m, int tiles_n,
+                          int pw, int rem_base, int rem_blocks, int nright, int ks, float* ws, hipStream_t st) {
+  if (ksw == 2 && ks == 1) {
+    auto kern = hgemm_mfma128_kernel<B_KN, 2>;
+    if (int rc = set_dyn_lds(kern, HGEMM128_LDS)) return rc;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), HGEMM128_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw, rem_base, rem_blocks, nright, 1,
+                       (float*)nullptr);
+  } else {
+    auto kern = hgemm_mfma128_kernel<B_KN, 1>;
+    if (int rc = set_dyn_lds(kern, HGEMM128_LDS)) return rc;
+    hipLaunchKernelGGL(kern, dim3(nblocks * ks), dim3(256), HGEMM128_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw, rem_base, rem_blocks, nright,
+                       ks, ws);
+  }
+  return check_launch();
+}
+
 template <bool B_KN>
 int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant,
                    int swizzle_stride, hipStream_t st) {
@@ -207,8 +232,6 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
     if (int rc = launch_w4_family(A, B, C, M, N, K, variant, B_KN, tiles_m, tiles_n, pw, split ? T - R : -1, st)) return rc;
     const int nb128 = (split ? 4 * R : 0) + nright + nbottom;
     if (nb128 == 0) return LC_OK;
-    auto kern = hgemm_mfma128_kernel<B_KN>;
-    if (int rc = set_dyn_lds(kern, HGEMM128_LDS)) return rc;
     // Split-K of these blocks (lc_tune_set "hgemm_splitk"): a lone 128-tile block walks its K range at a quarter of a CU's MFMA rate
     // (one barrier per K tile, nothing to overlap with), and the launch holds few of them — 8192 x 8320 x 8192: 64 blocks, 107 us
     // for 1.5 % of the FLOPs (profiles/r5a_hgemm_shapes.log).  ks blocks per tile (about 1.5 per CU, each
@@ -223,9 +246,10 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
     WorkspaceLease lease;
     if (ks > 1 && !stream_is_capturing(st)) lease = stream_workspace(st, (size_t)nb128 * ks * (128 * 128 * sizeof(float)));
     if (!lease.ptr) ks = 1;
-    hipLaunchKernelGGL(kern, dim3(nb128 * ks), dim3(256), HGEMM128_LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw, split ? T - R : -2,
-                       split ? 4 * R : 0, nright, ks, static_cast<float*>(lease.ptr));
-    if (int rc = check_launch()) return rc;
+    // (no workspace — graph capture, knob — and few blocks: the eight-wave form of the kernel is the next best thing)
+    if (int rc = launch_mfma128_blocks<B_KN>(mfma128_ksw(nb128), nb128, A, B, C, M, N, K, tiles_m, tiles_n, pw, split ? T - R : -2, split ? 4 * R : 0,
+                                             nright, ks, static_cast<float*>(lease.ptr), st))
+      return rc;
     if (ks > 1) {
       hipLaunchKernelGGL(hgemm_splitk_reduce_kernel, dim3(nb128), dim3(256), 0, st, static_cast<const float*>(lease.ptr), C, M, N, tiles_m,
                          tiles_n, pw, split ? T - R : -2, split ? 4 * R : 0, nright, ks);
@@ -257,11 +281,8 @@ int launch_mfma128(const half_t* A, const half_t* B, half_t* C, int M, int N, in
                    hipStream_t st) {
   const int tiles_m = M / BM1, tiles_n = N / BN1;
   const int pw = panel_tiles(swizzle_stride, tiles_n, BN1, ((size_t)M + N) * K * 2);
-  auto kern = hgemm_mfma128_kernel<B_KN>;
-  if (int rc = set_dyn_lds(kern, HGEMM128_LDS)) return rc;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), HGEMM128_LDS, st, A, B, C, M, N, K, tiles_m,
-                     tiles_n, pw, -1, 0, 0, 1, (float*)nullptr);
-  return check_launch();
+  return launch_mfma128_blocks<B_KN>(mfma128_ksw((long)tiles_m * tiles_n), tiles_m * tiles_n, A, B, C, M, N, K, tiles_m, tiles_n, pw, -1, 0, 0, 1,
+                                     nullptr, st);
 }
 
 template <bool B_KN>
@@ -565,7 +586,7 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
     else snprintf(buf, buflen, "hgemm_w4b_kernel<%s,%s,0>", nn, v == LC_HGEMM_MFMA256W4B ? "false" : "true");
   } else if (v == LC_HGEMM_MFMA256P2) snprintf(buf, buflen, "hgemm_pingpong2_kernel<%s,false>", nn);
   else if (v == LC_HGEMM_MFMA256) snprintf(buf, buflen, "hgemm_mfma256_kernel<%s>", nn);
-  else if (v == LC_HGEMM_MFMA128) snprintf(buf, buflen, "hgemm_mfma128_kernel<%s>", nn);
+  else if (v == LC_HGEMM_MFMA128) snprintf(buf, buflen, "hgemm_mfma128_kernel<%s,%d>", nn, mfma128_ksw((long)(M / BM1) * (N / BN1)));
   else snprintf(buf, buflen, "hgemm_generic_kernel<%s>", nn);
   return LC_OK;
 }
@@ -657,6 +678,7 @@ const Knob kKnobs[] = {
     {"hgemm_persist", &g_tune_hgemm_persist, 1, ok_01, false},
     {"hgemm_stagger", &g_tune_hgemm_stagger, 0, ok_stagger, false},
     {"hgemm_tail", &g_tune_hgemm_tail, 1, ok_01, false},
+    {"hgemm_128w", &g_tune_hgemm_128w, 0, ok_02, false},
     {"hgemm_splitk", &g_tune_hgemm_splitk, 0, ok_08, false},
     {"hgemm_raster", &g_tune_hgemm_raster, 0, ok_02, false},
     {"hgemm_auto", &g_tune_hgemm_auto, LC_HGEMM_MFMA256W4Y, ok_auto, false},

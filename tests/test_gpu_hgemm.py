@@ -131,7 +131,8 @@ def test_border_strips_split_k_factors(oracle, layout):
 @pytest.mark.parametrize("layout", ["nn", "tn"])
 @pytest.mark.parametrize("shape", [(128, 128, 96), (384, 128, 160), (256, 384, 224), (128, 256, 1056)])
 def test_mfma128_half_k_step(oracle, layout, shape):
-    """K % 64 == 32 on the 128-tile kernel (explicitly and as LC_HGEMM_AUTO's choice for small grids)."""
+    """K % 64 == 32 on the 128-tile kernel (explicitly and as LC_HGEMM_AUTO's choice for small grids), in its four-wave and eight-wave
+    forms (lc_tune_set "hgemm_128w": the eight-wave form splits every K tile's two k-steps over two groups of four waves)."""
     capi = _capi()
     M, N, K = shape
     torch.manual_seed(M * 13 + N + K)
@@ -139,9 +140,45 @@ def test_mfma128_half_k_step(oracle, layout, shape):
     b = torch.randn(K, N, dtype=torch.half, device="cuda")
     lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
     assert capi.hgemm_kernel_name(M, N, K, lay).startswith("hgemm_mfma128_kernel")
-    for var in (capi.HGEMM_MFMA128, capi.HGEMM_AUTO):
-        c, _ = _run(capi, a, b, lay, var, 256)
-        _check(oracle, capi, a, b, c, lay)
+    for w in (1, 2, 0):
+        capi.tune("hgemm_128w", w)
+        try:
+            assert capi.hgemm_kernel_name(M, N, K, lay).endswith(f",{w or 2}>")
+            for var in (capi.HGEMM_MFMA128, capi.HGEMM_AUTO):
+                c, _ = _run(capi, a, b, lay, var, 256)
+                _check(oracle, capi, a, b, c, lay)
+        finally:
+            capi.tune("hgemm_128w", 0)
+
+
+@pytest.mark.parametrize("layout", ["nn", "tn"])
+def test_mfma128_eight_waves_at_the_size_it_serves(oracle, layout):
+    """2048^3 = 256 blocks of 128 x 128 on 256 CUs: LC_HGEMM_AUTO's eight-wave 128-tile kernel (round 5) against the oracle, the four-wave
+    form (same products, the two k-steps of a K tile summed in a different order: fp16-rounding agreement) and the identity trick."""
+    capi = _capi()
+    n = 2048
+    torch.manual_seed(2048)
+    a = torch.randn(n, n, dtype=torch.half, device="cuda")
+    b = torch.randn(n, n, dtype=torch.half, device="cuda")
+    lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
+    nn = "true" if layout == "nn" else "false"
+    assert capi.hgemm_kernel_name(n, n, n, lay) == f"hgemm_mfma128_kernel<{nn},2>"
+    c8, _ = _run(capi, a, b, lay, capi.HGEMM_AUTO, 1024)
+    rows = [0, 63, 64, 127, 128, 1025, 2047]
+    truth = oracle.hgemm(a[rows].contiguous(), b, len(rows), n, n, 0, "f32")
+    ok, mx, _ = tol.hgemm_close(c8[rows].float().cpu().numpy(), truth, n)
+    assert ok, mx
+    capi.tune("hgemm_128w", 1)
+    try:
+        c4, _ = _run(capi, a, b, lay, capi.HGEMM_AUTO, 1024)
+    finally:
+        capi.tune("hgemm_128w", 0)
+    ulp = torch.clamp(c4.float().abs(), min=32.0) * 2.0 ** -10
+    assert ((c8.float() - c4.float()).abs() <= ulp).all()
+    eye = torch.eye(n, dtype=torch.half, device="cuda")
+    bq = (torch.arange(n * n, device="cuda").reshape(n, n) % 1021).half() / 4
+    c, _ = _run(capi, eye, bq, lay, capi.HGEMM_AUTO, 1024)
+    assert torch.equal(c, bq)
 
 
 @pytest.mark.parametrize("layout", ["nn", "tn"])
