@@ -136,11 +136,13 @@ const char* lc_build_info(int* is_diag);
  *                  CUs share one pass over the head's K / V: the fewest fabric bytes), 2 = round-robin over the XCDs (every XCD streams every
  *                  head: ~2 x the fabric bytes, but the 8 XCDs walk the same heads out of the Infinity Cache); 0 = auto: 2 for D = 1024
  *                  (+ 3.7 %), 1 for D = 512 (2: - 2 %).  Same bits
+ *   "attn_bigd_stagger" D = 1024 kernel: 1 = the workgroups of XCD x start their KV walk x eighths of the sequence in and wrap (A/B knob; only
+ *                  the fp32 summation order changes); 0 = every workgroup starts at key 0 (default)
  *   "hgemm_splitk" split-K of the 128-tile blocks that serve the border strips (M, N % 256 == 128) / the ragged last wave of
  *                  LC_HGEMM_MFMA256W4Y: 0 = auto (2 CUs' worth of blocks per tile when the launch holds fewer blocks than CUs, every K
  *                  range >= 8 tiles), 1 = off, 2 .. 8 = that factor; fp32 partials in the same workspace + a reduce kernel
  *   "hgemm_128w"   waves of LC_HGEMM_MFMA128: 0 = auto (eight — the two k-steps of every K tile on two groups of four waves, summed through LDS at the
- *                  end — on grids of <= 1.5 blocks per CU, where a lone four-wave block has nothing to overlap with), 1 = four, 2 = eight
+ *                  end — on grids of <= 0.6 blocks per CU: + 11 % at 1024^3 / 1536^3; level at 2048^3, slower for NN beyond), 1 = four, 2 = eight
  *   "hgemm_tail"   1 (default) = when the 256-tile grid's last wave holds at most 128 tiles, the generated-loop kernel computes the
  *                  full waves and the 128-tile kernel the four quadrants of each remaining tile; 0 = one launch
  *   "hgemm_raster" block -> C tile map of the tiled GEMM kernels: 0 = auto (2 when A + B exceed the 256 MiB Infinity Cache by half,

@@ -55,7 +55,7 @@ LC_DEVINL void bd4_rd_g(half8_t& f0, half8_t& f1, half8_t& f2, half8_t& f3, cons
 template <int SP8>   // the DMA pieces of a phase are spread over SP8 eighths of it (A/B knob, lc_tune_set "attn_d1024")
 __global__ __launch_bounds__(256) void attn_fwd_bigd4_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
-    half_t* __restrict__ O, int N, int nqb_arg, float sl2) {
+    half_t* __restrict__ O, int N, int nqb_arg, float sl2, int kv_stagger) {
   constexpr int D = 1024, DH = 512;        // head dim, the half a wave owns
   constexpr int ROWB = BD4_ROWB, TILE = BD4_TILE;
   constexpr int NKS = DH / 16;             // k-steps of this wave's half of Q·Kᵀ (32)
@@ -84,6 +84,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd4_kernel(
   const char* Vb = (const char*)(V + bh * (size_t)N * D);
   half_t* Ob = O + bh * (size_t)N * D;
   const int T = N / BD4_KVB;
+  // kv_stagger (lc_tune_set "attn_bigd_stagger", an A/B knob): the workgroups of XCD x start their KV walk x eighths of the sequence in and
+  // wrap — softmax does not care about the order of the keys (the fp32 sums do: results agree to rounding, not bit for bit)
+  const int toff = kv_stagger ? __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * (T / 8)) : 0;
   const uint32_t smem32 = lds_addr32(smem);
   char* const ksm = smem;
   char* const vsm = smem + TILE;
@@ -109,12 +112,14 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd4_kernel(
   }
   v_off = (unsigned)(((lane & 63) ^ ((wave & 3) << 2)) * 16);
   auto issue_k = [&](int i, int lohi, int t) {   // piece i (0 .. 7) of K-lo / K-hi of tile t (clamped)
-    const int te = t < T ? t : T - 1;
+    int te = (t < T ? t : T - 1) + toff;
+    if (te >= T) te -= T;
     const int P = 2 * (wave & 1) + lohi, pp = (wave >> 1) + 2 * i;
     blds16(rk, k_off[i & 3], (unsigned)te * TILE + (unsigned)(2 * pp) * ROWB + (unsigned)P * 512u, ksm + P * 16384 + pp * 1024);
   };
   auto issue_v = [&](int i, int lohi, int t) {   // piece i (0 .. 7) of V-lo / V-hi of tile t: half (i >> 2) of row 16 lohi + wave + 4 (i & 3)
-    const int te = t < T ? t : T - 1;
+    int te = (t < T ? t : T - 1) + toff;
+    if (te >= T) te -= T;
     const unsigned off = (unsigned)((16 * lohi + wave + 4 * (i & 3)) * ROWB + (i >> 2) * 1024);
     blds16(rv, v_off, (unsigned)te * TILE + off, vsm + off);
   };

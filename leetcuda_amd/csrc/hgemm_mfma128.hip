@@ -57,10 +57,10 @@ LC_DEVINL Tile128 mfma128_tile(int b, int nblocks, int M, int N, int tiles_m, in
 // KSW = 2 (round 5): EIGHT waves on the same 128 x 128 tile — waves 4 .. 7 repeat the 2 x 2 wave grid and each group of four takes ONE of
 // the two 32-wide k-steps of every K tile (intra-workgroup split-K: half the MFMAs per wave, the same LDS tile, half the DMA pieces per
 // wave); at the end group 1 hands its fp32 accumulators over through LDS (4 x 16 KiB = the whole allocation) and group 0 adds and runs
-// the epilogue.  Why: a LONE 4-wave block walks K at a quarter of a CU's MFMA rate — one wave per SIMD, one barrier per K tile, nothing
-// to overlap with (two co-resident blocks reach 937 TFLOP/s at 8192-class sizes, one per CU 715 at 2048^3) — and grids of <= 1.5 blocks
-// per CU are exactly what LC_HGEMM_AUTO sends here (2048^3: 256 blocks on 256 CUs).  Two waves per SIMD inside ONE block give the same
-// overlap without a second tile.  Not combined with the workspace split-K (ksplit must be 1).
+// the epilogue.  Two waves per SIMD inside ONE block: on grids that leave most CUs idle (1024^3: 64 blocks, 1536^3: 144) + 11 %; at one
+// block per CU (2048^3) level — the 128 x 128 tile is L2-bandwidth-bound there, not latency-bound — and the NN form loses from 2560^3 on
+// (profiles/r5g_hgemm_128w.log), so LC_HGEMM_AUTO uses it up to 0.6 blocks per CU (lc_abi.hip mfma128_ksw).  Never combined with the
+// workspace split-K (ksplit must be 1).
 template <bool B_KN, int KSW>
 __global__ __launch_bounds__(256 * KSW, KSW == 1 ? 2 : 1) void hgemm_mfma128_kernel(const half_t* __restrict__ A,
                                                                const half_t* __restrict__ B,

@@ -31,6 +31,7 @@ tune_t g_tune_w4y_sched{1};        // hgemm_w4y_kernel loop schedule 0..2 (lc_tu
 tune_t g_tune_hgemm_stamps{0};     // GEMM cycle-stamp builds (diagnosis only, LC_DIAG)
 tune_t g_tune_hgemm_persist{1};    // 1 (default) = hgemm_w4y_kernel as a persistent workgroup per CU when the tiles divide evenly (lc_tune_set "hgemm_persist")
 tune_t g_tune_hgemm_stagger{0};    // K-loop stagger of hgemm_w4y_kernel (lc_tune_set "hgemm_stagger"): 0 = auto (by XCD), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 | mask << 20
+tune_t g_tune_attn_bigd_stagger{0};   // attn_bigd4 (D = 1024): 1 = the KV walk of the workgroups on XCD x starts x eighths of the sequence in (A/B knob; results agree to rounding)
 tune_t g_tune_attn_bigd_map{0};    // block -> query block map of attn_bigd4 / attn_bigd6: 0 = auto (D = 1024: round-robin over the XCDs, D = 512: XCD-contiguous), 1 = XCD-contiguous, 2 = round-robin (same bits; profiles/r5f_bigd_map.log)
 tune_t g_tune_attn_d512{0};        // D = 256 / 512 / 1024: 0 = auto, 1 = column-split kernel, 2 = attn_bigd3, 3 = D = 256 / 512 on the other MFMA shape than auto (attn_bigd2 <-> attn_bigd7 / attn_bigd6), 4 = auto but attn_bigd7 on any grid
 }  // namespace lc
@@ -46,7 +47,7 @@ tune_t g_tune_attn_walk{0};                  // block walk of the merged-phase k
 tune_t g_tune_attn_split{0};                 // split-KV of the merged-phase kernel on grids that do not fill the GPU: 0 = auto (attn_split_auto), 1 = off, 2 / 4 / 8 / 16 = that many KV ranges per query block
 tune_t g_tune_hgemm_auto{LC_HGEMM_MFMA256W4Y};   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
 tune_t g_tune_hgemm_splitk{0};                 // split-K of the 128-tile blocks that serve border strips / the ragged last wave: 0 = auto (launch_mfma256), 1 = off, 2 .. 8 = that factor
-tune_t g_tune_hgemm_128w{0};                   // waves of the 128-tile kernel: 0 = auto (eight — intra-workgroup split-K — on grids of <= 1.5 blocks per CU), 1 = always four, 2 = always eight
+tune_t g_tune_hgemm_128w{0};                   // waves of the 128-tile kernel: 0 = auto (eight — intra-workgroup split-K — on grids of <= 0.6 blocks per CU), 1 = always four, 2 = always eight
 tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to the 128-tile kernel (launch_mfma256), 0 = one launch
 tune_t g_tune_hgemm_raster{0};                 // block -> C tile map: 0 = auto (by operand footprint, panel_tiles), 1 = the reference's block swizzle (N panels from
                                              // swizzle_stride, XCD-contiguous ids), 2 = XCD super-block raster (hgemm_mfma256.hip raster_xcd16)
@@ -186,11 +187,14 @@ int panel_tiles(int swizzle_stride, int tiles_n, int tile_n, size_t operand_byte
 }
 
 // Waves of hgemm_mfma128_kernel for a launch of `blocks` 128 x 128 tiles (lc_tune_set "hgemm_128w"): eight (KSW = 2, two waves per SIMD
-// inside one block) when the grid cannot put two blocks on a CU anyway, four (two co-resident blocks overlap each other) otherwise.
+// inside one block) on grids that leave CUs idle, four otherwise.  Measured (profiles/r5g_hgemm_128w.log, four vs eight waves, TN / NN):
+// 1024^3 (64 blocks) 172 / 167 -> 192 / 189 TFLOP/s, 1536^3 (144) 410 / 396 -> 454 / 425; 2048^3 (256 blocks = one per CU) 705 -> 701: level —
+// there the 128 x 128 tile is bound by L2 bandwidth (64 FLOP / B: 10 TB/s at 700 TFLOP/s), not by latency, and from 2560^3 on the NN form
+// LOSES (825 -> 587: twice the waves on the transpose reads).  Auto: eight up to 0.6 blocks per CU.
 int mfma128_ksw(long blocks) {
   const int k = g_tune_hgemm_128w;
   if (k == 1 || k == 2) return k;
-  return 2 * blocks <= 3 * (long)device_cu_count() ? 2 : 1;
+  return 5 * blocks <= 3 * (long)device_cu_count() ? 2 : 1;
 }
 template <bool B_KN>
 int launch_mfma128_blocks(int ksw, int nblocks, const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int tiles_m, int tiles_n,
@@ -670,6 +674,7 @@ const Knob kKnobs[] = {
     {"attn_walk", &g_tune_attn_walk, 0, ok_03, false},
     {"attn_split", &g_tune_attn_split, 0, ok_split, false},
     {"attn_bigd_map", &g_tune_attn_bigd_map, 0, ok_02, false},
+    {"attn_bigd_stagger", &g_tune_attn_bigd_stagger, 0, ok_01, false},
     {"attn_d1024", &g_tune_attn_d1024, 0, ok_span8, false},
     {"attn_w4i_sched", &g_tune_attn_w4i_sched, 1, ok_01, false},
     {"fp8_mx", &g_tune_fp8_mx, 3, ok_03, false},

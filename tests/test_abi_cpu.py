@@ -256,8 +256,9 @@ def test_hgemm_dispatch_covers_the_reference_legal_shapes(built):
             for v in (capi.HGEMM_MFMA256, capi.HGEMM_MFMA256W4C, capi.HGEMM_MFMA256W4X):
                 with pytest.raises(capi.LcError, match="Tensor size mismatch"):
                     capi.hgemm_kernel_name(*shp, lay, v)
-        for shp in ((384, 384, 128), (256, 256, 96), (128, 640, 160), (2048, 2048, 2080)):      # <= 128 interior tiles: the 128-tile kernel
-            assert capi.hgemm_kernel_name(*shp, lay) == f"hgemm_mfma128_kernel<{nn},2>", shp                 # <= 1.5 blocks per CU: the eight-wave form
+        for shp in ((384, 384, 128), (256, 256, 96), (128, 640, 160), (1536, 1536, 1568)):      # <= 128 interior tiles: the 128-tile kernel
+            assert capi.hgemm_kernel_name(*shp, lay) == f"hgemm_mfma128_kernel<{nn},2>", shp                 # <= 0.6 blocks per CU: the eight-wave form
+        assert capi.hgemm_kernel_name(2048, 2048, 2080, lay) == f"hgemm_mfma128_kernel<{nn},1>"               # one block per CU: four waves
         for shp in ((384, 384, 128), (256, 256, 96)):                                             # ... the flagship kernel when asked for
             assert capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_MFMA256W4Y) == f"hgemm_w4y_kernel<{nn},1>"
         for shp in ((256, 256, 32), (8192, 8192, 8200), (8192, 8256, 8192), (128, 128, 48)):     # K < 64, K % 32, N % 128: the edge kernel

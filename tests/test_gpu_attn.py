@@ -812,6 +812,16 @@ def test_bigd_block_map_knob_computes_the_same_bits(oracle, D, N):
             capi.tune("attn_bigd_map", 0)
     assert torch.equal(outs[0], outs[1])
     _check(oracle, q, k, v, outs[1])
+    if D == 1024:      # "attn_bigd_stagger": the KV walk of XCD x starts x eighths in — another summation order of the same attention
+        capi.tune("attn_bigd_stagger", 1)
+        try:
+            o = torch.full_like(q, float("nan"))
+            capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, o, 2)
+            torch.cuda.synchronize()
+        finally:
+            capi.tune("attn_bigd_stagger", 0)
+        _check(oracle, q, k, v, o)
+        assert float((o.float() - outs[0].float()).abs().max()) < 1e-3
 
 
 def test_split_kv_against_wave_quantisation(oracle):

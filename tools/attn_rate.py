@@ -26,7 +26,7 @@ import os  # noqa: E402
 if os.environ.get("LC_AB_LIB"):    # A/B of two builds on one box: point the ctypes view at another copy of the library
     capi.LIB_PATH = Path(os.environ["LC_AB_LIB"]).resolve()
 capi.load()
-KNOBS = {"bigd_map": "attn_bigd_map", "nw": "attn_nw", "walk": "attn_walk", "d512": "attn_d512", "d1024": "attn_d1024", "sched": "attn_w4i_sched", "split": "attn_split"}
+KNOBS = {"bigd_stagger": "attn_bigd_stagger", "bigd_map": "attn_bigd_map", "nw": "attn_nw", "walk": "attn_walk", "d512": "attn_d512", "d1024": "attn_d1024", "sched": "attn_w4i_sched", "split": "attn_split"}
 cache = {}
 
 
