@@ -136,8 +136,8 @@ const char* lc_build_info(int* is_diag);
  *                  CUs share one pass over the head's K / V: the fewest fabric bytes), 2 = round-robin over the XCDs (every XCD streams every
  *                  head: ~2 x the fabric bytes, but the 8 XCDs walk the same heads out of the Infinity Cache); 0 = auto: 2 for D = 1024
  *                  (+ 3.7 %), 1 for D = 512 (2: - 2 %).  Same bits
- *   "attn_bigd_stagger" D = 1024 kernel: 1 = the workgroups of XCD x start their KV walk x eighths of the sequence in and wrap (A/B knob; only
- *                  the fp32 summation order changes); 0 = every workgroup starts at key 0 (default)
+ *   "attn_bigd_stagger" D = 1024 kernel: the workgroups of XCD x start their KV walk x eighths of the sequence in and wrap (only the fp32 summation
+ *                  order changes): 0 = auto (on with the round-robin block map: + 2 %), 1 = off, 2 = on
  *   "hgemm_splitk" split-K of the 128-tile blocks that serve the border strips (M, N % 256 == 128) / the ragged last wave of
  *                  LC_HGEMM_MFMA256W4Y: 0 = auto (2 CUs' worth of blocks per tile when the launch holds fewer blocks than CUs, every K
  *                  range >= 8 tiles), 1 = off, 2 .. 8 = that factor; fp32 partials in the same workspace + a reduce kernel

@@ -84,8 +84,10 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd4_kernel(
   const char* Vb = (const char*)(V + bh * (size_t)N * D);
   half_t* Ob = O + bh * (size_t)N * D;
   const int T = N / BD4_KVB;
-  // kv_stagger (lc_tune_set "attn_bigd_stagger", an A/B knob): the workgroups of XCD x start their KV walk x eighths of the sequence in and
-  // wrap — softmax does not care about the order of the keys (the fp32 sums do: results agree to rounding, not bit for bit)
+  // kv_stagger (lc_tune_set "attn_bigd_stagger"; auto: on with the round-robin block map): the workgroups of XCD x start their KV walk x
+  // eighths of the sequence in and wrap — with the round-robin map all eight XCDs walk the same head, staggered they ask the fabric for
+  // eight different tiles at a time instead of the same one (+ 1.8 ... 2.1 %, profiles/r5h_bigd_stagger.log; the GEMM's K stagger by XCD is the
+  // same idea).  Softmax does not care about the order of the keys; the fp32 sums do: results agree to rounding, not bit for bit
   const int toff = kv_stagger ? __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * (T / 8)) : 0;
   const uint32_t smem32 = lds_addr32(smem);
   char* const ksm = smem;

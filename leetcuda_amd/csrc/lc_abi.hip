@@ -31,7 +31,7 @@ tune_t g_tune_w4y_sched{1};        // hgemm_w4y_kernel loop schedule 0..2 (lc_tu
 tune_t g_tune_hgemm_stamps{0};     // GEMM cycle-stamp builds (diagnosis only, LC_DIAG)
 tune_t g_tune_hgemm_persist{1};    // 1 (default) = hgemm_w4y_kernel as a persistent workgroup per CU when the tiles divide evenly (lc_tune_set "hgemm_persist")
 tune_t g_tune_hgemm_stagger{0};    // K-loop stagger of hgemm_w4y_kernel (lc_tune_set "hgemm_stagger"): 0 = auto (by XCD), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 | mask << 20
-tune_t g_tune_attn_bigd_stagger{0};   // attn_bigd4 (D = 1024): 1 = the KV walk of the workgroups on XCD x starts x eighths of the sequence in (A/B knob; results agree to rounding)
+tune_t g_tune_attn_bigd_stagger{0};   // attn_bigd4 (D = 1024): the KV walk of the workgroups on XCD x starts x eighths of the sequence in: 0 = auto (with the round-robin block map), 1 = off, 2 = on (results agree to rounding)
 tune_t g_tune_attn_bigd_map{0};    // block -> query block map of attn_bigd4 / attn_bigd6: 0 = auto (D = 1024: round-robin over the XCDs, D = 512: XCD-contiguous), 1 = XCD-contiguous, 2 = round-robin (same bits; profiles/r5f_bigd_map.log)
 tune_t g_tune_attn_d512{0};        // D = 256 / 512 / 1024: 0 = auto, 1 = column-split kernel, 2 = attn_bigd3, 3 = D = 256 / 512 on the other MFMA shape than auto (attn_bigd2 <-> attn_bigd7 / attn_bigd6), 4 = auto but attn_bigd7 on any grid
 }  // namespace lc
@@ -674,7 +674,7 @@ const Knob kKnobs[] = {
     {"attn_walk", &g_tune_attn_walk, 0, ok_03, false},
     {"attn_split", &g_tune_attn_split, 0, ok_split, false},
     {"attn_bigd_map", &g_tune_attn_bigd_map, 0, ok_02, false},
-    {"attn_bigd_stagger", &g_tune_attn_bigd_stagger, 0, ok_01, false},
+    {"attn_bigd_stagger", &g_tune_attn_bigd_stagger, 0, ok_02, false},
     {"attn_d1024", &g_tune_attn_d1024, 0, ok_span8, false},
     {"attn_w4i_sched", &g_tune_attn_w4i_sched, 1, ok_01, false},
     {"fp8_mx", &g_tune_fp8_mx, 3, ok_03, false},

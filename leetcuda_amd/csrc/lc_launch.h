@@ -128,7 +128,7 @@ inline bool stream_is_capturing(hipStream_t st) {
 using tune_t = std::atomic<int>;
 extern tune_t g_tune_attn_ablate, g_tune_w4_abl, g_tune_hgemm_stamps;
 extern tune_t g_tune_attn_d512;   // D = 256 / 512 attention kernel choice (lc_tune_set "attn_d512")
-extern tune_t g_tune_attn_bigd_stagger;   // 1 = attn_bigd4: the KV walk of XCD x starts x eighths in (A/B knob)
+extern tune_t g_tune_attn_bigd_stagger;   // attn_bigd4: the KV walk of XCD x starts x eighths in: 0 = auto (with the round-robin map), 1 = off, 2 = on
 extern tune_t g_tune_attn_bigd_map;     // query-block map of attn_bigd4 / attn_bigd6: 0 = auto (D = 1024 round-robin over the XCDs, D = 512 XCD-contiguous), 1 = contiguous, 2 = round-robin
 extern tune_t g_tune_hgemm_persist;   // 1 (default) = hgemm_w4y_kernel as a persistent workgroup per CU when the tiles divide evenly (tu_w4.hip)
 extern tune_t g_tune_hgemm_stagger;   // K-loop stagger of hgemm_w4y_kernel: 0 = auto (by XCD, step K / 64 / 8), 1 << 27 (exactly) = off, else cx | cm << 4 | cn << 8 | step << 12 | mask << 20 with mask < 128 (hgemm_w4y.hip)

@@ -16,7 +16,8 @@ int launch_bigd4_t(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   const dim3 grid((unsigned)((size_t)nqb * B * H)), block(256);
   const float sl2 = (1.0f / sqrtf(1024.0f)) * 1.4426950408889634f;
   hipLaunchKernelGGL(kern, grid, block, BD4_LDS, st, Q, K, V, O, N, (g_tune_attn_bigd_map == 1 ? nqb : -nqb)   /* auto = round-robin over the XCDs: + 3.7 % at twice the fabric bytes (MALL-resident K / V, L2 requests spread), profiles/r5f_bigd_map.log */, sl2,
-                     (int)g_tune_attn_bigd_stagger);
+                     /* KV-walk stagger by XCD: auto = with the round-robin map (+ 1.8 ... 2.1 %, profiles/r5h_bigd_stagger.log; nothing with the contiguous one) */
+                     (g_tune_attn_bigd_stagger == 2 || (g_tune_attn_bigd_stagger == 0 && g_tune_attn_bigd_map != 1)) ? 1 : 0);
   return check_launch();
 }
 }  // namespace

@@ -792,36 +792,38 @@ def test_n_multiple_of_128_runs_the_merged_phase_kernel(oracle, N, D, vt):
 
 @pytest.mark.parametrize("D,N", [(1024, 512), (512, 1024)])
 def test_bigd_block_map_knob_computes_the_same_bits(oracle, D, N):
-    """lc_tune_set "attn_bigd_map" = 1 deals a head's query blocks round-robin over the XCDs instead of giving every XCD consecutive ones:
-    an A/B knob for the fabric-traffic question (the counters equal the tile model) — the arithmetic of a block does not change."""
+    """lc_tune_set "attn_bigd_map": a head's query blocks dealt round-robin over the XCDs (2; auto for D = 1024) or every XCD owning consecutive
+    ones (1; auto for D = 512) — the fabric-traffic A/B of DESIGN.md section 4.4; the arithmetic of a block does not change.  With the
+    round-robin map the D = 1024 kernel also staggers its KV walk by XCD ("attn_bigd_stagger"): another summation order, so the maps are
+    compared with the stagger off, and the default against the oracle."""
     capi = _capi()
     B, H = 1, 5
     torch.manual_seed(D + N)
     q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
-    outs = []
-    for m in (0, 1):
+
+    def run(m, stag):
         capi.tune("attn_bigd_map", m)
+        capi.tune("attn_bigd_stagger", stag)
         try:
             o = torch.full_like(q, float("nan"))
             capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, o, 2)
             torch.cuda.synchronize()
-            outs.append(o)
+            return o
         finally:
             capi.tune("attn_bigd_map", 0)
-    assert torch.equal(outs[0], outs[1])
-    _check(oracle, q, k, v, outs[1])
-    if D == 1024:      # "attn_bigd_stagger": the KV walk of XCD x starts x eighths in — another summation order of the same attention
-        capi.tune("attn_bigd_stagger", 1)
-        try:
-            o = torch.full_like(q, float("nan"))
-            capi.attn_call("flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, o, 2)
-            torch.cuda.synchronize()
-        finally:
             capi.tune("attn_bigd_stagger", 0)
-        _check(oracle, q, k, v, o)
-        assert float((o.float() - outs[0].float()).abs().max()) < 1e-3
+    o1, o2 = run(1, 1), run(2, 1)
+    assert torch.equal(o1, o2)
+    _check(oracle, q, k, v, o2)
+    od = run(0, 0)                       # the defaults
+    _check(oracle, q, k, v, od)
+    assert torch.equal(od, run(0, 0))    # launch to launch
+    assert float((od.float() - o1.float()).abs().max()) < 1e-3
+    if D == 1024:
+        assert torch.equal(od, run(2, 2)) and not torch.equal(od, o2)     # auto = round-robin + stagger: a different summation order
+
 
 
 def test_split_kv_against_wave_quantisation(oracle):
