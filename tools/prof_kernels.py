@@ -57,6 +57,13 @@ if a.what in ("all", "attn"):
         capi.attn_fwd(q, k, v, o)
     torch.cuda.synchronize()
     del q, k, v, o, tv
+    # split-KV (round 5): (1,4,4096,128) = 64 query blocks on 256 CUs -> attn_fwd_w4u_kernel<128,false,3> with 4 KV ranges per block +
+    # attn_split_combine_kernel<128> (tools/prof_workloads.py: "attn_split_1x4x4096")
+    q, k, v, o, tv = host.get_qkvo(1, 4, 4096, 128, seed=0)
+    for _ in range(4 * a.iters):
+        capi.attn_fwd(q, k, v, o)
+    torch.cuda.synchronize()
+    del q, k, v, o, tv
     # the reference's published shape (1,48,8192,64) (tools/prof_workloads.py: "attn_d64")
     q, k, v, o, tv = host.get_qkvo(1, 48, 8192, 64, seed=0)
     for _ in range(a.iters):

@@ -7,6 +7,7 @@ WORKLOADS = [
     # attn_fwd_w4u_kernel<D, VT, WALK>: config 3 (N = 4096) runs the static persistent walk (1), config 4 / the D = 64 shape (N = 8192) one
     # block per workgroup (0); prof_kernels.py launches WALK 0 only at config 4's shape
     ("attn_fwd_w4u_kernel<128,false,1", "attn_cfg3"), ("attn_fwd_w4u_kernel<128,false,0", "attn_cfg4"), ("attn_fwd_w4u_kernel<128,false,2", "attn_cfg3"),
+    ("attn_fwd_w4u_kernel<128,false,3", "attn_split_1x4x4096"), ("attn_split_combine_kernel<128", "attn_split_1x4x4096"),
     ("attn_fwd_w4u_kernel<128,true", "attn_cfg3"), ("attn_fwd_w4i_kernel<128", "attn_cfg3"), ("attn_fwd_kernel<128", "attn_cfg3"),
     ("attn_fwd_w4u_kernel<64", "attn_d64"), ("attn_fwd_w4i_kernel<64", "attn_d64"), ("attn_fwd_kernel<64", "attn_d64"),
     ("attn_fwd_bigd2_kernel<512,false", "attn_d512_fp16"), ("attn_fwd_bigd2_kernel<512,true", "attn_d512_bf16"),
