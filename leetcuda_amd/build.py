@@ -121,12 +121,8 @@ def _unit_current(obj: Path, asm, dep: Path, flags) -> bool:
     if not deps or not all(d.exists() for d in deps):
         return False
     have = _stamps().get("unit:" + obj.stem)
-    if have is None:   # objects of a tree built before the per-unit stamps existed: trust mtimes once, then record the digest
-        t = min(obj.stat().st_mtime, asm.stat().st_mtime) if asm is not None else obj.stat().st_mtime
-        if all(d.stat().st_mtime <= t for d in deps):
-            _mark("unit:" + obj.stem, _unit_digest(dep, flags))
-            return True
-        return False
+    if have is None:   # no recorded digest (a tree built before the per-unit stamps existed, or a lost stamps.json): rebuild once — mtimes
+        return False   # say nothing after a snapshot, and a stale object accepted here would be stamped as current for good (round-4 advisor)
     return have == _unit_digest(dep, flags)
 
 

@@ -26,6 +26,7 @@ one buffer_load_dwordx2 each, one K tile ahead at the top of the tile (before th
 alternating with the tile parity.
 
 usage: tools/gen_gemm_fp8_w4k.py [--check]"""
+import re
 import sys
 from pathlib import Path
 
@@ -241,8 +242,25 @@ def gen(mx):
     return s.L
 
 
+def check_literal_vgprs(lines, clob, what):
+    """Round-4 advisor: the audit's rule R4 (no compiler instruction may name an asm-owned literal VGPR) cannot cover registers that are
+    owned only INSIDE one statement, so safety rests on the clobber list naming every literal v-register of the body — enforced here, at
+    generation time and on every build (`--check`): hipcc may then keep nothing of its own in them across the statement."""
+    used = set()
+    for ln in lines:
+        for m in re.finditer(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]", ln):
+            if m.group(1) is not None:
+                used.add(int(m.group(1)))
+            else:
+                used.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    missing = sorted(used - set(clob))
+    if missing:
+        raise SystemExit(f"{what}: literal VGPRs {missing[:8]} ... are not in the statement's clobber list")
+
+
 def render(mx):
     lines = gen(mx)
+    check_literal_vgprs(lines, VCLOB, f"gemm_fp8_w4k loop (mx = {mx})")
     body = "\n".join(f'    "{ln}\\n\\t"' for ln in lines)
     vclob = ", ".join(f'"v{r}"' for r in VCLOB)
     n_mfma = sum(ln.startswith("v_mfma") for ln in lines)

@@ -21,6 +21,7 @@ Ring, swizzles, piece order and the vmcnt(8) count are those of hgemm_w4b_kernel
 usage: tools/gen_hgemm_w4y.py [--check]     (--check: exit 1 if the committed .inc differs from what would be generated)
        tools/gen_hgemm_w4y.py --diag DIR   (LC_DIAG builds only: write the ablation loops 3..5 — results WRONG by design, never
                                             committed — into DIR, which leetcuda_amd/build.py puts on the include path)"""
+import re
 import sys
 from pathlib import Path
 
@@ -295,8 +296,25 @@ def gen_nn():
     return L
 
 
+def check_literal_vgprs(lines, clob, what):
+    """Round-4 advisor: the audit's rule R4 (no compiler instruction may name an asm-owned literal VGPR) cannot cover registers that are
+    owned only INSIDE one statement, so safety rests on the clobber list naming every literal v-register of the body — enforced here, at
+    generation time and on every build (`--check`): hipcc may then keep nothing of its own in them across the statement."""
+    used = set()
+    for ln in lines:
+        for m in re.finditer(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]", ln):
+            if m.group(1) is not None:
+                used.add(int(m.group(1)))
+            else:
+                used.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    missing = sorted(used - set(clob))
+    if missing:
+        raise SystemExit(f"{what}: literal VGPRs {missing[:8]} ... are not in the statement's clobber list")
+
+
 def render_nn():
     lines = gen_nn()
+    check_literal_vgprs(lines, range(108, 256), "hgemm_w4y NN loop")
     body = "\n".join(f'    "{ln}\\n\\t"' for ln in lines)
     vclob = ", ".join(f'"v{r}"' for r in range(108, 256))
     n_mfma = sum(ln.startswith("v_mfma") for ln in lines)
@@ -316,6 +334,7 @@ def render_nn():
 
 def render(sched):
     lines = gen(sched)
+    check_literal_vgprs(lines, VCLOB, f"hgemm_w4y TN loop, schedule {sched}")
     body = "\n".join(f'    "{ln}\\n\\t"' for ln in lines)
     vclob = ", ".join(f'"v{r}"' for r in VCLOB)
     n_mfma = sum(ln.startswith("v_mfma") for ln in lines)
