@@ -128,6 +128,35 @@ def test_border_strips_split_k_factors(oracle, layout):
         assert ((outs[ks].float() - outs[1].float()).abs() <= ulp).all(), ks
 
 
+def test_border_strips_inside_graph_capture(oracle):
+    """The split-K of the border blocks needs the cached workspace (hipMalloc on first use): while a stream is being captured the launcher
+    runs the blocks unsplit instead, so a captured 128-multiple GEMM is plain kernel nodes, and the replay computes the same product."""
+    capi = _capi()
+    M, N, K = 640, 384, 4192
+    torch.manual_seed(640)
+    a = torch.randn(M, K, dtype=torch.half, device="cuda")
+    b = torch.randn(K, N, dtype=torch.half, device="cuda")
+    bb = host.as_col_major(b)
+    c = torch.zeros(M, N, dtype=torch.half, device="cuda")
+    for ks in (0, 1):                      # warm-up of both forms outside capture (kernel attributes are set on first use)
+        capi.tune("hgemm_splitk", ks)
+        try:
+            capi.hgemm(a, bb, c, layout=capi.LAYOUT_TN, variant=capi.HGEMM_MFMA256W4Y, swizzle_stride=256)
+        finally:
+            capi.tune("hgemm_splitk", 0)
+    torch.cuda.synchronize()
+    c_eager = c.clone()
+    c.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        capi.hgemm(a, bb, c, layout=capi.LAYOUT_TN, variant=capi.HGEMM_MFMA256W4Y, swizzle_stride=256)
+    g.replay()
+    torch.cuda.synchronize()
+    _check(oracle, capi, a, b, c, capi.LAYOUT_TN)
+    ulp = torch.clamp(c_eager.float().abs(), min=32.0) * 2.0 ** -10
+    assert ((c.float() - c_eager.float()).abs() <= ulp).all()
+
+
 @pytest.mark.parametrize("layout", ["nn", "tn"])
 @pytest.mark.parametrize("shape", [(128, 128, 96), (384, 128, 160), (256, 384, 224), (128, 256, 1056)])
 def test_mfma128_half_k_step(oracle, layout, shape):
