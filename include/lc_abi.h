@@ -130,8 +130,11 @@ const char* lc_build_info(int* is_diag);
  *                  (the K = 128 fp8 kernel shares the stagger and the persistent walk of "hgemm_persist")
  *   "attn_split"   split-KV of the merged-phase kernel (attn_w4u.hip WALK 3) for grids that do not fill the GPU: 0 = auto (a cost model
  *                  over B x H, N, D and the CU count picks 1 / 2 / 4 / 8 / 16 KV ranges per 256-row query block, lc_abi.hip attn_split_auto),
- *                  1 = off, 2 / 4 / 8 / 16 = that factor on any grid (N / 64 divisible by it, >= 2 tiles per range).  Partials live in a
+ *                  1 = off: the merged-phase kernel itself on any grid (also switches off the small-grid substitution below), 2 / 4 / 8 / 16 = that
+ *                  factor on any grid (N / 64 divisible by it, >= 2 tiles per range).  Partials live in a
  *                  cached per-stream workspace (a few MiB, never freed); while a stream is being captured the unsplit kernel runs
+ *                  Small grids the rule leaves unsplit (<= half a GPU of 256-row blocks, N <= 2048) run the 4-wave lock-step kernel, whose
+ *                  128-row workgroups fill twice the CUs (+ 9 ... 12 %)
  *   "attn_bigd_map" block -> query block map of the D = 1024 / D = 512 kernels: 1 = every XCD owns consecutive query blocks of a head (its 32
  *                  CUs share one pass over the head's K / V: the fewest fabric bytes), 2 = round-robin over the XCDs (every XCD streams every
  *                  head: ~2 x the fabric bytes, but the 8 XCDs walk the same heads out of the Infinity Cache); 0 = auto: 2 for D = 1024

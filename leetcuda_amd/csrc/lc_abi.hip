@@ -368,7 +368,14 @@ int choose_attn_nw(int D, bool vt, int N, long bh = -1) {
   if (want == 512) want = 513;
   const bool merged = (D == 128 || D == 64) && N % 256 == 0;
   if (merged && g_tune_attn_ablate == 0) {
-    if (want == 0) return attn_split_auto(D, N, bh) > 1 ? 519 : 513 + 2 * attn_walk_auto(N);
+    if (want == 0) {
+      if (attn_split_auto(D, N, bh) > 1) return 519;
+      // Small grids the split rule leaves alone (too few KV tiles for the combine to pay): up to half a GPU of 256-row blocks and N <= 2048
+      // the 4-wave lock-step kernel's 128-row workgroups fill twice the CUs — (1,32,1024,128) 655 vs 601 TFLOP/s, (1,32,1024,64) 498 vs 444
+      // (profiles/r4q_small_grids_d128.log, r5i_small_grids.log); from one full round of blocks on the merged-phase kernel is far ahead (992 vs 760)
+      if (bh > 0 && 2 * bh * (N / 256) <= device_cu_count() && N <= 2048 && g_tune_attn_split != 1) return 4;
+      return 513 + 2 * attn_walk_auto(N);
+    }
     if (want == 513 || want == 515 || want == 517) return want;
     if (want == 514 && !vt) return 514;
   }

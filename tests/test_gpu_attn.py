@@ -623,7 +623,7 @@ def test_split_kv_on_grids_that_do_not_fill_the_gpu(oracle, shape, vt):
     vin = v.transpose(-2, -1).contiguous() if vt else v
     vts = "true" if vt else "false"
     if S < 0:
-        assert capi.attn_kernel_name(N, D, vt, bh=B * H).endswith(",1>")      # auto: not worth a split
+        assert capi.attn_kernel_name(N, D, vt, bh=B * H).startswith("attn_fwd_kernel<")      # auto: not worth a split -> the 128-row lock-step kernel on this small grid
         capi.tune("attn_split", -S)
     try:
         name = capi.attn_kernel_name(N, D, vt, bh=B * H)
