@@ -192,6 +192,76 @@ def test_hgemm_reference_legal_shapes_full_size(oracle, shape, layout):
         capi.vendor_destroy()
 
 
+@pytest.mark.parametrize("layout", ["nn", "tn"])
+def test_hgemm_tail_split_border_and_k_tail_together(oracle, layout):
+    """4480 x 4480 x 4128: 17 x 17 = 289 interior tiles on 256 CUs (33 in a ragged last wave -> 132 quadrant blocks on the 128-tile kernel),
+    128-wide right AND bottom strips (35 + 34 blocks in the same launch), K % 64 == 32 in every kernel, split-K over all of those blocks —
+    every special case of lc_abi.hip launch_mfma256 in one problem."""
+    capi = _capi()
+    M = N = 4480
+    K = 4128
+    lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
+    torch.manual_seed(4480)
+    a = torch.randn(M, K, dtype=torch.half, device="cuda")
+    b = torch.randn(K, N, dtype=torch.half, device="cuda")
+    bb = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
+    assert capi.hgemm_kernel_name(M, N, K, lay).startswith("hgemm_w4y_kernel")
+    outs = {}
+    for ks in (0, 1, 3):
+        capi.tune("hgemm_splitk", ks)
+        try:
+            c = torch.full((M, N), float("nan"), dtype=torch.half, device="cuda")
+            capi.hgemm(a, bb, c, layout=lay, variant=capi.HGEMM_AUTO, swizzle_stride=1024)
+            torch.cuda.synchronize()
+        finally:
+            capi.tune("hgemm_splitk", 0)
+        assert torch.isfinite(c).all(), ks
+        outs[ks] = c
+    rows = [0, 255, 256, 2241, 4351, 4352, 4479]
+    truth = oracle.hgemm(a[rows].contiguous(), b, len(rows), N, K, 0, "f32")
+    for ks, c in outs.items():
+        ok, mx, _ = tol.hgemm_close(c[rows].float().cpu().numpy(), truth, K)
+        assert ok, (ks, mx)
+    capi.vendor_init()
+    try:
+        cv = torch.empty_like(outs[0])
+        capi.hgemm_vendor(a, bb, cv, lay)
+        torch.cuda.synchronize()
+        ulp = torch.clamp(cv.float().abs(), min=64.0) * 2.0 ** -10
+        for ks, c in outs.items():
+            assert ((c.float() - cv.float()).abs() <= ulp).all(), ks
+    finally:
+        capi.vendor_destroy()
+
+
+def test_hgemm_random_reference_legal_shapes_against_the_vendor_gemm():
+    """Twelve random shapes with M, N multiples of 128 and K multiples of 32 (the reference's legality rule), LC_HGEMM_AUTO, NN and TN,
+    against hipBLASLt on the same operands to fp16 rounding: whatever mix of flagship kernel, border strips, tail quadrants, split-K,
+    four- / eight-wave 128-tile kernel the dispatcher picks."""
+    capi = _capi()
+    rng = np.random.default_rng(128)
+    capi.vendor_init()
+    try:
+        for _ in range(12):
+            M, N = (int(x) * 128 for x in rng.integers(2, 40, 2))
+            K = int(rng.integers(2, 70)) * 32
+            for lay in (capi.LAYOUT_NN, capi.LAYOUT_TN):
+                torch.manual_seed(M + N + K)
+                a = torch.randn(M, K, dtype=torch.half, device="cuda")
+                b = torch.randn(K, N, dtype=torch.half, device="cuda")
+                bb = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
+                c = torch.full((M, N), float("nan"), dtype=torch.half, device="cuda")
+                cv = torch.empty_like(c)
+                capi.hgemm(a, bb, c, layout=lay, variant=capi.HGEMM_AUTO, swizzle_stride=512)
+                capi.hgemm_vendor(a, bb, cv, lay)
+                torch.cuda.synchronize()
+                ulp = torch.clamp(cv.float().abs(), min=32.0) * 2.0 ** -10
+                bad = ((c.float() - cv.float()).abs() > ulp).sum().item()
+                assert bad == 0, (M, N, K, lay, capi.hgemm_kernel_name(M, N, K, lay), bad)
+    finally:
+        capi.vendor_destroy()
+
+
 def test_d256_full_size(oracle):
     """(1,48,8192,256) through the tiling-QKV entry and its shared-QKV stage-1 sibling (flash_attn_mma_share_qkv.cu:872-921: d = 256
     only with stages = 1)."""
