@@ -853,3 +853,34 @@ def test_split_kv_against_wave_quantisation(oracle):
     finally:
         capi.tune("attn_split", 0)
     assert float((o.float() - o1.float()).abs().max()) <= 2.0 ** -9 * float(v.float().abs().max())
+
+
+def test_random_shapes_through_every_dispatch_path(oracle):
+    """Sixteen random (B, H, N, D, V layout) with N a multiple of 64 and D in {64, 128}: whatever the dispatcher picks — merged-phase kernel
+    in any walk, split-KV, the ragged-N form, the lock-step kernel on small grids or odd N — must match the oracle; the kernel names seen
+    are collected so that a change of the rules shows up here."""
+    capi = _capi()
+    rng = np.random.default_rng(5)
+    seen = set()
+    for _ in range(16):
+        D = int(rng.choice([64, 128]))
+        N = int(rng.integers(1, 41)) * 64
+        bh = int(min(rng.integers(1, 41), max(1, 60_000_000 // (N * N))))
+        B = 2 if bh % 2 == 0 and rng.random() < 0.5 else 1
+        H = bh // B
+        vt = bool(rng.random() < 0.3)
+        torch.manual_seed(N + D + bh)
+        q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+        k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+        v = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
+        k[:, :, N - 1] = 2.5 * q[:, :, 0]
+        vin = v.transpose(-2, -1).contiguous() if vt else v
+        o = torch.full_like(q, float("nan"))
+        capi.attn_fwd(q, k, vin, o, v_transposed=vt)
+        torch.cuda.synchronize()
+        name = capi.attn_kernel_name(N, D, vt, bh=B * H)
+        seen.add(name.split("<")[0] + ("<..,3>" if name.endswith(",3>") else ""))
+        truth = oracle.attn(q, k, v, B, H, N, D, mode="f32")
+        ok, mx, ex = tol.attn_close(o.float().cpu().numpy(), truth, N, rtol=tol.ATTN_RTOL_SPIKE)
+        assert ok, (B, H, N, D, vt, name, mx, ex)
+    assert {"attn_fwd_kernel", "attn_fwd_w4u_kernel"} <= seen, seen
