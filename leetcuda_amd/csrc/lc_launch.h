@@ -159,7 +159,7 @@ const char* valu_rung_kernel_name(int rung);
 // tu_attn_w4u_{d128,d128t,d64,d64t}.hip: THE merged-phase attention kernel (attn_w4u.hip), one unit per (head dim, V layout): N % 256 == 0;
 // walk 0 = one 256-row query block per workgroup, 1 = persistent workgroup per CU with a static walk, 2 = persistent with a dynamic
 // per-XCD block queue (falls back to 0 when there are no more blocks than CUs), 3 = split-KV: nsplit workgroups per query block +
-// a combine kernel, partials in a stream-ordered workspace (falls back to 0 while the stream is being captured)
+// a combine kernel, partials in the stream's cached workspace (falls back to 0 while the stream is being captured)
 int launch_attn_w4u_d128(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int walk, int nsplit, hipStream_t st);
 int launch_attn_w4u_d128t(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int walk, int nsplit, hipStream_t st);   // V as [B,H,D,N]
 int launch_attn_w4u_d64(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int walk, int nsplit, hipStream_t st);

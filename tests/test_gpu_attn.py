@@ -607,7 +607,7 @@ SPLIT_SHAPES = [(1, 8, 1024, 128, 4), (1, 8, 2048, 64, 4), (1, 16, 2048, 128, 2)
 def test_split_kv_on_grids_that_do_not_fill_the_gpu(oracle, shape, vt):
     """Round-4 verdict (missing #2): the tuned kernels own 256 query rows per workgroup, so (1,8,1024,128) ran on 32 of 256 CUs.  Auto
     now launches attn_fwd_w4u_kernel<D, VT, 3>: S workgroups per query block over disjoint KV ranges (partials: normalised fp16 O + the
-    base-2 log-sum-exp per row in a stream-ordered workspace) + attn_split_combine_kernel.  Against the oracle on random data, with a
+    base-2 log-sum-exp per row in the cached per-stream workspace) + attn_split_combine_kernel.  Against the oracle on random data, with a
     spike key planted in the LAST KV range and one in a middle range (the combine must weight ranges by 2^(L_s - L): a range holding a
     spike dominates its row), against the unsplit kernel, for both V layouts, and bit-reproducible from launch to launch."""
     capi = _capi()
@@ -685,7 +685,7 @@ def test_split_kv_every_factor(oracle, S, D):
 
 
 def test_split_kv_inside_graph_capture_falls_back(oracle):
-    """The split needs a stream-ordered workspace (hipMallocAsync): while the stream is being captured into a graph the launcher runs
+    """The split needs the cached per-stream workspace (hipMalloc on first use): while the stream is being captured into a graph the launcher runs
     the one-block walk instead — a captured drop-in launch stays ONE kernel node, and the replay computes the same attention."""
     capi = _capi()
     B, H, N, D = 1, 4, 1024, 128
