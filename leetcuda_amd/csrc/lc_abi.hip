@@ -379,10 +379,12 @@ int choose_attn_nw(int D, bool vt, int N, long bh = -1) {
     if (want == 513 || want == 515 || want == 517) return want;
     if (want == 514 && !vt) return 514;
   }
-  // N % 256 == 128 (legal in the reference: flash_attn_mma_share_qkv.cu:839 asserts N % max(Br, Bc) = 128): the merged-phase kernel with
-  // one block per workgroup, the head's last 256-row block half real (its waves 2 / 3 compute on a copy of the last row and store
-  // nothing: 128 / (N + 128) of the work wasted) — from N = 1152 on (profiles/r5d_attn_n128.log: (4,32,4224,128) 1210 vs 901 TFLOP/s, (4,32,1152,128) 886 vs 771, (1,48,8320,64) 961 vs 799; (2,16,896,64) 372 vs 427: the lock-step kernel keeps N < 1152)
-  if ((D == 128 || D == 64) && N % 256 == 128 && N >= 1152 && g_tune_attn_ablate == 0 && (want == 0 || want == 513)) return 513;
+  // N % 256 != 0 (N % 64 == 0; N % 128 == 0 is what the reference's own kernels need: flash_attn_mma_share_qkv.cu:839 asserts
+  // N % max(Br, Bc) == 0): the merged-phase kernel with one block per workgroup, the head's last 256-row block partly real — the waves whose 64
+  // rows lie behind N compute on a clamped copy of the last row and store nothing ((256 - N % 256) / (N + 256 - N % 256) of the work wasted).
+  // From N = 1152 on that beats the lock-step kernel's MFMA-busy 0.46 vs 0.58 (profiles/r5d_attn_n128.log: (4,32,4224,128) 1210 vs 901 TFLOP/s,
+  // (4,32,1152,128) 886 vs 771, (1,48,8320,64) 961 vs 799; (2,16,896,64) 372 vs 427: the lock-step kernel keeps N < 1152)
+  if ((D == 128 || D == 64) && N % 256 != 0 && N % 64 == 0 && N >= 1152 && g_tune_attn_ablate == 0 && (want == 0 || want == 513)) return 513;
   // D = 96 / 32: only the generated kernel (attn_w4i.hip, 514) has a merged-phase instantiation (256-B / 128-B padded LDS rows)
   if ((D == 96 || D == 32) && !vt && N % 256 == 0 && (want == 0 || want >= 256)) return 514;
   if (N % 256 == 0 && (want == 0 || want >= 8)) return 8;

@@ -53,7 +53,7 @@ int launch_w4u_split(const half_t* Q, const half_t* K, const half_t* V, half_t* 
 // block; when the split cannot run on this stream (graph capture, allocator) the one-block walk runs instead.
 int W4U_CAT(launch_attn_w4u_, W4U_TAG)(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int walk,
                                        int nsplit, hipStream_t st) {
-  const size_t nblk = (size_t)((N + 255) / 256) * B * H;   // (N % 256 == 128: the head's last block is half real; one block per workgroup only)
+  const size_t nblk = (size_t)((N + 255) / 256) * B * H;   // (N % 256 != 0: the head's last block is partly real; one block per workgroup only)
   const int ncu = device_cu_count();   // one workgroup per CU: each takes a CU's whole register file and > half its LDS
   if (N % 256 != 0) walk = 0;          // the persistent walks stage the NEXT block's tiles into ring slots T % 4 == 0 expects; split-KV needs whole blocks
   if (walk == 3) {

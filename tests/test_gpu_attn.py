@@ -756,12 +756,13 @@ def test_split_kv_many_launches_on_two_streams(oracle):
 
 @pytest.mark.parametrize("vt", [False, True], ids=["v_nd", "v_dn"])
 @pytest.mark.parametrize("D", [128, 64])
-@pytest.mark.parametrize("N", [1152, 1408, 4224])
+@pytest.mark.parametrize("N", [1152, 1216, 1344, 4224])
 def test_n_multiple_of_128_runs_the_merged_phase_kernel(oracle, N, D, vt):
     """Round-4 verdict (missing #3): N % 256 == 128 is legal in the reference (flash_attn_mma_share_qkv.cu:839) and used to fall to the
-    lock-step kernel.  The merged-phase kernel takes it with one block per workgroup: the head's last query block has 128 real rows, its
-    waves 2 / 3 walk the KV tiles on a clamped copy of the last row and store nothing — so the rows behind the tensor must stay untouched
-    (O is allocated with a guard band) and the last real rows must be exact."""
+    lock-step kernel.  The merged-phase kernel takes it — and every other N % 64 == 0 (1216 = 4 x 256 + 192, 1344 = 5 x 256 + 64) — with
+    one block per workgroup: the head's last query block is partly real, the waves behind N walk the KV tiles on a clamped copy of the
+    last row and store nothing — so the rows behind the tensor must stay untouched (O is allocated with a guard band) and the last real
+    rows must be exact."""
     capi = _capi()
     B, H = 2, 3
     torch.manual_seed(N + D)
@@ -780,7 +781,7 @@ def test_n_multiple_of_128_runs_the_merged_phase_kernel(oracle, N, D, vt):
     truth = oracle.attn(q, k, v, B, H, N, D, mode="f32")
     ok, mx, ex = tol.attn_close(o.float().cpu().numpy(), truth, N, rtol=tol.ATTN_RTOL_SPIKE)
     assert ok, (mx, ex)
-    capi.tune("attn_nw", 4)                        # the lock-step kernel it replaces: agreement to the output's rounding
+    capi.tune("attn_nw", 4 if N % 128 == 0 else 2)   # the lock-step kernel it replaces: agreement to the output's rounding
     try:
         o2 = torch.zeros_like(q)
         capi.attn_fwd(q, k, vin, o2, v_transposed=vt)

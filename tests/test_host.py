@@ -377,7 +377,8 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     assert capi.attn_kernel_name(4096, 128, True) == "attn_fwd_w4u_kernel<128,true,1>"       # V handed over as [B,H,D,N]: the same kernel
     assert capi.attn_kernel_name(4096 + 128, 128) == "attn_fwd_w4u_kernel<128,false,0>"    # N % 256 == 128 from N = 1152 on: the merged-phase kernel, last block half real
     assert capi.attn_kernel_name(896, 64) == "attn_fwd_kernel<64,4,false,0>"               # ... below: lock-step (a wasted half block would cost more)
-    assert capi.attn_kernel_name(4096 + 64, 128) == "attn_fwd_kernel<128,2,false,0>"       # N % 128 != 0
+    assert capi.attn_kernel_name(4096 + 64, 128) == "attn_fwd_w4u_kernel<128,false,0>"     # ... and any other N % 64 == 0 (the last block a quarter real)
+    assert capi.attn_kernel_name(1024 + 64, 128) == "attn_fwd_kernel<128,2,false,0>"       # N % 128 != 0 below 1152: lock-step
     assert capi.attn_kernel_name(192, 64, True) == "attn_fwd_kernel<64,2,true,0>"
     assert capi.attn_kernel_name(8192, 64) == "attn_fwd_w4u_kernel<64,false,0>"               # the reference's published shapes
     assert capi.attn_kernel_name(8192, 64, True) == "attn_fwd_w4u_kernel<64,true,0>"
