@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd7_kernel(
   const char* Kb = (const char*)(K + bh * (size_t)N * D);
   const char* Vb = (const char*)(V + bh * (size_t)N * D);   // (either layout: a head is N * D elements)
   half_t* Ob = O + bh * (size_t)N * D;
-  const int T = N / BD7_KVB;               // a multiple of 8 (N % 256 == 0)
+  const int T = N / BD7_KVB;               // a multiple of 4 (N % 128 == 0): the tile loop walks four ring slots per trip
   const uint32_t smem32 = lds_addr32(smem);
   char* const ksm = smem;                  // K ring: slot s at s * TILE
   char* const vsm = smem + RING * TILE;    // V ring
@@ -131,10 +131,10 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd7_kernel(
 #pragma unroll
   for (int ds = 0; ds < NDS; ++ds)
 #pragma unroll
-    for (int qb = 0; qb < 3; ++qb) qf[ds][qb] = *(const half8_t*)(Qb + (size_t)(q0 + 16 * qb + l16) * D + 32 * ds + 8 * g4);
+    for (int qb = 0; qb < 3; ++qb) qf[ds][qb] = *(const half8_t*)(Qb + (size_t)min(q0 + 16 * qb + l16, N - 1) * D + 32 * ds + 8 * g4);   // (row clamp: N % 256 == 128, see the epilogue)
   char* const qpark = smem + 2 * RING * TILE + wave * (NDS * 1024) + lane * 16;
 #pragma unroll
-  for (int ds = 0; ds < NDS; ++ds) *(half8_t*)(qpark + ds * 1024) = *(const half8_t*)(Qb + (size_t)(q0 + 48 + l16) * D + 32 * ds + 8 * g4);
+  for (int ds = 0; ds < NDS; ++ds) *(half8_t*)(qpark + ds * 1024) = *(const half8_t*)(Qb + (size_t)min(q0 + 48 + l16, N - 1) * D + 32 * ds + 8 * g4);
   static_for<256>([&](auto r) { am_acc_zero<decltype(r)::value>(); });
 
   // ---- fragment read addresses (slot, ds >> 2, kvb / db >> 3 and the second kv block go into the immediate offsets)
@@ -363,11 +363,15 @@ __global__ __launch_bounds__(256) void attn_fwd_bigd7_kernel(
   });
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   half_t* ow = Ob + (size_t)q0 * D;
+  // N % 256 == 128 (round 5; legal in the reference, flash_attn_mma_share_qkv.cu:839): the head's last 256-row block has 128 real rows; its
+  // waves 2 / 3 walked the KV tiles on a clamped copy of row N - 1 and store nothing (wave-uniform)
+  if (q0 < N) {
 #pragma unroll
-  for (int it = 0; it < 32; ++it) {       // two 512-B rows per wave-instruction
-    const int row = 2 * it + (lane_e >> 5);
-    const u32x4_t v = *(const u32x4_t*)(stg + row * ESTR + (lane_e & 31) * 16);
-    *(u32x4_t*)(ow + (size_t)row * D + (lane_e & 31) * 8) = v;
+    for (int it = 0; it < 32; ++it) {       // two 512-B rows per wave-instruction
+      const int row = 2 * it + (lane_e >> 5);
+      const u32x4_t v = *(const u32x4_t*)(stg + row * ESTR + (lane_e & 31) * 16);
+      *(u32x4_t*)(ow + (size_t)row * D + (lane_e & 31) * 8) = v;
+    }
   }
 }
 

@@ -468,9 +468,10 @@ bool use_bigd6(int D, bool vt, int N) {
 // bh < 0: "a grid that fills the GPU" (lc_attn_kernel_name has no batch / head count; lc_attn_kernel_name_bh has).  Knob 4 forces attn_bigd7 (tests of small shapes).
 bool use_bigd7(int D, bool vt, int N, long bh) {
   const int k = g_tune_attn_d512;
-  if (D != 256 || N % 256 != 0 || (k != 0 && k != 4)) return false;
+  // N % 256 == 128 (round 5): the 256-row kernel with its last block half real, from N = 1152 (below, attn_bigd2's 128-row workgroups waste nothing)
+  if (D != 256 || (N % 256 != 0 && (N % 256 != 128 || N < 1152)) || (k != 0 && k != 4)) return false;
   if (k == 4 || bh < 0) return true;
-  const long ncu = device_cu_count(), g7 = bh * (N / 256);
+  const long ncu = device_cu_count(), g7 = bh * ((N + 255) / 256);
   if (g7 >= 4 * ncu) return true;
   const long c7 = (g7 + ncu - 1) / ncu, c2 = (2 * g7 + ncu - 1) / ncu;
   return 16 * c7 <= 10 * c2;

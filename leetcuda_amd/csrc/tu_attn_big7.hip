@@ -11,14 +11,14 @@ int launch_bigd7_t(const half_t* Q, const half_t* K, const half_t* V, half_t* O,
   auto kern = attn_fwd_bigd7_kernel<BF16, VT>;
   constexpr int lds = bd7_lds_bytes();
   if (int rc = set_dyn_lds(kern, lds)) return rc;
-  const int nqb = N / 256;
+  const int nqb = (N + 255) / 256;   // (N % 256 == 128: the head's last block is half real)
   const dim3 grid((unsigned)((size_t)nqb * B * H)), block(256);
   const float sl2 = (1.0f / sqrtf(256.0f)) * 1.4426950408889634f;
   hipLaunchKernelGGL(kern, grid, block, lds, st, Q, K, V, O, N, nqb, sl2);
   return check_launch();
 }
 }  // namespace
-// D = 256, N % 256 == 0, V as [B,H,N,D]; fp16 or bf16
+// D = 256, N % 256 == 0 (or N % 256 == 128: last block half real), V as [B,H,N,D]; fp16 or bf16
 int launch_attn_bigd7(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, bool bf16, hipStream_t st) {
   return bf16 ? launch_bigd7_t<true, false>(Q, K, V, O, B, H, N, st) : launch_bigd7_t<false, false>(Q, K, V, O, B, H, N, st);
 }

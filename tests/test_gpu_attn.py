@@ -885,3 +885,35 @@ def test_random_shapes_through_every_dispatch_path(oracle):
         ok, mx, ex = tol.attn_close(o.float().cpu().numpy(), truth, N, rtol=tol.ATTN_RTOL_SPIKE)
         assert ok, (B, H, N, D, vt, name, mx, ex)
     assert {"attn_fwd_kernel", "attn_fwd_w4u_kernel"} <= seen, seen
+
+
+@pytest.mark.parametrize("mode", ["fp16", "fp16_vt", "bf16"])
+def test_d256_n_multiple_of_128_runs_the_ring_kernel(oracle, mode):
+    """D = 256 with N % 256 == 128 (legal in the reference: its share_kv / tiling entries need N % 128 == 0): attn_bigd7 — 64 query rows
+    per wave, 256 per workgroup — with the head's last block half real (waves 2 / 3 on a clamped copy of the last row, nothing stored)
+    instead of attn_bigd2's 128-row workgroups (- 22 ... 28 %).  Guard band behind O, last real rows exact, both V layouts and bf16."""
+    capi = _capi()
+    B, H, N, D = 1, 3, 1408, 256
+    vt, bf = mode == "fp16_vt", mode == "bf16"
+    torch.manual_seed(1408 + len(mode))
+    dt = torch.bfloat16 if bf else torch.half
+    q = torch.randn(B, H, N, D, device="cuda").to(dt)
+    k = torch.randn(B, H, N, D, device="cuda").to(dt)
+    v = torch.randn(B, H, N, D, device="cuda").to(dt)
+    k[:, :, N - 1] = (2.0 * q[:, :, N - 1].float()).to(dt)
+    capi.tune("attn_d512", 4)        # (auto hands this 18-workgroup grid to attn_bigd2; 4 = attn_bigd7 on any grid)
+    try:
+        assert capi.attn_kernel_name(N, D, vt, bf, bh=B * H) == f"attn_fwd_bigd7_kernel<{'true' if bf else 'false'},{'true' if vt else 'false'}>"
+        buf = torch.full((B * H * N * D + 256 * D,), 7.0, dtype=dt, device="cuda")
+        o = buf[:B * H * N * D].view(B, H, N, D)
+        if bf:
+            capi.attn_fwd_bf16(q, k, v, o)
+        else:
+            capi.attn_fwd(q, k, v.transpose(-2, -1).contiguous() if vt else v, o, v_transposed=vt, family=capi.ATTN_TILING_QKV)
+        torch.cuda.synchronize()
+    finally:
+        capi.tune("attn_d512", 0)
+    assert (buf[B * H * N * D:].float() == 7.0).all()
+    truth = oracle.attn_bf16(q, k, v, B, H, N, D) if bf else oracle.attn(q, k, v, B, H, N, D, mode="f32")
+    ok, mx, ex = tol.attn_close(o.float().cpu().numpy(), truth, N, bf16=bf, rtol=(2.0 ** -6 if bf else tol.ATTN_RTOL_SPIKE))
+    assert ok, (mode, mx, ex)

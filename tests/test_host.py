@@ -459,7 +459,8 @@ def test_large_head_dim_kernel_names(built):
     assert capi.attn_kernel_name(384, 256, True) == "attn_fwd_bigd2_kernel<256,false,true>"
     assert capi.attn_kernel_name(8192, 256) == "attn_fwd_bigd7_kernel<false,false>"
     assert capi.attn_kernel_name(8192, 256, False, True) == "attn_fwd_bigd7_kernel<true,false>"
-    assert capi.attn_kernel_name(384, 256) == "attn_fwd_bigd2_kernel<256,false,false>"      # N % 256 == 128: the 32-rows-per-wave kernel
+    assert capi.attn_kernel_name(384, 256) == "attn_fwd_bigd2_kernel<256,false,false>"      # N % 256 == 128 below 1152: the 32-rows-per-wave kernel
+    assert capi.attn_kernel_name(4224, 256) == "attn_fwd_bigd7_kernel<false,false>"          # ... from 1152 on: the ring kernel, last block half real
     # D = 256 by grid size (lc_attn_kernel_name_bh; the rounds rule of use_bigd7 on the 256 CUs this test assumes when no GPU is present):
     # 8 heads x 4 blocks = 32 workgroups and 16 x 8 = 128 go to the 128-row kernel, 96 x 2 = 192 and everything from 256 up to the ring kernel
     if capi.attn_kernel_name(1024, 256, bh=64) == "attn_fwd_bigd7_kernel<false,false>":     # (a 256-CU device or the no-device default)
