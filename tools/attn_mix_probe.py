@@ -10,8 +10,9 @@ from leetcuda_amd import capi  # noqa: E402
 lib = capi.load_diag()
 out = torch.zeros(16, dtype=torch.int64, device="cuda")
 names = {0: "MFMAs only", 1: "D = 128 share (exp + add + fma + cvt/2 + ds_read/2 per two slots)", 2: "D = 64 share (the same per slot)",
-         3: "D = 64 share without the LDS read", 4: "D = 128 share without the LDS read"}
-for mix in (0, 1, 2, 3, 4):
+         3: "D = 64 share without the LDS read", 4: "D = 128 share without the LDS read",
+         5: "D = 64 share, exp2 as a packed-fp16 polynomial (10 VALU per 2 scores)", 6: "D = 128 share, exp2 as a packed-fp16 polynomial"}
+for mix in (0, 1, 2, 3, 4, 5, 6):
     row = []
     for waves in (4, 8):
         for _ in range(3):
