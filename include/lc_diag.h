@@ -30,7 +30,8 @@ int lc_probe_tr16(const void* src_64x4_u16, void* dst_64x4_u16, void* stream);
  * out = 16 x u64 (s_memtime cycles per wave). */
 int lc_probe_coissue(int filler, int k, int mode, void* out_u64x16, void* stream);
 /* one workgroup of `waves` (4 or 8) wave64 on one CU, each running v_mfma_f32_16x16x32_f16 + the softmax share of an MFMA slot
- * (mix 0 none, 1 D = 128, 2 D = 64, 3 / 4 = 2 / 1 without the LDS read): out[wave] = cycles of 2048 MFMAs (tools/attn_mix_probe.py) */
+ * (mix 0 none, 1 D = 128, 2 D = 64, 3 / 4 = 2 / 1 without the LDS read, 5 / 6 = 3 / 4 with exp2 as a packed-fp16 polynomial instead of v_exp_f32):
+ * out[wave] = cycles of 2048 MFMAs (tools/attn_mix_probe.py) */
 int lc_probe_attn_mix(int waves, int mix, void* out_u64x16, void* stream);
 /* v_mfma_f32_16x16x32_f16 with operands from VGPRs / AGPRs (form 0 all VGPR, 1 A/B AGPR + C/D VGPR, 2 A/B VGPR + C/D AGPR, 3 = 1 and 2
  * alternating, 4 all AGPR): out[wave] = cycles of 4096 MFMAs, one wave per SIMD (tools/attn_mix_probe.py) */
