@@ -492,3 +492,23 @@ def test_large_head_dim_kernel_names(built):
         assert capi.attn_kernel_name(8192, 256, True).startswith("attn_fwd_bigd_kernel<256,")
     finally:
         capi.tune("attn_d512", 0)
+
+
+def test_bench_compact_attention_scalars_and_traffic_models():
+    """bench.py's second headline is emitted as FLAT scalars inside `roofline` (the driver's parsed record drops nested objects): the helper
+    that builds them, and the two traffic models (GEMM tiles, attention passes) at the shapes DESIGN.md quotes."""
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    import bench
+    blk = {"value": 1250.0, "ms_per_step": 0.88, "steps": 10,
+           "roofline": {"peak": 2500.0, "kernel": "attn_fwd_w4u_kernel<128,false,1>", "kernel_ms": 0.87, "frac": 0.5, "traffic_ratio": 1.03}}
+    c = bench.compact_attn(blk, 2)
+    assert c["tflops"] == 1250.0 and c["frac"] == pytest.approx(1250.0 / 5000.0) and c["n_ranks"] == 2 and c["kernel_ms"] == 0.87
+    assert all(not isinstance(v, (dict, list)) for v in c.values())
+    assert bench.compact_attn({"skipped": "x"}, 1) is None and bench.compact_attn(None, 1) is None
+    assert bench.hgemm_traffic_model(8192, 8192, 8192) == 1744830464
+    assert bench.attn_traffic_model(48, 8192, 1024, 64) == pytest.approx(8.053e9, rel=1e-3)                     # 4 passes, XCD-contiguous
+    assert bench.attn_traffic_model(48, 8192, 1024, 64, round_robin=True) == pytest.approx(14.4955e9, rel=1e-4)   # 8 passes, round-robin
+    assert bench.attn_traffic_model(48, 8192, 512, 128) == pytest.approx(2.4159e9, rel=1e-4)
+    assert bench.attn_traffic_model(128, 4096, 128, 256) == 4 * 128 * 4096 * 128 * 2                            # config 3: one pass = algorithmic
