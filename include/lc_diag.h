@@ -33,6 +33,12 @@ int lc_probe_coissue(int filler, int k, int mode, void* out_u64x16, void* stream
  * (mix 0 none, 1 D = 128, 2 D = 64, 3 / 4 = 2 / 1 without the LDS read, 5 / 6 = 3 / 4 with exp2 as a packed-fp16 polynomial instead of v_exp_f32):
  * out[wave] = cycles of 2048 MFMAs (tools/attn_mix_probe.py) */
 int lc_probe_attn_mix(int waves, int mix, void* out_u64x16, void* stream);
+/* attn_fwd_w4u_kernel<128, false, 0 | 3> compiled with cycle stamps (csrc/diag/attn_w4u_stamps.hip): wave 0 of workgroup 0 records s_memtime at the
+ * milestones of its block — out[0 .. 11] shader cycles (entry, requests issued, Q parked, first tiles landed, first S, tile 0, tiles 1 .. T - 2, last
+ * tile, epilogue barrier, O staged, O stores issued / acknowledged), out[14] / out[15] s_memrealtime (100 MHz) at entry / exit.  nsplit == 1: whole
+ * heads into O; nsplit >= 2: the split-KV walk into partials O [nsplit][B H][N][128] + lse [nsplit][B H][N] (tools/attn_w4u_stamps.py) */
+int lc_diag_attn_w4u_stamps(const void* Q, const void* K, const void* V, void* O, void* lse, int B, int H, int N, int nsplit, void* out_u64x16,
+                            void* stream);
 /* v_mfma_f32_16x16x32_f16 with operands from VGPRs / AGPRs (form 0 all VGPR, 1 A/B AGPR + C/D VGPR, 2 A/B VGPR + C/D AGPR, 3 = 1 and 2
  * alternating, 4 all AGPR): out[wave] = cycles of 4096 MFMAs, one wave per SIMD (tools/attn_mix_probe.py) */
 int lc_probe_mfma_form(int form, void* out_u64x16, void* stream);

@@ -55,6 +55,20 @@ struct W4U {
   static_assert(LDS <= 160 * 1024, "ring + staging must fit a CU's LDS");
 };
 
+// W4U_STAMPS (liblc_diag.so only, csrc/diag/attn_w4u_stamps.hip): s_memtime stamps of wave 0 of workgroup 0 at the milestones of a block,
+// parked in 256 B of LDS behind the kernel's own allocation and copied to g_w4u_stamps at the end (tools/attn_w4u_stamps.py: where the
+// fixed cost of a block goes).  The production library never defines it.
+#ifdef W4U_STAMPS
+static __device__ unsigned long long g_w4u_stamps[32];
+#define W4U_STAMP(k)                                                                                                       \
+  do {                                                                                                                     \
+    if (blockIdx.x == 0 && wave == 0 && lane == 0)                                                                         \
+      *(volatile unsigned long long*)(smem + W4U<D>::LDS + 8 * (k)) = __builtin_readcyclecounter();                         \
+  } while (0)
+#else
+#define W4U_STAMP(k) do { } while (0)
+#endif
+
 template <int D, bool VT, int WALK>
 __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ V,
@@ -75,6 +89,10 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
   const int T = SPLIT ? N / KVB / nsplit : N / KVB;   // KV tiles this workgroup walks (SPLIT: its share of the head's, >= 2)
   const uint32_t smem32 = lds_addr32(smem);
   const size_t head_elems = (size_t)N * D;
+  W4U_STAMP(0);
+#ifdef W4U_STAMPS
+  if (blockIdx.x == 0 && wave == 0 && lane == 0) *(volatile unsigned long long*)(smem + W4U<D>::LDS + 8 * 14) = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- LDS-DMA: piece p = RPP rows x ROWB bytes; this wave stages pieces wave + 4 i (i = 0 .. PPW−1) of K and of V.
   // Lane -> row rr of the piece, 16-B slot cs of the row; the slot receives the logical chunk the read side expects there.
@@ -195,6 +213,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
     for (int i = 0; i < 2 * PPW; ++i) issue_piece(i);
   }
   load_q(bh, q0);
+  W4U_STAMP(1);     // tiles 0, 1 and Q requested
 
   for (;;) {
     // ---- the block after this one (or this one again when there is none: every address stays valid, nothing of it is used)
@@ -237,6 +256,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
       am_acc_write<GQ + 4 * i + 3>(w[3]);
     });
     static_for<16 * NDB>([&](auto r) { am_acc_zero<decltype(r)::value>(); });
+    W4U_STAMP(2);   // Q arrived, converted, parked in AGPRs; O zeroed
 
     uint32_t ka[NDS], vc[NVX], vp[NVX];
     auto set_tile_addrs = [&](int t) {
@@ -277,6 +297,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
 
     // ---- prologue (seam_sync: at the top of the block for the dynamic walk)
     if constexpr (WALK != 2) seam_sync();
+    W4U_STAMP(3);   // tiles 0, 1 landed, barrier passed
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using IB = std::integral_constant<int, NDB / 2>;
@@ -469,10 +490,12 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
     using F_LAST0 = std::integral_constant<int, PERSIST ? (1 | 2 | 8) : (1 | 2)>;   // j = 2T−2: stages "tile T + 1" = the next block's tile 1 (one block per workgroup: nothing left to stage)
     using F_LAST1 = std::integral_constant<int, 1>;
 
+    W4U_STAMP(4);   // first S^T (no P.V to overlap), row max
     set_tile_addrs(0);
     set_dma_tile(2);
     phase(I0{}, F_FIRST0{}, 0, sA, sB, pA, pB);
     phase(I1{}, F_MID1{}, 0, sB, sA, pB, pA);
+    W4U_STAMP(5);   // tile 0's two phases
     for (int t = 1; t + 1 < T; ++t) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       raw_barrier();
@@ -481,6 +504,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
       phase(I0{}, F_MID{}, t, sA, sB, pA, pB);
       phase(I1{}, F_MID1{}, t, sB, sA, pB, pA);
     }
+    W4U_STAMP(6);   // tiles 1 .. T - 2
     {
       const int t = T - 1;
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -506,6 +530,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
         an_pv<GO + 4 * (4 * db + qb)>(cat4(vlo[db], vhi[db]), pB[qb]);
       });
     }
+    W4U_STAMP(7);   // last tile + the P.V that has no Q.K^T to overlap
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (PERSIST) {
       if (has_next) claim_next();      // dynamic walk: the id of the block after next (consumed at the next block's seam)
@@ -517,6 +542,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
     am_drain();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     raw_barrier();                     // every wave is done with ring slots 2, 3
+    W4U_STAMP(8);   // MFMAs drained, epilogue barrier
     float inv[4];
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) {
@@ -541,6 +567,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
       });
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    W4U_STAMP(9);   // O normalised, converted, staged in LDS
     half_t* ow = Ob + (size_t)q0 * D;
     constexpr int LPR = ROWB / 16, RPI = 64 / LPR;
     if (q0 < N) {   // (wave-uniform; false only for waves 2 / 3 of the last query block when N % 256 == 128)
@@ -551,6 +578,15 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
         *(u32x4_t*)(ow + (size_t)row * D + (lane % LPR) * 8) = v;
       }
     }
+    W4U_STAMP(10);  // O stores issued
+#ifdef W4U_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W4U_STAMP(11);  // ... and acknowledged
+    if (blockIdx.x == 0 && wave == 0 && lane == 0) {
+      *(volatile unsigned long long*)(smem + W4U<D>::LDS + 8 * 15) = __builtin_amdgcn_s_memrealtime();
+      for (int i = 0; i < 16; ++i) g_w4u_stamps[i] = *(volatile unsigned long long*)(smem + W4U<D>::LDS + 8 * i);
+    }
+#endif
     if (!has_next) break;
     vb = vbn;
     bh = bhn;
