@@ -67,6 +67,7 @@ DIAG_SYMBOLS = {
     "lc_probe_mfma_war": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "lc_diag_pollute": (_i, [C.c_uint, _i, _vp]),
     "lc_diag_attn_w4i": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "lc_diag_attn_w4u_stamps": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
 }
 
 _lib = None

@@ -203,7 +203,9 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
     raw_barrier();
   };
 
-  // first block: tiles 0, 1 and Q from scratch
+  // first block: tiles 0, 1 and Q from scratch.  (Round 5 tried Q FIRST — vector-memory loads return in order, so Q arrives behind the 64 KiB
+  // of tiles 0 / 1 — and measured nothing: entry -> "tiles landed" 8500 vs 8716 cycles on an idle GPU, level with split-KV, longer on a full
+  // one, where issuing the 16 DMA pieces behind 16 Q loads takes longer: tools/attn_w4u_stamps.py, profiles/r5n_w4u_stamps.log.)
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     d_so = (unsigned)t * TILE;
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) {
       const float lsum = an_x4_sum(l_run[qb]);
-      inv[qb] = 1.0f / lsum;
+      inv[qb] = 1.0f / lsum;   // (IEEE division on purpose: attn_w4i.hip computes the same bits, and the tests compare the two kernels bit for bit)
       if constexpr (SPLIT) {   // base-2 log-sum-exp of this KV range for query row q0 + 16 qb + l16 (scores carry scale * log2 e already)
         if (g4 == 0) lse[((size_t)sp * nbh + bh) * N + q0 + 16 * qb + l16] = __builtin_log2f(lsum) - negm[qb][0];
       }
@@ -555,15 +557,21 @@ __global__ __launch_bounds__(256) void attn_fwd_w4u_kernel(
     char* stg = smem + W4U<D>::EPI_OFF + wave * (64 * G::EPI_STRIDE);
     static_for<4>([&](auto qc) {
       constexpr int qb = decltype(qc)::value;
-      static_for<NDB>([&](auto dc) {
-        constexpr int db = decltype(dc)::value;
-        constexpr int base = GO + 4 * (4 * db + qb);
-        half4_t h;
-        h[0] = (half_t)(am_acc_read<base + 0>() * inv[qb]);
-        h[1] = (half_t)(am_acc_read<base + 1>() * inv[qb]);
-        h[2] = (half_t)(am_acc_read<base + 2>() * inv[qb]);
-        h[3] = (half_t)(am_acc_read<base + 3>() * inv[qb]);
-        *(half4_t*)(stg + (16 * qb + l16) * G::EPI_STRIDE + (16 * db + 4 * g4) * 2) = h;
+      // sixteen accumulators per asm statement (lc_common.h acc_read16; round 5: the one-read-per-statement form was a serial chain of
+      // ~ 15 dependent instructions per four values, 3600 - 4300 cycles per block — tools/attn_w4u_stamps.py)
+      static_for<NDB / 4>([&](auto dc) {
+        constexpr int d0 = 4 * decltype(dc)::value;
+        float x[16];
+        acc_read16<GO + 4 * (4 * d0 + qb), GO + 4 * (4 * (d0 + 1) + qb), GO + 4 * (4 * (d0 + 2) + qb), GO + 4 * (4 * (d0 + 3) + qb)>(x);
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+          half4_t h;
+          h[0] = (half_t)(x[4 * dd + 0] * inv[qb]);
+          h[1] = (half_t)(x[4 * dd + 1] * inv[qb]);
+          h[2] = (half_t)(x[4 * dd + 2] * inv[qb]);
+          h[3] = (half_t)(x[4 * dd + 3] * inv[qb]);
+          *(half4_t*)(stg + (16 * qb + l16) * G::EPI_STRIDE + (16 * (d0 + dd) + 4 * g4) * 2) = h;
+        }
       });
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -188,3 +188,23 @@ LC_DEVINL void static_for(F&& f) { static_for_impl(std::make_integer_sequence<in
   "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234",  \
   "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246",  \
   "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+
+namespace lc {
+// Sixteen accumulator registers -> sixteen VGPRs in ONE asm statement: four groups of four consecutive AGPRs (first registers B0 .. B3).
+// Why one statement (round 5, tools/attn_w4u_stamps.py): an epilogue that reads accumulators one `asm volatile` at a time gets a pad behind
+// every statement and — volatile statements keep their order — a serial read / scale / convert / pack chain on four or five registers: ~ 15
+// dependent instructions per four values, 3600 – 4300 cycles for the 128 values of an attention block's wave, ~ 8000 for the 256 of a GEMM
+// tile's.  Sixteen independent values per statement let hipcc interleave the conversions.  The caller has drained the MFMAs.
+template <int B0, int B1, int B2, int B3>
+LC_DEVINL void acc_read16(float (&x)[16]) {
+  asm volatile("v_accvgpr_read_b32 %0, a[%16]\n\tv_accvgpr_read_b32 %1, a[%17]\n\tv_accvgpr_read_b32 %2, a[%18]\n\tv_accvgpr_read_b32 %3, a[%19]\n\t"
+               "v_accvgpr_read_b32 %4, a[%20]\n\tv_accvgpr_read_b32 %5, a[%21]\n\tv_accvgpr_read_b32 %6, a[%22]\n\tv_accvgpr_read_b32 %7, a[%23]\n\t"
+               "v_accvgpr_read_b32 %8, a[%24]\n\tv_accvgpr_read_b32 %9, a[%25]\n\tv_accvgpr_read_b32 %10, a[%26]\n\tv_accvgpr_read_b32 %11, a[%27]\n\t"
+               "v_accvgpr_read_b32 %12, a[%28]\n\tv_accvgpr_read_b32 %13, a[%29]\n\tv_accvgpr_read_b32 %14, a[%30]\n\tv_accvgpr_read_b32 %15, a[%31]"
+               : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]), "=v"(x[9]), "=v"(x[10]),
+                 "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15])
+               : "n"(B0), "n"(B0 + 1), "n"(B0 + 2), "n"(B0 + 3), "n"(B1), "n"(B1 + 1), "n"(B1 + 2), "n"(B1 + 3), "n"(B2), "n"(B2 + 1), "n"(B2 + 2),
+                 "n"(B2 + 3), "n"(B3), "n"(B3 + 1), "n"(B3 + 2), "n"(B3 + 3)
+               : LC_AGPR_ALL);
+}
+}  // namespace lc

@@ -12,8 +12,6 @@ import torch  # noqa: E402
 from leetcuda_amd import capi  # noqa: E402
 
 lib = capi.load_diag()
-lib.lc_diag_attn_w4u_stamps.restype = C.c_int
-lib.lc_diag_attn_w4u_stamps.argtypes = [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]
 NAMES = ["entry", "tiles 0,1 + Q requested", "Q parked in AGPRs, O zeroed", "tiles landed + barrier", "first S^T + row max", "tile 0 (2 phases)",
          "tiles 1 .. T-2", "last tile + tail P.V", "drain + epilogue barrier", "O staged in LDS", "O stores issued", "O stores acknowledged"]
 specs = sys.argv[1:] or ["1,8,1024", "1,8,1024:4", "1,8,1024:8", "1,4,4096", "1,4,4096:4", "4,32,4096"]
