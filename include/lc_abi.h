@@ -114,8 +114,8 @@ const char* lc_build_info(int* is_diag);
  *                  workgroup), 1 (persistent workgroup per CU, static walk) or 2 (persistent, dynamic per-XCD block queue) — the three compute
  *                  the same bits; 512 = round 2's name for 513; 514 = the same design with every phase as ONE generated asm statement
  *                  (attn_w4i.hip: D = 32 / 64 / 96 / 128, V as [B,H,N,D]; the only merged-phase kernel for D = 96 / 32, where auto picks it);
- *                  8 / 4 / 2 = lock-step kernel with that many waves (any N % (32 x waves) == 0, every D <= 128).  Auto: 515 up to N = 4096,
- *                  513 beyond (D = 64 / 128, N % 256 == 0); 514 for D = 96 / 32; else the lock-step kernel
+ *                  8 / 4 / 2 = lock-step kernel with that many waves (any N % (32 x waves) == 0, every D <= 128).  Auto: 515 up to N = 4096
+ *                  (D = 64: up to N = 8192), 513 beyond (D = 64 / 128, N % 256 == 0); 514 for D = 96 / 32; else the lock-step kernel
  *   "attn_walk"    block walk of the merged-phase kernel under "attn_nw" = 0: 0 = auto by N (above), 1 / 2 / 3 = WALK 0 / 1 / 2
  *   "attn_w4i_sched" schedule 0 / 1 (default) of attn_w4i's generated phase statements (tools/gen_attn_w4i.py; same bits, A/B knob)
  *   "attn_d1024"   D = 1024 pair kernel (attn_bigd4.hip): a batch of 8 LDS-DMA pieces is spread over this many eighths of a half-phase: 0 = default (8), 2 / 4 / 6

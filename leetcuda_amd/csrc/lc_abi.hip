@@ -320,14 +320,14 @@ int launch_attn(const half_t* Q, const half_t* K, const half_t* V, half_t* O, in
 //   8 / 4 / 2        the lock-step kernel with that many waves (attn_fwd.hip: every other shape)
 // 512 (round 2's attn_w4n) is accepted as an alias of 513: attn_w4u<128, false, 0> IS that kernel; 256 / 260 / 516 were retired in
 // round 4 with attn_w4m.hip / attn_w8g.hip.
-int attn_walk_auto(int N) {
-  // auto (lc_tune_set "attn_walk": 0 = this rule; measured, profiles/r3k, profiles/r4c_attn_walks.log): up to N = 4096 the persistent
-  // static walk (round 3: config 3 + 1.7 %, N = 2048 + 1.0 %; round 4's box: + 0.5 % / level), beyond it one block per workgroup — with
-  // 16+ blocks per CU the hardware dispatcher balances better than either walk (N = 8192: static − 1.1 %, dynamic queue − 1.2 %; the
-  // queue is a validated alternative, never the default: a claim one block ahead buys no balance the dispatcher does not already give)
+int attn_walk_auto(int N, int D) {
+  // auto (lc_tune_set "attn_walk": 0 = this rule; measured, profiles/r3k, profiles/r4c_attn_walks.log, r5p_attn_walks.log): up to N = 4096 the
+  // persistent static walk (round 3: config 3 + 1.7 %, N = 2048 + 1.0 %; later boxes: + 0.5 % / level), beyond it one block per workgroup —
+  // with 16+ blocks per CU the hardware dispatcher balances better than either walk (D = 128, N = 8192: static - 1.0 %, dynamic queue - 1.1 %;
+  // the queue is a validated alternative, never the default) — except D = 64, whose blocks are half as long: (1,48,8192,64) static + 1.4 %
   const int k = g_tune_attn_walk;
   if (k >= 1 && k <= 3) return k - 1;
-  return N <= 4096 ? 1 : 0;
+  return (N <= 4096 || (D == 64 && N <= 8192)) ? 1 : 0;
 }
 // Split-KV factor of the merged-phase kernel for a launch of `bh` (batch, head) problems (lc_tune_set "attn_split"; 1 = no split).
 // The kernel owns 256 query rows per workgroup and one workgroup per CU, so g = bh N / 256 workgroups on ncu CUs run ceil(g / ncu)
@@ -374,7 +374,7 @@ int choose_attn_nw(int D, bool vt, int N, long bh = -1) {
       // the 4-wave lock-step kernel's 128-row workgroups fill twice the CUs — (1,32,1024,128) 655 vs 601 TFLOP/s, (1,32,1024,64) 498 vs 444
       // (profiles/r4q_small_grids_d128.log, r5i_small_grids.log); from one full round of blocks on the merged-phase kernel is far ahead (992 vs 760)
       if (bh > 0 && 2 * bh * (N / 256) <= device_cu_count() && N <= 2048 && g_tune_attn_split != 1) return 4;
-      return 513 + 2 * attn_walk_auto(N);
+      return 513 + 2 * attn_walk_auto(N, D);
     }
     if (want == 513 || want == 515 || want == 517) return want;
     if (want == 514 && !vt) return 514;

@@ -380,8 +380,9 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     assert capi.attn_kernel_name(4096 + 64, 128) == "attn_fwd_w4u_kernel<128,false,0>"     # ... and any other N % 64 == 0 (the last block a quarter real)
     assert capi.attn_kernel_name(1024 + 64, 128) == "attn_fwd_kernel<128,2,false,0>"       # N % 128 != 0 below 1152: lock-step
     assert capi.attn_kernel_name(192, 64, True) == "attn_fwd_kernel<64,2,true,0>"
-    assert capi.attn_kernel_name(8192, 64) == "attn_fwd_w4u_kernel<64,false,0>"               # the reference's published shapes
-    assert capi.attn_kernel_name(8192, 64, True) == "attn_fwd_w4u_kernel<64,true,0>"
+    assert capi.attn_kernel_name(8192, 64) == "attn_fwd_w4u_kernel<64,false,1>"               # the reference's published shapes: D = 64 keeps the persistent walk up to N = 8192 (+ 1.4 %)
+    assert capi.attn_kernel_name(8192, 64, True) == "attn_fwd_w4u_kernel<64,true,1>"
+    assert capi.attn_kernel_name(16384, 64) == "attn_fwd_w4u_kernel<64,false,0>"
     assert capi.attn_kernel_name(8192, 96, True) == "attn_fwd_kernel<96,8,true,0>"            # D = 96 / 32 with V transposed: lock-step
     assert capi.attn_kernel_name(8192, 96) == "attn_fwd_w4i_kernel<96,1>"                     # only the generated kernel has a D = 96 instantiation
     assert capi.attn_kernel_name(8192 + 64, 96) == "attn_fwd_kernel<96,2,false,0>"            # N % 256 != 0: lock-step
