@@ -69,6 +69,10 @@ typedef enum lc_hgemm_variant {
   LC_HGEMM_MFMA256W4Y = 13, /* W4X with the K loop as one generated, hand-ordered instruction stream (hgemm_w4y.hip; TN and  */
                             /* NN): what LC_HGEMM_AUTO launches for large shapes.  Unlike the other 256-tile kernels (M, N % 256 == 0, */
                             /* K % 64 == 0) it takes M, N % 128 == 0 (>= 256) and K % 32 == 0 (>= 64): border strips + a half K-step  */
+  LC_HGEMM_MID = 14,        /* the mid-size kernel (hgemm_mid.hip, round 6): (64 | 128) x (128 | 192) x 64 tile, 4 wave64, 2 - 3 slot LDS */
+                            /* ring, hand-ordered asm K loop: LC_HGEMM_AUTO's choice between the eight-wave 128-tile kernel (small     */
+                            /* grids) and the 256-tile kernel (> 128 tiles of 256 x 256) — n = 1280 .. 2816 square — with the tile that */
+                            /* leaves the least work on the busiest CU.  M, N % 64 == 0 (a tile must divide them), K % 32 == 0 (>= 64)  */
   /* the reference's "CUDA-core" ladder as vector-ALU kernels (hgemm_valu.hip; NN only; v_dot2c_f32_f16, fp32 accumulate);
    * shapes a rung does not tile (and TN) run LC_HGEMM_GENERIC */
   LC_HGEMM_VALU_NAIVE = 20,                  /* one thread per C element, operands from global memory                       */
@@ -146,6 +150,10 @@ const char* lc_build_info(int* is_diag);
  *                  range >= 8 tiles), 1 = off, 2 .. 8 = that factor; fp32 partials in the same workspace + a reduce kernel
  *   "hgemm_128w"   waves of LC_HGEMM_MFMA128: 0 = auto (eight — the two k-steps of every K tile on two groups of four waves, summed through LDS at the
  *                  end — on grids of <= 0.6 blocks per CU: + 11 % at 1024^3 / 1536^3; level at 2048^3, slower for NN beyond), 1 = four, 2 = eight
+ *   "hgemm_mid"    LC_HGEMM_AUTO's use of LC_HGEMM_MID: 0 = auto (among the 128 x 128 / 128 x 192 / 64 x 128 / 64 x 192 tiles that divide the
+ *                  problem the one with the least ceil(workgroups / CUs) x tile area), 1 = never, 12 / 13 / 22 / 23 = that tile (rows / 64,
+ *                  columns / 64) whenever it divides the problem (A/B knob; also what an explicit LC_HGEMM_MID then runs)
+ *   "hgemm_mid_ns" LDS ring slots of LC_HGEMM_MID: 0 = auto (3 when the grid is one round of <= one workgroup per CU, else 2), 2, 3
  *   "hgemm_tail"   1 (default) = when the 256-tile grid's last wave holds at most 128 tiles, the generated-loop kernel computes the
  *                  full waves and the 128-tile kernel the four quadrants of each remaining tile; 0 = one launch
  *   "hgemm_raster" block -> C tile map of the tiled GEMM kernels: 0 = auto (2 when A + B exceed the 256 MiB Infinity Cache by half,
@@ -171,6 +179,14 @@ int lc_tune_set(const char* key, int value);
 int lc_tune_get(const char* key, int* value, int* default_value);
 int lc_tune_count(void);
 const char* lc_tune_key(int index);
+
+/* Internal workspace (split-KV attention partials, split-K border strips of the GEMM): one cached device buffer per
+ * (device, stream), grown geometrically, at most 16 per device and 1 GiB each; requests beyond that and launches on a stream that is
+ * being captured run the workspace-free form of the same computation.  lc_workspace_bytes: bytes currently cached over all devices;
+ * lc_workspace_release: hipFree every cached buffer (waits for the devices), returns the bytes given back — for callers that want
+ * the memory back after a phase of small-grid launches.  Neither has a reference counterpart (its kernels allocate nothing). */
+size_t lc_workspace_release(void);
+size_t lc_workspace_bytes(void);
 
 /* ---- HGEMM ------------------------------------------------------------------------------------
  * Replaces the host launchers + kernels of kernels/hgemm/mma/basic/hgemm_mma_stage.cu:644-1052,2284-2412

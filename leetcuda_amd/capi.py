@@ -16,6 +16,7 @@ LAYOUT_NN, LAYOUT_TN = 0, 1
 HGEMM_AUTO, HGEMM_MFMA256, HGEMM_GENERIC, HGEMM_MFMA256P2, HGEMM_MFMA128 = 0, 1, 3, 4, 6
 HGEMM_VALU_NAIVE, HGEMM_VALU_SLICED_K, HGEMM_VALU_T8X8_X4, HGEMM_VALU_T16X8_K32 = 20, 21, 22, 30   # the VALU ladder: 20..30
 HGEMM_MFMA256W4B, HGEMM_MFMA256W4C, HGEMM_MFMA256W4X, HGEMM_MFMA256W4Y = 9, 10, 12, 13
+HGEMM_MID = 14   # the one-round kernel (hgemm_mid.hip)
 ATTN_SPLIT_Q, ATTN_SHARED_QKV, ATTN_SHARED_KV, ATTN_TILING_QK, ATTN_TILING_QKV, ATTN_SPLIT_KV = range(6)
 
 # every symbol include/lc_abi.h declares: name -> (restype, argtypes)
@@ -29,6 +30,8 @@ SYMBOLS = {
     "lc_tune_get": (_i, [_cp, _ip, _ip]),
     "lc_tune_count": (_i, []),
     "lc_tune_key": (_cp, [_i]),
+    "lc_workspace_release": (C.c_size_t, []),
+    "lc_workspace_bytes": (C.c_size_t, []),
     "lc_hgemm_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "lc_vendor_init": (_i, []),
     "lc_vendor_destroy": (_i, []),
@@ -218,6 +221,16 @@ def tune_items():
         if k:
             out[k.decode()] = tune_get(k.decode())
     return out
+
+
+def workspace_bytes() -> int:
+    """Bytes of internal workspace (split-KV / split-K partials) currently cached, all devices."""
+    return int(load().lc_workspace_bytes())
+
+
+def workspace_release() -> int:
+    """hipFree every cached workspace buffer (waits for the devices); returns the bytes given back."""
+    return int(load().lc_workspace_release())
 
 
 def device_check() -> int:

@@ -47,6 +47,8 @@ tune_t g_tune_attn_walk{0};                  // block walk of the merged-phase k
 tune_t g_tune_attn_split{0};                 // split-KV of the merged-phase kernel on grids that do not fill the GPU: 0 = auto (attn_split_auto), 1 = off, 2 / 4 / 8 / 16 = that many KV ranges per query block
 tune_t g_tune_hgemm_auto{LC_HGEMM_MFMA256W4Y};   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
 tune_t g_tune_hgemm_splitk{0};                 // split-K of the 128-tile blocks that serve border strips / the ragged last wave: 0 = auto (launch_mfma256), 1 = off, 2 .. 8 = that factor
+tune_t g_tune_hgemm_mid{0};                    // mid-size kernel (hgemm_mid.hip): 0 = auto (mid_tile_auto), 1 = never, 12 / 13 / 22 / 23 = that tile (rows / 64, columns / 64)
+tune_t g_tune_hgemm_mid_ns{0};                 // ... its LDS ring slots: 0 = auto (3 for one-round grids, else 2), 2, 3
 tune_t g_tune_hgemm_128w{0};                   // waves of the 128-tile kernel: 0 = auto (eight — intra-workgroup split-K — on grids of <= 0.6 blocks per CU), 1 = always four, 2 = always eight
 tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to the 128-tile kernel (launch_mfma256), 0 = one launch
 tune_t g_tune_hgemm_raster{0};                 // block -> C tile map: 0 = auto (by operand footprint, panel_tiles), 1 = the reference's block swizzle (N panels from
@@ -289,6 +291,50 @@ int launch_mfma128(const half_t* A, const half_t* B, half_t* C, int M, int N, in
                                      nullptr, st);
 }
 
+// The mid-size kernel (hgemm_mid.hip; lc_tune_set "hgemm_mid", "hgemm_mid_ns"): which tile serves this shape, tmw == 0 = not this kernel.
+// Auto = hipBLASLt's own heuristic for these sizes read off its kernel names (profiles/r6a_vendor_kernels.log) and measured here tile by
+// tile (profiles/r6c_hgemm_mid_ab.log): when a tile's grid fits ONE ROUND of at most one workgroup per CU, the smallest such tile — most
+// workgroups, least work on the busiest CU — with three ring slots (the DMA two tiles ahead): 64 x 128 at 1024 / 1280, 64 x 192 at 1536
+// TN, 128 x 128 at 1536 NN / 1792 / 2048, 128 x 192 at 2304 TN (the 64-row tiles lose to the 128-row ones as soon as both need more than a
+// round: 2304 NN 780 vs 866 TFLOP/s, 2560 646 vs 983); otherwise 128 x 128 with two slots and two workgroups per CU (2304 NN, 2560, 2816).
+// `gated` (LC_HGEMM_AUTO): only where the 256-tile kernel does not apply anyway (resolve_hgemm_variant: <= 128 tiles of 256 x 256) and the
+// 128 x 128 grid holds more than kMidMinBlocks blocks (below — 768^3: 36 blocks, level — the eight-wave 128-tile kernel keeps the shape).
+struct MidTile { int tmw, tnw, ns; };
+constexpr int kMidMinBlocks = 48;
+MidTile mid_tile_auto(int M, int N, int K, bool b_kn, bool gated) {
+  MidTile none{0, 0, 0};
+  if (M % 64 != 0 || N % 64 != 0 || K % 32 != 0 || K < BK || K >= (1 << 22) || N >= (1 << 22)) return none;
+  const int k = g_tune_hgemm_mid, kns = g_tune_hgemm_mid_ns;
+  if (k == 1 && gated) return none;
+  const long ncu = device_cu_count();
+  if (gated && ((long)(M / 128) * (N / 128) <= kMidMinBlocks || M % 128 != 0 || N % 128 != 0)) return none;
+  MidTile best = none, big = none;   // best one-round tile; largest legal tile (the multi-round choice)
+  long best_area = 0, big_area = 0;
+  for (int tmw = 2; tmw >= 1; --tmw)
+    for (int tnw = 2; tnw <= 3; ++tnw) {
+      if (k >= 10 && k != 10 * tmw + tnw) continue;
+      if (M % (64 * tmw) != 0 || N % (64 * tnw) != 0 || (b_kn && tnw != 2)) continue;
+      const long wgs = (long)(M / (64 * tmw)) * (N / (64 * tnw)), area = 4096L * tmw * tnw;
+      if (wgs <= ncu && (best.tmw == 0 || area < best_area)) {
+        best = MidTile{tmw, tnw, 3};
+        best_area = area;
+      }
+      // multi-round: 128 x 128 before 128 x 192 (one workgroup per CU by registers) before the 64-row tiles
+      const long rank = (tmw == 2 && tnw == 2) ? 4 : (tmw == 2 ? 3 : tnw);
+      if (big.tmw == 0 || rank > big_area) {
+        big = MidTile{tmw, tnw, 2};
+        big_area = rank;
+      }
+    }
+  MidTile t = best.tmw ? best : big;
+  if (t.tmw && (kns == 2 || kns == 3)) t.ns = kns;
+  return t;
+}
+int launch_mid(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, MidTile t, int swizzle_stride, hipStream_t st) {
+  const int pw = panel_tiles(swizzle_stride, N / (64 * t.tnw), 64 * t.tnw, ((size_t)M + N) * K * 2);
+  return launch_hgemm_mid(A, B, C, M, N, K, b_kn, t.tmw, t.tnw, t.ns, pw, st);
+}
+
 template <bool B_KN>
 int launch_generic(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, hipStream_t st) {
   const dim3 grid((N + GN - 1) / GN, (M + GM - 1) / GM), block(256);
@@ -348,13 +394,15 @@ int attn_split_auto(int D, int N, long bh) {
   const int k = g_tune_attn_split;
   if ((D != 128 && D != 64) || N % 256 != 0 || bh <= 0 || k == 1) return 1;
   const int T = N / 64;
-  if (k >= 2) return (T % k == 0 && T / k >= 2) ? k : 1;
+  const double part = 4.0 * (double)bh * N * D;   // bytes of one range's partial O, written + read
+  const double part_cap = 2.0 * ((size_t)256 << 20);   // partials <= 256 MiB, forced factor or auto (round-5 advisor: a forced 16 on config 4 asked for 34 GiB)
+  if (k >= 2) return (T % k == 0 && T / k >= 2 && k * part <= part_cap) ? k : 1;
   const long ncu = device_cu_count(), g = bh * (N / 256);
-  const double tau = D == 128 ? 1.35 : 0.85, part = 4.0 * (double)bh * N * D;   // bytes of one range's partial O, written + read
+  const double tau = D == 128 ? 1.35 : 0.85;
   int best = 1;
   const double t1 = (double)((g + ncu - 1) / ncu) * T * tau;
   double tbest = 0.95 * t1;
-  for (int S = 2; S <= 16 && T % S == 0 && T / S >= kMinSplitTiles && S * part <= 2.0 * ((size_t)256 << 20); S *= 2) {
+  for (int S = 2; S <= 16 && T % S == 0 && T / S >= kMinSplitTiles && S * part <= part_cap; S *= 2) {
     const double t = (double)((g * S + ncu - 1) / ncu) * (T / S) * tau + kSplitFixedUs + S * part / kSplitBytesPerUs;
     if (t < tbest) {
       tbest = t;
@@ -363,13 +411,20 @@ int attn_split_auto(int D, int N, long bh) {
   }
   return best;
 }
-int choose_attn_nw(int D, bool vt, int N, long bh = -1) {
+// *nsplit (when given) receives the split-KV factor that goes with a 519 answer, 1 otherwise: the launcher must not evaluate the rule a
+// second time (round-5 advisor: a concurrent lc_tune_set between the two reads could pair walk 3 with one range).
+int choose_attn_nw(int D, bool vt, int N, long bh = -1, int* nsplit = nullptr) {
   int want = g_tune_attn_nw;   // 0 = auto (read once per launch)
   if (want == 512) want = 513;
+  if (nsplit) *nsplit = 1;
   const bool merged = (D == 128 || D == 64) && N % 256 == 0;
   if (merged && g_tune_attn_ablate == 0) {
     if (want == 0) {
-      if (attn_split_auto(D, N, bh) > 1) return 519;
+      const int ns = attn_split_auto(D, N, bh);
+      if (ns > 1) {
+        if (nsplit) *nsplit = ns;
+        return 519;
+      }
       // Small grids the split rule leaves alone (too few KV tiles for the combine to pay): up to half a GPU of 256-row blocks and N <= 2048
       // the 4-wave lock-step kernel's 128-row workgroups fill twice the CUs — (1,32,1024,128) 655 vs 601 TFLOP/s, (1,32,1024,64) 498 vs 444
       // (profiles/r4q_small_grids_d128.log, r5i_small_grids.log); from one full round of blocks on the merged-phase kernel is far ahead (992 vs 760)
@@ -395,11 +450,11 @@ int choose_attn_nw(int D, bool vt, int N, long bh = -1) {
 template <int D, bool VT>
 int launch_attn_nw(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N,
                    hipStream_t st) {
-  const int nw = choose_attn_nw(D, VT, N, (long)B * H);
+  int ns = 1;
+  const int nw = choose_attn_nw(D, VT, N, (long)B * H, &ns);
   if constexpr (D == 128 || D == 64) {
     if (nw == 513 || nw == 515 || nw == 517 || nw == 519) {
-      const int walk = (nw - 513) / 2;
-      const int ns = walk == 3 ? attn_split_auto(D, N, (long)B * H) : 1;   // (519 = split-KV: auto only)
+      const int walk = (nw - 513) / 2;   // (519 = split-KV with ns ranges: auto only)
       if constexpr (D == 128) return VT ? launch_attn_w4u_d128t(Q, K, V, O, B, H, N, walk, ns, st) : launch_attn_w4u_d128(Q, K, V, O, B, H, N, walk, ns, st);
       else return VT ? launch_attn_w4u_d64t(Q, K, V, O, B, H, N, walk, ns, st) : launch_attn_w4u_d64(Q, K, V, O, B, H, N, walk, ns, st);
     }
@@ -542,7 +597,7 @@ namespace {
 bool is_tile256_variant(int v) { return v == LC_HGEMM_MFMA256 || v == LC_HGEMM_MFMA256P2 || is_w4_variant(v); }
 bool is_valu_variant(int v) { return v >= LC_HGEMM_VALU_NAIVE && v <= LC_HGEMM_VALU_T16X8_K32; }
 bool is_hgemm_variant(int v) {
-  return v == LC_HGEMM_AUTO || v == LC_HGEMM_GENERIC || v == LC_HGEMM_MFMA128 || is_tile256_variant(v) || is_valu_variant(v);
+  return v == LC_HGEMM_AUTO || v == LC_HGEMM_GENERIC || v == LC_HGEMM_MFMA128 || v == LC_HGEMM_MID || is_tile256_variant(v) || is_valu_variant(v);
 }
 }  // namespace
 
@@ -567,6 +622,7 @@ int resolve_hgemm_variant(int variant, int M, int N, int K, bool al, bool b_kn) 
     const long wg256 = (long)(M / BM) * (N / BN);
     const int a = g_tune_hgemm_auto;
     if (wg256 > 128 && (tiles256 || (a == LC_HGEMM_MFMA256W4Y && w4y_ok))) return a;
+    if (tiles128 && mid_tile_auto(M, N, K, b_kn, true).tmw > 0) return LC_HGEMM_MID;   // the tile with the least work on the busiest CU (n = 1280 .. 2816 square)
     return tiles128 ? LC_HGEMM_MFMA128 : LC_HGEMM_GENERIC;
   }
   if (is_valu_variant(variant)) {   // a rung of the vector-ALU ladder: its own tile, else the edge kernel (never an error)
@@ -578,6 +634,7 @@ int resolve_hgemm_variant(int variant, int M, int N, int K, bool al, bool b_kn) 
   if (variant == LC_HGEMM_MFMA256W4Y && w4y_ok) return variant;
   if (is_tile256_variant(variant) && !tiles256) return LC_ERR_SHAPE;
   if (variant == LC_HGEMM_MFMA128 && !tiles128) return LC_ERR_SHAPE;
+  if (variant == LC_HGEMM_MID && !(al && mid_tile_auto(M, N, K, b_kn, false).tmw > 0)) return LC_ERR_SHAPE;
   return variant;
 }
 }  // namespace
@@ -600,7 +657,10 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
     else snprintf(buf, buflen, "hgemm_w4b_kernel<%s,%s,0>", nn, v == LC_HGEMM_MFMA256W4B ? "false" : "true");
   } else if (v == LC_HGEMM_MFMA256P2) snprintf(buf, buflen, "hgemm_pingpong2_kernel<%s,false>", nn);
   else if (v == LC_HGEMM_MFMA256) snprintf(buf, buflen, "hgemm_mfma256_kernel<%s>", nn);
-  else if (v == LC_HGEMM_MFMA128) snprintf(buf, buflen, "hgemm_mfma128_kernel<%s,%d>", nn, mfma128_ksw((long)(M / BM1) * (N / BN1)));
+  else if (v == LC_HGEMM_MID) {
+    const MidTile t = mid_tile_auto(M, N, K, layout == LC_LAYOUT_NN, variant != LC_HGEMM_MID);
+    snprintf(buf, buflen, "hgemm_mid_kernel<%s,%d,%d,%d>", nn, t.tmw, t.tnw, t.ns);
+  } else if (v == LC_HGEMM_MFMA128) snprintf(buf, buflen, "hgemm_mfma128_kernel<%s,%d>", nn, mfma128_ksw((long)(M / BM1) * (N / BN1)));
   else snprintf(buf, buflen, "hgemm_generic_kernel<%s>", nn);
   return LC_OK;
 }
@@ -659,6 +719,8 @@ bool ok_02(int v) { return v >= 0 && v <= 2; }
 bool ok_03(int v) { return v >= 0 && v <= 3; }
 bool ok_04(int v) { return v >= 0 && v <= 4; }
 bool ok_08(int v) { return v >= 0 && v <= 8; }
+bool ok_mid_ns(int v) { return v == 0 || v == 2 || v == 3; }
+bool ok_mid(int v) { return v == 0 || v == 1 || v == 12 || v == 13 || v == 22 || v == 23; }
 bool ok_split(int v) { return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16; }
 bool ok_span8(int v) { return v == 0 || v == 2 || v == 4 || v == 6; }
 bool ok_w4y_sched(int v) {
@@ -694,6 +756,8 @@ const Knob kKnobs[] = {
     {"hgemm_stagger", &g_tune_hgemm_stagger, 0, ok_stagger, false},
     {"hgemm_tail", &g_tune_hgemm_tail, 1, ok_01, false},
     {"hgemm_128w", &g_tune_hgemm_128w, 0, ok_02, false},
+    {"hgemm_mid", &g_tune_hgemm_mid, 0, ok_mid, false},
+    {"hgemm_mid_ns", &g_tune_hgemm_mid_ns, 0, ok_mid_ns, false},
     {"hgemm_splitk", &g_tune_hgemm_splitk, 0, ok_08, false},
     {"hgemm_raster", &g_tune_hgemm_raster, 0, ok_02, false},
     {"hgemm_auto", &g_tune_hgemm_auto, LC_HGEMM_MFMA256W4Y, ok_auto, false},
@@ -730,6 +794,8 @@ int lc_tune_get(const char* key, int* value, int* default_value) {
 }
 
 int lc_tune_count(void) { return (int)(sizeof(kKnobs) / sizeof(kKnobs[0])); }
+size_t lc_workspace_release(void) { return workspace_release_all(); }
+size_t lc_workspace_bytes(void) { return workspace_cached_bytes(); }
 const char* lc_tune_key(int index) {
   if (index < 0 || index >= lc_tune_count()) return nullptr;
 #ifndef LC_DIAG
@@ -760,9 +826,15 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   const half_t* b = static_cast<const half_t*>(B);
   half_t* c = static_cast<half_t*>(C);
   const bool al = aligned16(A) && aligned16(B) && aligned16(C);
+  const bool mid_forced = variant == LC_HGEMM_MID;
   variant = resolve_hgemm_variant(variant, M, N, K, al, layout == LC_LAYOUT_NN);
   if (variant < 0) return variant;
   if (int rc = launch_guard()) return rc;   // a sticky HIP error of an earlier call: report it, launch nothing
+  if (variant == LC_HGEMM_MID) {
+    const MidTile t = mid_tile_auto(M, N, K, layout == LC_LAYOUT_NN, !mid_forced);
+    if (t.tmw > 0) return launch_mid(a, b, c, M, N, K, layout == LC_LAYOUT_NN, t, swizzle_stride, st);
+    variant = LC_HGEMM_MFMA128;   // (the knob changed between the two reads: every LC_HGEMM_MID shape is a 128-tile shape)
+  }
   if (is_valu_variant(variant)) {
     if (layout == LC_LAYOUT_NN) return launch_valu_rung(a, b, c, M, N, K, variant, st);
     variant = LC_HGEMM_GENERIC;   // the ladder is NN only

@@ -54,45 +54,70 @@ inline int device_cu_count() {
 }
 
 // Scratch workspace for the two launch sequences that need partial results in HBM (split-KV attention: attn_w4u.hip WALK 3;
-// split-K border strips of the GEMM: hgemm_mfma128.hip): one cached buffer per (device, stream), grown on demand, at most 16 of them
+// split-K border strips of the GEMM: hgemm_mfma128.hip): one cached buffer per (device, stream), grown on demand, at most 16 per device
 // (least recently used evicted).  Why not hipMallocAsync per call: measured (profiles/r5a_attn_split.log) the allocation + free pair
 // costs about as much as the whole attention of a (1,8,1024,128) problem.  Safety: successive users on ONE stream are ordered by the
-// stream; different streams never share a buffer; the lease holds a process-wide mutex until the caller has enqueued its last kernel,
-// so two host threads enqueueing on the same stream cannot interleave their sequences.  hipMalloc / hipFree are illegal while a stream
-// is being captured — callers check hipStreamIsCapturing first and take their workspace-free path.  Nothing is freed at exit.
+// stream; different streams never share a buffer; the lease holds THE DEVICE's mutex until the caller has enqueued its last kernel, so
+// two host threads enqueueing on the same stream cannot interleave their sequences — and (round 6, advisor) threads that drive
+// DIFFERENT GPUs no longer serialise on one process-wide lock.  Growth is geometric (a regrow frees the old buffer, which waits for
+// the device: a sequence of slowly growing shapes regrows O(log) times, not once per shape), requests beyond kWorkspaceCapBytes are
+// refused (the callers then run their workspace-free form), and lc_workspace_release() (C-ABI) gives everything back.  hipMalloc /
+// hipFree are illegal while THIS stream is being captured — callers check stream_is_capturing first and take their workspace-free
+// path — and "potentially unsafe" while ANOTHER thread captures in the global mode (torch's default): the allocation runs under a
+// relaxed thread capture mode (hipThreadExchangeStreamCaptureMode), the idiom of torch's own caching allocator, so a first-use
+// allocation here cannot invalidate somebody else's capture.  Nothing is freed at exit.
 struct WorkspaceLease {
   std::unique_lock<std::mutex> lock;
   void* ptr = nullptr;
 };
+constexpr size_t kWorkspaceCapBytes = (size_t)1 << 30;   // per buffer; the split rules stay far below (partials <= 256 MiB)
+struct WorkspaceEntry { hipStream_t st; void* p; size_t bytes; unsigned long long tick; };
+struct WorkspacePool {
+  std::mutex mu;
+  std::vector<WorkspaceEntry> entries;
+  unsigned long long tick = 0;
+};
+inline WorkspacePool& workspace_pool(int dev) {
+  static WorkspacePool pools[64];
+  return pools[(dev >= 0 && dev < 64) ? dev : 0];
+}
+struct RelaxedCaptureMode {   // hipMalloc / hipFree while another thread's global-mode capture is open
+  hipStreamCaptureMode prev = hipStreamCaptureModeRelaxed;
+  bool ok;
+  RelaxedCaptureMode() { ok = hipThreadExchangeStreamCaptureMode(&prev) == hipSuccess; if (!ok) (void)hipGetLastError(); }
+  ~RelaxedCaptureMode() { if (ok) (void)hipThreadExchangeStreamCaptureMode(&prev); }
+};
 inline WorkspaceLease stream_workspace(hipStream_t st, size_t bytes) {
-  struct Entry { int dev; hipStream_t st; void* p; size_t bytes; unsigned long long tick; };
-  static std::mutex mu;
-  static std::vector<Entry> pool;
-  static unsigned long long tick = 0;
   WorkspaceLease lease;
-  lease.lock = std::unique_lock<std::mutex>(mu);
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return lease;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return lease;
+  }
+  WorkspacePool& pool = workspace_pool(dev);
+  lease.lock = std::unique_lock<std::mutex>(pool.mu);
+  if (bytes == 0 || bytes > kWorkspaceCapBytes) return lease;
   bytes = (bytes + ((size_t)1 << 22) - 1) & ~(((size_t)1 << 22) - 1);   // 4 MiB granules: a slightly larger next shape re-uses the buffer
-  Entry* e = nullptr;
-  for (auto& x : pool)
-    if (x.dev == dev && x.st == st) e = &x;
+  WorkspaceEntry* e = nullptr;
+  for (auto& x : pool.entries)
+    if (x.st == st) e = &x;
   if (e && e->bytes >= bytes) {
-    e->tick = ++tick;
+    e->tick = ++pool.tick;
     lease.ptr = e->p;
     return lease;
   }
-  if (!e && pool.size() >= 16) {   // evict the least recently used buffer (hipFree waits for the device: no kernel still reads it)
+  RelaxedCaptureMode relaxed;
+  if (!e && pool.entries.size() >= 16) {   // evict the least recently used buffer (hipFree waits for the device: no kernel still reads it)
     size_t lru = 0;
-    for (size_t i = 1; i < pool.size(); ++i)
-      if (pool[i].tick < pool[lru].tick) lru = i;
-    int cur = dev;
-    (void)hipSetDevice(pool[lru].dev);
-    (void)hipFree(pool[lru].p);
-    (void)hipSetDevice(cur);
-    pool.erase(pool.begin() + lru);
+    for (size_t i = 1; i < pool.entries.size(); ++i)
+      if (pool.entries[i].tick < pool.entries[lru].tick) lru = i;
+    (void)hipFree(pool.entries[lru].p);
+    pool.entries.erase(pool.entries.begin() + lru);
   }
   if (e) {
+    size_t grown = e->bytes + e->bytes / 2;   // geometric: at least 1.5 x the old size
+    grown = (grown + ((size_t)1 << 22) - 1) & ~(((size_t)1 << 22) - 1);
+    if (grown > bytes && grown <= kWorkspaceCapBytes) bytes = grown;
     (void)hipFree(e->p);   // (device-synchronising: the stream's earlier users are done with it)
     e->p = nullptr;
     e->bytes = 0;
@@ -100,18 +125,50 @@ inline WorkspaceLease stream_workspace(hipStream_t st, size_t bytes) {
   void* p = nullptr;
   if (hipMalloc(&p, bytes) != hipSuccess || !p) {
     (void)hipGetLastError();
-    if (e) pool.erase(pool.begin() + (e - pool.data()));
+    if (e) pool.entries.erase(pool.entries.begin() + (e - pool.entries.data()));
     return lease;
   }
   if (e) {
     e->p = p;
     e->bytes = bytes;
-    e->tick = ++tick;
+    e->tick = ++pool.tick;
   } else {
-    pool.push_back(Entry{dev, st, p, bytes, ++tick});
+    pool.entries.push_back(WorkspaceEntry{st, p, bytes, ++pool.tick});
   }
   lease.ptr = p;
   return lease;
+}
+// Gives every cached workspace buffer of every device back (lc_workspace_release; waits for the devices).  Returns the bytes freed.
+inline size_t workspace_release_all() {
+  size_t freed = 0;
+  int cur = 0;
+  const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+  RelaxedCaptureMode relaxed;
+  for (int dev = 0; dev < 64; ++dev) {
+    WorkspacePool& pool = workspace_pool(dev);
+    std::lock_guard<std::mutex> g(pool.mu);
+    if (pool.entries.empty()) continue;
+    if (hipSetDevice(dev) != hipSuccess) {
+      (void)hipGetLastError();
+      continue;
+    }
+    for (auto& x : pool.entries) {
+      (void)hipFree(x.p);
+      freed += x.bytes;
+    }
+    pool.entries.clear();
+  }
+  if (have_cur) (void)hipSetDevice(cur);
+  return freed;
+}
+inline size_t workspace_cached_bytes() {
+  size_t n = 0;
+  for (int dev = 0; dev < 64; ++dev) {
+    WorkspacePool& pool = workspace_pool(dev);
+    std::lock_guard<std::mutex> g(pool.mu);
+    for (auto& x : pool.entries) n += x.bytes;
+  }
+  return n;
 }
 inline bool stream_is_capturing(hipStream_t st) {
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -127,6 +184,7 @@ inline bool stream_is_capturing(hipStream_t st) {
 // while another launches is a data race on a plain int; a launch reads each knob ONCE into a local and decides from that.
 using tune_t = std::atomic<int>;
 extern tune_t g_tune_attn_ablate, g_tune_w4_abl, g_tune_hgemm_stamps;
+extern tune_t g_tune_hgemm_mid, g_tune_hgemm_mid_ns;   // one-round kernel: tile / ring depth (lc_tune_set "hgemm_mid", "hgemm_mid_ns")
 extern tune_t g_tune_attn_d512;   // D = 256 / 512 attention kernel choice (lc_tune_set "attn_d512")
 extern tune_t g_tune_attn_bigd_stagger;   // attn_bigd4: the KV walk of XCD x starts x eighths in: 0 = auto (with the round-robin map), 1 = off, 2 = on
 extern tune_t g_tune_attn_bigd_map;     // query-block map of attn_bigd4 / attn_bigd6: 0 = auto (D = 1024 round-robin over the XCDs, D = 512 XCD-contiguous), 1 = contiguous, 2 = round-robin
@@ -150,6 +208,9 @@ extern tune_t g_tune_w4y_sched;   // schedule of hgemm_w4y_kernel's generated lo
 // tu_w4.hip: LC_HGEMM_MFMA256W4 / W4S / W4B / W4C (M, N % 256 == 0, K % 64 == 0 checked by the caller)
 int w4_effective_variant(int variant, bool b_kn, int N, int K);   // W4C / W4X / W4Y -> W4B when 32-bit DMA offsets could overflow
 // nblk > 0: launch only the first nblk blocks (hgemm_w4y_kernel only; the caller hands the remaining raster ids to the 128-tile kernel)
+// the mid-size kernel (hgemm_mid.hip, tu_mid.hip): (64 tmw) x (64 tnw) tiles, ns ring slots
+int launch_hgemm_mid(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int tmw, int tnw, int ns, int pw,
+                     hipStream_t st);
 int launch_w4_family(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant, bool b_kn,
                      int tiles_m, int tiles_n, int panel_w, int nblk, hipStream_t st);
 // tu_valu.hip: the vector-ALU ladder (hgemm_valu.hip), rung = LC_HGEMM_VALU_*

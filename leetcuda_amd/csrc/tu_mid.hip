@@ -1,0 +1,38 @@
+// tu_mid.hip — translation unit of the mid-size HGEMM kernel (hgemm_mid.hip) — see lc_launch.h
+#include "lc_launch.h"
+#include "hgemm_mid.hip"
+
+namespace lc {
+namespace {
+template <bool B_KN, int TMW, int TNW, int NS>
+int launch_mid_one(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int pw, hipStream_t st) {
+  using G = Mid<TMW, TNW, NS>;
+  auto kern = hgemm_mid_kernel<B_KN, TMW, TNW, NS>;
+  if (int rc = set_dyn_lds(kern, G::LDS)) return rc;
+  const int tiles_m = M / G::TM, tiles_n = N / G::TN;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), G::LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
+  return check_launch();
+}
+template <bool B_KN, int TMW, int TNW>
+int launch_mid_ns(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int ns, int pw, hipStream_t st) {
+  if (ns == 2) return launch_mid_one<B_KN, TMW, TNW, 2>(A, B, C, M, N, K, pw, st);
+  if (ns == 3) return launch_mid_one<B_KN, TMW, TNW, 3>(A, B, C, M, N, K, pw, st);
+  return LC_ERR_ARG;
+}
+template <bool B_KN, int TNW>
+int launch_mid_tm(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int tmw, int ns, int pw, hipStream_t st) {
+  if (tmw == 1) return launch_mid_ns<B_KN, 1, TNW>(A, B, C, M, N, K, ns, pw, st);
+  return launch_mid_ns<B_KN, 2, TNW>(A, B, C, M, N, K, ns, pw, st);
+}
+}  // namespace
+
+// tmw: 1 / 2 = 64 / 128 tile rows; tnw: 2 / 3 = 128 / 192 tile columns (NN: 2); ns: ring slots 2 / 3; pw: block -> tile map (panel_tiles, lc_abi.hip)
+int launch_hgemm_mid(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int tmw, int tnw, int ns, int pw,
+                     hipStream_t st) {
+  if (tmw < 1 || tmw > 2 || tnw < 2 || tnw > 3 || (b_kn && tnw != 2)) return LC_ERR_ARG;
+  if (M % (64 * tmw) != 0 || N % (64 * tnw) != 0 || K % 32 != 0 || K < BK || K >= (1 << 22) || N >= (1 << 22)) return LC_ERR_SHAPE;
+  if (b_kn) return launch_mid_tm<true, 2>(A, B, C, M, N, K, tmw, ns, pw, st);
+  if (tnw == 2) return launch_mid_tm<false, 2>(A, B, C, M, N, K, tmw, ns, pw, st);
+  return launch_mid_tm<false, 3>(A, B, C, M, N, K, tmw, ns, pw, st);
+}
+}  // namespace lc

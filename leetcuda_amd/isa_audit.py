@@ -18,7 +18,7 @@ one does not hold:
       another statement — so hipcc may use them between two executions of it; until round 4 the rule covered them too, vacuously.)
   R3  no compiler instruction reads or writes the destination registers of an asm-issued LDS / global load between
       the load and the next `s_waitcnt ... lgkmcnt(0)` / `vmcnt(0)` that retires it
-  R5  no non-MFMA instruction names an arch VGPR written by an asm-issued MFMA before the MFMA's result latency has
+  R5  no non-MFMA instruction names an arch VGPR — and (round 6) no compiler-emitted v_accvgpr_* an AGPR — written by an asm-issued MFMA before the MFMA's result latency has
       passed (MFMA_STATES wait states, counted conservatively: s_nop N = N + 1, an MFMA = 4, anything else = 1).  hipcc
       does not know that the statement is an MFMA and inserts no wait states; the hardware does not interlock; a bare
       `asm volatile("s_nop ...")` is no fence for compiler-scheduled VALU code (the round-2 attention kernels read Sᵀ one
@@ -32,7 +32,11 @@ one does not hold:
   branch target are re-checked with the state as it stands at the branch — the hazard between the last instructions of a loop
   body and the first of the next iteration.  Forward branches (the if / else of the overflow slow paths)
   are still followed in file order only: the fall-through state reaches the join, the taken-branch state does not; the
-  bit-equality / determinism GPU tests remain the guard for those.
+  bit-equality / determinism GPU tests remain the guard for those.  One exception (round 6): a label that
+  file order cannot reach by fall-through — the instruction in front of it is an unconditional `s_branch` / `s_endpgm` — starts from
+  the state recorded at the forward branch(es) that target it (union of their hazards; the longest LDS queue) instead of the state of
+  the unrelated block that happens to precede it in the file (hipcc lays cold prologue / tail blocks out behind the loop they belong
+  in front of: hgemm_mid_kernel's K < NS tiles prologue sits behind its loop body).
   R6  no asm-issued MFMA reads an arch VGPR that a VALU instruction wrote fewer than VALU_TO_MFMA_STATES wait states
       earlier (hipcc pads this for its own MFMAs — LLVM's "legacy VALU write VGPR -> MFMA read" rule — but not in front of
       an asm statement: a v_cvt_pk of the P fragment scheduled right in front of the statement that consumes it made
@@ -119,6 +123,11 @@ def _step(st, cur, path, rec, owned, owned_v, count=True, tag=""):
     if m7:
         keep = int(m7.group(1))
         if len(lgkm) > keep:
+            # (round 6) what a counted wait retires is retired for R3 too: hgemm_mid_kernel settles one k-step's fragments with
+            # lgkmcnt(N) while the next k-step's reads stay outstanding, and hipcc may recycle the settled registers behind the MFMAs
+            for dst, from_asm in lgkm[:len(lgkm) - keep]:
+                if from_asm:
+                    pending -= {r for k, r in dst if k == "v"}
             st['lgkm'] = lgkm = lgkm[len(lgkm) - keep:] if keep else []
     elif s.startswith("ds_"):
         if lgkm:
@@ -159,6 +168,15 @@ def _step(st, cur, path, rec, owned, owned_v, count=True, tag=""):
                 valu_fresh[("a", r)] = VALU_TO_MFMA_STATES
     # ---- R5: result latency of asm-issued MFMAs that write arch VGPRs
     if mfma_busy:
+        if not in_asm and s.startswith("v_accvgpr_"):
+            # (round 6) AGPR results of asm MFMAs (keys 1000 + n): hipcc's own accumulator reads behind an asm MFMA — hgemm_mid_kernel's
+            # epilogue was hoisted above a bare `s_nop` statement and read one 16 x 16 block an MFMA early
+            hit_a = {1000 + r for r in _regs(s, "a")} & mfma_busy.keys()
+            if hit_a:
+                _viol(cur, tag, f"R5 {path.name}:{ln}: compiler `{s}` names a{sorted(h - 1000 for h in hit_a)[:4]} "
+                                      f"{max(mfma_busy[h] for h in hit_a)} wait states before the asm MFMA result is there")
+                for h in hit_a:
+                    del mfma_busy[h]
         if not s.startswith("v_mfma") and not s.startswith("s_"):
             hit = _regs(s, "v") & mfma_busy.keys()
             if hit:
@@ -176,6 +194,8 @@ def _step(st, cur, path, rec, owned, owned_v, count=True, tag=""):
             need = next((v for k, v in MFMA_STATES.items() if k in s.split()[0]), 20)
             for r in _regs(dst, "v"):
                 mfma_busy[r] = need
+            for r in _regs(dst, "a"):
+                mfma_busy[1000 + r] = need
     is_wait = s.startswith("s_waitcnt") and ("lgkmcnt(0)" in s or "vmcnt(0)" in s)
     if is_wait:
         # a counted wait retires everything older in program order; a plain lgkmcnt(0) retires LDS reads, a
@@ -210,8 +230,20 @@ def _step(st, cur, path, rec, owned, owned_v, count=True, tag=""):
 
 
 def audit_asm(path: Path) -> list[KernelReport]:
+    """Two walks over the file: the first only records the hazard state at EVERY branch (keyed by function and target label), the second
+    is the audit proper and starts every label that file order cannot reach by fall-through from the merged state of the branches that
+    do reach it — forward ones and loop back-edges alike (hipcc places a rotated loop's latch block in FRONT of its header, entered
+    only by a backward branch: hgemm_mid_kernel)."""
     lines = Path(path).read_text().splitlines()
+    _, known = _walk(path, lines, None)
+    out, _ = _walk(path, lines, known)
+    return out
+
+
+def _walk(path: Path, lines, known):
     reports: dict[str, KernelReport] = {}
+    seen: dict[tuple, list] = {}   # (function, label) -> hazard states at the branches that target it (returned for the second walk)
+    fn_name = ""
     cur: KernelReport | None = None
     owned: set[int] | None = None
     owned_v: set[int] = set()
@@ -224,6 +256,22 @@ def audit_asm(path: Path) -> list[KernelReport]:
     st = {"pending": pending, "mfma_busy": mfma_busy, "valu_fresh": valu_fresh, "lgkm": lgkm}
     fn_ins: list[tuple[str, bool, int]] = []     # instructions of the current function in file order
     fn_labels: dict[str, int] = {}               # label -> index into fn_ins of the first instruction behind it
+    fwd_states: dict[str, list[dict]] = {}       # label not yet seen -> hazard states at the forward branches that target it
+
+    def _copy(x):
+        return {"pending": set(x["pending"]), "mfma_busy": dict(x["mfma_busy"]), "valu_fresh": dict(x["valu_fresh"]), "lgkm": list(x["lgkm"])}
+
+    def _merge(states):
+        out = _copy(states[0])
+        for y in states[1:]:
+            out["pending"] |= y["pending"]
+            for key in ("mfma_busy", "valu_fresh"):
+                for r, n in y[key].items():
+                    out[key][r] = max(out[key].get(r, 0), n)
+            if len(y["lgkm"]) > len(out["lgkm"]):
+                out["lgkm"] = list(y["lgkm"])
+        return out
+
     for ln, raw in enumerate(lines, 1):
         line = raw.split(";", 1)[0] if not raw.lstrip().startswith(";;#") else raw
         s = line.strip()
@@ -238,7 +286,8 @@ def audit_asm(path: Path) -> list[KernelReport]:
                     owned_v = set(range(lo, hi + 1))
             in_asm = False
             st = {"pending": set(), "mfma_busy": {}, "valu_fresh": {}, "lgkm": []}
-            fn_ins, fn_labels = [], {}
+            fn_ins, fn_labels, fwd_states = [], {}, {}
+            fn_name = name
             continue
         if s.startswith(".Lfunc_end"):
             cur = None
@@ -265,12 +314,22 @@ def audit_asm(path: Path) -> list[KernelReport]:
         ml = re.match(r"(\.L[\w$]+):", s)
         if ml:
             fn_labels[ml.group(1)] = len(fn_ins)
+            if fn_ins and not in_asm and fn_ins[-1][0].split()[0] in ("s_branch", "s_endpgm"):
+                # no fall-through into this label: the state of the branches that reach it (second walk: every branch of the function)
+                reach = (known or {}).get((fn_name, ml.group(1))) or fwd_states.get(ml.group(1))
+                if reach:
+                    st = _merge(reach)
         if not s or s.endswith(":") or s.startswith("."):
             continue
         rec = (s, in_asm, ln)
         fn_ins.append(rec)
         _step(st, cur, path, rec, owned, owned_v, count=True)
         mb = _BRANCH.match(s)
+        # (an edge taken with EXEC == 0 carries no hazard: no lane is active to observe one)
+        if mb and not s.startswith("s_cbranch_execz"):
+            seen.setdefault((fn_name, mb.group(1)), []).append(_copy(st))
+        if mb and mb.group(1) not in fn_labels and not s.startswith("s_cbranch_execz"):
+            fwd_states.setdefault(mb.group(1), []).append(_copy(st))
         if mb and mb.group(1) in fn_labels:
             # backward branch: re-check the head of the loop with the state carried over from its tail
             st2 = {"pending": set(st["pending"]), "mfma_busy": dict(st["mfma_busy"]), "valu_fresh": dict(st["valu_fresh"]),
@@ -300,7 +359,7 @@ def audit_asm(path: Path) -> list[KernelReport]:
         if r.scratch != 0:
             r.violations.append(f"R2 {path.name}: {r.name} uses {r.scratch} B of scratch")
         out.append(r)
-    return out
+    return out, seen
 
 
 def audit_files(paths) -> tuple[list[KernelReport], list[str]]:

@@ -217,7 +217,7 @@ def test_status_strings_and_argument_errors(built):
     assert lib.lc_hgemm_f16(None, None, None, 256, 256, 256, 0, 0, 2, 1, None) == capi.LC_ERR_ARG
     one = C.c_void_p(16)
     assert lib.lc_hgemm_f16(one, one, one, 256, 256, 256, 7, 0, 2, 1, None) == capi.LC_ERR_ARG
-    for retired in (2, 5, 7, 8, 11, 14, 19, 31):       # round-1 experiment variants / out of range
+    for retired in (2, 5, 7, 8, 11, 15, 19, 31):       # round-1 experiment variants / out of range (14 = LC_HGEMM_MID since round 6)
         assert lib.lc_hgemm_f16(one, one, one, 256, 256, 256, 0, retired, 2, 1, None) == capi.LC_ERR_ARG
     assert lib.lc_hgemm_f16(one, one, one, 0, 256, 256, 0, 0, 2, 1, None) == capi.LC_ERR_SHAPE
     assert lib.lc_hgemm_f16(one, one, one, 128, 256, 256, 0, capi.HGEMM_MFMA256, 2, 1, None) == capi.LC_ERR_SHAPE
@@ -256,9 +256,26 @@ def test_hgemm_dispatch_covers_the_reference_legal_shapes(built):
             for v in (capi.HGEMM_MFMA256, capi.HGEMM_MFMA256W4C, capi.HGEMM_MFMA256W4X):
                 with pytest.raises(capi.LcError, match="Tensor size mismatch"):
                     capi.hgemm_kernel_name(*shp, lay, v)
-        for shp in ((384, 384, 128), (256, 256, 96), (128, 640, 160), (1536, 1536, 1568)):      # <= 128 interior tiles: the 128-tile kernel
+        for shp in ((384, 384, 128), (256, 256, 96), (128, 640, 160), (768, 768, 800)):         # <= 48 blocks of 128 x 128: the 128-tile kernel
             assert capi.hgemm_kernel_name(*shp, lay) == f"hgemm_mfma128_kernel<{nn},2>", shp                 # <= 0.6 blocks per CU: the eight-wave form
-        assert capi.hgemm_kernel_name(2048, 2048, 2080, lay) == f"hgemm_mfma128_kernel<{nn},1>"               # one block per CU: four waves
+        # between the small grids and > 128 tiles of 256 x 256: the mid-size kernel (round 6) with the smallest tile whose grid is one
+        # round of the 256 CUs this rule assumes without a device (three ring slots), else 128 x 128 at two workgroups per CU
+        for shp, tile in (((1024, 1024, 1024), "1,2,3"), ((1280, 1280, 1280), "1,2,3"), ((1536, 1536, 1568), "1,3,3" if nn == "false" else "2,2,3"),
+                          ((1792, 1792, 1792), "2,2,3"), ((2048, 2048, 2080), "2,2,3"), ((2304, 2304, 2304), "2,3,3" if nn == "false" else "2,2,2"),
+                          ((2560, 2560, 2560), "2,2,2"), ((2816, 2816, 2816), "2,2,2"), ((2816, 2560, 96), "2,2,2")):
+            assert capi.hgemm_kernel_name(*shp, lay) == f"hgemm_mid_kernel<{nn},{tile}>", shp
+            assert capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_MFMA128).startswith("hgemm_mfma128_kernel<")  # ... still there when asked for
+        assert capi.hgemm_kernel_name(3072, 3072, 3072, lay) == f"hgemm_w4y_kernel<{nn},1>"                   # 144 tiles of 256 x 256: the flagship kernel
+        # the knobs: never / a forced tile / the explicit variant on shapes LC_HGEMM_AUTO keeps away from it
+        capi.tune("hgemm_mid", 1)
+        try:
+            assert capi.hgemm_kernel_name(2048, 2048, 2080, lay) == f"hgemm_mfma128_kernel<{nn},1>"           # (round 5's choice: one block per CU, four waves)
+        finally:
+            capi.tune("hgemm_mid", 0)
+        assert capi.hgemm_kernel_name(384, 384, 128, lay, capi.HGEMM_MID) == f"hgemm_mid_kernel<{nn},1,2,3>"
+        assert capi.hgemm_kernel_name(8192, 8192, 8192, lay, capi.HGEMM_MID) == f"hgemm_mid_kernel<{nn},2,2,2>"
+        with pytest.raises(capi.LcError, match="Tensor size mismatch"):
+            capi.hgemm_kernel_name(192, 96, 64, lay, capi.HGEMM_MID)
         for shp in ((384, 384, 128), (256, 256, 96)):                                             # ... the flagship kernel when asked for
             assert capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_MFMA256W4Y) == f"hgemm_w4y_kernel<{nn},1>"
         for shp in ((256, 256, 32), (8192, 8192, 8200), (8192, 8256, 8192), (128, 128, 48)):     # K < 64, K % 32, N % 128: the edge kernel

@@ -210,6 +210,103 @@ def test_mfma128_eight_waves_at_the_size_it_serves(oracle, layout):
     assert torch.equal(c, bq)
 
 
+MID_COMBOS = [(lay, tmw, tnw, ns) for lay in ("tn", "nn") for tmw in (1, 2) for tnw in ((2, 3) if lay == "tn" else (2,)) for ns in (2, 3)]
+
+
+@pytest.mark.parametrize("layout,tmw,tnw,ns", MID_COMBOS)
+def test_mid_kernel_every_tile_and_ring_depth(oracle, layout, tmw, tnw, ns):
+    """hgemm_mid_kernel<B_KN, TMW, TNW, NS> (round 6: 64 TMW x 64 TNW tiles, NS ring slots, the hand-ordered k-loop rotated around a mid-tile
+    barrier) through LC_HGEMM_MID with the tile / depth knobs: against the oracle on shapes whose K walk is SHORTER than the ring (K = 64 ...
+    128: the prologue's clamped requests, the tail loop's wait counts), equal to it, longer (main loop + tail), and with the K % 64 == 32
+    half step; several tiles in M and N, both block maps; bit-equal to hgemm_mfma128_kernel (same products, k ascending into one fp32
+    accumulator) where that kernel tiles the shape."""
+    capi = _capi()
+    lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
+    tm, tn = 64 * tmw, 64 * tnw
+    capi.tune("hgemm_mid", 10 * tmw + tnw)
+    capi.tune("hgemm_mid_ns", ns)
+    try:
+        nnn = "true" if layout == "nn" else "false"
+        for (M, N, K) in [(tm, tn, 64), (tm, tn, 128), (2 * tm, 2 * tn, 192), (tm, tn, 256), (3 * tm, 3 * tn, 320), (2 * tm, tn, 96),
+                          (tm, 2 * tn, 160), (2 * tm, 2 * tn, 1056), (5 * tm, 3 * tn, 512)]:
+            assert capi.hgemm_kernel_name(M, N, K, lay, capi.HGEMM_MID) == f"hgemm_mid_kernel<{nnn},{tmw},{tnw},{ns}>"
+            torch.manual_seed(M + N + K + tnw)
+            a = torch.randn(M, K, dtype=torch.half, device="cuda")
+            b = torch.randn(K, N, dtype=torch.half, device="cuda")
+            for stride in (1, 2 * tn):
+                c, _ = _run(capi, a, b, lay, capi.HGEMM_MID, stride)
+                _check(oracle, capi, a, b, c, lay)
+            if M % 128 == 0 and N % 128 == 0:
+                capi.tune("hgemm_128w", 1)      # (the eight-wave form sums the two k-steps of a K tile apart)
+                try:
+                    c128, _ = _run(capi, a, b, lay, capi.HGEMM_MFMA128, 1)
+                finally:
+                    capi.tune("hgemm_128w", 0)
+                assert torch.equal(c, c128), (M, N, K)
+        # the identity trick: a wrong fragment / tile / transpose shows as a permutation
+        n = 3 * 128 if tnw == 3 else 256
+        eye = torch.eye(n, dtype=torch.half, device="cuda")
+        bq = (torch.arange(n * n, device="cuda").reshape(n, n) % 1021).half() / 4
+        c, _ = _run(capi, eye, bq, lay, capi.HGEMM_MID, 1)
+        assert torch.equal(c, bq)
+        # a shape the forced tile cannot divide is refused, never mis-computed
+        bad_n = tn + 64
+        with pytest.raises(RuntimeError):
+            bb = torch.zeros(bad_n, 64, dtype=torch.half, device="cuda") if lay == capi.LAYOUT_TN else torch.zeros(64, bad_n, dtype=torch.half, device="cuda")
+            capi.hgemm(torch.zeros(tm, 64, dtype=torch.half, device="cuda"), bb, torch.zeros(tm, bad_n, dtype=torch.half, device="cuda"),
+                       layout=lay, variant=capi.HGEMM_MID)
+    finally:
+        capi.tune("hgemm_mid", 0)
+        capi.tune("hgemm_mid_ns", 0)
+
+
+@pytest.mark.parametrize("layout", ["nn", "tn"])
+@pytest.mark.parametrize("n", [1280, 1536, 1792, 2048, 2304, 2560, 2816])
+def test_mid_kernel_at_the_sizes_it_serves(oracle, layout, n):
+    """The sizes of the reference's default sweep (hgemm.py:28-32: multiples of 256) that LC_HGEMM_AUTO hands to the mid-size kernel on a
+    256-CU device: the tile the rule picks, sampled rows x full K against the oracle, C x = A (B x) in fp64, equality with the 128-tile
+    kernel bit for bit, hipBLASLt within one fp16 ulp."""
+    capi = _capi()
+    lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
+    name = capi.hgemm_kernel_name(n, n, n, lay)
+    ncu = capi.device_check()
+    if ncu == 256:
+        want = {1792: "2,2,3", 2048: "2,2,3", 2304: "2,3,3" if layout == "tn" else "2,2,2", 2560: "2,2,2", 2816: "2,2,2"}.get(n)
+        if want:
+            assert name == f"hgemm_mid_kernel<{'true' if layout == 'nn' else 'false'},{want}>", name
+    torch.manual_seed(n)
+    a = torch.randn(n, n, dtype=torch.half, device="cuda")
+    b = torch.randn(n, n, dtype=torch.half, device="cuda")
+    stride = host.make_block_swizzle_stride(n, n)
+    c, bb = _run(capi, a, b, lay, capi.HGEMM_AUTO, stride)
+    rows = [0, 63, 64, 127, 128, n // 2 + 1, n - 129, n - 1]
+    truth = oracle.hgemm(a[rows].contiguous(), b, len(rows), n, n, 0, "f32")
+    ok, mx, _ = tol.hgemm_close(c[rows].float().cpu().numpy(), truth, n)
+    assert ok, mx
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n)
+    want = a.cpu().numpy().astype(np.float64) @ (b.cpu().numpy().astype(np.float64) @ x)
+    got = c.cpu().numpy().astype(np.float64) @ x
+    assert np.abs(got - want).max() / np.abs(want).max() < 2e-3
+    capi.tune("hgemm_mid", 1)
+    capi.tune("hgemm_128w", 1)
+    try:
+        c128, _ = _run(capi, a, b, lay, capi.HGEMM_MFMA128, stride)
+    finally:
+        capi.tune("hgemm_mid", 0)
+        capi.tune("hgemm_128w", 0)
+    assert torch.equal(c, c128)
+    capi.vendor_init()
+    try:
+        cv = torch.empty_like(c)
+        capi.hgemm_vendor(a, bb, cv, lay)
+        torch.cuda.synchronize()
+    finally:
+        capi.vendor_destroy()
+    ulp = torch.clamp(c.float().abs(), min=32.0) * 2.0 ** -10
+    assert ((c.float() - cv.float()).abs() <= ulp).all()
+
+
 @pytest.mark.parametrize("layout", ["nn", "tn"])
 @pytest.mark.parametrize("shape", [(3200, 3200, 96), (3072, 3456, 160), (3456, 3072, 128)])
 def test_auto_routes_128_multiples_with_a_large_interior_to_the_flagship_kernel(oracle, layout, shape):
