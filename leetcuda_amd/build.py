@@ -299,14 +299,14 @@ def build_torch_ext(force: bool = False):
     for name in ("toy_hgemm", "flash_attn_lib"):
         src = CSRC / "torch" / f"{name}.cpp"
         out = PKG / f"{name}{suffix}"
-        dg = _digest([src, CSRC / "torch" / "torch_shim.h", ROOT / "include" / "lc_abi.h"])
+        dg = _digest([src, CSRC / "torch" / "torch_shim.h", ROOT / "include" / "lc_abi.h"], extra="rpath: $ORIGIN/lib, $ORIGIN/leetcuda_amd/lib")
         if not force and _fresh(out, f"torch_{name}", dg):
             outs.append(out)
             continue
         cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1",
                "-DUSE_ROCM=1", f"-DTORCH_EXTENSION_NAME={name}", "-DTORCH_API_INCLUDE_EXTENSION_H",
                f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", *inc, src, "-o", out,
-               f"-L{LIBDIR}", "-lleetcuda_amd", f"-Wl,-rpath,$ORIGIN/lib", f"-L{torch_lib}",
+               f"-L{LIBDIR}", "-lleetcuda_amd", "-Wl,-rpath,$ORIGIN/lib", "-Wl,-rpath,$ORIGIN/leetcuda_amd/lib", f"-L{torch_lib}",   # (in-tree / installed top-level: setup.py)
                "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-ltorch_python",
                f"-Wl,-rpath,{torch_lib}"]
         _run(cmd)

@@ -373,3 +373,41 @@ def test_cpp_bench_harness_builds_and_fails_loudly_without_gpu(built):
     if not torch.cuda.is_available():
         p = subprocess.run([str(exe), "--mnk", "256", "256", "256"], capture_output=True, text=True)
         assert p.returncode == 4 and "no gfx950 device" in p.stderr
+
+
+def test_wheel_carries_the_drop_in_modules(built, tmp_path):
+    """Round-5 verdict (next #9; the reference ships `toy-hgemm` as a wheel: kernels/hgemm/setup.py:11,48): `pip install .` must make
+    `import toy_hgemm` / `import flash_attn_lib` work with no PYTHONPATH.  Build the wheel offline, unpack it and import the two TOP-LEVEL
+    modules from the unpacked tree alone (a fresh interpreter whose sys.path holds no source directory): the 38 + 29 names of the
+    reference's pybind tables must be there, resolved against the libleetcuda_amd.so INSIDE the wheel."""
+    import subprocess
+    import sys
+    import zipfile
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    (tmp_path / "egg").mkdir()
+    p = subprocess.run([sys.executable, "setup.py", "-q", "egg_info", "--egg-base", str(tmp_path / "egg"), "build", "--build-base", str(tmp_path / "b"),
+                        "bdist_wheel", "-d", str(tmp_path / "dist"), "--bdist-dir", str(tmp_path / "bd")],
+                       cwd=root, capture_output=True, text=True, timeout=900)       # (nothing is left behind in the source tree)
+    assert p.returncode == 0, p.stderr[-3000:]
+    whl = next((tmp_path / "dist").glob("leetcuda_amd-*.whl"))
+    assert "linux" in whl.name and "none-any" not in whl.name          # a platform wheel (gfx950 code objects, CPython-ABI modules)
+    site = tmp_path / "site"
+    with zipfile.ZipFile(whl) as z:
+        names = z.namelist()
+        z.extractall(site)
+    assert "leetcuda_amd/lib/libleetcuda_amd.so" in names and "leetcuda_amd/include/lc_abi.h" in names and "leetcuda_amd/capi.py" in names
+    assert any(n.startswith("toy_hgemm.") and n.endswith(".so") for n in names) and any(n.startswith("flash_attn_lib.") and n.endswith(".so") for n in names)
+    code = ("import sys; sys.path[:] = [p for p in sys.path if p and not p.startswith(%r)]; sys.path.insert(0, %r)\n"
+            "import torch, toy_hgemm, flash_attn_lib, leetcuda_amd\n"
+            "from leetcuda_amd import capi\n"
+            "assert toy_hgemm.__file__.startswith(%r) and capi.LIB_PATH.as_posix().startswith(%r), (toy_hgemm.__file__, capi.LIB_PATH)\n"
+            "lib = capi.load()\n"
+            "h = [lib.lc_hgemm_entry_name(i).decode() for i in range(lib.lc_hgemm_entry_count())]\n"
+            "a = [lib.lc_attn_entry_name(i).decode() for i in range(lib.lc_attn_entry_count())]\n"
+            "assert len(h) == 38 and len(a) == 29\n"
+            "assert all(callable(getattr(toy_hgemm, n)) for n in h) and all(callable(getattr(flash_attn_lib, n)) for n in a)\n"
+            "print('ok', len(h), len(a))\n") % (str(root), str(site), str(site), str(site))
+    env = {k: v for k, v in __import__("os").environ.items() if k != "PYTHONPATH"}
+    q = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+    assert q.returncode == 0 and q.stdout.strip().endswith("ok 38 29"), (q.stdout[-500:], q.stderr[-3000:])

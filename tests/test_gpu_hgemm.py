@@ -182,9 +182,18 @@ def test_mfma128_half_k_step(oracle, layout, shape):
 
 @pytest.mark.parametrize("layout", ["nn", "tn"])
 def test_mfma128_eight_waves_at_the_size_it_serves(oracle, layout):
-    """1536^3 = 144 blocks of 128 x 128 on 256 CUs: LC_HGEMM_AUTO's eight-wave 128-tile kernel (round 5) against the oracle, the four-wave
-    form (same products, the two k-steps of a K tile summed in a different order: fp16-rounding agreement) and the identity trick."""
+    """1536^3 = 144 blocks of 128 x 128 on 256 CUs: the eight-wave 128-tile kernel (round 5's LC_HGEMM_AUTO choice at this size; since round 6
+    the mid-size kernel takes it — "hgemm_mid" = 1 restores the old rule, which still serves grids of <= 48 blocks) against the oracle, the
+    four-wave form (same products, the two k-steps of a K tile summed in a different order: fp16-rounding agreement) and the identity trick."""
     capi = _capi()
+    capi.tune("hgemm_mid", 1)
+    try:
+        _eight_waves_body(oracle, capi, layout)
+    finally:
+        capi.tune("hgemm_mid", 0)
+
+
+def _eight_waves_body(oracle, capi, layout):
     n = 1536
     torch.manual_seed(1536)
     a = torch.randn(n, n, dtype=torch.half, device="cuda")

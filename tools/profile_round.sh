@@ -8,6 +8,8 @@ pmc() { local name=$1; shift; timeout 400 rocprofv3 --pmc "$@" -d $OUT/pmc_$name
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES
+# (round 6) requests the L2 sends to LOCAL MEMORY: the closest thing to a DRAM counter rocprofv3 exposes on gfx950 — it cannot separate Infinity-Cache hits
+pmc dram TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum
 pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 # summarise ON the box (the databases can exceed what gpurun merges back) and ship the summaries inside gpurun_out/
 python tools/summarize_prof.py $TAG > $OUT/summary.log 2>&1; echo "summary rc=$?" | tee -a $OUT/steps.log
