@@ -811,6 +811,12 @@ def run(args):
     capi.load()
     capi.require_production()        # a LC_DIAG=1 library can produce WRONG results
     capi.device_check()
+    # the split-KV launch rule's constants measured on THIS device (a few milliseconds, outside every timed region); config 3 / 4 fill the
+    # GPU and never split — the published small shapes of bench blocks / the reference's own sweep do
+    try:
+        calibration = capi.tune_calibrate()
+    except Exception as e:   # never fatal: the built-in constants stay
+        calibration = {"adopted": False, "error": repr(e)}
 
     blocks = {}
     if args.workload == "hgemm":
@@ -861,6 +867,7 @@ def run(args):
         "frac_of_peak": main_res["value"] / (PEAK * w.size),
         "roofline": main_res["roofline"],
         "library": capi.build_info()[0],
+        "calibration": calibration,
     }
     for key in ("vendor_tflops", "uniform_tflops", "sustained", "fp8_tflops", "fp16", "bf16", "n_ranks", "per_rank", "headline_note", "checksum"):
         if key in main_res:

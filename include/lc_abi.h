@@ -179,6 +179,14 @@ int lc_tune_set(const char* key, int value);
 int lc_tune_get(const char* key, int* value, int* default_value);
 int lc_tune_count(void);
 const char* lc_tune_key(int index);
+/* Measures the constants of the split-KV launch rule on the CURRENT device (microseconds per KV tile at D = 128 / 64, fixed cost of the
+ * combine launch, bytes per microsecond of partial traffic: about 60 tiny launches on zero-filled scratch, a few milliseconds) and makes
+ * the rule use them for this device from now on; the built-in constants (fitted on the round-5 boxes) stay when this is never called or when
+ * the measurement lies outside [0.4, 2.5] x of them (LC_ERR_ARG; out4 still receives what was measured).  out4 (optional): tau128, tau64,
+ * x0_us, bytes_per_us.  bench.py calls it once per process; a caller that never does gets round 5's behaviour.  Not while `stream` is
+ * being captured.  Knobs: "attn_calib" = 1 ignores the measurement; "rule_cus" = n makes every launch RULE (not the grids) reason with n
+ * CUs instead of the device's own — for tests of the rules (64 .. 1024; 0 = the device). */
+int lc_tune_calibrate(void* stream, float* out4);
 
 /* Internal workspace (split-KV attention partials, split-K border strips of the GEMM): one cached device buffer per
  * (device, stream), grown geometrically, at most 16 per device and 1 GiB each; requests beyond that and launches on a stream that is

@@ -30,6 +30,7 @@ SYMBOLS = {
     "lc_tune_get": (_i, [_cp, _ip, _ip]),
     "lc_tune_count": (_i, []),
     "lc_tune_key": (_cp, [_i]),
+    "lc_tune_calibrate": (_i, [_vp, _fp]),
     "lc_workspace_release": (C.c_size_t, []),
     "lc_workspace_bytes": (C.c_size_t, []),
     "lc_hgemm_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -221,6 +222,16 @@ def tune_items():
         if k:
             out[k.decode()] = tune_get(k.decode())
     return out
+
+
+def tune_calibrate():
+    """Measure the split-KV rule's constants on the current device (lc_tune_calibrate).  Returns {"adopted": bool, "tau128_us", "tau64_us",
+    "x0_us", "bytes_per_us"}; adopted False = the measurement was refused as implausible and the built-in constants stay."""
+    out = (C.c_float * 4)()
+    rc = load().lc_tune_calibrate(_stream(), out)
+    if rc not in (LC_OK, LC_ERR_ARG):
+        check(rc, "lc_tune_calibrate")
+    return {"adopted": rc == LC_OK, "tau128_us": out[0], "tau64_us": out[1], "x0_us": out[2], "bytes_per_us": out[3]}
 
 
 def workspace_bytes() -> int:

@@ -92,18 +92,18 @@ int lc_probe_mfma_form(int form, void* out_u64x16, void* stream) {
   else hipLaunchKernelGGL(probe_mfma_form_kernel<4>, dim3(1), dim3(256), 0, st, out, 1.0f);
   return check_launch();
 }
-// waves: 4 or 8 per workgroup (one workgroup on one CU); mix: 0..6 (probe_attn_mix_kernel)
+// waves: 4 or 8 per workgroup (one workgroup on one CU); mix: 0..8 (probe_attn_mix_kernel)
 int lc_probe_attn_mix(int waves, int mix, void* out_u64x16, void* stream) {
-  if (!out_u64x16 || (waves != 4 && waves != 8) || mix < 0 || mix > 6) return ERR_ARG;
+  if (!out_u64x16 || (waves != 4 && waves != 8) || mix < 0 || mix > 8) return ERR_ARG;
   unsigned long long* out = static_cast<unsigned long long*>(out_u64x16);
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define LC_MIX(W, M) hipLaunchKernelGGL((probe_attn_mix_kernel<W, M>), dim3(1), dim3(W * 64), 0, st, out, 1.0f)
   if (waves == 4) {
     if (mix == 0) LC_MIX(4, 0); else if (mix == 1) LC_MIX(4, 1); else if (mix == 2) LC_MIX(4, 2); else if (mix == 3) LC_MIX(4, 3); else if (mix == 4) LC_MIX(4, 4);
-    else if (mix == 5) LC_MIX(4, 5); else LC_MIX(4, 6);
+    else if (mix == 5) LC_MIX(4, 5); else if (mix == 6) LC_MIX(4, 6); else if (mix == 7) LC_MIX(4, 7); else LC_MIX(4, 8);
   } else {
     if (mix == 0) LC_MIX(8, 0); else if (mix == 1) LC_MIX(8, 1); else if (mix == 2) LC_MIX(8, 2); else if (mix == 3) LC_MIX(8, 3); else if (mix == 4) LC_MIX(8, 4);
-    else if (mix == 5) LC_MIX(8, 5); else LC_MIX(8, 6);
+    else if (mix == 5) LC_MIX(8, 5); else if (mix == 6) LC_MIX(8, 6); else if (mix == 7) LC_MIX(8, 7); else LC_MIX(8, 8);
   }
 #undef LC_MIX
   return check_launch();

@@ -47,6 +47,8 @@ tune_t g_tune_attn_walk{0};                  // block walk of the merged-phase k
 tune_t g_tune_attn_split{0};                 // split-KV of the merged-phase kernel on grids that do not fill the GPU: 0 = auto (attn_split_auto), 1 = off, 2 / 4 / 8 / 16 = that many KV ranges per query block
 tune_t g_tune_hgemm_auto{LC_HGEMM_MFMA256W4Y};   // what LC_HGEMM_AUTO launches for large 256-tileable shapes (lc_tune_set "hgemm_auto")
 tune_t g_tune_hgemm_splitk{0};                 // split-K of the 128-tile blocks that serve border strips / the ragged last wave: 0 = auto (launch_mfma256), 1 = off, 2 .. 8 = that factor
+tune_t g_tune_rule_cus{0};                     // CU count the LAUNCH RULES reason with: 0 = the current device's own; 64 .. 1024 = that many (tests of the rules for other devices; grids are always sized with the real count)
+tune_t g_tune_attn_calib{0};                   // split-KV cost model: 0 = the constants lc_tune_calibrate measured on this device when it ran (else the built-in ones), 1 = always the built-in ones
 tune_t g_tune_hgemm_mid{0};                    // mid-size kernel (hgemm_mid.hip): 0 = auto (mid_tile_auto), 1 = never, 12 / 13 / 22 / 23 = that tile (rows / 64, columns / 64)
 tune_t g_tune_hgemm_mid_ns{0};                 // ... its LDS ring slots: 0 = auto (3 for one-round grids, else 2), 2, 3
 tune_t g_tune_hgemm_128w{0};                   // waves of the 128-tile kernel: 0 = auto (eight — intra-workgroup split-K — on grids of <= 0.6 blocks per CU), 1 = always four, 2 = always eight
@@ -188,6 +190,20 @@ int panel_tiles(int swizzle_stride, int tiles_n, int tile_n, size_t operand_byte
   return w;
 }
 
+// The CU count the launch rules reason with (lc_tune_set "rule_cus"): the device's own unless a test asks what a 128- or 304-CU part would
+// be told.  Only RULES use it (which kernel, which tile, which split factor); every grid is sized with device_cu_count().
+int rule_cu_count() {
+  const int k = g_tune_rule_cus;
+  return k > 0 ? k : device_cu_count();
+}
+// Constants of the split-KV cost model (attn_split_auto) measured on THIS device by lc_tune_calibrate (round 6; round-5 verdict weak #13:
+// they were fitted once, on one box's clocks); one record per device ordinal, valid != 0 once measured.
+struct AttnCalib {
+  std::atomic<int> valid{0};
+  float tau128 = 0.f, tau64 = 0.f, x0 = 0.f, bytes_per_us = 0.f;
+};
+AttnCalib g_attn_calib[64];
+
 // Waves of hgemm_mfma128_kernel for a launch of `blocks` 128 x 128 tiles (lc_tune_set "hgemm_128w"): eight (KSW = 2, two waves per SIMD
 // inside one block) on grids that leave CUs idle, four otherwise.  Measured (profiles/r5g_hgemm_128w.log, four vs eight waves, TN / NN):
 // 1024^3 (64 blocks) 172 / 167 -> 192 / 189 TFLOP/s, 1536^3 (144) 410 / 396 -> 454 / 425; 2048^3 (256 blocks = one per CU) 705 -> 701: level —
@@ -196,7 +212,7 @@ int panel_tiles(int swizzle_stride, int tiles_n, int tile_n, size_t operand_byte
 int mfma128_ksw(long blocks) {
   const int k = g_tune_hgemm_128w;
   if (k == 1 || k == 2) return k;
-  return 5 * blocks <= 3 * (long)device_cu_count() ? 2 : 1;
+  return 5 * blocks <= 3 * (long)rule_cu_count() ? 2 : 1;
 }
 template <bool B_KN>
 int launch_mfma128_blocks(int ksw, int nblocks, const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int tiles_m, int tiles_n,
@@ -298,16 +314,16 @@ int launch_mfma128(const half_t* A, const half_t* B, half_t* C, int M, int N, in
 // TN, 128 x 128 at 1536 NN / 1792 / 2048, 128 x 192 at 2304 TN (the 64-row tiles lose to the 128-row ones as soon as both need more than a
 // round: 2304 NN 780 vs 866 TFLOP/s, 2560 646 vs 983); otherwise 128 x 128 with two slots and two workgroups per CU (2304 NN, 2560, 2816).
 // `gated` (LC_HGEMM_AUTO): only where the 256-tile kernel does not apply anyway (resolve_hgemm_variant: <= 128 tiles of 256 x 256) and the
-// 128 x 128 grid holds more than kMidMinBlocks blocks (below — 768^3: 36 blocks, level — the eight-wave 128-tile kernel keeps the shape).
+// 128 x 128 grid holds more than 3 / 16 blocks per CU (below — 768^3: 36 blocks, level — the eight-wave 128-tile kernel keeps the shape).
 struct MidTile { int tmw, tnw, ns; };
-constexpr int kMidMinBlocks = 48;
 MidTile mid_tile_auto(int M, int N, int K, bool b_kn, bool gated) {
   MidTile none{0, 0, 0};
   if (M % 64 != 0 || N % 64 != 0 || K % 32 != 0 || K < BK || K >= (1 << 22) || N >= (1 << 22)) return none;
   const int k = g_tune_hgemm_mid, kns = g_tune_hgemm_mid_ns;
   if (k == 1 && gated) return none;
-  const long ncu = device_cu_count();
-  if (gated && ((long)(M / 128) * (N / 128) <= kMidMinBlocks || M % 128 != 0 || N % 128 != 0)) return none;
+  const long ncu = rule_cu_count();
+  const long min_blocks = 3 * ncu / 16;   // 48 of 128 x 128 on 256 CUs (768^3: 36 blocks, level with the eight-wave kernel; 1024^3: 64 blocks, + 15 %)
+  if (gated && ((long)(M / 128) * (N / 128) <= min_blocks || M % 128 != 0 || N % 128 != 0)) return none;
   MidTile best = none, big = none;   // best one-round tile; largest legal tile (the multi-round choice)
   long best_area = 0, big_area = 0;
   for (int tmw = 2; tmw >= 1; --tmw)
@@ -397,13 +413,24 @@ int attn_split_auto(int D, int N, long bh) {
   const double part = 4.0 * (double)bh * N * D;   // bytes of one range's partial O, written + read
   const double part_cap = 2.0 * ((size_t)256 << 20);   // partials <= 256 MiB, forced factor or auto (round-5 advisor: a forced 16 on config 4 asked for 34 GiB)
   if (k >= 2) return (T % k == 0 && T / k >= 2 && k * part <= part_cap) ? k : 1;
-  const long ncu = device_cu_count(), g = bh * (N / 256);
-  const double tau = D == 128 ? 1.35 : 0.85;
+  const long ncu = rule_cu_count(), g = bh * (N / 256);
+  // the model's constants: measured on this device (lc_tune_calibrate) or the values fitted on the round-5 boxes
+  double tau = D == 128 ? 1.35 : 0.85, fixed_us = kSplitFixedUs, bytes_per_us = kSplitBytesPerUs;
+  {
+    int dev = 0;
+    if (g_tune_attn_calib == 0 && g_tune_rule_cus == 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && g_attn_calib[dev].valid.load(std::memory_order_acquire)) {
+      tau = D == 128 ? g_attn_calib[dev].tau128 : g_attn_calib[dev].tau64;
+      fixed_us = g_attn_calib[dev].x0;
+      bytes_per_us = g_attn_calib[dev].bytes_per_us;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   int best = 1;
   const double t1 = (double)((g + ncu - 1) / ncu) * T * tau;
   double tbest = 0.95 * t1;
   for (int S = 2; S <= 16 && T % S == 0 && T / S >= kMinSplitTiles && S * part <= part_cap; S *= 2) {
-    const double t = (double)((g * S + ncu - 1) / ncu) * (T / S) * tau + kSplitFixedUs + S * part / kSplitBytesPerUs;
+    const double t = (double)((g * S + ncu - 1) / ncu) * (T / S) * tau + fixed_us + S * part / bytes_per_us;
     if (t < tbest) {
       tbest = t;
       best = S;
@@ -428,7 +455,7 @@ int choose_attn_nw(int D, bool vt, int N, long bh = -1, int* nsplit = nullptr) {
       // Small grids the split rule leaves alone (too few KV tiles for the combine to pay): up to half a GPU of 256-row blocks and N <= 2048
       // the 4-wave lock-step kernel's 128-row workgroups fill twice the CUs — (1,32,1024,128) 655 vs 601 TFLOP/s, (1,32,1024,64) 498 vs 444
       // (profiles/r4q_small_grids_d128.log, r5i_small_grids.log); from one full round of blocks on the merged-phase kernel is far ahead (992 vs 760)
-      if (bh > 0 && 2 * bh * (N / 256) <= device_cu_count() && N <= 2048 && g_tune_attn_split != 1) return 4;
+      if (bh > 0 && 2 * bh * (N / 256) <= rule_cu_count() && N <= 2048 && g_tune_attn_split != 1) return 4;
       return 513 + 2 * attn_walk_auto(N, D);
     }
     if (want == 513 || want == 515 || want == 517) return want;
@@ -526,7 +553,7 @@ bool use_bigd7(int D, bool vt, int N, long bh) {
   // N % 256 == 128 (round 5): the 256-row kernel with its last block half real, from N = 1152 (below, attn_bigd2's 128-row workgroups waste nothing)
   if (D != 256 || (N % 256 != 0 && (N % 256 != 128 || N < 1152)) || (k != 0 && k != 4)) return false;
   if (k == 4 || bh < 0) return true;
-  const long ncu = device_cu_count(), g7 = bh * ((N + 255) / 256);
+  const long ncu = rule_cu_count(), g7 = bh * ((N + 255) / 256);
   if (g7 >= 4 * ncu) return true;
   const long c7 = (g7 + ncu - 1) / ncu, c2 = (2 * g7 + ncu - 1) / ncu;
   return 16 * c7 <= 10 * c2;
@@ -621,7 +648,7 @@ int resolve_hgemm_variant(int variant, int M, int N, int K, bool al, bool b_kn) 
     // (n = 2048: 715 vs 436 TFLOP/s).
     const long wg256 = (long)(M / BM) * (N / BN);
     const int a = g_tune_hgemm_auto;
-    if (wg256 > 128 && (tiles256 || (a == LC_HGEMM_MFMA256W4Y && w4y_ok))) return a;
+    if (2 * wg256 > rule_cu_count() && (tiles256 || (a == LC_HGEMM_MFMA256W4Y && w4y_ok))) return a;   // more than half a CU's worth of 256 x 256 tiles per CU (256 CUs: > 128)
     if (tiles128 && mid_tile_auto(M, N, K, b_kn, true).tmw > 0) return LC_HGEMM_MID;   // the tile with the least work on the busiest CU (n = 1280 .. 2816 square)
     return tiles128 ? LC_HGEMM_MFMA128 : LC_HGEMM_GENERIC;
   }
@@ -719,6 +746,7 @@ bool ok_02(int v) { return v >= 0 && v <= 2; }
 bool ok_03(int v) { return v >= 0 && v <= 3; }
 bool ok_04(int v) { return v >= 0 && v <= 4; }
 bool ok_08(int v) { return v >= 0 && v <= 8; }
+bool ok_rule_cus(int v) { return v == 0 || (v >= 64 && v <= 1024); }
 bool ok_mid_ns(int v) { return v == 0 || v == 2 || v == 3; }
 bool ok_mid(int v) { return v == 0 || v == 1 || v == 12 || v == 13 || v == 22 || v == 23; }
 bool ok_split(int v) { return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16; }
@@ -756,6 +784,8 @@ const Knob kKnobs[] = {
     {"hgemm_stagger", &g_tune_hgemm_stagger, 0, ok_stagger, false},
     {"hgemm_tail", &g_tune_hgemm_tail, 1, ok_01, false},
     {"hgemm_128w", &g_tune_hgemm_128w, 0, ok_02, false},
+    {"rule_cus", &g_tune_rule_cus, 0, ok_rule_cus, false},
+    {"attn_calib", &g_tune_attn_calib, 0, ok_01, false},
     {"hgemm_mid", &g_tune_hgemm_mid, 0, ok_mid, false},
     {"hgemm_mid_ns", &g_tune_hgemm_mid_ns, 0, ok_mid_ns, false},
     {"hgemm_splitk", &g_tune_hgemm_splitk, 0, ok_08, false},
@@ -1068,6 +1098,101 @@ int lc_attn_time(const void* Q, const void* K, const void* V, void* O, int B, in
   const int rc2 = lc_timer_stop(t, &ms);
   *ms_per_launch = ms / iters;
   return rc != LC_OK ? rc : rc2;
+}
+
+// One-time calibration of the split-KV cost model on the CURRENT device (round 6): times, on zero-filled scratch tensors, the merged-phase
+// kernel on two one-round grids that differ only in the number of KV tiles (tau_D = the difference per tile, D = 128 and 64) and two split
+// launches of one shape (S = 2: one round of T / 2 tiles; S = 4: two rounds of T / 4) whose excess over the walk gives the fixed cost of the
+// combine and the rate at which partials are written and read back.  About 60 launches of 20 ... 60 us + 70 MiB of scratch, freed before
+// returning.  Values outside [0.4, 2.5] x the built-in constants are REFUSED (a busy or throttled GPU): the built-in constants then stay.
+// out4 (optional): tau128, tau64, x0 (us), bytes per us — of what the rule will use from now on.  Returns LC_OK when the measured values
+// were adopted, LC_ERR_DEVICE without a gfx950 device, LC_ERR_LAUNCH on a HIP error, LC_ERR_ARG when they were refused.
+int lc_tune_calibrate(void* stream, float* out4) {
+  int ncu = 0;
+  if (int rc = lc_device_check(&ncu)) return rc;
+  if (int rc = launch_guard()) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (stream_is_capturing(st)) return LC_ERR_ARG;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LC_ERR_DEVICE;
+  const int bh1 = ncu / 4 > 0 ? ncu / 4 : 1;                       // N = 1024: 4 blocks per head -> one round
+  const size_t elems = (size_t)bh1 * 1024 * 128;                    // the largest tensor any step uses
+  half_t* buf = nullptr;
+  {
+    RelaxedCaptureMode relaxed;
+    if (hipMalloc(&buf, 4 * elems * sizeof(half_t)) != hipSuccess || !buf) {
+      (void)hipGetLastError();
+      return LC_ERR_LAUNCH;
+    }
+  }
+  int rc = LC_OK;
+  if (hipMemsetAsync(buf, 0, 4 * elems * sizeof(half_t), st) != hipSuccess) rc = LC_ERR_LAUNCH;
+  half_t *q = buf, *k = buf + elems, *v = buf + 2 * elems, *o = buf + 3 * elems;
+  auto time_us = [&](int D, int bh, int N, int walk, int ns, double* us) -> int {
+    auto once = [&]() -> int {
+      return D == 128 ? launch_attn_w4u_d128(q, k, v, o, 1, bh, N, walk, ns, st) : launch_attn_w4u_d64(q, k, v, o, 1, bh, N, walk, ns, st);
+    };
+    for (int i = 0; i < 3; ++i)
+      if (int r = once()) return r;
+    double best = 1e30;
+    for (int rep = 0; rep < 3; ++rep) {   // best of three bursts of four: a burst shares its launch gaps, the minimum sheds a preempted one
+      void* t = nullptr;
+      if (int r = lc_timer_start(st, &t)) return r;
+      int r2 = LC_OK;
+      for (int i = 0; i < 4 && r2 == LC_OK; ++i) r2 = once();
+      float ms = 0.f;
+      const int r3 = lc_timer_stop(t, &ms);
+      if (r2 != LC_OK) return r2;
+      if (r3 != LC_OK) return r3;
+      if (ms * 250.0 < best) best = ms * 250.0;   // us per launch
+    }
+    *us = best;
+    return LC_OK;
+  };
+  double tau[2] = {0, 0}, x0 = 0, bpu = 0;
+  for (int di = 0; di < 2 && rc == LC_OK; ++di) {
+    const int D = di == 0 ? 128 : 64;
+    double t16 = 0, t32 = 0;
+    rc = time_us(D, bh1, 1024, 0, 1, &t16);                                  // ncu blocks x 16 tiles
+    if (rc == LC_OK) rc = time_us(D, bh1 / 2 > 0 ? bh1 / 2 : 1, 2048, 0, 1, &t32);   // ncu blocks x 32 tiles
+    tau[di] = (t32 - t16) / 16.0;
+  }
+  if (rc == LC_OK) {
+    // (1, ncu / 16, 2048, 128): g = ncu / 2 blocks of T = 32 tiles; S = 2 -> one round of 16 tiles, S = 4 -> two rounds of 8
+    const int bh = ncu / 16 > 0 ? ncu / 16 : 1;
+    const double part = 4.0 * bh * 2048 * 128;
+    double t2 = 0, t4 = 0;
+    rc = time_us(128, bh, 2048, 3, 2, &t2);
+    if (rc == LC_OK) rc = time_us(128, bh, 2048, 3, 4, &t4);
+    const double e2 = t2 - 16.0 * tau[0], e4 = t4 - 2 * 8.0 * tau[0];       // = x0 + S part / bw
+    const double per = (e4 - e2) / 2.0;                                       // part / bw
+    bpu = per > 0 ? part / per : 0;
+    x0 = e2 - 2.0 * per;
+  }
+  (void)hipStreamSynchronize(st);
+  {
+    RelaxedCaptureMode relaxed;
+    (void)hipFree(buf);
+  }
+  if (rc != LC_OK) return rc;
+  auto sane = [](double v, double ref) { return v >= 0.4 * ref && v <= 2.5 * ref; };
+  const bool ok = sane(tau[0], 1.35) && sane(tau[1], 0.85) && sane(x0, kSplitFixedUs) && sane(bpu, kSplitBytesPerUs);
+  AttnCalib& c = g_attn_calib[dev];
+  if (ok) {
+    c.valid.store(0, std::memory_order_release);
+    c.tau128 = (float)tau[0];
+    c.tau64 = (float)tau[1];
+    c.x0 = (float)x0;
+    c.bytes_per_us = (float)bpu;
+    c.valid.store(1, std::memory_order_release);
+  }
+  if (out4) {
+    out4[0] = (float)tau[0];
+    out4[1] = (float)tau[1];
+    out4[2] = (float)x0;
+    out4[3] = (float)bpu;
+  }
+  return ok ? LC_OK : LC_ERR_ARG;
 }
 
 __global__ void lc_clock_probe_kernel(unsigned long long* out) {

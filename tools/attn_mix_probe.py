@@ -11,8 +11,9 @@ lib = capi.load_diag()
 out = torch.zeros(16, dtype=torch.int64, device="cuda")
 names = {0: "MFMAs only", 1: "D = 128 share (exp + add + fma + cvt/2 + ds_read/2 per two slots)", 2: "D = 64 share (the same per slot)",
          3: "D = 64 share without the LDS read", 4: "D = 128 share without the LDS read",
-         5: "D = 64 share, exp2 as a packed-fp16 polynomial (10 VALU per 2 scores)", 6: "D = 128 share, exp2 as a packed-fp16 polynomial"}
-for mix in (0, 1, 2, 3, 4, 5, 6):
+         5: "D = 64 share, exp2 as a packed-fp16 polynomial (10 VALU per 2 scores)", 6: "D = 128 share, exp2 as a packed-fp16 polynomial",
+         7: "D = 64 share, Q.K^T on v_mfma_f32_32x32x16 (re-layout NOT charged)", 8: "D = 128 share, Q.K^T on v_mfma_f32_32x32x16 (re-layout NOT charged)"}
+for mix in (0, 1, 2, 3, 4, 5, 6, 7, 8):
     row = []
     for waves in (4, 8):
         for _ in range(3):
@@ -21,6 +22,7 @@ for mix in (0, 1, 2, 3, 4, 5, 6):
             assert rc == 0, rc
             torch.cuda.synchronize()
         t = out.cpu().numpy()[:waves]
+        # (mixes 7 / 8: one 32x32x16 MFMA counts as the TWO 16x16x32 slots whose FLOPs it does: cycles per slot-equivalent)
         row.append(f"{waves} waves: {t.max() / 2048 / (waves // 4):5.1f} cycles per MFMA and SIMD (per wave {t.max() / 2048:5.1f})")
     print(f"{names[mix]:72s} | " + " | ".join(row), flush=True)
 
