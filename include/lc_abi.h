@@ -123,7 +123,7 @@ const char* lc_build_info(int* is_diag);
  *   "attn_walk"    block walk of the merged-phase kernel under "attn_nw" = 0: 0 = auto by N (above), 1 / 2 / 3 = WALK 0 / 1 / 2
  *   "attn_w4i_sched" schedule 0 / 1 (default) of attn_w4i's generated phase statements (tools/gen_attn_w4i.py; same bits, A/B knob)
  *   "attn_d1024"   D = 1024 pair kernel (attn_bigd4.hip): a batch of 8 LDS-DMA pieces is spread over this many eighths of a half-phase: 0 = default (8), 2 / 4 / 6
- *   "w4y_sched"    schedule 0..2 of LC_HGEMM_MFMA256W4Y's generated loop body (tools/gen_hgemm_w4y.py; same bits, A/B knob)
+ *   "w4y_sched"    schedule 0..2 of LC_HGEMM_MFMA256W4Y's generated loop body (tools/gen_hgemm_w4y.py; same bits, A/B knob; default 2 since round 6)
  *   "hgemm_persist" 1 (default) = LC_HGEMM_MFMA256W4Y as one persistent workgroup per CU walking the C tiles, when their number is a
  *                  multiple of the CU count and larger (same bits as the one-tile launch, 0: + 0.2 % at the cap, + 0.7 % zero-filled)
  *   "hgemm_stagger" K-loop stagger of LC_HGEMM_MFMA256W4Y (hgemm_w4y.hip): the workgroup starts its K walk at tile ((index & mask)
@@ -156,7 +156,7 @@ const char* lc_build_info(int* is_diag);
  *   "hgemm_mid_ns" LDS ring slots of LC_HGEMM_MID: 0 = auto (3 when the grid is one round of <= one workgroup per CU, else 2), 2, 3
  *   "hgemm_tail"   1 (default) = when the 256-tile grid's last wave holds at most 128 tiles, the generated-loop kernel computes the
  *                  full waves and the 128-tile kernel the four quadrants of each remaining tile; 0 = one launch
- *   "hgemm_raster" block -> C tile map of the tiled GEMM kernels: 0 = auto (2 when A + B exceed the 256 MiB Infinity Cache by half,
+ *   "hgemm_raster" block -> C tile map of the tiled GEMM kernels: 0 = auto (2 when A + B exceed 272 MiB — the 256 MiB Infinity Cache and a margin,
  *                  else 1), 1 = the reference's block swizzle (N panels of swizzle_stride columns, every XCD a contiguous id
  *                  range), 2 = XCD super-block raster (16 x 16 tile steps shared through the Infinity Cache, 4 x 8 per XCD;
  *                  swizzle_stride ignored)

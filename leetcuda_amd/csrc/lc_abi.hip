@@ -27,7 +27,7 @@ using namespace lc;
 namespace lc {
 tune_t g_tune_attn_ablate{0};      // attention ablation / stamp builds (diagnosis only, LC_DIAG)
 tune_t g_tune_w4_abl{0};           // hgemm_w4 ablation bits (diagnosis only, LC_DIAG)
-tune_t g_tune_w4y_sched{1};        // hgemm_w4y_kernel loop schedule 0..2 (lc_tune_set "w4y_sched")
+tune_t g_tune_w4y_sched{2};        // hgemm_w4y_kernel loop schedule 0..2 (lc_tune_set "w4y_sched"; same bits; 2 since round 6: + 0.4 ... 4 % at 8704 ... 12800, level at 8192, profiles/r6i_hgemm_knob_sched_ab.log)
 tune_t g_tune_hgemm_stamps{0};     // GEMM cycle-stamp builds (diagnosis only, LC_DIAG)
 tune_t g_tune_hgemm_persist{1};    // 1 (default) = hgemm_w4y_kernel as a persistent workgroup per CU when the tiles divide evenly (lc_tune_set "hgemm_persist")
 tune_t g_tune_hgemm_stagger{0};    // K-loop stagger of hgemm_w4y_kernel (lc_tune_set "hgemm_stagger"): 0 = auto (by XCD), 1 << 27 = off, else cx | cm << 4 | cn << 8 | step << 12 | mask << 20
@@ -181,7 +181,9 @@ bool is_w4_variant(int v) {
 // raster streams every panel from HBM about a third as often: 12544^3 +5.7 %, 15360^3 +8.3 %, 16384^3 +5.3 % TN (+4.7 ... 6.9 %
 // NN), which is what lifts AUTO from 4 ... 9 % behind hipBLASLt TN to level with it on the reference's published sizes.
 int panel_tiles(int swizzle_stride, int tiles_n, int tile_n, size_t operand_bytes) {
-  const bool xcd16 = g_tune_hgemm_raster == 2 || (g_tune_hgemm_raster == 0 && operand_bytes > ((size_t)384 << 20));
+  // (round 6: the threshold came down from 1.5 x to 1.0625 x the Infinity Cache — 8704^3 + 3.2 %, 8960^3 + 4.2 %, 9728^3 + 4.3 % with the super-block
+  // raster, 9216^3 level, 8192^3 and below 0.3 ... 1.3 % better on the block swizzle: profiles/r6i_hgemm_knob_sched_ab.log)
+  const bool xcd16 = g_tune_hgemm_raster == 2 || (g_tune_hgemm_raster == 0 && operand_bytes > ((size_t)272 << 20));
   if (xcd16) return -1;                     // the kernel ignores the stride
   if (swizzle_stride <= 1) return tiles_n;  // no thread-block swizzle: plain N-major raster
   int w = swizzle_stride / tile_n;
@@ -779,7 +781,7 @@ const Knob kKnobs[] = {
     {"attn_w4i_sched", &g_tune_attn_w4i_sched, 1, ok_01, false},
     {"fp8_mx", &g_tune_fp8_mx, 3, ok_03, false},
     {"attn_d512", &g_tune_attn_d512, 0, ok_04, false},
-    {"w4y_sched", &g_tune_w4y_sched, 1, ok_w4y_sched, false},
+    {"w4y_sched", &g_tune_w4y_sched, 2, ok_w4y_sched, false},
     {"hgemm_persist", &g_tune_hgemm_persist, 1, ok_01, false},
     {"hgemm_stagger", &g_tune_hgemm_stagger, 0, ok_stagger, false},
     {"hgemm_tail", &g_tune_hgemm_tail, 1, ok_01, false},

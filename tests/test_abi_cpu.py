@@ -250,8 +250,9 @@ def test_hgemm_dispatch_covers_the_reference_legal_shapes(built):
     from leetcuda_amd import capi
     capi.load()
     for lay, nn in ((capi.LAYOUT_NN, "true"), (capi.LAYOUT_TN, "false")):
+        sch = 1 if nn == "true" else 2      # (the NN loop has one schedule; TN: "w4y_sched", 2 since round 6)
         for shp in ((8320, 8320, 8320), (8192, 8320, 8192), (8320, 8192, 8192), (8192, 8192, 8224), (3200, 3200, 96)):
-            assert capi.hgemm_kernel_name(*shp, lay) == f"hgemm_w4y_kernel<{nn},1>", shp
+            assert capi.hgemm_kernel_name(*shp, lay) == f"hgemm_w4y_kernel<{nn},{sch}>", shp
             assert capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_MFMA128) == f"hgemm_mfma128_kernel<{nn},1>"     # thousands of blocks: four waves, two blocks per CU
             for v in (capi.HGEMM_MFMA256, capi.HGEMM_MFMA256W4C, capi.HGEMM_MFMA256W4X):
                 with pytest.raises(capi.LcError, match="Tensor size mismatch"):
@@ -265,7 +266,7 @@ def test_hgemm_dispatch_covers_the_reference_legal_shapes(built):
                           ((2560, 2560, 2560), "2,2,2"), ((2816, 2816, 2816), "2,2,2"), ((2816, 2560, 96), "2,2,2")):
             assert capi.hgemm_kernel_name(*shp, lay) == f"hgemm_mid_kernel<{nn},{tile}>", shp
             assert capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_MFMA128).startswith("hgemm_mfma128_kernel<")  # ... still there when asked for
-        assert capi.hgemm_kernel_name(3072, 3072, 3072, lay) == f"hgemm_w4y_kernel<{nn},1>"                   # 144 tiles of 256 x 256: the flagship kernel
+        assert capi.hgemm_kernel_name(3072, 3072, 3072, lay) == f"hgemm_w4y_kernel<{nn},{sch}>"                   # 144 tiles of 256 x 256: the flagship kernel
         # the knobs: never / a forced tile / the explicit variant on shapes LC_HGEMM_AUTO keeps away from it
         capi.tune("hgemm_mid", 1)
         try:
@@ -277,7 +278,7 @@ def test_hgemm_dispatch_covers_the_reference_legal_shapes(built):
         with pytest.raises(capi.LcError, match="Tensor size mismatch"):
             capi.hgemm_kernel_name(192, 96, 64, lay, capi.HGEMM_MID)
         for shp in ((384, 384, 128), (256, 256, 96)):                                             # ... the flagship kernel when asked for
-            assert capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_MFMA256W4Y) == f"hgemm_w4y_kernel<{nn},1>"
+            assert capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_MFMA256W4Y) == f"hgemm_w4y_kernel<{nn},{sch}>"
         for shp in ((256, 256, 32), (8192, 8192, 8200), (8192, 8256, 8192), (128, 128, 48)):     # K < 64, K % 32, N % 128: the edge kernel
             assert capi.hgemm_kernel_name(*shp, lay) == f"hgemm_generic_kernel<{nn}>", shp
             with pytest.raises(capi.LcError, match="Tensor size mismatch"):
@@ -447,9 +448,9 @@ def test_launch_rules_reason_with_any_cu_count(built):
             n1 = 128 * int((cus * 0.9) ** 0.5)                                   # ~ 0.8 cus blocks of 128 x 128
             name = capi.hgemm_kernel_name(n1, n1, 2048, capi.LAYOUT_TN)
             assert name.startswith("hgemm_mid_kernel<false,") and name.endswith(",3>"), (cus, n1, name)      # one round: three ring slots
-            assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN) == "hgemm_w4y_kernel<false,1>"
+            assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN) == "hgemm_w4y_kernel<false,2>"
             big = 256 * (int((cus / 2) ** 0.5) + 1)                              # just over cus / 2 tiles of 256 x 256
-            assert capi.hgemm_kernel_name(big, big, 4096, capi.LAYOUT_TN) == "hgemm_w4y_kernel<false,1>", (cus, big)
+            assert capi.hgemm_kernel_name(big, big, 4096, capi.LAYOUT_TN) == "hgemm_w4y_kernel<false,2>", (cus, big)
     finally:
         capi.tune("rule_cus", 0)
     with pytest.raises(capi.LcError):

@@ -523,12 +523,12 @@ def test_full_size_config2_properties(oracle, layout):
             capi.tune("hgemm_stagger", 0)
         assert torch.equal(outs["w4x"], plain)
         assert not torch.equal(outs["w4y"], plain) and ((outs["w4y"].float() - plain.float()).abs() <= ulp).all()
-        for sched in (0, 2):                            # the other generated schedules of the loop body: same bits
+        for sched in (0, 1):                            # the other generated schedules of the loop body (2 = the default): same bits
             capi.tune("w4y_sched", sched)
             try:
                 alt, _ = _run(capi, a, b, lay, VARIANTS["w4y"], stride)
             finally:
-                capi.tune("w4y_sched", 1)
+                capi.tune("w4y_sched", 2)
             assert torch.equal(alt, outs["w4y"]), sched
     c = outs["w4c"]
     # (2) C·x == A·(B·x) in fp64 on the host, x random: any wrong tile shifts thousands of entries

@@ -367,7 +367,7 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     sump = importlib.util.module_from_spec(spec2)
     spec2.loader.exec_module(sump)
     # dispatcher names == demangled symbol names of the kernels actually in the library
-    assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN) == "hgemm_w4y_kernel<false,1>"
+    assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN) == "hgemm_w4y_kernel<false,2>"
     assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_NN) == "hgemm_w4y_kernel<true,1>"
     assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_NN, capi.HGEMM_MFMA256P2) == "hgemm_pingpong2_kernel<true,false>"
     assert capi.hgemm_kernel_name(1024, 1024, 1024, capi.LAYOUT_NN) == "hgemm_mid_kernel<true,1,2,3>"       # (round 6: 64 x 128 tiles, one round)

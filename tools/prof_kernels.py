@@ -36,6 +36,18 @@ if a.what in ("all", "hgemm"):
         for _ in range(a.iters):
             capi.hgemm_vendor(A, bb, C, layout=lay)
     torch.cuda.synchronize()
+    # round 6: the mid-size kernel at 2048^3 (hgemm_mid_kernel<.,2,2,3>: 256 workgroups of 128 x 128, one round; tools/prof_workloads.py
+    # "hgemm_2048") next to hipBLASLt's MT128x128x64 kernel on the same operands
+    m = 2048
+    A2, B2, C2 = A[:m, :m].contiguous(), B[:m, :m].contiguous(), torch.zeros(m, m, dtype=torch.half, device="cuda")
+    Bt2 = host.as_col_major(B2)
+    for lay, bb in ((capi.LAYOUT_TN, Bt2), (capi.LAYOUT_NN, B2)):
+        for _ in range(4 * a.iters):
+            capi.hgemm(A2, bb, C2, layout=lay, variant=capi.HGEMM_AUTO, swizzle_stride=1024)
+        for _ in range(4 * a.iters):
+            capi.hgemm_vendor(A2, bb, C2, layout=lay)
+    torch.cuda.synchronize()
+    del A2, B2, C2, Bt2
 if a.what in ("all", "attn"):
     q, k, v, o, tv = host.get_qkvo(4, 32, 4096, 128, seed=0)
     for nw in (0, 517, 514, 8):     # default (persistent merged-phase kernel, static walk), the dynamic-queue walk, the generated one-statement-per-phase twin, lock-step
