@@ -1,5 +1,6 @@
 // tu_attn_w4u_impl.h — body of the four translation units tu_attn_w4u_{d128,d128t,d64,d64t}.hip: the merged-phase attention kernel
 // (attn_w4u.hip) for ONE (head dim, V layout) and its three block walks.  The includer defines W4U_D, W4U_VT and W4U_TAG.
+#include <limits.h>
 #include <math.h>
 
 #include <atomic>
@@ -40,6 +41,7 @@ int launch_w4u_split(const half_t* Q, const half_t* K, const half_t* V, half_t* 
   half_t* op = static_cast<half_t*>(ws.ptr);
   float* lse = reinterpret_cast<float*>(static_cast<char*>(ws.ptr) + obytes);
   const size_t nblk = (size_t)(N / 256) * B * H * nsplit;
+  if (nblk > (size_t)INT_MAX) return LC_ERR_ARG;   // (the grid and the kernel's block count are ints: the caller runs the unsplit walk)
   if (int rc = launch_w4u_walk<3>(Q, K, V, op, B, H, N, (int)nblk, nblk, st, nsplit, lse)) return rc;
   const size_t threads = rows * (D / 8);
   hipLaunchKernelGGL(attn_split_combine_kernel<D>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, op, lse, O, nsplit, rows);
@@ -54,6 +56,7 @@ int launch_w4u_split(const half_t* Q, const half_t* K, const half_t* V, half_t* 
 int W4U_CAT(launch_attn_w4u_, W4U_TAG)(const half_t* Q, const half_t* K, const half_t* V, half_t* O, int B, int H, int N, int walk,
                                        int nsplit, hipStream_t st) {
   const size_t nblk = (size_t)((N + 255) / 256) * B * H;   // (N % 256 != 0: the head's last block is partly real; one block per workgroup only)
+  if (nblk > (size_t)INT_MAX) return LC_ERR_SHAPE;           // (int grid / block-count arguments; 2^31 query blocks = 2^39 query rows)
   const int ncu = device_cu_count();   // one workgroup per CU: each takes a CU's whole register file and > half its LDS
   if (N % 256 != 0) walk = 0;          // the persistent walks stage the NEXT block's tiles into ring slots T % 4 == 0 expects; split-KV needs whole blocks
   if (walk == 3) {

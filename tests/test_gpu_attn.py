@@ -1018,3 +1018,51 @@ def test_split_rule_calibration_on_this_device():
     for n in names.values():
         assert n[0].endswith(",3>") and n[1].endswith(",3>") and n[2].endswith(",3>")          # grids far below a round: split with either set
         assert n[3].endswith(",1>") and n[4].endswith(",0>")                                    # config 3 / config 4: never
+
+
+def test_graph_capture_first_use_of_the_fallback_kernels_in_a_fresh_process():
+    """Round-5 advisor: the capture tests above warm the fallback kernel up BEFORE capturing; the realistic sequence is an eager warm-up that
+    runs the workspace path (split-KV; split-K border strips) and a capture in which the workspace-free kernel is used for the FIRST time —
+    its dynamic-LDS attribute (hipFuncSetAttribute, lc_launch.h set_dyn_lds) is then set while the stream is capturing.  A fresh
+    interpreter, shapes no other test touches first: the captured call must be legal, replay must compute the attention / the GEMM."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import torch
+from leetcuda_amd import capi, host
+capi.load()
+torch.manual_seed(5)
+B, H, N, D = 1, 6, 1024, 64
+q = torch.randn(B, H, N, D, dtype=torch.half, device="cuda"); k = torch.randn_like(q); v = torch.randn_like(q)
+vt = v.transpose(-2, -1).contiguous()
+o = torch.zeros_like(q)
+assert capi.attn_kernel_name(N, D, True, bh=B * H).endswith(",3>")
+capi.attn_fwd(q, k, vt, o, v_transposed=True)          # eager: the split path (workspace allocated here)
+torch.cuda.synchronize()
+eager = o.clone(); o.zero_()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    capi.attn_fwd(q, k, vt, o, v_transposed=True)      # capture: attn_fwd_w4u_kernel<64,true,0> for the first time in this process
+g.replay(); torch.cuda.synchronize()
+ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())
+assert (o.float() - ref).abs().max().item() < 2e-3 and (o.float() - eager.float()).abs().max().item() < 2e-3
+M, Nn, K = 640, 384, 2080
+a = torch.randn(M, K, dtype=torch.half, device="cuda"); b = torch.randn(K, Nn, dtype=torch.half, device="cuda")
+bb = host.as_col_major(b); c = torch.zeros(M, Nn, dtype=torch.half, device="cuda")
+capi.hgemm(a, bb, c, layout=capi.LAYOUT_TN, variant=capi.HGEMM_MFMA256W4Y, swizzle_stride=256)   # eager: border strips with split-K
+torch.cuda.synchronize()
+ce = c.clone(); c.zero_()
+g2 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g2):
+    capi.hgemm(a, bb, c, layout=capi.LAYOUT_TN, variant=capi.HGEMM_MFMA256W4Y, swizzle_stride=256)   # capture: the unsplit border form, first use
+g2.replay(); torch.cuda.synchronize()
+want = a.float() @ b.float()
+assert (c.float() - want).abs().max().item() < 0.25 and (c.float() - ce.float()).abs().max().item() <= 0.125
+print("captured ok")
+''' % str(root)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "captured ok" in p.stdout, (p.stdout[-500:], p.stderr[-3000:])
