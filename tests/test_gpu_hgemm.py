@@ -749,3 +749,30 @@ def test_concurrent_host_threads_on_two_streams():
         t.join()
     torch.cuda.synchronize()
     assert not errs, errs
+
+
+def test_random_shapes_through_the_auto_dispatch(oracle):
+    """Thirty random (M, N, K, layout) with M, N multiples of 64 and K of 32 — whatever LC_HGEMM_AUTO picks (eight-wave 128-tile kernel,
+    the mid-size kernel in any tile / ring depth, the 256-tile kernel with border strips and half K-steps, the edge kernel for the
+    64-multiples no 128-tile divides) must match the oracle; the kernel families seen are collected so that a change of the rules shows up
+    here (round 6: the mid-size kernel must be among them)."""
+    capi = _capi()
+    rng = np.random.default_rng(6)
+    seen = set()
+    for i in range(30):
+        M = int(rng.integers(2, 41)) * 64
+        N = int(rng.integers(2, 41)) * 64
+        K = int(rng.integers(2, 66)) * 32
+        if i % 3 == 0:                       # a third of them in the mid-size kernel's home range
+            M, N = int(rng.integers(8, 23)) * 128, int(rng.integers(8, 23)) * 128
+        lay = capi.LAYOUT_NN if rng.random() < 0.5 else capi.LAYOUT_TN
+        torch.manual_seed(M + 3 * N + 7 * K)
+        a = torch.randn(M, K, dtype=torch.half, device="cuda")
+        b = torch.randn(K, N, dtype=torch.half, device="cuda")
+        name = capi.hgemm_kernel_name(M, N, K, lay)
+        seen.add(name.split("<")[0])
+        c, _ = _run(capi, a, b, lay, capi.HGEMM_AUTO, host.make_block_swizzle_stride(N, K))
+        truth = oracle.hgemm(a, b, M, N, K, 0, "f32")
+        ok, mx, ex = tol.hgemm_close(c.float().cpu().numpy(), truth, K)
+        assert ok, (M, N, K, lay, name, mx, ex)
+    assert {"hgemm_mid_kernel", "hgemm_generic_kernel"} <= seen and ({"hgemm_mfma128_kernel", "hgemm_w4y_kernel"} & seen), seen
