@@ -56,6 +56,10 @@ int lc_diag_pollute(unsigned pattern, int what, void* stream);
  * wait + barrier, 32 = no guard decision; available: 1, 2, 3, 4, 7, 8, 23, 55.  Results are WRONG by design: timing only (tools/attn_w4i_ablate.py). */
 int lc_diag_attn_w4i(int abl, const void* Q, const void* K, const void* V, void* O, int B, int H, int N, int D, void* stream);
 
+/* hgemm_mid_kernel<B_KN, 4, 4, 2> (csrc/diag/mid256_probe.hip): the mid-size kernel's rotated hand-ordered loop on a 256 x 256 tile with two ring slots.
+ * M, N % 256 == 0, K % 64 == 0; panel_w: tiles per N panel of the block swizzle.  0 on success. */
+int lc_probe_mid256(const void* A, const void* B, void* C, int M, int N, int K, int b_kn, int panel_w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -218,7 +218,7 @@ def build_diag(force: bool = False) -> Path:
     LIBDIR.mkdir(parents=True, exist_ok=True)
     out = LIBDIR / "liblc_diag.so"
     srcs = sorted((CSRC / "diag").glob("*.hip")) + [CSRC / "lc_common.h", ROOT / "include" / "lc_diag.h", CSRC / "attn_w4i.hip", CSRC / "attn_w4u.hip", CSRC / "attn_mp.h", CSRC / "attn_fwd.hip",
-                                                     ROOT / "tools" / "gen_attn_w4i.py"]
+                                                     CSRC / "hgemm_mid.hip", ROOT / "tools" / "gen_attn_w4i.py"]
     dg = _digest(srcs)
     if not force and _fresh(out, "diag", dg):
         return out
@@ -235,7 +235,8 @@ def build_diag(force: bool = False) -> Path:
     base = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-inline-asm",
             "-fno-honor-nans", "-mno-amdgpu-ieee", f"-I{ROOT / 'include'}", f"-I{gen}", f"-I{CSRC}"]
     jobs = [(objdir / "diag_main.o", [*base, "-c", "-o", objdir / "diag_main.o", CSRC / "diag" / "lc_diag.hip"]),
-            (objdir / "diag_w4u_stamps.o", [*base, "-c", "-o", objdir / "diag_w4u_stamps.o", CSRC / "diag" / "attn_w4u_stamps.hip"])]
+            (objdir / "diag_w4u_stamps.o", [*base, "-c", "-o", objdir / "diag_w4u_stamps.o", CSRC / "diag" / "attn_w4u_stamps.hip"]),
+            (objdir / "diag_mid256.o", [*base, "-c", "-o", objdir / "diag_mid256.o", CSRC / "diag" / "mid256_probe.hip"])]
     for k in abls:
         o = objdir / f"diag_w4i_abl{k}.o"
         jobs.append((o, [*base, f"-DW4I_ABL={k}", f'-DW4I_INC32="attn_w4i_d32_abl{k}.inc"', f'-DW4I_INC64="attn_w4i_d64_abl{k}.inc"', f'-DW4I_INC96="attn_w4i_d96_abl{k}.inc"', f'-DW4I_INC128="attn_w4i_d128_abl{k}.inc"',

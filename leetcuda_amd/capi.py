@@ -62,6 +62,7 @@ SYMBOLS = {
 }
 # every symbol include/lc_diag.h declares (liblc_diag.so)
 DIAG_SYMBOLS = {
+    "lc_probe_mid256": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "lc_probe_mfma16": (_i, [_vp, _vp, _vp, _vp]),
     "lc_probe_mfma32": (_i, [_vp, _vp, _vp, _vp]),
     "lc_probe_tr16": (_i, [_vp, _vp, _vp]),

@@ -42,7 +42,7 @@ struct Mid {
   static constexpr int EPI_ROW = 64 * TNW + 16;       // bytes per staged C row of a wave tile (32 TNW halves + 16 B pad)
   static constexpr int EPI = 4 * (32 * TMW) * EPI_ROW;
   static constexpr int LDS = NS * STAGE > EPI ? NS * STAGE : EPI;
-  static_assert(TMW >= 1 && TMW <= 2 && TNW >= 2 && TNW <= 3 && NS >= 2 && NS <= 3, "64 / 128 x 128 / 192 tiles, 2 .. 3 ring slots");
+  static_assert((TMW == 1 || TMW == 2 || TMW == 4) && TNW >= 2 && TNW <= 4 && NS >= 2 && NS <= 3, "64 / 128 / 256 x 128 / 192 / 256 tiles, 2 .. 3 ring slots");
   static_assert(LDS <= 160 * 1024, "ring must fit a CU's LDS");
   static_assert((NS - 1) * PPW <= 63, "vmcnt is a 6-bit counter");
 };
@@ -77,20 +77,20 @@ LC_DEVINL void dma_piece(uint32_t m0_lds, uint32_t voff, const void* sbase) {   
 // The statement NAMES every accumulator ("+a"): a bare s_nop statement is no fence for hipcc's own register reads — round 6 found the
 // epilogue's v_accvgpr_read hoisted above it, and one 16 x 16 block per wave read one MFMA early (only on the K % 64 == 32 path, where the
 // last MFMA had nothing behind it).
-#define LC_MID_ACC4(r) "+a"(acc[r][0]), "+a"(acc[r][1]), "+a"(acc[r][2]), "+a"(acc[r][3])
-#define LC_MID_ACC6(r) LC_MID_ACC4(r), "+a"(acc[r][4]), "+a"(acc[r][5])
-#define LC_MID_SETTLE "s_nop 15\n\ts_nop 15\n\ts_nop 7"
+// A register (tuple) named by an EMPTY volatile statement: volatile statements keep their order, so nothing of hipcc's that reads the
+// register can be scheduled above the statement in front of this one (the wait / the settle nops), whatever the number of registers.
+template <class T>
+LC_DEVINL void name_vgpr(T& x) { asm volatile("" : "+v"(x)); }
+template <class T>
+LC_DEVINL void name_agpr(T& x) { asm volatile("" : "+a"(x)); }
 template <int MI, int NI>
 LC_DEVINL void mid_acc_settle(f32x4_t (&acc)[MI][NI]) {
-  static_assert((MI == 2 || MI == 4) && (NI == 4 || NI == 6), "accumulator shapes of hgemm_mid_kernel");
-  if constexpr (MI == 2 && NI == 4) asm volatile(LC_MID_SETTLE : LC_MID_ACC4(0), LC_MID_ACC4(1));
-  else if constexpr (MI == 2 && NI == 6) asm volatile(LC_MID_SETTLE : LC_MID_ACC6(0), LC_MID_ACC6(1));
-  else if constexpr (MI == 4 && NI == 4) asm volatile(LC_MID_SETTLE : LC_MID_ACC4(0), LC_MID_ACC4(1), LC_MID_ACC4(2), LC_MID_ACC4(3));
-  else asm volatile(LC_MID_SETTLE : LC_MID_ACC6(0), LC_MID_ACC6(1), LC_MID_ACC6(2), LC_MID_ACC6(3));
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) name_agpr(acc[mi][ni]);
 }
-#undef LC_MID_ACC4
-#undef LC_MID_ACC6
-#undef LC_MID_SETTLE
 LC_DEVINL const char* sgpr_ptr(const void* p) {   // a pointer hipcc can PROVE wave-uniform (an "s" operand otherwise gets a waterfall loop)
   const uint64_t v = (uint64_t)p;
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kerne
                                                            half_t* __restrict__ C, int M, int N, int K, int tiles_m, int tiles_n,
                                                            int panel_w) {
   using G = Mid<TMW, TNW, NS>;
-  static_assert(!B_KN || TNW == 2, "NN: one whole [64 k][128 n] transpose image");
+  static_assert(!B_KN || TNW == 2 || TNW == 4, "NN: whole [64 k][128 n] transpose images");
   constexpr int MI = G::MI, NI = G::NI, PA = G::PA, PB = G::PB, TM = G::TM, TN = G::TN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -128,12 +128,12 @@ __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kerne
     if constexpr (!B_KN) {
       const int row = (4 * i + wave) * 8 + (lane >> 3);
       vb[i] = ((uint32_t)row * (uint32_t)K + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 8)) * 2u;
-    } else {   // [64 k][128 n] image, 256-byte rows = 8 pairs of 16-byte chunks, piece = 4 k rows
-      const int p = wave * 4 + i;
+    } else {   // sub-image i >> 2 = columns 128 (i >> 2) ..: [64 k][128 n], 256-byte rows = 8 pairs of 16-byte chunks, piece = 4 k rows
+      const int p = wave * 4 + (i & 3);
       const int k = p * 4 + (lane >> 4), pp = lane & 15;
       const int h = (k & 3) | (((k >> 3) & 1) << 2);
       const int nc = (((pp >> 1) ^ h) << 1) | (pp & 1);
-      vb[i] = ((uint32_t)k * (uint32_t)N + (uint32_t)(nc * 8)) * 2u;
+      vb[i] = ((uint32_t)k * (uint32_t)N + (uint32_t)((i >> 2) * 128 + nc * 8)) * 2u;
     }
   }
   const uint32_t smem32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr32(smem));
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kerne
   auto piece_lds = [&](int p) -> uint32_t {
     if (p < PA) return (uint32_t)((4 * p + wave) * 1024);
     const int i = p - PA;
-    return (uint32_t)(G::A_TILE + (B_KN ? (wave * 4 + i) * 1024 : (4 * i + wave) * 1024));
+    return (uint32_t)(G::A_TILE + (B_KN ? (i >> 2) * 16384 + (wave * 4 + (i & 3)) * 1024 : (4 * i + wave) * 1024));
   };
   // ---- fragment read addresses inside slot 0, per k-step (the k-step flips bit 6 of the swizzled offset: not an immediate)
   const int pc0 = g ^ ((lane >> 1) & 7);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kerne
     const int h = (i16 >> 2) | ((g & 1) << 2);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
-      bt[ni] = smem32 + (uint32_t)(G::A_TILE + k * 256 + (((wc * NI + ni) ^ h) * 32) + (i16 & 3) * 8);
+      bt[ni] = smem32 + (uint32_t)(G::A_TILE + ((wc * NI + ni) >> 3) * 16384 + k * 256 + ((((wc * NI + ni) & 7) ^ h) * 32) + (i16 & 3) * 8);
   }
 
   struct Frag {
@@ -186,25 +186,18 @@ __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kerne
   // every read of f has returned (in-order LDS queue: lgkmcnt(0)); the statement names the registers so that nothing of hipcc's that
   // touches them can be scheduled above it
   auto settle = [&](Frag& f) {
-#define LC_MID_A2 "+v"(f.a[0]), "+v"(f.a[1])
-#define LC_MID_B4 "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2]), "+v"(f.b[3])
-#define LC_MID_B6 LC_MID_B4, "+v"(f.b[4]), "+v"(f.b[5])
-#define LC_MID_R8 "+v"(f.raw[0]), "+v"(f.raw[1]), "+v"(f.raw[2]), "+v"(f.raw[3]), "+v"(f.raw[4]), "+v"(f.raw[5]), "+v"(f.raw[6]), "+v"(f.raw[7])
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) name_vgpr(f.a[mi]);
     if constexpr (!B_KN) {
-      if constexpr (MI == 2 && NI == 4) asm volatile("s_waitcnt lgkmcnt(0)" : LC_MID_A2, LC_MID_B4);
-      else if constexpr (MI == 2 && NI == 6) asm volatile("s_waitcnt lgkmcnt(0)" : LC_MID_A2, LC_MID_B6);
-      else if constexpr (MI == 4 && NI == 4) asm volatile("s_waitcnt lgkmcnt(0)" : LC_MID_A2, "+v"(f.a[MI - 2]), "+v"(f.a[MI - 1]), LC_MID_B4);
-      else asm volatile("s_waitcnt lgkmcnt(0)" : LC_MID_A2, "+v"(f.a[MI - 2]), "+v"(f.a[MI - 1]), LC_MID_B6);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) name_vgpr(f.b[ni]);
     } else {
-      if constexpr (MI == 2) asm volatile("s_waitcnt lgkmcnt(0)" : LC_MID_A2, LC_MID_R8);
-      else asm volatile("s_waitcnt lgkmcnt(0)" : LC_MID_A2, "+v"(f.a[MI - 2]), "+v"(f.a[MI - 1]), LC_MID_R8);
+#pragma unroll
+      for (int r = 0; r < 2 * NI; ++r) name_vgpr(f.raw[r]);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) f.b[ni] = cat4(f.raw[2 * ni], f.raw[2 * ni + 1]);
     }
-#undef LC_MID_A2
-#undef LC_MID_B4
-#undef LC_MID_B6
-#undef LC_MID_R8
   };
   using KS0 = std::integral_constant<int, 0>;
   using KS1 = std::integral_constant<int, 1>;

@@ -14,5 +14,5 @@ pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAI
 # summarise ON the box (the databases can exceed what gpurun merges back) and ship the summaries inside gpurun_out/
 python tools/summarize_prof.py $TAG > $OUT/summary.log 2>&1; echo "summary rc=$?" | tee -a $OUT/steps.log
 cp profiles/${TAG}_* $OUT/ 2>/dev/null
-find $OUT -name "*.db" -size +20M -delete
+find $OUT -name "*.db" -delete   # (the summaries above are what is kept: gpurun merges back at most 64 MiB)
 du -sh $OUT | tee -a $OUT/steps.log
