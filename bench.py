@@ -336,6 +336,28 @@ def bench_hgemm(w, args):
                 ven["error"] = repr(e)
             ven[lname + "_ours"] = sustained(lambda: capi.hgemm(a, b2, c, layout=l2, variant=var, swizzle_stride=stride),
                                              flops, 1.0)["tflops"]
+        # round 6: four more points of the reference bench's DEFAULT sweep (hgemm.py:28-32: multiples of 256), where LC_HGEMM_AUTO runs other
+        # kernels than at 8192^3 — the eight-wave 128-tile kernel's neighbour 1024, the mid-size kernel at 2048 / 2816, the 256-tile kernel on a
+        # one-round grid at 4096 — against hipBLASLt on the same operands: 0.3 s sustained each, ours and theirs alternating (three rounds).
+        # The whole sweep (100 cells): tools/hgemm_sizes.py sweep -> profiles/r6Z_hgemm_sweep.*.
+        pts = {}
+        for m in (1024, 2048, 2816, 4096):
+            am, bm, cm = a[:m, :m].contiguous(), host.as_col_major(b[:m, :m].contiguous()), torch.empty(m, m, dtype=torch.half, device="cuda")
+            sm = host.make_block_swizzle_stride(m, m)
+            fo = lambda: capi.hgemm(am, bm, cm, layout=capi.LAYOUT_TN, variant=capi.HGEMM_AUTO, swizzle_stride=sm)   # noqa: E731
+            fv = lambda: capi.hgemm_vendor(am, bm, cm, capi.LAYOUT_TN)   # noqa: E731
+            t = [0.0, 0.0]
+            n_l = [0, 0]
+            for r in range(3):
+                for i in ((0, 1) if r % 2 == 0 else (1, 0)):
+                    sres = sustained(fo if i == 0 else fv, 2.0 * m ** 3, 0.1)
+                    t[i] += sres["seconds"]
+                    n_l[i] += sres["launches"]
+            pts[str(m)] = {"tn_ours": 2.0 * m ** 3 * n_l[0] / t[0] * 1e-12, "tn_hipblaslt": 2.0 * m ** 3 * n_l[1] / t[1] * 1e-12,
+                           "kernel": capi.hgemm_kernel_name(m, m, m, capi.LAYOUT_TN)}
+            pts[str(m)]["ratio"] = pts[str(m)]["tn_ours"] / pts[str(m)]["tn_hipblaslt"]
+            del am, bm, cm
+        ven["sweep_points"] = pts
         capi.vendor_destroy()
         res["vendor_tflops"] = ven
         # uniform[-1,1) operands: the fill /opt/skills/guides/cdna_hip_programming.md quotes its 8192^3 figures on
@@ -901,6 +923,8 @@ def run(args):
     if args.workload == "hgemm":
         head["vendor_tn_ratio"] = ratio("tn")
         head["vendor_nn_ratio"] = ratio("nn")
+        for m, pt in (ven.get("sweep_points") or {}).items():
+            head[f"vendor_tn_ratio_{m}"] = pt["ratio"]
     for tag, keys in (("attn_cfg4", ("tflops", "frac", "ms_per_step", "n_ranks")), ("attn_cfg3", ("tflops", "frac"))):
         for k in keys:
             if f"{tag}_{k}" in flat:
