@@ -94,15 +94,15 @@ def test_bench_default_workload_keeps_one_headline_workload_at_every_n():
 
 def test_bench_default_line_carries_the_vendor_comparator_first():
     """Round-5 verdict (weak #4): the one same-node comparator behind the HGEMM claim must sit where the driver's parse of `roofline` keeps it —
-    right behind the contract's six fields — incl. the four extra points of the reference's default sweep (1024 / 2048 / 2816 / 4096: the sizes
+    right behind the contract's six fields — incl. the four extra points of the reference's default sweep (1024 / 2048 / 2816 / 3072: the sizes
     where other kernels than the 8192^3 one run); the mid-size kernel must be the one that serves 2048 and 2816 on a 256-CU device."""
     out = _run(["--steps", "5", "--warmup", "2", "--no-attention", "--no-cpu-baseline"], timeout=900)
     r = out["roofline"]
     assert list(r)[:12] == ["bound", "achieved", "peak", "unit", "frac", "traffic", "vendor_tn_ratio", "vendor_nn_ratio", "vendor_tn_ratio_1024",
-                            "vendor_tn_ratio_2048", "vendor_tn_ratio_2816", "vendor_tn_ratio_4096"]
+                            "vendor_tn_ratio_2048", "vendor_tn_ratio_2816", "vendor_tn_ratio_3072"]
     pts = out["vendor_tflops"]["sweep_points"]
     assert 0.9 < r["vendor_tn_ratio"] < 1.15 and r["vendor_nn_ratio"] > 1.0
-    for m in ("1024", "2048", "2816", "4096"):
+    for m in ("1024", "2048", "2816", "3072"):
         assert r[f"vendor_tn_ratio_{m}"] == pts[m]["ratio"] > 0.9, (m, pts[m])
     assert pts["2048"]["kernel"].startswith("hgemm_mid_kernel<false,") and pts["2816"]["kernel"].startswith("hgemm_mid_kernel<false,")
     assert out["calibration"]["adopted"] in (True, False) and "tau128_us" in out["calibration"]
