@@ -154,8 +154,9 @@ const char* lc_build_info(int* is_diag);
  *                  problem the one with the least ceil(workgroups / CUs) x tile area), 1 = never, 12 / 13 / 22 / 23 = that tile (rows / 64,
  *                  columns / 64) whenever it divides the problem (A/B knob; also what an explicit LC_HGEMM_MID then runs)
  *   "hgemm_mid_ns" LDS ring slots of LC_HGEMM_MID: 0 = auto (3 when the grid is one round of <= one workgroup per CU, else 2), 2, 3
- *   "hgemm_tail"   1 (default) = when the 256-tile grid's last wave holds at most 128 tiles, the generated-loop kernel computes the
- *                  full waves and the 128-tile kernel the four quadrants of each remaining tile; 0 = one launch
+ *   "hgemm_tail"   (2 = as 1, but the quadrants on the 128-tile kernel with a workspace split-K: round 5's form, kept for A/B and for shapes with
+ *                  border strips; 3 / 4 = as 1 with remainders up to 0.75 / 1.0 of the CUs: measured 8 ... 18 % slower, A/B only)  1 (default) = when the 256-tile grid's last wave holds at most 128 tiles, the generated-loop kernel computes the
+ *                  full waves and 128 x 128 blocks the four quadrants of each remaining tile (round 6: on the mid-size kernel, + 4 ... 6 % at 4352 ... 6400); 0 = one launch
  *   "hgemm_raster" block -> C tile map of the tiled GEMM kernels: 0 = auto (2 when A + B exceed 272 MiB — the 256 MiB Infinity Cache and a margin,
  *                  else 1), 1 = the reference's block swizzle (N panels of swizzle_stride columns, every XCD a contiguous id
  *                  range), 2 = XCD super-block raster (16 x 16 tile steps shared through the Infinity Cache, 4 x 8 per XCD;

@@ -100,7 +100,7 @@ LC_DEVINL const char* sgpr_ptr(const void* p) {   // a pointer hipcc can PROVE w
 template <bool B_KN, int TMW, int TNW, int NS>
 __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B,
                                                            half_t* __restrict__ C, int M, int N, int K, int tiles_m, int tiles_n,
-                                                           int panel_w) {
+                                                           int panel_w, int rem_base) {
   using G = Mid<TMW, TNW, NS>;
   static_assert(!B_KN || TNW == 2 || TNW == 4, "NN: whole [64 k][128 n] transpose images");
   constexpr int MI = G::MI, NI = G::NI, PA = G::PA, PB = G::PB, TM = G::TM, TN = G::TN;
@@ -109,8 +109,20 @@ __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kerne
   const int wave = wave_id();
   const int wr = wave >> 1, wc = wave & 1;
   const int i16 = lane & 15, g = lane >> 4;
-  const TileCoord tc = block_tile((int)blockIdx.x, (int)gridDim.x, tiles_m, tiles_n, panel_w);
-  const int m0 = tc.tm * TM, n0 = tc.tn * TN;
+  // rem_base < 0: this kernel's own grid of TM x TN tiles.  rem_base >= 0 (128 x 128 only; lc_abi.hip launch_mfma256): tiles_m / tiles_n /
+  // panel_w describe the 256 x 256 tile grid of hgemm_w4y_kernel and block b is quadrant b & 3 of the 256-tile whose raster id is
+  // rem_base + (b >> 2) — the ids that kernel's truncated grid left out (its ragged last round; hgemm_mfma128.hip mfma128_tile's map).
+  int m0, n0;
+  if (rem_base < 0) {
+    const TileCoord tc = block_tile((int)blockIdx.x, (int)gridDim.x, tiles_m, tiles_n, panel_w);
+    m0 = tc.tm * TM;
+    n0 = tc.tn * TN;
+  } else {
+    const int id = rem_base + ((int)blockIdx.x >> 2), qd = (int)blockIdx.x & 3;
+    const TileCoord tc = panel_w < 0 ? raster_xcd16(id, tiles_m * tiles_n, tiles_m, tiles_n) : raster(id, tiles_m, tiles_n, panel_w);
+    m0 = tc.tm * 256 + (qd >> 1) * 128;
+    n0 = tc.tn * 256 + (qd & 1) * 128;
+  }
 
   // ---- LDS-DMA sources: wave-uniform 64-bit bases (advanced per K tile on the scalar unit) + 32-bit per-lane byte offsets.
   // hgemm_mfma128.hip's piece map: piece i of this wave = 8-row block 4 i + wave of a K-contiguous operand.

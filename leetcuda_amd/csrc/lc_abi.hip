@@ -52,7 +52,7 @@ tune_t g_tune_attn_calib{0};                   // split-KV cost model: 0 = the c
 tune_t g_tune_hgemm_mid{0};                    // mid-size kernel (hgemm_mid.hip): 0 = auto (mid_tile_auto), 1 = never, 12 / 13 / 22 / 23 = that tile (rows / 64, columns / 64)
 tune_t g_tune_hgemm_mid_ns{0};                 // ... its LDS ring slots: 0 = auto (3 for one-round grids, else 2), 2, 3
 tune_t g_tune_hgemm_128w{0};                   // waves of the 128-tile kernel: 0 = auto (eight — intra-workgroup split-K — on grids of <= 0.6 blocks per CU), 1 = always four, 2 = always eight
-tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to the 128-tile kernel (launch_mfma256), 0 = one launch
+tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to 128 x 128 blocks (launch_mfma256: the mid-size kernel; 2 = round 5's 128-tile kernel + split-K), 0 = one launch
 tune_t g_tune_hgemm_raster{0};                 // block -> C tile map: 0 = auto (by operand footprint, panel_tiles), 1 = the reference's block swizzle (N panels from
                                              // swizzle_stride, XCD-contiguous ids), 2 = XCD super-block raster (hgemm_mfma256.hip raster_xcd16)
 
@@ -252,8 +252,15 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
     const bool w4y = w4_effective_variant(variant, B_KN, N, K) == LC_HGEMM_MFMA256W4Y;
     const int nright = (N % BN) ? M / BM1 : 0, nbottom = (M % BM) ? 2 * tiles_n : 0;   // border strips in 128 x 128 tiles
     if ((nright || nbottom || (K % BK)) && !w4y) return LC_ERR_SHAPE;   // (resolve_hgemm_variant never lets this happen)
-    const bool split = g_tune_hgemm_tail != 0 && T > ncu && R > 0 && 2 * R <= ncu && w4y;
+    const int tail_knob = g_tune_hgemm_tail;
+    // (knob 3 / 4: the remainder up to 0.75 / 1.0 of the CUs instead of 0.5 — A/B of the threshold, profiles/r6l_hgemm_tail_mid.log)
+    const bool split = tail_knob != 0 && T > ncu && R > 0 && w4y && (tail_knob == 3 ? 4 * R <= 3 * ncu : tail_knob == 4 ? true : 2 * R <= ncu);
     if (int rc = launch_w4_family(A, B, C, M, N, K, variant, B_KN, tiles_m, tiles_n, pw, split ? T - R : -1, st)) return rc;
+    // Round 6 (lc_tune_set "hgemm_tail" = 1, the default; 2 = round 5's path below): with no border strips the quadrants of the left-out
+    // tiles run on the mid-size kernel — three ring slots when they fit one round of the CUs, two slots at two workgroups per CU beyond; no
+    // workspace, no reduce launch, legal under graph capture (profiles/r6l_hgemm_tail_mid.log: + 3 ... 7 % at 4352 ... 4864, 6144, 10240)
+    if (split && nright == 0 && nbottom == 0 && tail_knob != 2 && g_tune_hgemm_mid != 1 && K < (1 << 22) && N < (1 << 22))
+      return launch_hgemm_mid_rem(A, B, C, M, N, K, B_KN, 4 * R <= ncu ? 3 : 2, tiles_m, tiles_n, pw, T - R, 4 * R, st);
     const int nb128 = (split ? 4 * R : 0) + nright + nbottom;
     if (nb128 == 0) return LC_OK;
     // Split-K of these blocks (lc_tune_set "hgemm_splitk"): a lone 128-tile block walks its K range at a quarter of a CU's MFMA rate
@@ -784,7 +791,7 @@ const Knob kKnobs[] = {
     {"w4y_sched", &g_tune_w4y_sched, 2, ok_w4y_sched, false},
     {"hgemm_persist", &g_tune_hgemm_persist, 1, ok_01, false},
     {"hgemm_stagger", &g_tune_hgemm_stagger, 0, ok_stagger, false},
-    {"hgemm_tail", &g_tune_hgemm_tail, 1, ok_01, false},
+    {"hgemm_tail", &g_tune_hgemm_tail, 1, ok_04, false},
     {"hgemm_128w", &g_tune_hgemm_128w, 0, ok_02, false},
     {"rule_cus", &g_tune_rule_cus, 0, ok_rule_cus, false},
     {"attn_calib", &g_tune_attn_calib, 0, ok_01, false},

@@ -10,7 +10,16 @@ int launch_mid_one(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   auto kern = hgemm_mid_kernel<B_KN, TMW, TNW, NS>;
   if (int rc = set_dyn_lds(kern, G::LDS)) return rc;
   const int tiles_m = M / G::TM, tiles_n = N / G::TN;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), G::LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), G::LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw, -1);
+  return check_launch();
+}
+template <bool B_KN, int NS>
+int launch_mid_rem_one(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int tiles_m256, int tiles_n256, int pw256, int rem_base,
+                       int nblocks, hipStream_t st) {
+  using G = Mid<2, 2, NS>;
+  auto kern = hgemm_mid_kernel<B_KN, 2, 2, NS>;
+  if (int rc = set_dyn_lds(kern, G::LDS)) return rc;
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), G::LDS, st, A, B, C, M, N, K, tiles_m256, tiles_n256, pw256, rem_base);
   return check_launch();
 }
 template <bool B_KN, int TMW, int TNW>
@@ -34,5 +43,17 @@ int launch_hgemm_mid(const half_t* A, const half_t* B, half_t* C, int M, int N, 
   if (b_kn) return launch_mid_tm<true, 2>(A, B, C, M, N, K, tmw, ns, pw, st);
   if (tnw == 2) return launch_mid_tm<false, 2>(A, B, C, M, N, K, tmw, ns, pw, st);
   return launch_mid_tm<false, 3>(A, B, C, M, N, K, tmw, ns, pw, st);
+}
+
+// The ragged last round of hgemm_w4y_kernel's 256 x 256 grid as 128 x 128 quadrants on this kernel (round 6; until then on hgemm_mfma128_kernel
+// with a workspace split-K): nblocks = 4 x (tiles left out), rem_base = first raster id left out, tiles_m256 / tiles_n256 / pw256 = that grid's
+// dimensions and block map.  ns: 3 when the quadrants fit one round of the CUs, else 2.
+int launch_hgemm_mid_rem(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int ns, int tiles_m256, int tiles_n256,
+                         int pw256, int rem_base, int nblocks, hipStream_t st) {
+  if (K % 32 != 0 || K < BK || K >= (1 << 22) || N >= (1 << 22) || rem_base < 0 || nblocks <= 0) return LC_ERR_SHAPE;
+  if (b_kn) return ns == 3 ? launch_mid_rem_one<true, 3>(A, B, C, M, N, K, tiles_m256, tiles_n256, pw256, rem_base, nblocks, st)
+                           : launch_mid_rem_one<true, 2>(A, B, C, M, N, K, tiles_m256, tiles_n256, pw256, rem_base, nblocks, st);
+  return ns == 3 ? launch_mid_rem_one<false, 3>(A, B, C, M, N, K, tiles_m256, tiles_n256, pw256, rem_base, nblocks, st)
+                 : launch_mid_rem_one<false, 2>(A, B, C, M, N, K, tiles_m256, tiles_n256, pw256, rem_base, nblocks, st);
 }
 }  // namespace lc
