@@ -102,6 +102,7 @@ class PowerSampler:
 
     def __init__(self, device_index: int):
         self.path = None
+        self.freq_path = None       # freq1_input of the same hwmon node: the SMU's current shader clock in Hz
         self.samples = []
         self._stop = False
         self._thread = None
@@ -113,13 +114,16 @@ class PowerSampler:
                 if hits:
                     self.path = hits[0]
                     break
+            if self.path is not None and (self.path.parent / "freq1_input").exists():
+                self.freq_path = self.path.parent / "freq1_input"
         except Exception:
             self.path = None
 
     def _run(self):
         while not self._stop:
             try:
-                self.samples.append(int(self.path.read_text()) * 1e-6)
+                f = int(self.freq_path.read_text()) * 1e-9 if self.freq_path is not None else None
+                self.samples.append((time.perf_counter(), int(self.path.read_text()) * 1e-6, f))
             except Exception:
                 pass
             time.sleep(0.02)
@@ -137,57 +141,60 @@ class PowerSampler:
             self._thread.join(timeout=1.0)
         return False
 
-    def result(self):
-        if not self.samples:
-            return {"mean_w": None, "max_w": None, "samples": 0, "source": str(self.path) if self.path else None}
-        return {"mean_w": sum(self.samples) / len(self.samples), "max_w": max(self.samples), "samples": len(self.samples),
+    def result(self, t_begin=None, t_end=None):
+        """Samples taken inside [t_begin, t_end] (perf_counter stamps of the timed bracket; the sampler itself is started earlier, so that its
+        start-up — a sysfs glob, a thread — never sits between the clock probe and the first timed launch)."""
+        pick = [x for x in self.samples if (t_begin is None or x[0] >= t_begin) and (t_end is None or x[0] <= t_end)]
+        if not pick:
+            pick = self.samples[-1:]      # a bracket shorter than one sampling period: the sample next to it
+        if not pick:
+            return {"mean_w": None, "max_w": None, "sclk_ghz": None, "samples": 0, "source": str(self.path) if self.path else None}
+        vals = [x[1] for x in pick]
+        fr = [x[2] for x in pick if x[2] is not None]
+        return {"mean_w": sum(vals) / len(vals), "max_w": max(vals), "sclk_ghz": (sum(fr) / len(fr)) if fr else None, "samples": len(vals),
                 "source": str(self.path)}
 
 
 def timed_region(w, step, steps, warmup, prewarm=PREWARM):
     """W untimed + exactly K timed steps, barrier+sync on both sides; returns local seconds.  Side results (never inside the wall-clock
-    bracket): timed_region.event_ms (HIP events around the K launches), .eff_clock_ghz (shader-clock / 100 MHz reference-clock deltas of
-    two lc_clock_probe stamps enqueued right in front of and right behind the bracket), .power (PowerSampler over the bracket)."""
-    stamps = torch.zeros(4, dtype=torch.int64, device="cuda")
-    t_pre = time.perf_counter()
-    n_pre = 0
-    while n_pre < prewarm or (prewarm >= PREWARM and time.perf_counter() - t_pre < PREWARM_SECONDS):
-        step()                 # setup: clocks / code objects / allocator, not part of W or K
-        n_pre += 1
-        if n_pre % 16 == 0:
-            torch.cuda.synchronize()   # (bounds the launch queue; the wall clock above then tracks GPU time)
-    for _ in range(warmup):
-        step()
-    capi.clock_probe(stamps[0:2])
+    bracket): timed_region.event_ms (HIP events around the K launches), .power (PowerSampler over the bracket: board power and the SMU's
+    shader clock, amdgpu hwmon).  (Round 6 first stamped s_memtime around the bracket with two lc_clock_probe launches: the counter is
+    per CU / not synchronised across the chip, two one-workgroup launches land on different CUs, and over a 15 ms bracket the stamps
+    "measured" 8.1, 2.0 and - 5.1 GHz; `sustained` keeps that method over >= 1 s, where the offset is < 1 %.)"""
     ps = PowerSampler(torch.cuda.current_device())
-    with ps:
+    with ps:                       # (sampling from here on; only the samples inside the bracket are reported)
+        t_pre = time.perf_counter()
+        n_pre = 0
+        while n_pre < prewarm or (prewarm >= PREWARM and time.perf_counter() - t_pre < PREWARM_SECONDS):
+            step()                 # setup: clocks / code objects / allocator, not part of W or K
+            n_pre += 1
+            if n_pre % 16 == 0:
+                torch.cuda.synchronize()   # (bounds the launch queue; the wall clock above then tracks GPU time)
+        for _ in range(warmup):
+            step()
         lcd.barrier(w)
         t0 = time.perf_counter()
         with capi.Timer() as tm:        # HIP events on the launch stream around the SAME K launches: the roofline's kernel time
             for _ in range(steps):
                 step()
         lcd.barrier(w)
-        secs = time.perf_counter() - t0
-    capi.clock_probe(stamps[2:4])
-    torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        secs = t1 - t0
     timed_region.event_ms = tm.ms   # (events are recorded inside the wall-clock bracket: kernel time <= step time)
-    st = stamps.cpu().tolist()
-    d_cyc, d_ref = st[2] - st[0], st[3] - st[1]
-    timed_region.eff_clock_ghz = (d_cyc / (d_ref / 100e6) * 1e-9) if d_ref > 0 else None
-    timed_region.power = ps.result()
+    timed_region.power = ps.result(t0, t1)
     return secs
 
 
 def per_rank_rows(w, ms_kernel_local, tflops_local):
-    """One row per rank — kernel ms, TFLOP/s, effective shader clock, mean / max board power over the timed bracket — gathered with the
+    """One row per rank — kernel ms, TFLOP/s, the SMU's shader clock (hwmon freq1_input), mean / max board power over the timed bracket — gathered with the
     same small fp64 all-gather as the timings (no data-path collective).  NaN = not available on that rank."""
     nan = float("nan")
     pw = timed_region.power or {}
-    row = [float(w.rank), ms_kernel_local, tflops_local, timed_region.eff_clock_ghz or nan,
+    row = [float(w.rank), ms_kernel_local, tflops_local, pw.get("sclk_ghz") or nan,
            pw.get("mean_w") if pw.get("mean_w") is not None else nan, pw.get("max_w") if pw.get("max_w") is not None else nan]
     rows = lcd.gather_row(w, row).tolist()
     clean = lambda x: None if x != x else x   # noqa: E731
-    return [{"rank": int(r[0]), "kernel_ms": r[1], "tflops": r[2], "eff_clock_ghz": clean(r[3]), "power_mean_w": clean(r[4]),
+    return [{"rank": int(r[0]), "kernel_ms": r[1], "tflops": r[2], "sclk_ghz": clean(r[3]), "power_mean_w": clean(r[4]),
              "power_max_w": clean(r[5])} for r in rows]
 
 
@@ -317,7 +324,7 @@ def bench_hgemm(w, args):
         "scaling": "weak",
         "roofline": roofline(kname, flops, 3.0 * n * n * 2, ms_kernel, workload=f"hgemm_{n}"),
         "n_ranks": w.size,
-        "per_rank": {"ranks": ranks, "note": "eff_clock_ghz / power_*_w span the timed bracket of each rank's own GPU (power: amdgpu hwmon, 20 ms samples)"},
+        "per_rank": {"ranks": ranks, "note": "sclk_ghz / power_*_w: amdgpu hwmon freq1_input / power1_* of each rank's own GPU, 20 ms samples inside the timed bracket"},
     }
     if n % 2048 == 0:
         res["roofline"]["traffic_model"] = {

@@ -129,8 +129,8 @@ def test_bench_default_line_at_eight_ranks_on_one_gpu():
     """Round-5 verdict (next #4): no 8-GPU node has been available to any round, so the N = 8 launch itself is exercised here — the default
     line, self-spawned, eight gloo ranks sharing this GPU (config 4's shard = 1 GiB per tensor and rank).  The keys the driver's SCALE
     record needs are the first fields of `roofline`; config 4's outputs are the one-GPU run's bit for bit (checksum of the fp16 bit
-    patterns, data drawn per (batch, head) unit so they do not depend on W); every rank reports its clock and, where the box exposes the
-    hwmon file, its board power; exactly one cpu_baseline."""
+    patterns, data drawn per (batch, head) unit so they do not depend on W); every rank reports, where the box exposes the
+    hwmon files, its shader clock and board power; exactly one cpu_baseline."""
     out = _run(["--gpus", "8", "--steps", "2", "--warmup", "1"], {"LC_DIST_BACKEND": "gloo"}, timeout=2400)
     assert out["n_gpus"] == 8 and out["scaling"] == "weak" and "HGEMM M=N=K=8192" in out["config"]["workload"]
     r = out["roofline"]
@@ -142,7 +142,7 @@ def test_bench_default_line_at_eight_ranks_on_one_gpu():
     c4 = out["attention_cfg4"]
     assert c4["per_rank"]["problems"] == [4, 32] and "4x32 (batch,head) problems per rank" in c4["workload"]
     ranks = c4["per_rank"]["ranks"]
-    assert sorted(x["rank"] for x in ranks) == list(range(8)) and all(x["kernel_ms"] > 0 and x["eff_clock_ghz"] > 0.5 for x in ranks)
+    assert sorted(x["rank"] for x in ranks) == list(range(8)) and all(x["kernel_ms"] > 0 and (x["sclk_ghz"] is None or 0.3 < x["sclk_ghz"] < 3.0) for x in ranks)
     assert len(out["per_rank"]["ranks"]) == 8
     assert isinstance(out["cpu_baseline"], dict) and out["cpu_baseline"]["value"] > 0
     one = _run(["--workload", "attn_cfg4", "--steps", "2", "--warmup", "1", "--quick"], timeout=1500)
