@@ -421,6 +421,32 @@ def test_every_reference_entry_name_computes_the_gemm(oracle):
         capi.hgemm_call("destroy_cublas_handle", a, b, a)
 
 
+def test_cross_check_entry_names_run_the_auto_kernel_on_small_grids():
+    """Round 6: the entry names that map to the 256-tile cross-check kernels / the 128-tile kernel keep them on large grids (the reference
+    bench's rows stay distinct there) but run what LC_HGEMM_AUTO runs where a 256 x 256 tile serves nobody — 2048^3 is 64 such tiles on 256
+    CUs: 330 TFLOP/s against 818 in the reference's own unmodified sweep (profiles/r6Z_f1_hgemm_default_sweep.log) — so a drop-in caller
+    of ANY name gets the mid-size kernel's bits and speed there."""
+    capi = _capi()
+    n = 2048
+    torch.manual_seed(2048)
+    a = torch.randn(n, n, dtype=torch.half, device="cuda")
+    b = torch.randn(n, n, dtype=torch.half, device="cuda")
+    bcol = host.as_col_major(b)
+    ref = {}
+    for lay, bb in ((capi.LAYOUT_NN, b), (capi.LAYOUT_TN, bcol)):
+        c = torch.zeros(n, n, dtype=torch.half, device="cuda")
+        capi.hgemm(a, bb, c, layout=lay, variant=capi.HGEMM_AUTO, swizzle_stride=1024)
+        ref[lay] = c
+    torch.cuda.synchronize()
+    for name in ("hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem_tn", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem", "hgemm_mma_m16n8k16_mma2x4_warp4x4",
+                 "hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages_dsmem", "hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", "hgemm_wmma_m16n16k16_mma4x2_warp2x4"):
+        lay = dict((nm, l) for nm, l, _ in capi.hgemm_entries())[name]
+        c = torch.full((n, n), float("nan"), dtype=torch.half, device="cuda")
+        capi.hgemm_call(name, a, bcol if lay == capi.LAYOUT_TN else b, c, 2, True, 1024)
+        torch.cuda.synchronize()
+        assert torch.equal(c, ref[lay]), name
+
+
 @pytest.mark.parametrize("rung", list(range(20, 31)))
 def test_vector_alu_ladder_rungs(oracle, rung):
     """f2: the reference's CUDA-core ladder (naive/hgemm.cu) as real vector-ALU kernels (hgemm_valu.hip): every rung against

@@ -11,6 +11,9 @@ set +e
 timeout 600 $R $S/hgemm/hgemm.py --mma-all --wmma-all --cuda-all --mma-tn --cute-tn --torch --MNK 8192 --sleep 0.02 > $OUT/f1_hgemm_8192_all.log 2>&1; echo "hgemm all rc=$?" | tee -a $OUT/f1_steps.log
 # 2. the --plot path (hgemm.py:362-416): MMA families + the two vendor lines over 1024..8192, PNG saved
 timeout 600 $R $S/hgemm/hgemm.py --mma-all --mma-tn --cute-tn --MMNK 8192 --SEP 1024 --plot --topk 8 --sleep 0.02 --dir $PWD/$OUT --tag f1_mma > $OUT/f1_hgemm_plot.log 2>&1; echo "hgemm plot rc=$?" | tee -a $OUT/f1_steps.log
+# 2b. (round 6) the script's DEFAULT sweep — every M = N = K multiple of 256 up to 12800 (hgemm.py:28-32,419-421), the sweep its README's
+#     "98 - 100 % of cuBLAS" is made over — TN families + the cuBLAS (= hipBLASLt) TN line, PNG saved
+timeout 1500 $R $S/hgemm/hgemm.py --mma-tn --cute-tn --plot --topk 8 --sleep 0.02 --dir $PWD/$OUT --tag f1_sweep > $OUT/f1_hgemm_default_sweep.log 2>&1; echo "hgemm default sweep rc=$?" | tee -a $OUT/f1_steps.log
 # 3. flash_attn_mma.py --check (allclose atol 1e-2 against the flash-attn / SDPA comparators, flash_attn_mma.py:465-494) at
 #    config 3 and at the reference's own published shapes
 timeout 600 $R $S/flash-attn/flash_attn_mma.py --B 4 --H 32 --N 4096 --D 128 --check --show-all --others --seed 1 > $OUT/f1_fa_cfg3_check.log 2>&1; echo "fa cfg3 rc=$?" | tee -a $OUT/f1_steps.log
