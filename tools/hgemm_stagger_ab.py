@@ -40,10 +40,14 @@ for n in sizes:
         if LAYS not in ("both", lname):
             continue
         b2 = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
-        knobs = {"auto": 0, "off": OFF,
+        if len(sys.argv) > 4 and sys.argv[4] == "steps":     # odd / neighbouring steps of the by-XCD stagger (auto: KT / 8)
+            base = kt // 8
+            knobs = {"auto": 0, **{f"x8 step {st_}": enc(1, 0, 0, st_, 7) for st_ in (base - 3, base - 1, base + 1, base + 3, base + 5, base // 2, base // 2 + 1, 2 * base + 1)}}
+        else:
+            knobs = {"auto": 0, "off": OFF,
                  "x8": enc(1, 0, 0, kt // 8, 7), "x8+m": enc(1, 1, 0, kt // 8, 7), "x8+n": enc(1, 0, 1, kt // 8, 7), "x8+m+n": enc(1, 1, 1, kt // 8, 7),
                  "x+8m/64": enc(1, 8, 0, kt // 64, 63), "x+8n/64": enc(1, 0, 8, kt // 64, 63), "x+8m/32": enc(1, 8, 0, kt // 32, 31),
-                 "m+n/16": enc(0, 1, 1, kt // 16, 15), "x/8 s1": enc(1, 0, 0, 1, 7), "x+8m s1": enc(1, 8, 0, 1, 63), "x+8m+n s3": enc(1, 8, 1, 3, 127)}
+                     "m+n/16": enc(0, 1, 1, kt // 16, 15), "x/8 s1": enc(1, 0, 0, 1, 7), "x+8m s1": enc(1, 8, 0, 1, 63), "x+8m+n s3": enc(1, 8, 1, 3, 127)}
 
         def mk(v):
             def f():
