@@ -151,7 +151,7 @@ const char* lc_build_info(int* is_diag);
  *   "hgemm_128w"   waves of LC_HGEMM_MFMA128: 0 = auto (eight — the two k-steps of every K tile on two groups of four waves, summed through LDS at the
  *                  end — on grids of <= 0.6 blocks per CU: + 11 % at 1024^3 / 1536^3; level at 2048^3, slower for NN beyond), 1 = four, 2 = eight
  *   "hgemm_mid"    LC_HGEMM_AUTO's use of LC_HGEMM_MID: 0 = auto (among the 128 x 128 / 128 x 192 / 64 x 128 / 64 x 192 tiles that divide the
- *                  problem the one with the least ceil(workgroups / CUs) x tile area), 1 = never, 12 / 13 / 22 / 23 = that tile (rows / 64,
+ *                  problem the one with the least ceil(workgroups / CUs) x tile area), 1 = never, 12 / 13 / 22 / 23 / 32 = that tile (rows / 64,
  *                  columns / 64) whenever it divides the problem (A/B knob; also what an explicit LC_HGEMM_MID then runs)
  *   "hgemm_mid_ns" LDS ring slots of LC_HGEMM_MID: 0 = auto (3 when the grid is one round of <= one workgroup per CU, else 2), 2, 3
  *   "hgemm_tail"   (2 = as 1, but the quadrants on the 128-tile kernel with a workspace split-K: round 5's form, kept for A/B and for shapes with

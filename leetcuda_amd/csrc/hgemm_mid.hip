@@ -1,4 +1,4 @@
-// hgemm_mid.hip — the mid-size HGEMM kernel (round 6): (64 | 128) x (128 | 192) x 64 workgroup tile, 4 wave64 as 2 x 2, an NS-slot LDS ring
+// hgemm_mid.hip — the mid-size HGEMM kernel (round 6): (64 | 128 | 192) x (128 | 192) x 64 workgroup tile, 4 wave64 as 2 x 2, an NS-slot LDS ring
 // (NS = 3: one workgroup per CU with two K tiles in flight; NS = 2: two workgroups per CU), every instruction of the K loop an asm
 // statement in hand-written order: the LDS reads of the next k-step and the LDS-DMA of a later K tile ride in the shadow of this
 // k-step's MFMAs.  Reference: the same contraction as kernels/hgemm/mma/basic/hgemm_mma_stage.cu:644-1052 (NN) and
@@ -22,7 +22,9 @@
 //     (The builtin form of this loop: hipcc un-ties D from C of the MFMAs and repairs the permutation with 116 v_accvgpr moves per K
 //     tile, and its s_waitcnt bookkeeping falls back to lgkmcnt(0) in front of each MFMA group.)
 // Shapes: M % (64 TMW) == 0, N % (64 TNW) == 0, K % 32 == 0, K >= 64 (K % 64 == 32: the half k-step of hgemm_mfma128.hip), row strides
-// below 2^22 elements (32-bit DMA offsets).  NN (B as [K,N]): TNW = 2 (hgemm_mfma128.hip's [64 k][128 n] transpose image).  Operands,
+// below 2^22 elements (32-bit DMA offsets).  NN (B as [K,N]): TNW = 2 (hgemm_mfma128.hip's [64 k][128 n] transpose image) — its 192-wide
+// counterpart is the 192 x 128 tile (TMW = 3: 2304^3 NN in one round of 216 workgroups).  The same kernel also computes the 128 x 128
+// quadrants of hgemm_w4y_kernel's ragged last round (rem_base >= 0), and lc_probe_mid256 (liblc_diag.so) instantiates it at 256 x 256.  Operands,
 // LDS images and swizzles are the ones of hgemm_mfma128.hip (conflict-freedom: tests/test_layouts.py); arithmetic order per output =
 // that kernel's (k ascending, one fp32 accumulator), so the two agree bit for bit (GPU test).
 #pragma once
@@ -42,7 +44,7 @@ struct Mid {
   static constexpr int EPI_ROW = 64 * TNW + 16;       // bytes per staged C row of a wave tile (32 TNW halves + 16 B pad)
   static constexpr int EPI = 4 * (32 * TMW) * EPI_ROW;
   static constexpr int LDS = NS * STAGE > EPI ? NS * STAGE : EPI;
-  static_assert((TMW == 1 || TMW == 2 || TMW == 4) && TNW >= 2 && TNW <= 4 && NS >= 2 && NS <= 3, "64 / 128 / 256 x 128 / 192 / 256 tiles, 2 .. 3 ring slots");
+  static_assert(TMW >= 1 && TMW <= 4 && TNW >= 2 && TNW <= 4 && NS >= 2 && NS <= 3, "64 ... 256 x 128 / 192 / 256 tiles, 2 .. 3 ring slots");
   static_assert(LDS <= 160 * 1024, "ring must fit a CU's LDS");
   static_assert((NS - 1) * PPW <= 63, "vmcnt is a 6-bit counter");
 };

@@ -49,7 +49,7 @@ tune_t g_tune_hgemm_auto{LC_HGEMM_MFMA256W4Y};   // what LC_HGEMM_AUTO launches 
 tune_t g_tune_hgemm_splitk{0};                 // split-K of the 128-tile blocks that serve border strips / the ragged last wave: 0 = auto (launch_mfma256), 1 = off, 2 .. 8 = that factor
 tune_t g_tune_rule_cus{0};                     // CU count the LAUNCH RULES reason with: 0 = the current device's own; 64 .. 1024 = that many (tests of the rules for other devices; grids are always sized with the real count)
 tune_t g_tune_attn_calib{0};                   // split-KV cost model: 0 = the constants lc_tune_calibrate measured on this device when it ran (else the built-in ones), 1 = always the built-in ones
-tune_t g_tune_hgemm_mid{0};                    // mid-size kernel (hgemm_mid.hip): 0 = auto (mid_tile_auto), 1 = never, 12 / 13 / 22 / 23 = that tile (rows / 64, columns / 64)
+tune_t g_tune_hgemm_mid{0};                    // mid-size kernel (hgemm_mid.hip): 0 = auto (mid_tile_auto), 1 = never, 12 / 13 / 22 / 23 / 32 = that tile (rows / 64, columns / 64)
 tune_t g_tune_hgemm_mid_ns{0};                 // ... its LDS ring slots: 0 = auto (3 for one-round grids, else 2), 2, 3
 tune_t g_tune_hgemm_128w{0};                   // waves of the 128-tile kernel: 0 = auto (eight — intra-workgroup split-K — on grids of <= 0.6 blocks per CU), 1 = always four, 2 = always eight
 tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to 128 x 128 blocks (launch_mfma256: the mid-size kernel; 2 = round 5's 128-tile kernel + split-K), 0 = one launch
@@ -320,7 +320,7 @@ int launch_mfma128(const half_t* A, const half_t* B, half_t* C, int M, int N, in
 // Auto = hipBLASLt's own heuristic for these sizes read off its kernel names (profiles/r6a_vendor_kernels.log) and measured here tile by
 // tile (profiles/r6c_hgemm_mid_ab.log): when a tile's grid fits ONE ROUND of at most one workgroup per CU, the smallest such tile — most
 // workgroups, least work on the busiest CU — with three ring slots (the DMA two tiles ahead): 64 x 128 at 1024 / 1280, 64 x 192 at 1536
-// TN, 128 x 128 at 1536 NN / 1792 / 2048, 128 x 192 at 2304 TN (the 64-row tiles lose to the 128-row ones as soon as both need more than a
+// TN, 128 x 128 at 1536 NN / 1792 / 2048, 128 x 192 at 2304 TN, 192 x 128 at 2304 NN (the 64-row tiles lose to the 128-row ones as soon as both need more than a
 // round: 2304 NN 780 vs 866 TFLOP/s, 2560 646 vs 983); otherwise 128 x 128 with two slots and two workgroups per CU (2304 NN, 2560, 2816).
 // `gated` (LC_HGEMM_AUTO): only where the 256-tile kernel does not apply anyway (resolve_hgemm_variant: <= 128 tiles of 256 x 256) and the
 // 128 x 128 grid holds more than 3 / 16 blocks per CU (below — 768^3: 36 blocks, level — the eight-wave 128-tile kernel keeps the shape).
@@ -335,17 +335,17 @@ MidTile mid_tile_auto(int M, int N, int K, bool b_kn, bool gated) {
   if (gated && ((long)(M / 128) * (N / 128) <= min_blocks || M % 128 != 0 || N % 128 != 0)) return none;
   MidTile best = none, big = none;   // best one-round tile; largest legal tile (the multi-round choice)
   long best_area = 0, big_area = 0;
-  for (int tmw = 2; tmw >= 1; --tmw)
+  for (int tmw : {2, 3, 1})        // (ties between equal areas go to the tile seen first: 128 x 192 before 192 x 128)
     for (int tnw = 2; tnw <= 3; ++tnw) {
       if (k >= 10 && k != 10 * tmw + tnw) continue;
-      if (M % (64 * tmw) != 0 || N % (64 * tnw) != 0 || (b_kn && tnw != 2)) continue;
+      if (M % (64 * tmw) != 0 || N % (64 * tnw) != 0 || (b_kn && tnw != 2) || (tmw == 3 && tnw != 2)) continue;
       const long wgs = (long)(M / (64 * tmw)) * (N / (64 * tnw)), area = 4096L * tmw * tnw;
       if (wgs <= ncu && (best.tmw == 0 || area < best_area)) {
         best = MidTile{tmw, tnw, 3};
         best_area = area;
       }
       // multi-round: 128 x 128 before 128 x 192 (one workgroup per CU by registers) before the 64-row tiles
-      const long rank = (tmw == 2 && tnw == 2) ? 4 : (tmw == 2 ? 3 : tnw);
+      const long rank = (tmw == 2 && tnw == 2) ? 5 : (tmw == 2 ? 4 : tmw == 3 ? 3 : tnw - 1);
       if (big.tmw == 0 || rank > big_area) {
         big = MidTile{tmw, tnw, 2};
         big_area = rank;
@@ -757,7 +757,7 @@ bool ok_04(int v) { return v >= 0 && v <= 4; }
 bool ok_08(int v) { return v >= 0 && v <= 8; }
 bool ok_rule_cus(int v) { return v == 0 || (v >= 64 && v <= 1024); }
 bool ok_mid_ns(int v) { return v == 0 || v == 2 || v == 3; }
-bool ok_mid(int v) { return v == 0 || v == 1 || v == 12 || v == 13 || v == 22 || v == 23; }
+bool ok_mid(int v) { return v == 0 || v == 1 || v == 12 || v == 13 || v == 22 || v == 23 || v == 32; }
 bool ok_split(int v) { return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16; }
 bool ok_span8(int v) { return v == 0 || v == 2 || v == 4 || v == 6; }
 bool ok_w4y_sched(int v) {

@@ -31,14 +31,17 @@ int launch_mid_ns(const half_t* A, const half_t* B, half_t* C, int M, int N, int
 template <bool B_KN, int TNW>
 int launch_mid_tm(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int tmw, int ns, int pw, hipStream_t st) {
   if (tmw == 1) return launch_mid_ns<B_KN, 1, TNW>(A, B, C, M, N, K, ns, pw, st);
+  if constexpr (TNW == 2) {   // 192 x 128: the NN counterpart of the 128 x 192 tile (NN has no 192-wide transpose image)
+    if (tmw == 3) return launch_mid_ns<B_KN, 3, 2>(A, B, C, M, N, K, ns, pw, st);
+  }
   return launch_mid_ns<B_KN, 2, TNW>(A, B, C, M, N, K, ns, pw, st);
 }
 }  // namespace
 
-// tmw: 1 / 2 = 64 / 128 tile rows; tnw: 2 / 3 = 128 / 192 tile columns (NN: 2); ns: ring slots 2 / 3; pw: block -> tile map (panel_tiles, lc_abi.hip)
+// tmw: 1 / 2 / 3 = 64 / 128 / 192 tile rows (3: with tnw = 2 only); tnw: 2 / 3 = 128 / 192 tile columns (NN: 2); ns: ring slots 2 / 3; pw: block -> tile map (panel_tiles, lc_abi.hip)
 int launch_hgemm_mid(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int tmw, int tnw, int ns, int pw,
                      hipStream_t st) {
-  if (tmw < 1 || tmw > 2 || tnw < 2 || tnw > 3 || (b_kn && tnw != 2)) return LC_ERR_ARG;
+  if (tmw < 1 || tmw > 3 || tnw < 2 || tnw > 3 || (tmw == 3 && tnw != 2) || (b_kn && tnw != 2)) return LC_ERR_ARG;
   if (M % (64 * tmw) != 0 || N % (64 * tnw) != 0 || K % 32 != 0 || K < BK || K >= (1 << 22) || N >= (1 << 22)) return LC_ERR_SHAPE;
   if (b_kn) return launch_mid_tm<true, 2>(A, B, C, M, N, K, tmw, ns, pw, st);
   if (tnw == 2) return launch_mid_tm<false, 2>(A, B, C, M, N, K, tmw, ns, pw, st);

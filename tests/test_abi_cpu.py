@@ -262,7 +262,7 @@ def test_hgemm_dispatch_covers_the_reference_legal_shapes(built):
         # between the small grids and > 128 tiles of 256 x 256: the mid-size kernel (round 6) with the smallest tile whose grid is one
         # round of the 256 CUs this rule assumes without a device (three ring slots), else 128 x 128 at two workgroups per CU
         for shp, tile in (((1024, 1024, 1024), "1,2,3"), ((1280, 1280, 1280), "1,2,3"), ((1536, 1536, 1568), "1,3,3" if nn == "false" else "2,2,3"),
-                          ((1792, 1792, 1792), "2,2,3"), ((2048, 2048, 2080), "2,2,3"), ((2304, 2304, 2304), "2,3,3" if nn == "false" else "2,2,2"),
+                          ((1792, 1792, 1792), "2,2,3"), ((2048, 2048, 2080), "2,2,3"), ((2304, 2304, 2304), "2,3,3" if nn == "false" else "3,2,3"),
                           ((2560, 2560, 2560), "2,2,2"), ((2816, 2816, 2816), "2,2,2"), ((2816, 2560, 96), "2,2,2")):
             assert capi.hgemm_kernel_name(*shp, lay) == f"hgemm_mid_kernel<{nn},{tile}>", shp
             assert capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_MFMA128).startswith("hgemm_mfma128_kernel<")  # ... still there when asked for

@@ -219,7 +219,7 @@ def _eight_waves_body(oracle, capi, layout):
     assert torch.equal(c, bq)
 
 
-MID_COMBOS = [(lay, tmw, tnw, ns) for lay in ("tn", "nn") for tmw in (1, 2) for tnw in ((2, 3) if lay == "tn" else (2,)) for ns in (2, 3)]
+MID_COMBOS = [(lay, tmw, tnw, ns) for lay in ("tn", "nn") for tmw in (1, 2, 3) for tnw in ((2, 3) if lay == "tn" and tmw < 3 else (2,)) for ns in (2, 3)]
 
 
 @pytest.mark.parametrize("layout,tmw,tnw,ns", MID_COMBOS)
@@ -253,7 +253,7 @@ def test_mid_kernel_every_tile_and_ring_depth(oracle, layout, tmw, tnw, ns):
                     capi.tune("hgemm_128w", 0)
                 assert torch.equal(c, c128), (M, N, K)
         # the identity trick: a wrong fragment / tile / transpose shows as a permutation
-        n = 3 * 128 if tnw == 3 else 256
+        n = 3 * 128 if tnw == 3 or tmw == 3 else 256
         eye = torch.eye(n, dtype=torch.half, device="cuda")
         bq = (torch.arange(n * n, device="cuda").reshape(n, n) % 1021).half() / 4
         c, _ = _run(capi, eye, bq, lay, capi.HGEMM_MID, 1)
@@ -280,7 +280,7 @@ def test_mid_kernel_at_the_sizes_it_serves(oracle, layout, n):
     name = capi.hgemm_kernel_name(n, n, n, lay)
     ncu = capi.device_check()
     if ncu == 256:
-        want = {1792: "2,2,3", 2048: "2,2,3", 2304: "2,3,3" if layout == "tn" else "2,2,2", 2560: "2,2,2", 2816: "2,2,2"}.get(n)
+        want = {1792: "2,2,3", 2048: "2,2,3", 2304: "2,3,3" if layout == "tn" else "3,2,3", 2560: "2,2,2", 2816: "2,2,2"}.get(n)
         if want:
             assert name == f"hgemm_mid_kernel<{'true' if layout == 'nn' else 'false'},{want}>", name
     torch.manual_seed(n)

@@ -45,9 +45,9 @@ for n in sizes:
             return f
         cands["old-auto"] = mk(1, 0, capi.HGEMM_AUTO)
         cands["auto"] = mk(0, 0, capi.HGEMM_AUTO)
-        for tmw in (2, 1):
+        for tmw in (2, 3, 1):
             for w in (2, 3):
-                if n % (64 * w) or (lname == "nn" and w == 3):
+                if n % (64 * w) or n % (64 * tmw) or (lname == "nn" and w == 3) or (tmw == 3 and w == 3):
                     continue
                 for ns in (2, 3):
                     cands[f"mid{tmw}{w}x{ns}"] = mk(10 * tmw + w, ns, capi.HGEMM_MID)
