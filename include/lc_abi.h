@@ -157,6 +157,8 @@ const char* lc_build_info(int* is_diag);
  *   "hgemm_tail"   (2 = as 1, but the quadrants on the 128-tile kernel with a workspace split-K: round 5's form, kept for A/B and for shapes with
  *                  border strips; 3 / 4 = as 1 with remainders up to 0.75 / 1.0 of the CUs: measured 8 ... 18 % slower, A/B only)  1 (default) = when the 256-tile grid's last wave holds at most 128 tiles, the generated-loop kernel computes the
  *                  full waves and 128 x 128 blocks the four quadrants of each remaining tile (round 6: on the mid-size kernel, + 4 ... 6 % at 4352 ... 6400); 0 = one launch
+ *   "hgemm_tail_tile"  sub-tiles of that tail on the mid-size kernel: 0 = auto (64 x 128 eighths while 8 x the remaining tiles fit one round of the
+ *                  CUs, else 128 x 128 quadrants), 1 = eighths, 2 = quadrants (bit-identical results; A/B knob)
  *   "hgemm_raster" block -> C tile map of the tiled GEMM kernels: 0 = auto (2 when A + B exceed 272 MiB — the 256 MiB Infinity Cache and a margin,
  *                  else 1), 1 = the reference's block swizzle (N panels of swizzle_stride columns, every XCD a contiguous id
  *                  range), 2 = XCD super-block raster (16 x 16 tile steps shared through the Infinity Cache, 4 x 8 per XCD;

@@ -111,19 +111,23 @@ __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kerne
   const int wave = wave_id();
   const int wr = wave >> 1, wc = wave & 1;
   const int i16 = lane & 15, g = lane >> 4;
-  // rem_base < 0: this kernel's own grid of TM x TN tiles.  rem_base >= 0 (128 x 128 only; lc_abi.hip launch_mfma256): tiles_m / tiles_n /
-  // panel_w describe the 256 x 256 tile grid of hgemm_w4y_kernel and block b is quadrant b & 3 of the 256-tile whose raster id is
-  // rem_base + (b >> 2) — the ids that kernel's truncated grid left out (its ragged last round; hgemm_mfma128.hip mfma128_tile's map).
+  // rem_base < 0: this kernel's own grid of TM x TN tiles.  rem_base >= 0 (tiles that divide 256 x 256: 128 x 128, 64 x 128; lc_abi.hip
+  // launch_mfma256): tiles_m / tiles_n / panel_w describe the 256 x 256 tile grid of hgemm_w4y_kernel and block b is sub-tile b % SUBS
+  // (row-major inside the 256-tile) of the 256-tile whose raster id is rem_base + b / SUBS — the ids that kernel's truncated grid left out
+  // (its ragged last round; hgemm_mfma128.hip mfma128_tile's map).
   int m0, n0;
   if (rem_base < 0) {
     const TileCoord tc = block_tile((int)blockIdx.x, (int)gridDim.x, tiles_m, tiles_n, panel_w);
     m0 = tc.tm * TM;
     n0 = tc.tn * TN;
-  } else {
-    const int id = rem_base + ((int)blockIdx.x >> 2), qd = (int)blockIdx.x & 3;
+  } else if constexpr (256 % TM == 0 && 256 % TN == 0) {
+    constexpr int SUBN = 256 / TN, SUBS = (256 / TM) * SUBN;
+    const int id = rem_base + (int)blockIdx.x / SUBS, sub = (int)blockIdx.x % SUBS;
     const TileCoord tc = panel_w < 0 ? raster_xcd16(id, tiles_m * tiles_n, tiles_m, tiles_n) : raster(id, tiles_m, tiles_n, panel_w);
-    m0 = tc.tm * 256 + (qd >> 1) * 128;
-    n0 = tc.tn * 256 + (qd & 1) * 128;
+    m0 = tc.tm * 256 + (sub / SUBN) * TM;
+    n0 = tc.tn * 256 + (sub % SUBN) * TN;
+  } else {
+    return;   // (never launched: the remainder launcher instantiates 64 / 128 x 128 only)
   }
 
   // ---- LDS-DMA sources: wave-uniform 64-bit bases (advanced per K tile on the scalar unit) + 32-bit per-lane byte offsets.

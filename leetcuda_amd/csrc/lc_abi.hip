@@ -53,6 +53,7 @@ tune_t g_tune_hgemm_mid{0};                    // mid-size kernel (hgemm_mid.hip
 tune_t g_tune_hgemm_mid_ns{0};                 // ... its LDS ring slots: 0 = auto (3 for one-round grids, else 2), 2, 3
 tune_t g_tune_hgemm_128w{0};                   // waves of the 128-tile kernel: 0 = auto (eight — intra-workgroup split-K — on grids of <= 0.6 blocks per CU), 1 = always four, 2 = always eight
 tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to 128 x 128 blocks (launch_mfma256: the mid-size kernel; 2 = round 5's 128-tile kernel + split-K), 0 = one launch
+tune_t g_tune_hgemm_tail_tile{0};              // sub-tiles of the ragged tail on the mid-size kernel: 0 = auto (launch_mfma256), 1 = 64 x 128 eighths, 2 = 128 x 128 quadrants
 tune_t g_tune_hgemm_raster{0};                 // block -> C tile map: 0 = auto (by operand footprint, panel_tiles), 1 = the reference's block swizzle (N panels from
                                              // swizzle_stride, XCD-contiguous ids), 2 = XCD super-block raster (hgemm_mfma256.hip raster_xcd16)
 
@@ -260,7 +261,14 @@ int launch_mfma256(const half_t* A, const half_t* B, half_t* C, int M, int N, in
     // tiles run on the mid-size kernel — three ring slots when they fit one round of the CUs, two slots at two workgroups per CU beyond; no
     // workspace, no reduce launch, legal under graph capture (profiles/r6l_hgemm_tail_mid.log: + 3 ... 7 % at 4352 ... 4864, 6144, 10240)
     if (split && nright == 0 && nbottom == 0 && tail_knob != 2 && g_tune_hgemm_mid != 1 && K < (1 << 22) && N < (1 << 22))
-      return launch_hgemm_mid_rem(A, B, C, M, N, K, B_KN, 4 * R <= ncu ? 3 : 2, tiles_m, tiles_n, pw, T - R, 4 * R, st);
+    {
+      // sub-tile (lc_tune_set "hgemm_tail_tile"): 64 x 128 eighths while they fit ONE round of the CUs (R <= ncu / 8: twice the workgroups
+      // of the quadrants on CUs that would otherwise idle), else 128 x 128 quadrants
+      const int tile_knob = g_tune_hgemm_tail_tile;
+      const int tmw = tile_knob == 1 ? 1 : tile_knob == 2 ? 2 : (8 * R <= ncu ? 1 : 2);
+      const int blocks = (tmw == 1 ? 8 : 4) * R;
+      return launch_hgemm_mid_rem(A, B, C, M, N, K, B_KN, tmw, blocks <= ncu ? 3 : 2, tiles_m, tiles_n, pw, T - R, R, st);
+    }
     const int nb128 = (split ? 4 * R : 0) + nright + nbottom;
     if (nb128 == 0) return LC_OK;
     // Split-K of these blocks (lc_tune_set "hgemm_splitk"): a lone 128-tile block walks its K range at a quarter of a CU's MFMA rate
@@ -792,6 +800,7 @@ const Knob kKnobs[] = {
     {"hgemm_persist", &g_tune_hgemm_persist, 1, ok_01, false},
     {"hgemm_stagger", &g_tune_hgemm_stagger, 0, ok_stagger, false},
     {"hgemm_tail", &g_tune_hgemm_tail, 1, ok_04, false},
+    {"hgemm_tail_tile", &g_tune_hgemm_tail_tile, 0, ok_02, false},
     {"hgemm_128w", &g_tune_hgemm_128w, 0, ok_02, false},
     {"rule_cus", &g_tune_rule_cus, 0, ok_rule_cus, false},
     {"attn_calib", &g_tune_attn_calib, 0, ok_01, false},

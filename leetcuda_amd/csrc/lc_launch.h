@@ -211,8 +211,8 @@ int w4_effective_variant(int variant, bool b_kn, int N, int K);   // W4C / W4X /
 // the mid-size kernel (hgemm_mid.hip, tu_mid.hip): (64 tmw) x (64 tnw) tiles, ns ring slots
 int launch_hgemm_mid(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int tmw, int tnw, int ns, int pw,
                      hipStream_t st);
-int launch_hgemm_mid_rem(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int ns, int tiles_m256, int tiles_n256,
-                         int pw256, int rem_base, int nblocks, hipStream_t st);   // the 256-tile kernel's ragged last round as 128 x 128 quadrants
+int launch_hgemm_mid_rem(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int tmw, int ns, int tiles_m256,
+                         int tiles_n256, int pw256, int rem_base, int rem_tiles, hipStream_t st);   // the 256-tile kernel's ragged last round as 128 x 128 quadrants
 int launch_w4_family(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant, bool b_kn,
                      int tiles_m, int tiles_n, int panel_w, int nblk, hipStream_t st);
 // tu_valu.hip: the vector-ALU ladder (hgemm_valu.hip), rung = LC_HGEMM_VALU_*

@@ -13,14 +13,23 @@ int launch_mid_one(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), G::LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw, -1);
   return check_launch();
 }
-template <bool B_KN, int NS>
+template <bool B_KN, int TMW, int NS>
 int launch_mid_rem_one(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int tiles_m256, int tiles_n256, int pw256, int rem_base,
-                       int nblocks, hipStream_t st) {
-  using G = Mid<2, 2, NS>;
-  auto kern = hgemm_mid_kernel<B_KN, 2, 2, NS>;
+                       int rem_tiles, hipStream_t st) {
+  using G = Mid<TMW, 2, NS>;
+  auto kern = hgemm_mid_kernel<B_KN, TMW, 2, NS>;
   if (int rc = set_dyn_lds(kern, G::LDS)) return rc;
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), G::LDS, st, A, B, C, M, N, K, tiles_m256, tiles_n256, pw256, rem_base);
+  hipLaunchKernelGGL(kern, dim3(rem_tiles * (256 / G::TM) * 2), dim3(256), G::LDS, st, A, B, C, M, N, K, tiles_m256, tiles_n256, pw256, rem_base);
   return check_launch();
+}
+template <bool B_KN>
+int launch_mid_rem(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int tmw, int ns, int tiles_m256, int tiles_n256, int pw256,
+                   int rem_base, int rem_tiles, hipStream_t st) {
+  if (tmw == 1)
+    return ns == 3 ? launch_mid_rem_one<B_KN, 1, 3>(A, B, C, M, N, K, tiles_m256, tiles_n256, pw256, rem_base, rem_tiles, st)
+                   : launch_mid_rem_one<B_KN, 1, 2>(A, B, C, M, N, K, tiles_m256, tiles_n256, pw256, rem_base, rem_tiles, st);
+  return ns == 3 ? launch_mid_rem_one<B_KN, 2, 3>(A, B, C, M, N, K, tiles_m256, tiles_n256, pw256, rem_base, rem_tiles, st)
+                 : launch_mid_rem_one<B_KN, 2, 2>(A, B, C, M, N, K, tiles_m256, tiles_n256, pw256, rem_base, rem_tiles, st);
 }
 template <bool B_KN, int TMW, int TNW>
 int launch_mid_ns(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int ns, int pw, hipStream_t st) {
@@ -48,15 +57,14 @@ int launch_hgemm_mid(const half_t* A, const half_t* B, half_t* C, int M, int N, 
   return launch_mid_tm<false, 3>(A, B, C, M, N, K, tmw, ns, pw, st);
 }
 
-// The ragged last round of hgemm_w4y_kernel's 256 x 256 grid as 128 x 128 quadrants on this kernel (round 6; until then on hgemm_mfma128_kernel
-// with a workspace split-K): nblocks = 4 x (tiles left out), rem_base = first raster id left out, tiles_m256 / tiles_n256 / pw256 = that grid's
-// dimensions and block map.  ns: 3 when the quadrants fit one round of the CUs, else 2.
-int launch_hgemm_mid_rem(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int ns, int tiles_m256, int tiles_n256,
-                         int pw256, int rem_base, int nblocks, hipStream_t st) {
-  if (K % 32 != 0 || K < BK || K >= (1 << 22) || N >= (1 << 22) || rem_base < 0 || nblocks <= 0) return LC_ERR_SHAPE;
-  if (b_kn) return ns == 3 ? launch_mid_rem_one<true, 3>(A, B, C, M, N, K, tiles_m256, tiles_n256, pw256, rem_base, nblocks, st)
-                           : launch_mid_rem_one<true, 2>(A, B, C, M, N, K, tiles_m256, tiles_n256, pw256, rem_base, nblocks, st);
-  return ns == 3 ? launch_mid_rem_one<false, 3>(A, B, C, M, N, K, tiles_m256, tiles_n256, pw256, rem_base, nblocks, st)
-                 : launch_mid_rem_one<false, 2>(A, B, C, M, N, K, tiles_m256, tiles_n256, pw256, rem_base, nblocks, st);
+// The ragged last round of hgemm_w4y_kernel's 256 x 256 grid as 128 x 128 quadrants (tmw = 2) or 64 x 128 eighths (tmw = 1) on this kernel
+// (round 6; until then on hgemm_mfma128_kernel with a workspace split-K): rem_tiles 256-tiles from raster id rem_base on, tiles_m256 /
+// tiles_n256 / pw256 = that grid's dimensions and block map.  ns: ring slots (3 when the blocks fit one round of the CUs, else 2).
+int launch_hgemm_mid_rem(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int tmw, int ns, int tiles_m256,
+                         int tiles_n256, int pw256, int rem_base, int rem_tiles, hipStream_t st) {
+  if (K % 32 != 0 || K < BK || K >= (1 << 22) || N >= (1 << 22) || rem_base < 0 || rem_tiles <= 0) return LC_ERR_SHAPE;
+  if ((tmw != 1 && tmw != 2) || (ns != 2 && ns != 3)) return LC_ERR_ARG;
+  return b_kn ? launch_mid_rem<true>(A, B, C, M, N, K, tmw, ns, tiles_m256, tiles_n256, pw256, rem_base, rem_tiles, st)
+              : launch_mid_rem<false>(A, B, C, M, N, K, tmw, ns, tiles_m256, tiles_n256, pw256, rem_base, rem_tiles, st);
 }
 }  // namespace lc

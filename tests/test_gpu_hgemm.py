@@ -694,7 +694,8 @@ def test_xcd_super_block_raster_computes_the_same_bits(layout):
 def test_ragged_last_wave_goes_to_the_128_tile_kernel(oracle, layout, raster):
     """lc_tune_set "hgemm_tail" = 1 (default): when the 256-tile grid's last wave holds at most 128 tiles, hgemm_w4y_kernel runs the
     full waves and 128 x 128 blocks the four quadrants of every remaining tile (lc_abi.hip launch_mfma256) — since round 6 on
-    hgemm_mid_kernel (three ring slots when the quadrants fit one round, two beyond; no workspace), "hgemm_tail" = 2 keeps round 5's
+    hgemm_mid_kernel (three ring slots when the blocks fit one round, two beyond; no workspace; 64 x 128 eighths instead of quadrants while
+    THEY fit one round, "hgemm_tail_tile"), "hgemm_tail" = 2 keeps round 5's
     hgemm_mfma128_kernel + split-K form.  Every element is written exactly once, all three agree with the one-launch result to fp16
     rounding of differently ordered fp32 sums — the two quadrant kernels with each other bit for bit when the 128-tile kernel does not
     split K — and sampled rows match the oracle, with both block -> tile maps (the remainder ids differ between them)."""
@@ -710,8 +711,9 @@ def test_ragged_last_wave_goes_to_the_128_tile_kernel(oracle, layout, raster):
         outs = []
         capi.tune("hgemm_raster", raster)
         try:
-            for tail, splitk in ((0, 0), (1, 0), (2, 1)):
+            for tail, splitk, tile in ((0, 0, 0), (1, 0, 2), (2, 1, 0), (1, 0, 1), (1, 0, 0)):
                 capi.tune("hgemm_tail", tail)
+                capi.tune("hgemm_tail_tile", tile)     # (quadrants, 64 x 128 eighths, the rule's choice: same sums in the same order)
                 capi.tune("hgemm_splitk", splitk)      # (2: round 5's kernel without its split-K and on four waves, so that it sums k in the
                 capi.tune("hgemm_128w", 1 if tail == 2 else 0)    #  mid-size kernel's order)
                 c = torch.full((M, N), float("nan"), dtype=torch.half, device="cuda")
@@ -720,11 +722,13 @@ def test_ragged_last_wave_goes_to_the_128_tile_kernel(oracle, layout, raster):
                 outs.append(c)
         finally:
             capi.tune("hgemm_tail", 1)
+            capi.tune("hgemm_tail_tile", 0)
             capi.tune("hgemm_splitk", 0)
             capi.tune("hgemm_128w", 0)
             capi.tune("hgemm_raster", 0)
         assert torch.isfinite(outs[1]).all() and torch.isfinite(outs[2]).all()
         assert torch.equal(outs[1], outs[2])          # mid-size kernel == 128-tile kernel on the quadrants, bit for bit
+        assert torch.equal(outs[1], outs[3]) and torch.equal(outs[1], outs[4])   # ... and its 64 x 128 eighths / the rule's choice too
         d = (outs[0].float() - outs[1].float()).abs()
         # (the two kernels' fp32 accumulation orders differ — 16x16x32 vs 32x32x16 chains — yet on these shapes they round to the same
         #  fp16 almost everywhere, often everywhere: the bound below is what is asserted, not a difference)

@@ -34,7 +34,7 @@ for n in sizes:
             continue
         b2 = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
         if len(sys.argv) > 4 and sys.argv[4] == "tail":
-            sets = {"auto": {}, "tail2 (mfma128 + split-K)": {"hgemm_tail": 2}, "tail0 (one launch)": {"hgemm_tail": 0}, "tail3 (R <= 0.75 CUs)": {"hgemm_tail": 3},
+            sets = {"auto": {}, "eighths": {"hgemm_tail_tile": 1}, "quadrants": {"hgemm_tail_tile": 2}, "tail2 (mfma128 + split-K)": {"hgemm_tail": 2}, "tail0 (one launch)": {"hgemm_tail": 0}, "tail3 (R <= 0.75 CUs)": {"hgemm_tail": 3},
                     "tail4 (any R)": {"hgemm_tail": 4}}
         elif len(sys.argv) > 4 and sys.argv[4] == "sched":
             sets = {"auto": {}, "sched1": {"w4y_sched": 1}, "sched2": {"w4y_sched": 2}, "raster1": {"hgemm_raster": 1}, "raster2": {"hgemm_raster": 2},
