@@ -150,10 +150,13 @@ const char* lc_build_info(int* is_diag);
  *                  range >= 8 tiles), 1 = off, 2 .. 8 = that factor; fp32 partials in the same workspace + a reduce kernel
  *   "hgemm_128w"   waves of LC_HGEMM_MFMA128: 0 = auto (eight — the two k-steps of every K tile on two groups of four waves, summed through LDS at the
  *                  end — on grids of <= 0.6 blocks per CU: + 11 % at 1024^3 / 1536^3; level at 2048^3, slower for NN beyond), 1 = four, 2 = eight
- *   "hgemm_mid"    LC_HGEMM_AUTO's use of LC_HGEMM_MID: 0 = auto (among the 128 x 128 / 128 x 192 / 64 x 128 / 64 x 192 tiles that divide the
- *                  problem the one with the least ceil(workgroups / CUs) x tile area), 1 = never, 12 / 13 / 22 / 23 / 32 = that tile (rows / 64,
+ *   "hgemm_mid"    LC_HGEMM_AUTO's use of LC_HGEMM_MID: 0 = auto (among the 64 / 128 / 192 x 128 / 192 tiles that divide the
+ *                  problem the one with the least ceil(workgroups / CUs) x tile area), 1 = never, 12 / 13 / 22 / 23 / 32 / 33 = that tile (rows / 64,
  *                  columns / 64) whenever it divides the problem (A/B knob; also what an explicit LC_HGEMM_MID then runs)
  *   "hgemm_mid_ns" LDS ring slots of LC_HGEMM_MID: 0 = auto (3 when the grid is one round of <= one workgroup per CU, else 2), 2, 3
+ *   "hgemm_mid_splitk"  split-K of LC_HGEMM_MID (64 / 128 x 128 tiles; fp32 partials in the stream's workspace + a reduce launch; none under graph
+ *                  capture): 0 = auto (a one-round grid on <= half the CUs with >= 64 K tiles: as many ranges as fill the CUs, >= 32 K tiles each,
+ *                  <= 8), 1 = never, 2 .. 8 = that many ranges wherever legal (A/B)
  *   "hgemm_tail"   (2 = as 1, but the quadrants on the 128-tile kernel with a workspace split-K: round 5's form, kept for A/B and for shapes with
  *                  border strips; 3 / 4 = as 1 with remainders up to 0.75 / 1.0 of the CUs: measured 8 ... 18 % slower, A/B only)  1 (default) = when the 256-tile grid's last wave holds at most 128 tiles, the generated-loop kernel computes the
  *                  full waves and 128 x 128 blocks the four quadrants of each remaining tile (round 6: on the mid-size kernel, + 4 ... 6 % at 4352 ... 6400); 0 = one launch

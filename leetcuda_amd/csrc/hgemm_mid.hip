@@ -99,10 +99,13 @@ LC_DEVINL const char* sgpr_ptr(const void* p) {   // a pointer hipcc can PROVE w
   return (const char*)(((uint64_t)hi << 32) | lo);
 }
 
-template <bool B_KN, int TMW, int TNW, int NS>
+// SK (split-K, round 6): the grid holds ks copies of the tile grid, block b = tile b % tiles of K range b / tiles (whole K tiles, split
+// evenly; the last range takes the K % 64 == 32 half step); fp32 partials go to part[ks][M][N] and hgemm_mid_reduce_kernel adds them in
+// range order and rounds once.  For shapes whose one-round tile grid covers at most half the CUs and whose K is long (1024 x 1024 x 8192).
+template <bool B_KN, int TMW, int TNW, int NS, bool SK = false>
 __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B,
                                                            half_t* __restrict__ C, int M, int N, int K, int tiles_m, int tiles_n,
-                                                           int panel_w, int rem_base) {
+                                                           int panel_w, int rem_base, float* __restrict__ part, int ks) {
   using G = Mid<TMW, TNW, NS>;
   static_assert(!B_KN || TNW == 2 || TNW == 4, "NN: whole [64 k][128 n] transpose images");
   constexpr int MI = G::MI, NI = G::NI, PA = G::PA, PB = G::PB, TM = G::TM, TN = G::TN;
@@ -116,8 +119,14 @@ __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kerne
   // (row-major inside the 256-tile) of the 256-tile whose raster id is rem_base + b / SUBS — the ids that kernel's truncated grid left out
   // (its ragged last round; hgemm_mfma128.hip mfma128_tile's map).
   int m0, n0;
+  int bid = (int)blockIdx.x, nblk = (int)gridDim.x, srange = 0;
+  if constexpr (SK) {
+    nblk = tiles_m * tiles_n;
+    srange = __builtin_amdgcn_readfirstlane(bid / nblk);
+    bid -= srange * nblk;
+  }
   if (rem_base < 0) {
-    const TileCoord tc = block_tile((int)blockIdx.x, (int)gridDim.x, tiles_m, tiles_n, panel_w);
+    const TileCoord tc = block_tile(bid, nblk, tiles_m, tiles_n, panel_w);
     m0 = tc.tm * TM;
     n0 = tc.tn * TN;
   } else if constexpr (256 % TM == 0 && 256 % TN == 0) {
@@ -132,8 +141,14 @@ __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kerne
 
   // ---- LDS-DMA sources: wave-uniform 64-bit bases (advanced per K tile on the scalar unit) + 32-bit per-lane byte offsets.
   // hgemm_mfma128.hip's piece map: piece i of this wave = 8-row block 4 i + wave of a K-contiguous operand.
-  const char* a_src = sgpr_ptr(A + (size_t)m0 * K);
-  const char* b_src = sgpr_ptr(B_KN ? B + n0 : B + (size_t)n0 * K);
+  const int KT_all = K / BK;
+  int kt0 = 0, KT = KT_all;   // this block's K tiles: kt0 .. kt0 + KT - 1
+  if constexpr (SK) {
+    kt0 = (int)((long)srange * KT_all / ks);
+    KT = (int)((long)(srange + 1) * KT_all / ks) - kt0;
+  }
+  const char* a_src = sgpr_ptr(A + (size_t)m0 * K + (size_t)kt0 * BK);
+  const char* b_src = sgpr_ptr(B_KN ? B + n0 + (size_t)kt0 * BK * N : B + (size_t)n0 * K + (size_t)kt0 * BK);
   const uint32_t b_step = B_KN ? (uint32_t)N * (BK * 2) : (uint32_t)(BK * 2);   // bytes between consecutive K tiles of B
   uint32_t va[PA], vb[PB];
 #pragma unroll
@@ -252,7 +267,6 @@ __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kerne
   using NEXT = std::true_type;
   using NONEXT = std::false_type;
 
-  const int KT = K / BK;
   // ---- prologue: tiles 0 .. NS - 1 requested (every slot), tile 0 landed and visible, its k-step 0 fragments read
   {
     const char* ap = a_src;
@@ -314,8 +328,8 @@ __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kerne
   settle(f1);
   kstep(f1, f0, NONEXT{}, 0u, KS0{}, NODMA{}, 0u, nullptr, nullptr);
   mid_acc_settle<MI, NI>(acc);   // (hipcc may move accumulators between register sets around the branch below: only settled ones)
-  if (__builtin_amdgcn_readfirstlane(K) & 32) {   // (a scalar branch) K % 64 == 32: the last half K-step, fragments straight from global memory in the MFMA operand layout (hgemm_mfma128.hip)
-    const int k0 = KT * BK + 8 * g;
+  if ((__builtin_amdgcn_readfirstlane(K) & 32) && (!SK || srange == ks - 1)) {   // (a scalar branch) K % 64 == 32: the last half K-step, fragments straight from global memory in the MFMA operand layout (hgemm_mfma128.hip)
+    const int k0 = KT_all * BK + 8 * g;
     Frag f;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) f.a[mi] = *(const half8_t*)(A + (size_t)(m0 + wr * (TM / 2) + mi * 16 + i16) * K + k0);
@@ -330,6 +344,28 @@ __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kerne
     }
     kstep(f, f0, NONEXT{}, 0u, KS0{}, NODMA{}, 0u, nullptr, nullptr);
     mid_acc_settle<MI, NI>(acc);
+  }
+  if constexpr (SK) {   // fp32 partials: a lane owns 4 consecutive n of rows mi * 16 + i16 (16-byte stores, 64 B per row and MFMA block)
+    float* P = part + ((size_t)srange * M + (size_t)(m0 + wr * (TM / 2))) * N + n0 + wc * (TN / 2);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) *(f32x4_t*)(P + (size_t)(mi * 16 + i16) * N + ni * 16 + g * 4) = acc[mi][ni];
+    return;
+  }
+  if constexpr (TMW * TNW >= 9) {   // 192 x 192: straight from the accumulators, 8 bytes per lane (the staged epilogue below makes hipcc keep a second
+    // copy of the accumulators across the branch above, and 2 x 144 registers exceed the 256 AGPRs)
+    half_t* P = C + (size_t)(m0 + wr * (TM / 2)) * N + n0 + wc * (TN / 2);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const f32x4_t v = acc[mi][ni];
+        half4_t h;
+        h[0] = (half_t)v[0]; h[1] = (half_t)v[1]; h[2] = (half_t)v[2]; h[3] = (half_t)v[3];
+        *(half4_t*)(P + (size_t)(mi * 16 + i16) * N + ni * 16 + g * 4) = h;
+      }
+    return;
   }
   // ---- epilogue: each wave stages its (TM / 2) x (TN / 2) sub-tile through LDS, stores whole 16-byte chunks of 64 TNW-byte row segments
   char* stg = smem + wave * ((TM / 2) * G::EPI_ROW);
@@ -353,6 +389,24 @@ __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kerne
     const u32x4_t v = *(const u32x4_t*)(stg + row * G::EPI_ROW + c * 16);
     *(u32x4_t*)(C + (size_t)(m0 + wr * (TM / 2) + row) * N + n0 + wc * (TN / 2) + c * 8) = v;
   }
+}
+
+// Sum of the split-K partials part[ks][mn] in range order, rounded once to fp16: 8 elements per thread.
+__global__ __launch_bounds__(256) void hgemm_mid_reduce_kernel(const float* __restrict__ part, half_t* __restrict__ C, size_t mn, int ks) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i >= mn) return;
+  f32x4_t s0 = *(const f32x4_t*)(part + i), s1 = *(const f32x4_t*)(part + i + 4);
+  for (int r = 1; r < ks; ++r) {
+    s0 += *(const f32x4_t*)(part + (size_t)r * mn + i);
+    s1 += *(const f32x4_t*)(part + (size_t)r * mn + i + 4);
+  }
+  half8_t h;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = (half_t)s0[e];
+    h[4 + e] = (half_t)s1[e];
+  }
+  *(half8_t*)(C + i) = h;
 }
 
 }  // namespace lc

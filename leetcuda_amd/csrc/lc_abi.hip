@@ -49,11 +49,12 @@ tune_t g_tune_hgemm_auto{LC_HGEMM_MFMA256W4Y};   // what LC_HGEMM_AUTO launches 
 tune_t g_tune_hgemm_splitk{0};                 // split-K of the 128-tile blocks that serve border strips / the ragged last wave: 0 = auto (launch_mfma256), 1 = off, 2 .. 8 = that factor
 tune_t g_tune_rule_cus{0};                     // CU count the LAUNCH RULES reason with: 0 = the current device's own; 64 .. 1024 = that many (tests of the rules for other devices; grids are always sized with the real count)
 tune_t g_tune_attn_calib{0};                   // split-KV cost model: 0 = the constants lc_tune_calibrate measured on this device when it ran (else the built-in ones), 1 = always the built-in ones
-tune_t g_tune_hgemm_mid{0};                    // mid-size kernel (hgemm_mid.hip): 0 = auto (mid_tile_auto), 1 = never, 12 / 13 / 22 / 23 / 32 = that tile (rows / 64, columns / 64)
+tune_t g_tune_hgemm_mid{0};                    // mid-size kernel (hgemm_mid.hip): 0 = auto (mid_tile_auto), 1 = never, 12 / 13 / 22 / 23 / 32 / 33 = that tile (rows / 64, columns / 64)
 tune_t g_tune_hgemm_mid_ns{0};                 // ... its LDS ring slots: 0 = auto (3 for one-round grids, else 2), 2, 3
 tune_t g_tune_hgemm_128w{0};                   // waves of the 128-tile kernel: 0 = auto (eight — intra-workgroup split-K — on grids of <= 0.6 blocks per CU), 1 = always four, 2 = always eight
 tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to 128 x 128 blocks (launch_mfma256: the mid-size kernel; 2 = round 5's 128-tile kernel + split-K), 0 = one launch
 tune_t g_tune_hgemm_tail_tile{0};              // sub-tiles of the ragged tail on the mid-size kernel: 0 = auto (launch_mfma256), 1 = 64 x 128 eighths, 2 = 128 x 128 quadrants
+tune_t g_tune_hgemm_mid_splitk{0};             // split-K of the mid-size kernel: 0 = auto (mid_tile_auto), 1 = never, 2 .. 8 = that many K ranges wherever legal (A/B)
 tune_t g_tune_hgemm_raster{0};                 // block -> C tile map: 0 = auto (by operand footprint, panel_tiles), 1 = the reference's block swizzle (N panels from
                                              // swizzle_stride, XCD-contiguous ids), 2 = XCD super-block raster (hgemm_mfma256.hip raster_xcd16)
 
@@ -332,40 +333,65 @@ int launch_mfma128(const half_t* A, const half_t* B, half_t* C, int M, int N, in
 // round: 2304 NN 780 vs 866 TFLOP/s, 2560 646 vs 983); otherwise 128 x 128 with two slots and two workgroups per CU (2304 NN, 2560, 2816).
 // `gated` (LC_HGEMM_AUTO): only where the 256-tile kernel does not apply anyway (resolve_hgemm_variant: <= 128 tiles of 256 x 256) and the
 // 128 x 128 grid holds more than 3 / 16 blocks per CU (below — 768^3: 36 blocks, level — the eight-wave 128-tile kernel keeps the shape).
-struct MidTile { int tmw, tnw, ns; };
+struct MidTile { int tmw, tnw, ns, ks; long wgs; };   // ks > 1: split-K, needs ks x M x N floats of workspace (launch_mid; none under graph capture)
 MidTile mid_tile_auto(int M, int N, int K, bool b_kn, bool gated) {
-  MidTile none{0, 0, 0};
+  MidTile none{0, 0, 0, 1, 0};
   if (M % 64 != 0 || N % 64 != 0 || K % 32 != 0 || K < BK || K >= (1 << 22) || N >= (1 << 22)) return none;
   const int k = g_tune_hgemm_mid, kns = g_tune_hgemm_mid_ns;
   if (k == 1 && gated) return none;
   const long ncu = rule_cu_count();
   const long min_blocks = 3 * ncu / 16;   // 48 of 128 x 128 on 256 CUs (768^3: 36 blocks, level with the eight-wave kernel; 1024^3: 64 blocks, + 15 %)
-  if (gated && ((long)(M / 128) * (N / 128) <= min_blocks || M % 128 != 0 || N % 128 != 0)) return none;
-  MidTile best = none, big = none;   // best one-round tile; largest legal tile (the multi-round choice)
+  // (... unless K is long enough to split: 512 x 512 x 8192 runs 32 workgroups x 8 K ranges here)
+  const bool long_k = g_tune_hgemm_mid_splitk != 1 && K / BK >= 64;   // (two ranges of 32 K tiles)
+  // (M or N a multiple of 64 only — 2880^3 — has no other tiled kernel: any tile that divides it beats hgemm_generic_kernel by 10 x)
+  if (gated && M % 128 == 0 && N % 128 == 0 && (long)(M / 128) * (N / 128) <= min_blocks && !long_k) return none;
+  MidTile best = none, big = none;
+  long best_wgs = 0;   // best one-round tile; largest legal tile (the multi-round choice)
   long best_area = 0, big_area = 0;
   for (int tmw : {2, 3, 1})        // (ties between equal areas go to the tile seen first: 128 x 192 before 192 x 128)
     for (int tnw = 2; tnw <= 3; ++tnw) {
       if (k >= 10 && k != 10 * tmw + tnw) continue;
-      if (M % (64 * tmw) != 0 || N % (64 * tnw) != 0 || (b_kn && tnw != 2) || (tmw == 3 && tnw != 2)) continue;
+      if (M % (64 * tmw) != 0 || N % (64 * tnw) != 0 || (b_kn && tnw != 2)) continue;
       const long wgs = (long)(M / (64 * tmw)) * (N / (64 * tnw)), area = 4096L * tmw * tnw;
       if (wgs <= ncu && (best.tmw == 0 || area < best_area)) {
-        best = MidTile{tmw, tnw, 3};
+        best = MidTile{tmw, tnw, 3, 1, wgs};
         best_area = area;
+        best_wgs = wgs;
       }
       // multi-round: 128 x 128 before 128 x 192 (one workgroup per CU by registers) before the 64-row tiles
       const long rank = (tmw == 2 && tnw == 2) ? 5 : (tmw == 2 ? 4 : tmw == 3 ? 3 : tnw - 1);
       if (big.tmw == 0 || rank > big_area) {
-        big = MidTile{tmw, tnw, 2};
+        big = MidTile{tmw, tnw, 2, 1, 0};
         big_area = rank;
       }
     }
+  // 192 x 192 is the one tile with more work per CU (36864 outputs) than a double round of 128 x 128 at two workgroups per CU (2 x 16384):
+  // it wins only where the 128 x 128 grid needs more than one such round (3072^3: 576 blocks; 3072 x 2304: 432 blocks, 950 vs 1016 TFLOP/s)
+  if (best.tmw && best_area > 32768 && k < 10 && big.tmw == 2 && big.tnw == 2 && (long)(M / 128) * (N / 128) <= 2 * ncu) best = none;
   MidTile t = best.tmw ? best : big;
+  if (!best.tmw && t.tmw * t.tnw >= 6) t.ns = 3;   // one workgroup per CU by registers anyway: the third slot is free (8192 x 8256 x 4096 TN: 1004 -> 1108)
   if (t.tmw && (kns == 2 || kns == 3)) t.ns = kns;
+  // split-K (round 6, lc_tune_set "hgemm_mid_splitk"): a one-round grid on at most half the CUs with a long K — as many K ranges as fill
+  // the CUs, each of at least 32 K tiles (1024 x 1024 x 8192: 128 workgroups x 2, 512 -> 620 TFLOP/s; 1024 x 1024 x 2048 with 16 tiles per range: 415 -> 306;
+  // profiles/r6p_hgemm_rect_splitk.log); never at the reference sweep's sizes (1024^3: 16 K tiles)
+  const int ksk = g_tune_hgemm_mid_splitk, KT = K / BK;
+  if (best.tmw && t.tnw == 2 && t.tmw <= 2 && ksk != 1) {
+    long ks = ksk >= 2 ? ksk : std::min<long>(std::min<long>(ncu / best_wgs, KT / 32), 8);
+    while (ks > 1 && KT < 2 * ks) --ks;
+    if (ks > 1 && (size_t)ks * M * N * sizeof(float) <= ((size_t)256 << 20)) {
+      t.ks = (int)ks;
+      t.ns = 3;
+    }
+  }
   return t;
 }
 int launch_mid(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, MidTile t, int swizzle_stride, hipStream_t st) {
   const int pw = panel_tiles(swizzle_stride, N / (64 * t.tnw), 64 * t.tnw, ((size_t)M + N) * K * 2);
-  return launch_hgemm_mid(A, B, C, M, N, K, b_kn, t.tmw, t.tnw, t.ns, pw, st);
+  if (t.ks > 1 && !stream_is_capturing(st)) {
+    WorkspaceLease lease = stream_workspace(st, (size_t)t.ks * M * N * sizeof(float));
+    if (lease.ptr) return launch_hgemm_mid(A, B, C, M, N, K, b_kn, t.tmw, t.tnw, 3, pw, st, static_cast<float*>(lease.ptr), t.ks);
+  }
+  return launch_hgemm_mid(A, B, C, M, N, K, b_kn, t.tmw, t.tnw, t.ns, pw, st);   // (no workspace — graph capture, allocation failure: one K range)
 }
 
 template <bool B_KN>
@@ -665,8 +691,17 @@ int resolve_hgemm_variant(int variant, int M, int N, int K, bool al, bool b_kn) 
     // (n = 2048: 715 vs 436 TFLOP/s).
     const long wg256 = (long)(M / BM) * (N / BN);
     const int a = g_tune_hgemm_auto;
-    if (2 * wg256 > rule_cu_count() && (tiles256 || (a == LC_HGEMM_MFMA256W4Y && w4y_ok))) return a;   // more than half a CU's worth of 256 x 256 tiles per CU (256 CUs: > 128)
-    if (tiles128 && mid_tile_auto(M, N, K, b_kn, true).tmw > 0) return LC_HGEMM_MID;   // the tile with the least work on the busiest CU (n = 1280 .. 2816 square)
+    const bool tiles64 = (M % 64 == 0) && (N % 64 == 0) && k32 && al;
+    if (2 * wg256 > rule_cu_count() && (tiles256 || (a == LC_HGEMM_MFMA256W4Y && w4y_ok))) {   // more than half a CU's worth of 256 x 256 tiles per CU (256 CUs: > 128)
+      // ... unless those tiles leave CUs idle in their ONE round and a mid-size tile fills more of them in one round of its own
+      // (3072^3 TN: 144 tiles of 256 x 256 against 256 of 192 x 192, 1050 -> 1110 TFLOP/s, profiles/r6p_hgemm_rect_splitk.log)
+      if (wg256 < rule_cu_count()) {
+        const MidTile t = mid_tile_auto(M, N, K, b_kn, true);
+        if (t.tmw > 0 && t.wgs > wg256) return LC_HGEMM_MID;
+      }
+      return a;
+    }
+    if (tiles64 && mid_tile_auto(M, N, K, b_kn, true).tmw > 0) return LC_HGEMM_MID;   // the tile with the least work on the busiest CU (n = 1280 .. 2816 square)
     return tiles128 ? LC_HGEMM_MFMA128 : LC_HGEMM_GENERIC;
   }
   if (is_valu_variant(variant)) {   // a rung of the vector-ALU ladder: its own tile, else the edge kernel (never an error)
@@ -703,7 +738,8 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
   else if (v == LC_HGEMM_MFMA256) snprintf(buf, buflen, "hgemm_mfma256_kernel<%s>", nn);
   else if (v == LC_HGEMM_MID) {
     const MidTile t = mid_tile_auto(M, N, K, layout == LC_LAYOUT_NN, variant != LC_HGEMM_MID);
-    snprintf(buf, buflen, "hgemm_mid_kernel<%s,%d,%d,%d>", nn, t.tmw, t.tnw, t.ns);
+    if (t.ks > 1) snprintf(buf, buflen, "hgemm_mid_kernel<%s,%d,%d,%d,true> x%d", nn, t.tmw, t.tnw, t.ns, t.ks);   // (+ hgemm_mid_reduce_kernel; one K range under graph capture)
+    else snprintf(buf, buflen, "hgemm_mid_kernel<%s,%d,%d,%d>", nn, t.tmw, t.tnw, t.ns);
   } else if (v == LC_HGEMM_MFMA128) snprintf(buf, buflen, "hgemm_mfma128_kernel<%s,%d>", nn, mfma128_ksw((long)(M / BM1) * (N / BN1)));
   else snprintf(buf, buflen, "hgemm_generic_kernel<%s>", nn);
   return LC_OK;
@@ -765,7 +801,7 @@ bool ok_04(int v) { return v >= 0 && v <= 4; }
 bool ok_08(int v) { return v >= 0 && v <= 8; }
 bool ok_rule_cus(int v) { return v == 0 || (v >= 64 && v <= 1024); }
 bool ok_mid_ns(int v) { return v == 0 || v == 2 || v == 3; }
-bool ok_mid(int v) { return v == 0 || v == 1 || v == 12 || v == 13 || v == 22 || v == 23 || v == 32; }
+bool ok_mid(int v) { return v == 0 || v == 1 || v == 12 || v == 13 || v == 22 || v == 23 || v == 32 || v == 33; }
 bool ok_split(int v) { return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16; }
 bool ok_span8(int v) { return v == 0 || v == 2 || v == 4 || v == 6; }
 bool ok_w4y_sched(int v) {
@@ -801,6 +837,7 @@ const Knob kKnobs[] = {
     {"hgemm_stagger", &g_tune_hgemm_stagger, 0, ok_stagger, false},
     {"hgemm_tail", &g_tune_hgemm_tail, 1, ok_04, false},
     {"hgemm_tail_tile", &g_tune_hgemm_tail_tile, 0, ok_02, false},
+    {"hgemm_mid_splitk", &g_tune_hgemm_mid_splitk, 0, ok_08, false},
     {"hgemm_128w", &g_tune_hgemm_128w, 0, ok_02, false},
     {"rule_cus", &g_tune_rule_cus, 0, ok_rule_cus, false},
     {"attn_calib", &g_tune_attn_calib, 0, ok_01, false},
@@ -881,7 +918,7 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   if (variant == LC_HGEMM_MID) {
     const MidTile t = mid_tile_auto(M, N, K, layout == LC_LAYOUT_NN, !mid_forced);
     if (t.tmw > 0) return launch_mid(a, b, c, M, N, K, layout == LC_LAYOUT_NN, t, swizzle_stride, st);
-    variant = LC_HGEMM_MFMA128;   // (the knob changed between the two reads: every LC_HGEMM_MID shape is a 128-tile shape)
+    variant = (M % BM1 == 0 && N % BN1 == 0) ? LC_HGEMM_MFMA128 : LC_HGEMM_GENERIC;   // (the knob changed between the two reads)
   }
   if (is_valu_variant(variant)) {
     if (layout == LC_LAYOUT_NN) return launch_valu_rung(a, b, c, M, N, K, variant, st);

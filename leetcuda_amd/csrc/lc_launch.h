@@ -210,7 +210,7 @@ int w4_effective_variant(int variant, bool b_kn, int N, int K);   // W4C / W4X /
 // nblk > 0: launch only the first nblk blocks (hgemm_w4y_kernel only; the caller hands the remaining raster ids to the 128-tile kernel)
 // the mid-size kernel (hgemm_mid.hip, tu_mid.hip): (64 tmw) x (64 tnw) tiles, ns ring slots
 int launch_hgemm_mid(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int tmw, int tnw, int ns, int pw,
-                     hipStream_t st);
+                     hipStream_t st, float* part = nullptr, int ks = 1);
 int launch_hgemm_mid_rem(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int tmw, int ns, int tiles_m256,
                          int tiles_n256, int pw256, int rem_base, int rem_tiles, hipStream_t st);   // the 256-tile kernel's ragged last round as 128 x 128 quadrants
 int launch_w4_family(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant, bool b_kn,

@@ -266,7 +266,25 @@ def test_hgemm_dispatch_covers_the_reference_legal_shapes(built):
                           ((2560, 2560, 2560), "2,2,2"), ((2816, 2816, 2816), "2,2,2"), ((2816, 2560, 96), "2,2,2")):
             assert capi.hgemm_kernel_name(*shp, lay) == f"hgemm_mid_kernel<{nn},{tile}>", shp
             assert capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_MFMA128).startswith("hgemm_mfma128_kernel<")  # ... still there when asked for
-        assert capi.hgemm_kernel_name(3072, 3072, 3072, lay) == f"hgemm_w4y_kernel<{nn},{sch}>"                   # 144 tiles of 256 x 256: the flagship kernel
+        # 144 tiles of 256 x 256 leave 112 CUs idle in their one round: TN has a tile that fills all 256 in one round (192 x 192), NN has not
+        assert capi.hgemm_kernel_name(3072, 3072, 3072, lay) == (f"hgemm_w4y_kernel<{nn},{sch}>" if nn == "true" else "hgemm_mid_kernel<false,3,3,3>")
+        assert capi.hgemm_kernel_name(3328, 3328, 3328, lay) == f"hgemm_w4y_kernel<{nn},{sch}>"                   # 169 tiles, no mid-size tile in one round
+        # split-K (round 6): a one-round grid on at most half the CUs with at least 32 K tiles per range; never at the reference sweep's sizes
+        assert capi.hgemm_kernel_name(1024, 1024, 8192, lay) == f"hgemm_mid_kernel<{nn},1,2,3,true> x2"
+        assert capi.hgemm_kernel_name(512, 512, 8192, lay) == f"hgemm_mid_kernel<{nn},1,2,3,true> x4"
+        assert capi.hgemm_kernel_name(1024, 1024, 2048, lay) == f"hgemm_mid_kernel<{nn},1,2,3>"
+        capi.tune("hgemm_mid_splitk", 1)
+        try:
+            assert capi.hgemm_kernel_name(1024, 1024, 8192, lay) == f"hgemm_mid_kernel<{nn},1,2,3>"
+            assert capi.hgemm_kernel_name(512, 512, 8192, lay) == f"hgemm_mfma128_kernel<{nn},2>"
+        finally:
+            capi.tune("hgemm_mid_splitk", 0)
+        # M, N multiples of 64 only (not legal in the reference): a mid-size tile where one divides the shape, else the edge kernel
+        assert capi.hgemm_kernel_name(2880, 2880, 2880, lay) == ("hgemm_mid_kernel<false,3,3,3>" if nn == "false" else "hgemm_generic_kernel<true>")
+        assert capi.hgemm_kernel_name(8192, 8256, 8192, lay) == ("hgemm_mid_kernel<false,2,3,3>" if nn == "false" else "hgemm_generic_kernel<true>")
+        # 192 x 192 only where 128 x 128 at two per CU needs more than one double round (3072^3: 576 blocks on 512 slots)
+        assert capi.hgemm_kernel_name(3072, 2304, 3072, lay) == f"hgemm_mid_kernel<{nn},2,2,2>"
+        assert capi.hgemm_kernel_name(1088, 1152, 512, lay) == f"hgemm_mid_kernel<{nn},1,2,3>"
         # the knobs: never / a forced tile / the explicit variant on shapes LC_HGEMM_AUTO keeps away from it
         capi.tune("hgemm_mid", 1)
         try:
@@ -279,7 +297,7 @@ def test_hgemm_dispatch_covers_the_reference_legal_shapes(built):
             capi.hgemm_kernel_name(192, 96, 64, lay, capi.HGEMM_MID)
         for shp in ((384, 384, 128), (256, 256, 96)):                                             # ... the flagship kernel when asked for
             assert capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_MFMA256W4Y) == f"hgemm_w4y_kernel<{nn},{sch}>"
-        for shp in ((256, 256, 32), (8192, 8192, 8200), (8192, 8256, 8192), (128, 128, 48)):     # K < 64, K % 32, N % 128: the edge kernel
+        for shp in ((256, 256, 32), (8192, 8192, 8200), (8192, 8224, 8192), (128, 128, 48)):     # K < 64, K % 32, N % 64: the edge kernel
             assert capi.hgemm_kernel_name(*shp, lay) == f"hgemm_generic_kernel<{nn}>", shp
             with pytest.raises(capi.LcError, match="Tensor size mismatch"):
                 capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_MFMA256W4Y)
@@ -450,7 +468,10 @@ def test_launch_rules_reason_with_any_cu_count(built):
             assert name.startswith("hgemm_mid_kernel<false,") and name.endswith(",3>"), (cus, n1, name)      # one round: three ring slots
             assert capi.hgemm_kernel_name(8192, 8192, 8192, capi.LAYOUT_TN) == "hgemm_w4y_kernel<false,2>"
             big = 256 * (int((cus / 2) ** 0.5) + 1)                              # just over cus / 2 tiles of 256 x 256
-            assert capi.hgemm_kernel_name(big, big, 4096, capi.LAYOUT_TN) == "hgemm_w4y_kernel<false,2>", (cus, big)
+            assert capi.hgemm_kernel_name(big, big, 4096, capi.LAYOUT_NN) == "hgemm_w4y_kernel<true,1>", (cus, big)
+            name = capi.hgemm_kernel_name(big, big, 4096, capi.LAYOUT_TN)       # TN: unless 192 x 192 tiles fill more CUs in ONE round (256 CUs: 3072)
+            fills = big % 192 == 0 and (big // 256) ** 2 < (big // 192) ** 2 <= cus
+            assert name == ("hgemm_mid_kernel<false,3,3,3>" if fills else "hgemm_w4y_kernel<false,2>"), (cus, big, name)
     finally:
         capi.tune("rule_cus", 0)
     with pytest.raises(capi.LcError):

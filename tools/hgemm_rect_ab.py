@@ -42,19 +42,24 @@ for (M, N, K) in shapes:
         b2 = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
         cands = {}
 
-        def mk(mid, ns, var):
+        def mk(mid, ns, var, sk=1):
             def f():
                 capi.tune("hgemm_mid", mid)
                 capi.tune("hgemm_mid_ns", ns)
+                capi.tune("hgemm_mid_splitk", sk)
                 capi.hgemm(a, b2, c, layout=lay, variant=var, swizzle_stride=st)
             return f
-        cands["auto"] = mk(0, 0, capi.HGEMM_AUTO)
+        cands["auto"] = mk(0, 0, capi.HGEMM_AUTO, 0)
         for tmw in (2, 3, 1):
             for w in (2, 3):
-                if N % (64 * w) or M % (64 * tmw) or (lname == "nn" and w == 3) or (tmw == 3 and w == 3):
+                if N % (64 * w) or M % (64 * tmw) or (lname == "nn" and w == 3):
                     continue
                 for ns in (2, 3):
                     cands[f"mid{tmw}{w}x{ns}"] = mk(10 * tmw + w, ns, capi.HGEMM_MID)
+                if w == 2 and tmw <= 2 and (M // (64 * tmw)) * (N // 128) <= 128:
+                    for sk in (2, 4, 8):
+                        if K // 64 >= 4 * sk:
+                            cands[f"mid{tmw}{w}sk{sk}"] = mk(10 * tmw + w, 3, capi.HGEMM_MID, sk)
         if M % 256 == 0 and N % 256 == 0:
             cands["w4y"] = mk(1, 0, capi.HGEMM_MFMA256W4Y)
         if M % 128 == 0 and N % 128 == 0:
@@ -71,8 +76,9 @@ for (M, N, K) in shapes:
                 t[k] += burst(cands[k], cnt)
         capi.tune("hgemm_mid", 0)
         capi.tune("hgemm_mid_ns", 0)
+        capi.tune("hgemm_mid_splitk", 0)
         rate = {k: fl * cnt * 3 / v * 1e-12 for k, v in t.items()}
-        best = max((k for k in rate if k not in ("auto", "hipBLASLt")), key=lambda k: rate[k])
+        best = max((k for k in rate if k not in ("auto", "hipBLASLt")), key=lambda k: rate[k], default="auto")
         worst.append((rate["auto"] / rate[best], rate["auto"] / rate["hipBLASLt"], M, N, K, lname, best))
         print(f"{M}x{N}x{K} {lname} auto={capi.hgemm_kernel_name(M, N, K, lay)} {rate['auto']:6.1f} | best forced {best} {rate[best]:6.1f} "
               f"(auto / best {rate['auto'] / rate[best]:.3f}) | hipBLASLt {rate['hipBLASLt']:6.1f} (auto / vendor {rate['auto'] / rate['hipBLASLt']:.3f}) | "
