@@ -348,8 +348,8 @@ def bench_hgemm(w, args):
             ven[lname + "_ours"] = sustained(lambda: capi.hgemm(a, b2, c, layout=l2, variant=var, swizzle_stride=stride),
                                              flops, 1.0)["tflops"]
         # round 6: four more points of the reference bench's DEFAULT sweep (hgemm.py:28-32: multiples of 256), where LC_HGEMM_AUTO runs other
-        # kernels than at 8192^3 — the mid-size kernel on 64 x 128 (1024) and 128 x 128 tiles (2048: one round; 2816: two per CU), the 256-tile
-        # kernel on its smallest grid (3072: 144 workgroups) — against hipBLASLt on the same operands: 0.3 s sustained each, ours and theirs alternating (three rounds).
+        # kernels than at 8192^3 — the mid-size kernel on 64 x 128 (1024) and 128 x 128 tiles (2048: one round; 2816: two per CU), the 192 x 192
+        # tile where 144 tiles of 256 x 256 would leave 112 CUs idle (3072) — against hipBLASLt on the same operands: 0.3 s sustained each, ours and theirs alternating (three rounds).
         # The whole sweep (100 cells): tools/hgemm_sizes.py sweep -> profiles/r6Z_hgemm_sweep.*.
         pts = {}
         for m in (1024, 2048, 2816, 3072):
