@@ -13,11 +13,11 @@ extern "C" int lc_probe_mid256(const void* A, const void* B, void* C, int M, int
   if (b_kn) {
     auto kern = hgemm_mid_kernel<true, 4, 4, 2>;
     if (int rc = set_dyn_lds(kern, G::LDS)) return rc;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), G::LDS, st, (const half_t*)A, (const half_t*)B, (half_t*)C, M, N, K, tiles_m, tiles_n, panel_w, -1, (float*)nullptr, 1);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), G::LDS, st, (const half_t*)A, (const half_t*)B, (half_t*)C, M, N, K, tiles_m, tiles_n, panel_w, -1);
   } else {
     auto kern = hgemm_mid_kernel<false, 4, 4, 2>;
     if (int rc = set_dyn_lds(kern, G::LDS)) return rc;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), G::LDS, st, (const half_t*)A, (const half_t*)B, (half_t*)C, M, N, K, tiles_m, tiles_n, panel_w, -1, (float*)nullptr, 1);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), G::LDS, st, (const half_t*)A, (const half_t*)B, (half_t*)C, M, N, K, tiles_m, tiles_n, panel_w, -1);
   }
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }

@@ -102,10 +102,11 @@ LC_DEVINL const char* sgpr_ptr(const void* p) {   // a pointer hipcc can PROVE w
 // SK (split-K, round 6): the grid holds ks copies of the tile grid, block b = tile b % tiles of K range b / tiles (whole K tiles, split
 // evenly; the last range takes the K % 64 == 32 half step); fp32 partials go to part[ks][M][N] and hgemm_mid_reduce_kernel adds them in
 // range order and rounds once.  For shapes whose one-round tile grid covers at most half the CUs and whose K is long (1024 x 1024 x 8192).
-template <bool B_KN, int TMW, int TNW, int NS, bool SK = false>
-__global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B,
-                                                           half_t* __restrict__ C, int M, int N, int K, int tiles_m, int tiles_n,
-                                                           int panel_w, int rem_base, float* __restrict__ part, int ks) {
+// (One body, two entry points below: hgemm_mid_kernel<B_KN, TMW, TNW, NS> and hgemm_mid_sk_kernel<B_KN, TMW, NS> — the names rocprofv3 shows
+// and lc_hgemm_kernel_name() reports.)
+template <bool B_KN, int TMW, int TNW, int NS, bool SK>
+LC_DEVINL void hgemm_mid_body(const half_t* __restrict__ A, const half_t* __restrict__ B, half_t* __restrict__ C, int M, int N, int K, int tiles_m,
+                              int tiles_n, int panel_w, int rem_base, float* __restrict__ part, int ks) {
   using G = Mid<TMW, TNW, NS>;
   static_assert(!B_KN || TNW == 2 || TNW == 4, "NN: whole [64 k][128 n] transpose images");
   constexpr int MI = G::MI, NI = G::NI, PA = G::PA, PB = G::PB, TM = G::TM, TN = G::TN;
@@ -389,6 +390,18 @@ __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kerne
     const u32x4_t v = *(const u32x4_t*)(stg + row * G::EPI_ROW + c * 16);
     *(u32x4_t*)(C + (size_t)(m0 + wr * (TM / 2) + row) * N + n0 + wc * (TN / 2) + c * 8) = v;
   }
+}
+
+template <bool B_KN, int TMW, int TNW, int NS>
+__global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B,
+                                                           half_t* __restrict__ C, int M, int N, int K, int tiles_m, int tiles_n,
+                                                           int panel_w, int rem_base) {
+  hgemm_mid_body<B_KN, TMW, TNW, NS, false>(A, B, C, M, N, K, tiles_m, tiles_n, panel_w, rem_base, nullptr, 1);
+}
+template <bool B_KN, int TMW, int NS>
+__global__ __launch_bounds__(256, 2) void hgemm_mid_sk_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B, int M, int N, int K,
+                                                              int tiles_m, int tiles_n, int panel_w, float* __restrict__ part, int ks) {
+  hgemm_mid_body<B_KN, TMW, 2, NS, true>(A, B, nullptr, M, N, K, tiles_m, tiles_n, panel_w, -1, part, ks);
 }
 
 // Sum of the split-K partials part[ks][mn] in range order, rounded once to fp16: 8 elements per thread.

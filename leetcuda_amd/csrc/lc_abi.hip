@@ -738,7 +738,7 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
   else if (v == LC_HGEMM_MFMA256) snprintf(buf, buflen, "hgemm_mfma256_kernel<%s>", nn);
   else if (v == LC_HGEMM_MID) {
     const MidTile t = mid_tile_auto(M, N, K, layout == LC_LAYOUT_NN, variant != LC_HGEMM_MID);
-    if (t.ks > 1) snprintf(buf, buflen, "hgemm_mid_kernel<%s,%d,%d,%d,true> x%d", nn, t.tmw, t.tnw, t.ns, t.ks);   // (+ hgemm_mid_reduce_kernel; one K range under graph capture)
+    if (t.ks > 1) snprintf(buf, buflen, "hgemm_mid_sk_kernel<%s,%d,%d> x%d", nn, t.tmw, t.ns, t.ks);   // (x K ranges, + hgemm_mid_reduce_kernel; hgemm_mid_kernel under graph capture)
     else snprintf(buf, buflen, "hgemm_mid_kernel<%s,%d,%d,%d>", nn, t.tmw, t.tnw, t.ns);
   } else if (v == LC_HGEMM_MFMA128) snprintf(buf, buflen, "hgemm_mfma128_kernel<%s,%d>", nn, mfma128_ksw((long)(M / BM1) * (N / BN1)));
   else snprintf(buf, buflen, "hgemm_generic_kernel<%s>", nn);

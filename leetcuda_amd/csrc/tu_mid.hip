@@ -11,7 +11,7 @@ int launch_mid_one(const half_t* A, const half_t* B, half_t* C, int M, int N, in
   auto kern = hgemm_mid_kernel<B_KN, TMW, TNW, NS>;
   if (int rc = set_dyn_lds(kern, G::LDS)) return rc;
   const int tiles_m = M / G::TM, tiles_n = N / G::TN;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), G::LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw, -1, (float*)nullptr, 1);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), G::LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw, -1);
   return check_launch();
 }
 template <bool B_KN, int TMW, int NS>
@@ -20,8 +20,7 @@ int launch_mid_rem_one(const half_t* A, const half_t* B, half_t* C, int M, int N
   using G = Mid<TMW, 2, NS>;
   auto kern = hgemm_mid_kernel<B_KN, TMW, 2, NS>;
   if (int rc = set_dyn_lds(kern, G::LDS)) return rc;
-  hipLaunchKernelGGL(kern, dim3(rem_tiles * (256 / G::TM) * 2), dim3(256), G::LDS, st, A, B, C, M, N, K, tiles_m256, tiles_n256, pw256, rem_base,
-                     (float*)nullptr, 1);
+  hipLaunchKernelGGL(kern, dim3(rem_tiles * (256 / G::TM) * 2), dim3(256), G::LDS, st, A, B, C, M, N, K, tiles_m256, tiles_n256, pw256, rem_base);
   return check_launch();
 }
 template <bool B_KN>
@@ -37,10 +36,10 @@ int launch_mid_rem(const half_t* A, const half_t* B, half_t* C, int M, int N, in
 template <bool B_KN, int TMW>
 int launch_mid_sk(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int pw, float* part, int ks, hipStream_t st) {
   using G = Mid<TMW, 2, 3>;
-  auto kern = hgemm_mid_kernel<B_KN, TMW, 2, 3, true>;
+  auto kern = hgemm_mid_sk_kernel<B_KN, TMW, 3>;
   if (int rc = set_dyn_lds(kern, G::LDS)) return rc;
   const int tiles_m = M / G::TM, tiles_n = N / G::TN;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * ks), dim3(256), G::LDS, st, A, B, C, M, N, K, tiles_m, tiles_n, pw, -1, part, ks);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * ks), dim3(256), G::LDS, st, A, B, M, N, K, tiles_m, tiles_n, pw, part, ks);
   if (int rc = check_launch()) return rc;
   const size_t mn = (size_t)M * N;
   hipLaunchKernelGGL(hgemm_mid_reduce_kernel, dim3((unsigned)((mn / 8 + 255) / 256)), dim3(256), 0, st, (const float*)part, C, mn, ks);

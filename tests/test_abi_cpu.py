@@ -270,8 +270,8 @@ def test_hgemm_dispatch_covers_the_reference_legal_shapes(built):
         assert capi.hgemm_kernel_name(3072, 3072, 3072, lay) == (f"hgemm_w4y_kernel<{nn},{sch}>" if nn == "true" else "hgemm_mid_kernel<false,3,3,3>")
         assert capi.hgemm_kernel_name(3328, 3328, 3328, lay) == f"hgemm_w4y_kernel<{nn},{sch}>"                   # 169 tiles, no mid-size tile in one round
         # split-K (round 6): a one-round grid on at most half the CUs with at least 32 K tiles per range; never at the reference sweep's sizes
-        assert capi.hgemm_kernel_name(1024, 1024, 8192, lay) == f"hgemm_mid_kernel<{nn},1,2,3,true> x2"
-        assert capi.hgemm_kernel_name(512, 512, 8192, lay) == f"hgemm_mid_kernel<{nn},1,2,3,true> x4"
+        assert capi.hgemm_kernel_name(1024, 1024, 8192, lay) == f"hgemm_mid_sk_kernel<{nn},1,3> x2"
+        assert capi.hgemm_kernel_name(512, 512, 8192, lay) == f"hgemm_mid_sk_kernel<{nn},1,3> x4"
         assert capi.hgemm_kernel_name(1024, 1024, 2048, lay) == f"hgemm_mid_kernel<{nn},1,2,3>"
         capi.tune("hgemm_mid_splitk", 1)
         try:

@@ -320,7 +320,7 @@ def test_mid_kernel_at_the_sizes_it_serves(oracle, layout, n):
 
 @pytest.mark.parametrize("layout", ["nn", "tn"])
 def test_mid_kernel_split_k_and_64_multiples(oracle, layout):
-    """Late round 6.  (i) Split-K of the mid-size kernel (hgemm_mid_kernel<.., true> + hgemm_mid_reduce_kernel; fp32 partials in the stream's
+    """Late round 6.  (i) Split-K of the mid-size kernel (hgemm_mid_sk_kernel + hgemm_mid_reduce_kernel; fp32 partials in the stream's
     workspace): LC_HGEMM_AUTO picks it for one-round grids on at most half the CUs with a long K; every forced factor against the oracle
     incl. the K % 64 == 32 half step and K ranges of unequal length, equal to the unsplit launch to the rounding of differently grouped
     fp32 sums, bit-identical from run to run; one K range under graph capture (no workspace inside a graph).  (ii) M, N multiples of 64
@@ -330,7 +330,7 @@ def test_mid_kernel_split_k_and_64_multiples(oracle, layout):
     lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
     nnn = "true" if layout == "nn" else "false"
     if capi.device_check() == 256:
-        assert capi.hgemm_kernel_name(1024, 1024, 8192, lay) == f"hgemm_mid_kernel<{nnn},1,2,3,true> x2"
+        assert capi.hgemm_kernel_name(1024, 1024, 8192, lay) == f"hgemm_mid_sk_kernel<{nnn},1,3> x2"
     for (M, N, K) in ((512, 512, 8224), (256, 384, 4128), (1024, 1024, 8192)):
         torch.manual_seed(M + N + K)
         a = torch.randn(M, K, dtype=torch.half, device="cuda")
@@ -355,7 +355,7 @@ def test_mid_kernel_split_k_and_64_multiples(oracle, layout):
                     capi.tune("hgemm_mid", 0)
                     capi.tune("hgemm_mid_splitk", 0)
                 if ks >= 2:
-                    assert name.endswith(f",true> x{ks}"), name
+                    assert name.startswith("hgemm_mid_sk_kernel<") and name.endswith(f"> x{ks}"), name
                 assert torch.equal(c, c2), (M, N, K, tile, ks)                 # another block map, another run: the same bits
                 ok, mx, _ = tol.hgemm_close(c[rows].float().cpu().numpy(), truth, K)
                 assert ok, (M, N, K, tile, ks, mx)
