@@ -55,7 +55,7 @@ typedef enum lc_layout { LC_LAYOUT_NN = 0, LC_LAYOUT_TN = 1 } lc_layout;
 typedef enum lc_hgemm_variant {
   LC_HGEMM_AUTO = 0,       /* best available for the shape: the reference's legal shapes (M, N % 128 == 0, K % 32 == 0, K >= 64;
                               hgemm_mma_stage.cu:650,675-676) run MFMA256W4Y when the 256-tileable interior has > 128 tiles (128-wide
-                              border strips on MFMA128 in a second launch), MFMA128 otherwise; every other shape GENERIC          */
+                              border strips on MFMA128 in a second launch), MID / MFMA128 otherwise; every other shape EDGE or GENERIC */
   LC_HGEMM_MFMA256 = 1,    /* 256x256x64 WG tile, 8 wave64, LDS-DMA double buffer, one barrier / K-tile (simplest)      */
   LC_HGEMM_GENERIC = 3,    /* 64x64x32 edge-predicated MFMA kernel: any M,N,K                                           */
   LC_HGEMM_MFMA256P2 = 4,  /* 8-wave ping-pong, 2 phases of 16 MFMAs per K tile, DMA issued inside the MFMA clusters:
@@ -73,6 +73,9 @@ typedef enum lc_hgemm_variant {
                             /* ring, hand-ordered asm K loop: LC_HGEMM_AUTO's choice between the eight-wave 128-tile kernel (small     */
                             /* grids) and the 256-tile kernel (> 128 tiles of 256 x 256) — n = 1280 .. 2816 square — with the tile that */
                             /* leaves the least work on the busiest CU.  M, N % 64 == 0 (a tile must divide them), K % 32 == 0 (>= 64)  */
+  LC_HGEMM_EDGE = 15,       /* the vectorised edge kernel (hgemm_edge.hip, late round 6): 128 x 128 x 32 tile, any M and N, K % 8 == 0 (NN: */
+                            /* N % 8 == 0), 16-byte chunks with whole-chunk predication: what LC_HGEMM_AUTO runs where no tiled kernel     */
+                            /* divides the shape; every other shape (K % 8, unaligned pointers) stays on LC_HGEMM_GENERIC                   */
   /* the reference's "CUDA-core" ladder as vector-ALU kernels (hgemm_valu.hip; NN only; v_dot2c_f32_f16, fp32 accumulate);
    * shapes a rung does not tile (and TN) run LC_HGEMM_GENERIC */
   LC_HGEMM_VALU_NAIVE = 20,                  /* one thread per C element, operands from global memory                       */

@@ -17,6 +17,7 @@ HGEMM_AUTO, HGEMM_MFMA256, HGEMM_GENERIC, HGEMM_MFMA256P2, HGEMM_MFMA128 = 0, 1,
 HGEMM_VALU_NAIVE, HGEMM_VALU_SLICED_K, HGEMM_VALU_T8X8_X4, HGEMM_VALU_T16X8_K32 = 20, 21, 22, 30   # the VALU ladder: 20..30
 HGEMM_MFMA256W4B, HGEMM_MFMA256W4C, HGEMM_MFMA256W4X, HGEMM_MFMA256W4Y = 9, 10, 12, 13
 HGEMM_MID = 14   # the one-round kernel (hgemm_mid.hip)
+HGEMM_EDGE = 15  # the vectorised edge kernel (hgemm_edge.hip): any M, N; K % 8 == 0 (NN: N % 8 == 0)
 ATTN_SPLIT_Q, ATTN_SHARED_QKV, ATTN_SHARED_KV, ATTN_TILING_QK, ATTN_TILING_QKV, ATTN_SPLIT_KV = range(6)
 
 # every symbol include/lc_abi.h declares: name -> (restype, argtypes)

@@ -18,6 +18,7 @@
 #include "lc_launch.h"
 #include "attn_fwd.hip"
 #include "hgemm_generic.hip"
+#include "hgemm_edge.hip"
 #include "hgemm_mfma128.hip"
 #include "hgemm_mfma256.hip"
 #include "hgemm_pingpong.hip"
@@ -395,6 +396,12 @@ int launch_mid(const half_t* A, const half_t* B, half_t* C, int M, int N, int K,
 }
 
 template <bool B_KN>
+int launch_edge(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, hipStream_t st) {
+  const dim3 grid((N + EN - 1) / EN, (M + EM - 1) / EM), block(256);
+  hipLaunchKernelGGL(hgemm_edge_kernel<B_KN>, grid, block, 0, st, A, B, C, M, N, K);
+  return check_launch();
+}
+template <bool B_KN>
 int launch_generic(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, hipStream_t st) {
   const dim3 grid((N + GN - 1) / GN, (M + GM - 1) / GM), block(256);
   hipLaunchKernelGGL(hgemm_generic_kernel<B_KN>, grid, block, 0, st, A, B, C, M, N, K);
@@ -667,7 +674,7 @@ namespace {
 bool is_tile256_variant(int v) { return v == LC_HGEMM_MFMA256 || v == LC_HGEMM_MFMA256P2 || is_w4_variant(v); }
 bool is_valu_variant(int v) { return v >= LC_HGEMM_VALU_NAIVE && v <= LC_HGEMM_VALU_T16X8_K32; }
 bool is_hgemm_variant(int v) {
-  return v == LC_HGEMM_AUTO || v == LC_HGEMM_GENERIC || v == LC_HGEMM_MFMA128 || v == LC_HGEMM_MID || is_tile256_variant(v) || is_valu_variant(v);
+  return v == LC_HGEMM_AUTO || v == LC_HGEMM_GENERIC || v == LC_HGEMM_EDGE || v == LC_HGEMM_MFMA128 || v == LC_HGEMM_MID || is_tile256_variant(v) || is_valu_variant(v);
 }
 }  // namespace
 
@@ -683,6 +690,7 @@ int resolve_hgemm_variant(int variant, int M, int N, int K, bool al, bool b_kn) 
   const bool k64 = K % BK == 0, k32 = K % 32 == 0 && K >= BK;
   const bool tiles256 = (M % BM == 0) && (N % BN == 0) && k64 && al;
   const bool tiles128 = (M % BM1 == 0) && (N % BN1 == 0) && k32 && al;
+  const bool edge_ok = al && K % 8 == 0 && (!b_kn || N % 8 == 0);   // hgemm_edge_kernel: whole 16-byte chunks
   // hgemm_w4y_kernel itself (not the 64-bit-address kernel w4_effective_variant substitutes for huge operands) on this shape
   const bool w4y_ok = tiles128 && M >= BM && N >= BN && w4_effective_variant(LC_HGEMM_MFMA256W4Y, b_kn, N, K) == LC_HGEMM_MFMA256W4Y;
   if (variant == LC_HGEMM_AUTO) {
@@ -702,7 +710,7 @@ int resolve_hgemm_variant(int variant, int M, int N, int K, bool al, bool b_kn) 
       return a;
     }
     if (tiles64 && mid_tile_auto(M, N, K, b_kn, true).tmw > 0) return LC_HGEMM_MID;   // the tile with the least work on the busiest CU (n = 1280 .. 2816 square)
-    return tiles128 ? LC_HGEMM_MFMA128 : LC_HGEMM_GENERIC;
+    return tiles128 ? LC_HGEMM_MFMA128 : (edge_ok ? LC_HGEMM_EDGE : LC_HGEMM_GENERIC);
   }
   if (is_valu_variant(variant)) {   // a rung of the vector-ALU ladder: its own tile, else the edge kernel (never an error)
     int tm, tn, tk;
@@ -714,6 +722,7 @@ int resolve_hgemm_variant(int variant, int M, int N, int K, bool al, bool b_kn) 
   if (is_tile256_variant(variant) && !tiles256) return LC_ERR_SHAPE;
   if (variant == LC_HGEMM_MFMA128 && !tiles128) return LC_ERR_SHAPE;
   if (variant == LC_HGEMM_MID && !(al && mid_tile_auto(M, N, K, b_kn, false).tmw > 0)) return LC_ERR_SHAPE;
+  if (variant == LC_HGEMM_EDGE && !edge_ok) return LC_ERR_SHAPE;
   return variant;
 }
 }  // namespace
@@ -741,6 +750,7 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
     if (t.ks > 1) snprintf(buf, buflen, "hgemm_mid_sk_kernel<%s,%d,%d> x%d", nn, t.tmw, t.ns, t.ks);   // (x K ranges, + hgemm_mid_reduce_kernel; hgemm_mid_kernel under graph capture)
     else snprintf(buf, buflen, "hgemm_mid_kernel<%s,%d,%d,%d>", nn, t.tmw, t.tnw, t.ns);
   } else if (v == LC_HGEMM_MFMA128) snprintf(buf, buflen, "hgemm_mfma128_kernel<%s,%d>", nn, mfma128_ksw((long)(M / BM1) * (N / BN1)));
+  else if (v == LC_HGEMM_EDGE) snprintf(buf, buflen, "hgemm_edge_kernel<%s>", nn);
   else snprintf(buf, buflen, "hgemm_generic_kernel<%s>", nn);
   return LC_OK;
 }
@@ -918,7 +928,7 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   if (variant == LC_HGEMM_MID) {
     const MidTile t = mid_tile_auto(M, N, K, layout == LC_LAYOUT_NN, !mid_forced);
     if (t.tmw > 0) return launch_mid(a, b, c, M, N, K, layout == LC_LAYOUT_NN, t, swizzle_stride, st);
-    variant = (M % BM1 == 0 && N % BN1 == 0) ? LC_HGEMM_MFMA128 : LC_HGEMM_GENERIC;   // (the knob changed between the two reads)
+    variant = (M % BM1 == 0 && N % BN1 == 0) ? LC_HGEMM_MFMA128 : LC_HGEMM_EDGE;   // (the knob changed between the two reads; every LC_HGEMM_MID shape is an edge-kernel shape)
   }
   if (is_valu_variant(variant)) {
     if (layout == LC_LAYOUT_NN) return launch_valu_rung(a, b, c, M, N, K, variant, st);
@@ -931,6 +941,9 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   if (variant == LC_HGEMM_MFMA128) {
     return layout == LC_LAYOUT_NN ? launch_mfma128<true>(a, b, c, M, N, K, swizzle_stride, st)
                                   : launch_mfma128<false>(a, b, c, M, N, K, swizzle_stride, st);
+  }
+  if (variant == LC_HGEMM_EDGE) {
+    return layout == LC_LAYOUT_NN ? launch_edge<true>(a, b, c, M, N, K, st) : launch_edge<false>(a, b, c, M, N, K, st);
   }
   return layout == LC_LAYOUT_NN ? launch_generic<true>(a, b, c, M, N, K, st)
                                 : launch_generic<false>(a, b, c, M, N, K, st);

@@ -392,7 +392,7 @@ def test_mid_kernel_split_k_and_64_multiples(oracle, layout):
         if layout == "tn" or N % 128 == 0:
             assert name.startswith("hgemm_mid_kernel<"), (M, N, K, name)
         else:
-            assert name.startswith("hgemm_generic_kernel<"), (M, N, K, name)  # (NN has 128-column tiles only)
+            assert name.startswith("hgemm_edge_kernel<"), (M, N, K, name)  # (NN has 128-column tiles only: the vectorised edge kernel)
         torch.manual_seed(M + N)
         a = torch.randn(M, K, dtype=torch.half, device="cuda")
         b = torch.randn(K, N, dtype=torch.half, device="cuda")
@@ -440,6 +440,47 @@ def test_generic_kernel_ragged_shapes(oracle, layout, shape):
     lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
     c, _ = _run(capi, a, b, lay, VARIANTS["generic"])
     _check(oracle, capi, a, b, c, lay)
+
+
+@pytest.mark.parametrize("layout", ["nn", "tn"])
+@pytest.mark.parametrize("shape", [(64, 64, 64), (128, 128, 32), (100, 72, 56), (1, 8, 8), (257, 136, 72), (384, 640, 96), (129, 1000, 40),
+                                   (1000, 3000, 520), (130, 130, 64), (2880, 2944, 264)])
+def test_edge_kernel_ragged_shapes(oracle, layout, shape):
+    """Late round 6: hgemm_edge_kernel (16-byte chunks, whole-chunk predication) is what LC_HGEMM_AUTO runs where no tiled kernel divides
+    the shape (any M, N; K % 8 == 0; NN: N % 8 == 0).  Against the oracle, against the element-wise hgemm_generic_kernel (other fp32 order:
+    one output ulp), bit-identical from run to run, NaN canaries around C untouched; (130, 130, 64) is TN-only (N % 8 != 0)."""
+    capi = _capi()
+    M, N, K = shape
+    lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
+    nnn = "true" if layout == "nn" else "false"
+    if layout == "nn" and N % 8:
+        with pytest.raises(capi.LcError, match="Tensor size mismatch"):
+            capi.hgemm_kernel_name(M, N, K, lay, capi.HGEMM_EDGE)
+        assert capi.hgemm_kernel_name(M, N, K, lay) == "hgemm_generic_kernel<true>"
+        return
+    assert capi.hgemm_kernel_name(M, N, K, lay, capi.HGEMM_EDGE) == f"hgemm_edge_kernel<{nnn}>"
+    torch.manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, dtype=torch.half, device="cuda")
+    b = torch.randn(K, N, dtype=torch.half, device="cuda")
+    bb = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
+    pad = 4096                                                       # C inside a larger buffer: nothing outside [0, M * N) is written
+    buf = torch.full((M * N + 2 * pad,), float("nan"), dtype=torch.half, device="cuda")
+    c = buf[pad:pad + M * N].view(M, N)
+    capi.hgemm(a, bb, c, layout=lay, variant=capi.HGEMM_EDGE)
+    torch.cuda.synchronize()
+    assert torch.isnan(buf[:pad]).all() and torch.isnan(buf[pad + M * N:]).all()
+    rows = list(range(M)) if M * N * K <= 1 << 28 else sorted({0, 1, 63, 64, 127, 128, M // 2 + 3, M - 129, M - 2, M - 1})
+    truth = oracle.hgemm(a[rows].contiguous(), b.contiguous(), len(rows), N, K, 0, "f32")
+    ok, mx, ex = tol.hgemm_close(c[rows].float().cpu().numpy(), truth, K)
+    assert ok and torch.isfinite(c).all(), (mx, ex)
+    cgen, _ = _run(capi, a, b, lay, capi.HGEMM_GENERIC)
+    ulp = torch.clamp(cgen.float().abs(), min=32.0) * 2.0 ** -10
+    assert ((c.float() - cgen.float()).abs() <= ulp).all()
+    c2, _ = _run(capi, a, b, lay, capi.HGEMM_EDGE)
+    assert torch.equal(c2, c)
+    if capi.hgemm_kernel_name(M, N, K, lay).startswith("hgemm_edge_kernel"):     # ... and through LC_HGEMM_AUTO where the rule picks it
+        c3, _ = _run(capi, a, b, lay, capi.HGEMM_AUTO, 256)
+        assert torch.equal(c3, c)
 
 
 @pytest.mark.parametrize("variant", ["mfma256", "pingpong2", "w4b", "w4c", "w4x", "w4y", "generic"])
@@ -902,4 +943,4 @@ def test_random_shapes_through_the_auto_dispatch(oracle):
         truth = oracle.hgemm(a, b, M, N, K, 0, "f32")
         ok, mx, ex = tol.hgemm_close(c.float().cpu().numpy(), truth, K)
         assert ok, (M, N, K, lay, name, mx, ex)
-    assert {"hgemm_mid_kernel", "hgemm_generic_kernel"} <= seen and ({"hgemm_mfma128_kernel", "hgemm_w4y_kernel"} & seen), seen
+    assert {"hgemm_mid_kernel", "hgemm_edge_kernel"} <= seen and ({"hgemm_mfma128_kernel", "hgemm_w4y_kernel"} & seen), seen
