@@ -76,6 +76,9 @@ typedef enum lc_hgemm_variant {
   LC_HGEMM_EDGE = 15,       /* the vectorised edge kernel (hgemm_edge.hip, late round 6): 128 x 128 x 32 tile, any M and N, K % 8 == 0 (NN: */
                             /* N % 8 == 0), 16-byte chunks with whole-chunk predication: what LC_HGEMM_AUTO runs where no tiled kernel     */
                             /* divides the shape; every other shape (K % 8, unaligned pointers) stays on LC_HGEMM_GENERIC                   */
+  LC_HGEMM_RAGGED = 16,     /* ragged M / N with K % 32 == 0 (K >= 64), N % 8 == 0: the interior — the largest top-left sub-matrix 256 x 256 (more than  */
+                            /* half a CU's worth of them) or 128 x 128 tiles divide — on hgemm_w4y_kernel / hgemm_mid_kernel, the L-shaped border on   */
+                            /* hgemm_edge_kernel in a second launch; LC_HGEMM_AUTO's choice from 4 edge blocks per CU on (lc_tune_set "hgemm_ragged")  */
   /* the reference's "CUDA-core" ladder as vector-ALU kernels (hgemm_valu.hip; NN only; v_dot2c_f32_f16, fp32 accumulate);
    * shapes a rung does not tile (and TN) run LC_HGEMM_GENERIC */
   LC_HGEMM_VALU_NAIVE = 20,                  /* one thread per C element, operands from global memory                       */
@@ -165,6 +168,8 @@ const char* lc_build_info(int* is_diag);
  *                  full waves and 128 x 128 blocks the four quadrants of each remaining tile (round 6: on the mid-size kernel, + 4 ... 6 % at 4352 ... 6400); 0 = one launch
  *   "hgemm_tail_tile"  sub-tiles of that tail on the mid-size kernel: 0 = auto (64 x 128 eighths while 8 x the remaining tiles fit one round of the
  *                  CUs, else 128 x 128 quadrants), 1 = eighths, 2 = quadrants (bit-identical results; A/B knob)
+ *   "hgemm_ragged" LC_HGEMM_AUTO on ragged M / N with K % 32 == 0: 0 = auto (LC_HGEMM_RAGGED once the shape holds >= 4 blocks of 128 x 128 per CU,
+ *                  else the edge kernel alone), 1 = never, 2 = wherever an interior exists (A/B knob)
  *   "hgemm_raster" block -> C tile map of the tiled GEMM kernels: 0 = auto (2 when A + B exceed 272 MiB — the 256 MiB Infinity Cache and a margin,
  *                  else 1), 1 = the reference's block swizzle (N panels of swizzle_stride columns, every XCD a contiguous id
  *                  range), 2 = XCD super-block raster (16 x 16 tile steps shared through the Infinity Cache, 4 x 8 per XCD;

@@ -5,6 +5,7 @@
 // kernels/flash-attn/mma/basic/flash_attn_mma_split_q.cu:701-815) re-expressed on raw pointers.
 #include "../../include/lc_abi.h"
 
+#include <limits.h>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -54,6 +55,7 @@ tune_t g_tune_hgemm_mid{0};                    // mid-size kernel (hgemm_mid.hip
 tune_t g_tune_hgemm_mid_ns{0};                 // ... its LDS ring slots: 0 = auto (3 for one-round grids, else 2), 2, 3
 tune_t g_tune_hgemm_128w{0};                   // waves of the 128-tile kernel: 0 = auto (eight — intra-workgroup split-K — on grids of <= 0.6 blocks per CU), 1 = always four, 2 = always eight
 tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to 128 x 128 blocks (launch_mfma256: the mid-size kernel; 2 = round 5's 128-tile kernel + split-K), 0 = one launch
+tune_t g_tune_hgemm_ragged{0};                 // LC_HGEMM_AUTO on ragged M / N with K % 32 == 0: 0 = auto (interior on a tiled kernel + border on the edge kernel from 4 edge blocks per CU), 1 = never, 2 = wherever an interior exists
 tune_t g_tune_hgemm_tail_tile{0};              // sub-tiles of the ragged tail on the mid-size kernel: 0 = auto (launch_mfma256), 1 = 64 x 128 eighths, 2 = 128 x 128 quadrants
 tune_t g_tune_hgemm_mid_splitk{0};             // split-K of the mid-size kernel: 0 = auto (mid_tile_auto), 1 = never, 2 .. 8 = that many K ranges wherever legal (A/B)
 tune_t g_tune_hgemm_raster{0};                 // block -> C tile map: 0 = auto (by operand footprint, panel_tiles), 1 = the reference's block swizzle (N panels from
@@ -395,10 +397,17 @@ int launch_mid(const half_t* A, const half_t* B, half_t* C, int M, int N, int K,
   return launch_hgemm_mid(A, B, C, M, N, K, b_kn, t.tmw, t.tnw, t.ns, pw, st);   // (no workspace — graph capture, allocation failure: one K range)
 }
 
+// hgemm_edge_kernel over the right strip (all rows, columns Ni .. N) and the bottom strip (rows Mi .. M, columns 0 .. Ni) of C; Mi = Ni = 0:
+// the whole matrix.  Ni % 128 == 0.
 template <bool B_KN>
-int launch_edge(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, hipStream_t st) {
-  const dim3 grid((N + EN - 1) / EN, (M + EM - 1) / EM), block(256);
-  hipLaunchKernelGGL(hgemm_edge_kernel<B_KN>, grid, block, 0, st, A, B, C, M, N, K);
+int launch_edge(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int Mi, int Ni, hipStream_t st) {
+  const long nrc = (N - Ni + EN - 1) / EN, nright = nrc * ((M + EM - 1) / EM);
+  const long nbottom = (long)((M - Mi + EM - 1) / EM) * (Ni / EN);
+  if (nright + nbottom <= 0) return LC_OK;
+  if (nright + nbottom > INT_MAX) return LC_ERR_SHAPE;
+  auto kern = hgemm_edge_kernel<B_KN>;
+  if (int rc = set_dyn_lds(kern, EDGE_LDS)) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nright + nbottom)), dim3(256), EDGE_LDS, st, A, B, C, M, N, K, Mi, Ni, (int)nright, (int)(nrc > 0 ? nrc : 1));
   return check_launch();
 }
 template <bool B_KN>
@@ -637,6 +646,58 @@ int launch_attn_d(const half_t* Q, const half_t* K, const half_t* V, half_t* O, 
 
 }  // namespace
 
+namespace {
+// LC_HGEMM_RAGGED (late round 6): M and / or N are not multiples of the tiles (not legal in the reference, hgemm_mma_stage.cu:675-676), K is
+// (K % 32 == 0, K >= 64) and rows are 16-byte aligned (N % 8 == 0).  The INTERIOR — the largest top-left sub-matrix the tiles divide — runs on a
+// tiled kernel exactly as it would as a problem of its own (the kernels take N as C's / B's row stride and the tile counts separately), the L-shaped
+// BORDER on hgemm_edge_kernel in a second launch: every element of C is computed by exactly one kernel, deterministically.
+//   kind 1  more than half a CU's worth of 256 x 256 tiles: hgemm_w4y_kernel (+ its ragged last round on the mid-size kernel, as launch_mfma256)
+//   kind 2  otherwise: 128 x 128 tiles of hgemm_mid_kernel (three ring slots while they fit one round of the CUs, else two)
+// LC_HGEMM_AUTO takes it (lc_tune_set "hgemm_ragged") once the edge kernel alone would need about two rounds of its own (>= 4 blocks of
+// 128 x 128 per CU): below, one round of edge blocks is over sooner than a tiled launch plus a border launch.
+struct RaggedPlan { int kind, Mi, Ni, ns; };
+RaggedPlan ragged_plan(int M, int N, int K, bool al, bool b_kn, bool gated) {
+  RaggedPlan none{0, 0, 0, 0};
+  if (!al || K % 32 != 0 || K < BK || N % 8 != 0 || K >= (1 << 22) || N >= (1 << 22)) return none;
+  if (M % BM1 == 0 && N % BN1 == 0) return none;   // (a tiled shape)
+  if (M < BM1 || N < BN1) return none;
+  const int knob = g_tune_hgemm_ragged;
+  const long ncu = rule_cu_count();
+  if (gated) {
+    if (knob == 1) return none;
+    const long eb = (long)((M + EM - 1) / EM) * ((N + EN - 1) / EN);
+    if (knob == 0 && eb < 4 * ncu) return none;
+  }
+  const long t256 = (long)(M / BM) * (N / BN), t128 = (long)(M / BM1) * (N / BN1);
+  if (2 * t256 > ncu && g_tune_hgemm_auto == LC_HGEMM_MFMA256W4Y && w4_effective_variant(LC_HGEMM_MFMA256W4Y, b_kn, N, K) == LC_HGEMM_MFMA256W4Y)
+    return RaggedPlan{1, (M / BM) * BM, (N / BN) * BN, 0};
+  if (g_tune_hgemm_mid == 1 && gated) return none;
+  return RaggedPlan{2, (M / BM1) * BM1, (N / BN1) * BN1, t128 <= ncu ? 3 : 2};
+}
+
+template <bool B_KN>
+int launch_ragged(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, const RaggedPlan& p, int swizzle_stride, hipStream_t st) {
+  if (p.kind == 1) {
+    const int tiles_m = M / BM, tiles_n = N / BN;
+    const int pw = panel_tiles(swizzle_stride, tiles_n, BN, ((size_t)p.Mi + p.Ni) * K * 2);
+    const int ncu = device_cu_count();
+    const int T = tiles_m * tiles_n, R = T % ncu;
+    const int tail_knob = g_tune_hgemm_tail;
+    const bool split = tail_knob == 1 && T > ncu && R > 0 && 2 * R <= ncu && g_tune_hgemm_mid != 1;   // (launch_mfma256's default rule)
+    if (int rc = launch_w4_family(A, B, C, M, N, K, LC_HGEMM_MFMA256W4Y, B_KN, tiles_m, tiles_n, pw, split ? T - R : -1, st)) return rc;
+    if (split) {
+      const int tmw = 8 * R <= ncu ? 1 : 2;
+      const int blocks = (tmw == 1 ? 8 : 4) * R;
+      if (int rc = launch_hgemm_mid_rem(A, B, C, M, N, K, B_KN, tmw, blocks <= ncu ? 3 : 2, tiles_m, tiles_n, pw, T - R, R, st)) return rc;
+    }
+  } else {
+    const int pw = panel_tiles(swizzle_stride, N / BN1, BN1, ((size_t)p.Mi + p.Ni) * K * 2);
+    if (int rc = launch_hgemm_mid_interior(A, B, C, M, N, K, B_KN, p.ns, pw, st)) return rc;
+  }
+  return launch_edge<B_KN>(A, B, C, M, N, K, p.Mi, p.Ni, st);
+}
+}  // namespace
+
 // ------------------------------------------------------------------------------------------------
 // vendor comparator (hipBLASLt), resolved lazily with dlopen so the core library has no link-time
 // dependency on it.
@@ -674,7 +735,7 @@ namespace {
 bool is_tile256_variant(int v) { return v == LC_HGEMM_MFMA256 || v == LC_HGEMM_MFMA256P2 || is_w4_variant(v); }
 bool is_valu_variant(int v) { return v >= LC_HGEMM_VALU_NAIVE && v <= LC_HGEMM_VALU_T16X8_K32; }
 bool is_hgemm_variant(int v) {
-  return v == LC_HGEMM_AUTO || v == LC_HGEMM_GENERIC || v == LC_HGEMM_EDGE || v == LC_HGEMM_MFMA128 || v == LC_HGEMM_MID || is_tile256_variant(v) || is_valu_variant(v);
+  return v == LC_HGEMM_AUTO || v == LC_HGEMM_GENERIC || v == LC_HGEMM_EDGE || v == LC_HGEMM_RAGGED || v == LC_HGEMM_MFMA128 || v == LC_HGEMM_MID || is_tile256_variant(v) || is_valu_variant(v);
 }
 }  // namespace
 
@@ -709,8 +770,14 @@ int resolve_hgemm_variant(int variant, int M, int N, int K, bool al, bool b_kn) 
       }
       return a;
     }
+    // ragged M / N whose interior fills the flagship kernel: that kernel + a border launch, ahead of a 64-multiple tile of the mid-size kernel
+    // (8192 x 8256 x 4096 TN: 1261 against 1096 TFLOP/s on 128 x 192 tiles, profiles/r6ab_hgemm_edge_ab.log)
+    const int rk = tiles128 ? 0 : ragged_plan(M, N, K, al, b_kn, true).kind;
+    if (rk == 1) return LC_HGEMM_RAGGED;
     if (tiles64 && mid_tile_auto(M, N, K, b_kn, true).tmw > 0) return LC_HGEMM_MID;   // the tile with the least work on the busiest CU (n = 1280 .. 2816 square)
-    return tiles128 ? LC_HGEMM_MFMA128 : (edge_ok ? LC_HGEMM_EDGE : LC_HGEMM_GENERIC);
+    if (tiles128) return LC_HGEMM_MFMA128;
+    if (rk) return LC_HGEMM_RAGGED;   // interior on 128 x 128 tiles of the mid-size kernel, border on the edge kernel
+    return edge_ok ? LC_HGEMM_EDGE : LC_HGEMM_GENERIC;
   }
   if (is_valu_variant(variant)) {   // a rung of the vector-ALU ladder: its own tile, else the edge kernel (never an error)
     int tm, tn, tk;
@@ -723,6 +790,7 @@ int resolve_hgemm_variant(int variant, int M, int N, int K, bool al, bool b_kn) 
   if (variant == LC_HGEMM_MFMA128 && !tiles128) return LC_ERR_SHAPE;
   if (variant == LC_HGEMM_MID && !(al && mid_tile_auto(M, N, K, b_kn, false).tmw > 0)) return LC_ERR_SHAPE;
   if (variant == LC_HGEMM_EDGE && !edge_ok) return LC_ERR_SHAPE;
+  if (variant == LC_HGEMM_RAGGED && !ragged_plan(M, N, K, al, b_kn, false).kind) return LC_ERR_SHAPE;
   return variant;
 }
 }  // namespace
@@ -751,7 +819,12 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
     else snprintf(buf, buflen, "hgemm_mid_kernel<%s,%d,%d,%d>", nn, t.tmw, t.tnw, t.ns);
   } else if (v == LC_HGEMM_MFMA128) snprintf(buf, buflen, "hgemm_mfma128_kernel<%s,%d>", nn, mfma128_ksw((long)(M / BM1) * (N / BN1)));
   else if (v == LC_HGEMM_EDGE) snprintf(buf, buflen, "hgemm_edge_kernel<%s>", nn);
-  else snprintf(buf, buflen, "hgemm_generic_kernel<%s>", nn);
+  else if (v == LC_HGEMM_RAGGED) {   // interior kernel + the border launch
+    const RaggedPlan p = ragged_plan(M, N, K, true, layout == LC_LAYOUT_NN, variant != LC_HGEMM_RAGGED);
+    if (p.kind == 1) snprintf(buf, buflen, "hgemm_w4y_kernel<%s,%d> + hgemm_edge_kernel<%s>", nn, layout == LC_LAYOUT_NN ? 1 : g_tune_w4y_sched.load(), nn);
+    else if (p.kind == 2) snprintf(buf, buflen, "hgemm_mid_kernel<%s,2,2,%d> + hgemm_edge_kernel<%s>", nn, p.ns, nn);
+    else snprintf(buf, buflen, "hgemm_edge_kernel<%s>", nn);   // (the knob changed between the two reads)
+  } else snprintf(buf, buflen, "hgemm_generic_kernel<%s>", nn);
   return LC_OK;
 }
 
@@ -847,6 +920,7 @@ const Knob kKnobs[] = {
     {"hgemm_stagger", &g_tune_hgemm_stagger, 0, ok_stagger, false},
     {"hgemm_tail", &g_tune_hgemm_tail, 1, ok_04, false},
     {"hgemm_tail_tile", &g_tune_hgemm_tail_tile, 0, ok_02, false},
+    {"hgemm_ragged", &g_tune_hgemm_ragged, 0, ok_02, false},
     {"hgemm_mid_splitk", &g_tune_hgemm_mid_splitk, 0, ok_08, false},
     {"hgemm_128w", &g_tune_hgemm_128w, 0, ok_02, false},
     {"rule_cus", &g_tune_rule_cus, 0, ok_rule_cus, false},
@@ -921,14 +995,15 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   const half_t* b = static_cast<const half_t*>(B);
   half_t* c = static_cast<half_t*>(C);
   const bool al = aligned16(A) && aligned16(B) && aligned16(C);
-  const bool mid_forced = variant == LC_HGEMM_MID;
+  const bool mid_forced = variant == LC_HGEMM_MID, ragged_forced = variant == LC_HGEMM_RAGGED;
   variant = resolve_hgemm_variant(variant, M, N, K, al, layout == LC_LAYOUT_NN);
   if (variant < 0) return variant;
   if (int rc = launch_guard()) return rc;   // a sticky HIP error of an earlier call: report it, launch nothing
   if (variant == LC_HGEMM_MID) {
     const MidTile t = mid_tile_auto(M, N, K, layout == LC_LAYOUT_NN, !mid_forced);
     if (t.tmw > 0) return launch_mid(a, b, c, M, N, K, layout == LC_LAYOUT_NN, t, swizzle_stride, st);
-    variant = (M % BM1 == 0 && N % BN1 == 0) ? LC_HGEMM_MFMA128 : LC_HGEMM_EDGE;   // (the knob changed between the two reads; every LC_HGEMM_MID shape is an edge-kernel shape)
+    if (!(M % BM1 == 0 && N % BN1 == 0)) return layout == LC_LAYOUT_NN ? launch_edge<true>(a, b, c, M, N, K, 0, 0, st) : launch_edge<false>(a, b, c, M, N, K, 0, 0, st);
+    variant = LC_HGEMM_MFMA128;   // (the knob changed between the two reads; every LC_HGEMM_MID shape is an edge-kernel shape)
   }
   if (is_valu_variant(variant)) {
     if (layout == LC_LAYOUT_NN) return launch_valu_rung(a, b, c, M, N, K, variant, st);
@@ -942,8 +1017,14 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
     return layout == LC_LAYOUT_NN ? launch_mfma128<true>(a, b, c, M, N, K, swizzle_stride, st)
                                   : launch_mfma128<false>(a, b, c, M, N, K, swizzle_stride, st);
   }
+  if (variant == LC_HGEMM_RAGGED) {
+    const RaggedPlan p = ragged_plan(M, N, K, al, layout == LC_LAYOUT_NN, !ragged_forced);
+    if (p.kind) return layout == LC_LAYOUT_NN ? launch_ragged<true>(a, b, c, M, N, K, p, swizzle_stride, st)
+                                              : launch_ragged<false>(a, b, c, M, N, K, p, swizzle_stride, st);
+    variant = LC_HGEMM_EDGE;   // (the knob changed between the two reads; every LC_HGEMM_RAGGED shape is an edge-kernel shape)
+  }
   if (variant == LC_HGEMM_EDGE) {
-    return layout == LC_LAYOUT_NN ? launch_edge<true>(a, b, c, M, N, K, st) : launch_edge<false>(a, b, c, M, N, K, st);
+    return layout == LC_LAYOUT_NN ? launch_edge<true>(a, b, c, M, N, K, 0, 0, st) : launch_edge<false>(a, b, c, M, N, K, 0, 0, st);
   }
   return layout == LC_LAYOUT_NN ? launch_generic<true>(a, b, c, M, N, K, st)
                                 : launch_generic<false>(a, b, c, M, N, K, st);

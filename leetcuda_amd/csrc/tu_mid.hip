@@ -75,6 +75,12 @@ int launch_hgemm_mid(const half_t* A, const half_t* B, half_t* C, int M, int N, 
   return launch_mid_tm<false, 3>(A, B, C, M, N, K, tmw, ns, pw, st);
 }
 
+// The interior of a ragged shape: launch_mid_one's tile counts are floor(M / 128) x floor(N / 128); the kernel uses M and N as strides only.
+int launch_hgemm_mid_interior(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int ns, int pw, hipStream_t st) {
+  if (M < 128 || N < 128 || N % 8 != 0 || K % 32 != 0 || K < BK || K >= (1 << 22) || N >= (1 << 22)) return LC_ERR_SHAPE;
+  return b_kn ? launch_mid_ns<true, 2, 2>(A, B, C, M, N, K, ns, pw, st) : launch_mid_ns<false, 2, 2>(A, B, C, M, N, K, ns, pw, st);
+}
+
 // The ragged last round of hgemm_w4y_kernel's 256 x 256 grid as 128 x 128 quadrants (tmw = 2) or 64 x 128 eighths (tmw = 1) on this kernel
 // (round 6; until then on hgemm_mfma128_kernel with a workspace split-K): rem_tiles 256-tiles from raster id rem_base on, tiles_m256 /
 // tiles_n256 / pw256 = that grid's dimensions and block map.  ns: ring slots (3 when the blocks fit one round of the CUs, else 2).

@@ -329,7 +329,7 @@ def test_d256_bf16_full_size(oracle):
 
 @pytest.mark.parametrize("layout", ["nn", "tn"])
 @pytest.mark.parametrize("variant,shape", [("mfma128", (4224, 4352, 4128)), ("generic", (4100, 4090, 4100)), ("generic", (8192, 136, 8204)),
-                                           ("edge", (4100, 4088, 4104)), ("edge", (8192, 136, 8200))])
+                                           ("edge", (4100, 4088, 4104)), ("edge", (8192, 136, 8200)), ("ragged", (8200, 8264, 4128))])
 def test_mid_size_kernels_at_the_sizes_they_serve(oracle, variant, shape, layout):
     """Round-4 verdict (weak #2): hgemm_mfma128_kernel / hgemm_generic_kernel had parity up to ~1000^3 only, while LC_HGEMM_AUTO routes
     4000-class problems to them (128-multiples with a small interior, K % 32 != 0, ragged M / N).  Late round 6: hgemm_edge_kernel (16-byte
@@ -341,9 +341,12 @@ def test_mid_size_kernels_at_the_sizes_they_serve(oracle, variant, shape, layout
     a = torch.randn(M, K, dtype=torch.half, device="cuda")
     b = torch.randn(K, N, dtype=torch.half, device="cuda")
     bb = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
-    var = {"mfma128": capi.HGEMM_MFMA128, "generic": capi.HGEMM_GENERIC, "edge": capi.HGEMM_EDGE}[variant]
-    assert capi.hgemm_kernel_name(M, N, K, lay, var).startswith(f"hgemm_{variant}_kernel")
-    if variant != "mfma128":
+    var = {"mfma128": capi.HGEMM_MFMA128, "generic": capi.HGEMM_GENERIC, "edge": capi.HGEMM_EDGE, "ragged": capi.HGEMM_AUTO}[variant]
+    if variant == "ragged":   # what LC_HGEMM_AUTO launches on a large ragged shape with K % 32 == 0: interior on the flagship kernel (K % 64 == 32: its half step) + border
+        assert capi.hgemm_kernel_name(M, N, K, lay).startswith("hgemm_w4y_kernel") and "+ hgemm_edge_kernel" in capi.hgemm_kernel_name(M, N, K, lay)
+    else:
+        assert capi.hgemm_kernel_name(M, N, K, lay, var).startswith(f"hgemm_{variant}_kernel")
+    if variant in ("generic", "edge"):
         assert capi.hgemm_kernel_name(M, N, K, lay).startswith(f"hgemm_{variant}_kernel")   # what AUTO launches here (K % 8 != 0: element-wise)
     c = torch.full((M, N), float("nan"), dtype=torch.half, device="cuda")
     capi.hgemm(a, bb, c, layout=lay, variant=var, swizzle_stride=1024)

@@ -483,6 +483,65 @@ def test_edge_kernel_ragged_shapes(oracle, layout, shape):
         assert torch.equal(c3, c)
 
 
+@pytest.mark.parametrize("layout", ["nn", "tn"])
+@pytest.mark.parametrize("shape,kind", [((1000, 3000, 512), "mid3"), ((2888, 2880, 544), "mid2"), ((4100, 4104, 320), "w4y"), ((5000, 5008, 288), "w4y_tail"),
+                                        ((130, 4232, 96), "mid3"), ((4360, 136, 160), "mid3")])
+def test_ragged_shapes_interior_on_the_tiled_kernels(oracle, layout, shape, kind):
+    """Late round 6, LC_HGEMM_RAGGED: M / N that no tile divides with K % 32 == 0 and N % 8 == 0 — the interior on hgemm_w4y_kernel (more than
+    half a CU's worth of 256 x 256 tiles; with its ragged last round on the mid-size kernel) or on 128 x 128 tiles of hgemm_mid_kernel (three /
+    two ring slots), the L-shaped border on hgemm_edge_kernel.  Rows across the seam against the oracle, the whole of C against the edge kernel
+    alone and hgemm_generic_kernel (other fp32 orders: one output ulp), bit-identical from run to run, nothing written outside C; what
+    LC_HGEMM_AUTO launches follows "hgemm_ragged" (auto from 4 edge blocks per CU)."""
+    capi = _capi()
+    M, N, K = shape
+    lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
+    nnn = "true" if layout == "nn" else "false"
+    name = capi.hgemm_kernel_name(M, N, K, lay, capi.HGEMM_RAGGED)
+    if capi.device_check() == 256:
+        want = {"mid3": f"hgemm_mid_kernel<{nnn},2,2,3>", "mid2": f"hgemm_mid_kernel<{nnn},2,2,2>"}.get(kind, f"hgemm_w4y_kernel<{nnn},")
+        assert name.startswith(want) and name.endswith(f" + hgemm_edge_kernel<{nnn}>"), name
+    torch.manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, dtype=torch.half, device="cuda")
+    b = torch.randn(K, N, dtype=torch.half, device="cuda")
+    bb = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
+    pad = 4096
+    buf = torch.full((M * N + 2 * pad,), float("nan"), dtype=torch.half, device="cuda")
+    c = buf[pad:pad + M * N].view(M, N)
+    capi.hgemm(a, bb, c, layout=lay, variant=capi.HGEMM_RAGGED, swizzle_stride=host.make_block_swizzle_stride(N, K))
+    torch.cuda.synchronize()
+    assert torch.isnan(buf[:pad]).all() and torch.isnan(buf[pad + M * N:]).all() and torch.isfinite(c).all()
+    mi = M // 128 * 128
+    rows = sorted(r for r in {0, 1, 127, 128, 255, 256, M // 2 + 3, mi - 257, mi - 129, mi - 1, mi, M - 2, M - 1} if 0 <= r < M)
+    truth = oracle.hgemm(a[rows].contiguous(), b.contiguous(), len(rows), N, K, 0, "f32")
+    ok, mx, ex = tol.hgemm_close(c[rows].float().cpu().numpy(), truth, K)
+    assert ok, (mx, ex)
+    for other in (capi.HGEMM_EDGE, capi.HGEMM_GENERIC):
+        co, _ = _run(capi, a, b, lay, other)
+        ulp = torch.clamp(co.float().abs(), min=32.0) * 2.0 ** -10
+        assert ((c.float() - co.float()).abs() <= ulp).all(), other
+    c2, _ = _run(capi, a, b, lay, capi.HGEMM_RAGGED, host.make_block_swizzle_stride(N, K))
+    assert torch.equal(c2, c)
+    for knob, want in ((1, "hgemm_edge_kernel"), (2, name)):
+        capi.tune("hgemm_ragged", knob)
+        try:
+            assert capi.hgemm_kernel_name(M, N, K, lay).startswith(want)
+            c3, _ = _run(capi, a, b, lay, capi.HGEMM_AUTO, host.make_block_swizzle_stride(N, K))
+        finally:
+            capi.tune("hgemm_ragged", 0)
+        if knob == 2:
+            assert torch.equal(c3, c)
+    # under graph capture (no workspace anywhere on this path)
+    cg = torch.full((M, N), float("nan"), dtype=torch.half, device="cuda")
+    st = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(g, stream=st):
+            capi.hgemm(a, bb, cg, layout=lay, variant=capi.HGEMM_RAGGED, swizzle_stride=host.make_block_swizzle_stride(N, K))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cg, c)
+
+
 @pytest.mark.parametrize("variant", ["mfma256", "pingpong2", "w4b", "w4c", "w4x", "w4y", "generic"])
 def test_identity_times_asymmetric_b_detects_transposes(variant):
     capi = _capi()
