@@ -170,6 +170,9 @@ const char* lc_build_info(int* is_diag);
  *                  CUs, else 128 x 128 quadrants), 1 = eighths, 2 = quadrants (bit-identical results; A/B knob)
  *   "hgemm_ragged" LC_HGEMM_AUTO on ragged M / N with K % 32 == 0: 0 = auto (LC_HGEMM_RAGGED once the shape holds >= 4 blocks of 128 x 128 per CU,
  *                  else the edge kernel alone), 1 = never, 2 = wherever an interior exists (A/B knob)
+ *   "hgemm_ragged_fork"  LC_HGEMM_RAGGED's border launch on a per-device side stream forked from / joined to the caller's stream by events (runs beside
+ *                  the interior; never while the caller's stream is being captured): 0 = auto (only beside a ragged last round of the 256-tile grid that
+ *                  leaves a quarter to a half of the CUs to the mid-size kernel: + 4 ... 7 %; beside full rounds it costs 5 ... 18 %), 1 = never, 2 = always
  *   "hgemm_raster" block -> C tile map of the tiled GEMM kernels: 0 = auto (2 when A + B exceed 272 MiB — the 256 MiB Infinity Cache and a margin,
  *                  else 1), 1 = the reference's block swizzle (N panels of swizzle_stride columns, every XCD a contiguous id
  *                  range), 2 = XCD super-block raster (16 x 16 tile steps shared through the Infinity Cache, 4 x 8 per XCD;

@@ -56,6 +56,7 @@ tune_t g_tune_hgemm_mid_ns{0};                 // ... its LDS ring slots: 0 = au
 tune_t g_tune_hgemm_128w{0};                   // waves of the 128-tile kernel: 0 = auto (eight — intra-workgroup split-K — on grids of <= 0.6 blocks per CU), 1 = always four, 2 = always eight
 tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to 128 x 128 blocks (launch_mfma256: the mid-size kernel; 2 = round 5's 128-tile kernel + split-K), 0 = one launch
 tune_t g_tune_hgemm_ragged{0};                 // LC_HGEMM_AUTO on ragged M / N with K % 32 == 0: 0 = auto (interior on a tiled kernel + border on the edge kernel from 4 edge blocks per CU), 1 = never, 2 = wherever an interior exists
+tune_t g_tune_hgemm_ragged_fork{0};            // LC_HGEMM_RAGGED's border launch on a side stream, forked from and joined to the caller's (runs beside the interior): 0 = auto (launch_ragged), 1 = never, 2 = always
 tune_t g_tune_hgemm_tail_tile{0};              // sub-tiles of the ragged tail on the mid-size kernel: 0 = auto (launch_mfma256), 1 = 64 x 128 eighths, 2 = 128 x 128 quadrants
 tune_t g_tune_hgemm_mid_splitk{0};             // split-K of the mid-size kernel: 0 = auto (mid_tile_auto), 1 = never, 2 .. 8 = that many K ranges wherever legal (A/B)
 tune_t g_tune_hgemm_raster{0};                 // block -> C tile map: 0 = auto (by operand footprint, panel_tiles), 1 = the reference's block swizzle (N panels from
@@ -675,8 +676,32 @@ RaggedPlan ragged_plan(int M, int N, int K, bool al, bool b_kn, bool gated) {
   return RaggedPlan{2, (M / BM1) * BM1, (N / BN1) * BN1, t128 <= ncu ? 3 : 2};
 }
 
+// The border launch beside the interior (lc_tune_set "hgemm_ragged_fork"): one side stream per device, forked from the caller's stream
+// by an event and joined back by another, so that the edge blocks (one 72 KiB workgroup per CU at best, a latency-bound K walk) fill the CUs
+// the interior's last round leaves idle instead of holding the whole GPU for a round of their own.  The device's mutex (the one the workspace
+// leases hold) covers the enqueue sequence: two host threads cannot interleave their fork / join events.  Not while the caller's stream is being
+// captured, not when the side stream cannot be created: both launches on the caller's stream then.
+struct ForkLane { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool tried = false; };
+ForkLane* fork_lane(int dev) {   // (call with the device's mutex held)
+  static ForkLane lanes[64];
+  if (dev < 0 || dev >= 64) return nullptr;
+  ForkLane& l = lanes[dev];
+  if (!l.tried) {
+    l.tried = true;
+    RelaxedCaptureMode relaxed;
+    int least = 0, greatest = 0;   // (the lowest priority, for what it is worth)
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    if (hipStreamCreateWithPriority(&l.side, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      l.side = nullptr;
+    }
+  }
+  return l.side ? &l : nullptr;
+}
+
 template <bool B_KN>
-int launch_ragged(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, const RaggedPlan& p, int swizzle_stride, hipStream_t st) {
+int launch_ragged_interior(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, const RaggedPlan& p, int swizzle_stride, hipStream_t st) {
   if (p.kind == 1) {
     const int tiles_m = M / BM, tiles_n = N / BN;
     const int pw = panel_tiles(swizzle_stride, tiles_n, BN, ((size_t)p.Mi + p.Ni) * K * 2);
@@ -688,12 +713,45 @@ int launch_ragged(const half_t* A, const half_t* B, half_t* C, int M, int N, int
     if (split) {
       const int tmw = 8 * R <= ncu ? 1 : 2;
       const int blocks = (tmw == 1 ? 8 : 4) * R;
-      if (int rc = launch_hgemm_mid_rem(A, B, C, M, N, K, B_KN, tmw, blocks <= ncu ? 3 : 2, tiles_m, tiles_n, pw, T - R, R, st)) return rc;
+      return launch_hgemm_mid_rem(A, B, C, M, N, K, B_KN, tmw, blocks <= ncu ? 3 : 2, tiles_m, tiles_n, pw, T - R, R, st);
     }
-  } else {
-    const int pw = panel_tiles(swizzle_stride, N / BN1, BN1, ((size_t)p.Mi + p.Ni) * K * 2);
-    if (int rc = launch_hgemm_mid_interior(A, B, C, M, N, K, B_KN, p.ns, pw, st)) return rc;
+    return LC_OK;
   }
+  const int pw = panel_tiles(swizzle_stride, N / BN1, BN1, ((size_t)p.Mi + p.Ni) * K * 2);
+  return launch_hgemm_mid_interior(A, B, C, M, N, K, B_KN, p.ns, pw, st);
+}
+
+template <bool B_KN>
+int launch_ragged(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, const RaggedPlan& p, int swizzle_stride, hipStream_t st) {
+  // Fork rule (profiles/r6ac … r6ae_hgemm_edge_ab.log; the hardware interleaves the two queues whatever their order or priority): beside an interior of
+  // FULL rounds every CU a border block holds costs the interior a round of its own (4100 x 4104 x 4096, 256 tiles: 883 -> 719 TFLOP/s; 8192 x 8256 x
+  // 4096: − 7 %), beside a ragged last round of at least a quarter of the CUs (the tail the mid-size kernel takes) the border fills idle CUs
+  // (5000 x 5000 x 4096, 361 tiles: 957 -> 1000; 777 x 50264 x 4096: 861 -> 920).
+  const int fork_knob = g_tune_hgemm_ragged_fork;
+  bool fork = fork_knob == 2;
+  if (fork_knob == 0 && p.kind == 1) {
+    const int ncu = device_cu_count(), T = (M / BM) * (N / BN), R = T % ncu;
+    const bool split = g_tune_hgemm_tail == 1 && T > ncu && 2 * R <= ncu && g_tune_hgemm_mid != 1;   // (launch_ragged_interior's)
+    fork = split ? 4 * R >= ncu : (R > 0 && 8 * (ncu - R) >= 3 * ncu);   // ... or an unsplit last round that leaves 3 / 8 of the CUs idle (5200 x 5200 x 4096, 400 tiles: 976 -> 1067)
+  }
+  int dev = 0;
+  if (fork && !stream_is_capturing(st) && hipGetDevice(&dev) == hipSuccess) {
+    std::unique_lock<std::mutex> lock(workspace_pool(dev).mu);
+    ForkLane* l = fork_lane(dev);
+    if (l && hipEventRecord(l->fork, st) == hipSuccess && hipStreamWaitEvent(l->side, l->fork, 0) == hipSuccess) {
+      // (the order of the two launches and the side stream's priority change nothing measurable)
+      int rc = launch_ragged_interior<B_KN>(A, B, C, M, N, K, p, swizzle_stride, st);
+      if (rc == LC_OK) rc = launch_edge<B_KN>(A, B, C, M, N, K, p.Mi, p.Ni, l->side);
+      const bool joined = hipEventRecord(l->join, l->side) == hipSuccess;
+      if (!joined || hipStreamWaitEvent(st, l->join, 0) != hipSuccess) {   // (cannot order the caller's stream behind the border: wait for it here)
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(l->side);
+      }
+      return rc;
+    }
+    (void)hipGetLastError();
+  }
+  if (int rc = launch_ragged_interior<B_KN>(A, B, C, M, N, K, p, swizzle_stride, st)) return rc;
   return launch_edge<B_KN>(A, B, C, M, N, K, p.Mi, p.Ni, st);
 }
 }  // namespace
@@ -921,6 +979,7 @@ const Knob kKnobs[] = {
     {"hgemm_tail", &g_tune_hgemm_tail, 1, ok_04, false},
     {"hgemm_tail_tile", &g_tune_hgemm_tail_tile, 0, ok_02, false},
     {"hgemm_ragged", &g_tune_hgemm_ragged, 0, ok_02, false},
+    {"hgemm_ragged_fork", &g_tune_hgemm_ragged_fork, 0, ok_02, false},
     {"hgemm_mid_splitk", &g_tune_hgemm_mid_splitk, 0, ok_08, false},
     {"hgemm_128w", &g_tune_hgemm_128w, 0, ok_02, false},
     {"rule_cus", &g_tune_rule_cus, 0, ok_rule_cus, false},

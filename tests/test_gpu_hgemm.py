@@ -530,7 +530,28 @@ def test_ragged_shapes_interior_on_the_tiled_kernels(oracle, layout, shape, kind
             capi.tune("hgemm_ragged", 0)
         if knob == 2:
             assert torch.equal(c3, c)
-    # under graph capture (no workspace anywhere on this path)
+    # the border launch on the side stream ("hgemm_ragged_fork" 2) / behind the interior (1): the same bits; on a stream of the caller's with
+    # the operands still being produced on it (the fork event orders the border behind them, the join event the caller's next kernel behind it)
+    for fork in (1, 2):
+        capi.tune("hgemm_ragged_fork", fork)
+        try:
+            s2 = torch.cuda.Stream()
+            a2, bb2 = torch.zeros_like(a), torch.zeros_like(bb)
+            c4 = torch.full((M, N), float("nan"), dtype=torch.half, device="cuda")
+            torch.cuda.synchronize()
+            with torch.cuda.stream(s2):
+                for _ in range(3):
+                    a2.copy_(a)
+                    bb2.copy_(bb)
+                    capi.hgemm(a2, bb2, c4, layout=lay, variant=capi.HGEMM_RAGGED, swizzle_stride=host.make_block_swizzle_stride(N, K))
+                    c5 = c4.clone()                    # (reads C right behind the join)
+                    a2.zero_()
+                    bb2.zero_()
+            torch.cuda.synchronize()
+        finally:
+            capi.tune("hgemm_ragged_fork", 0)
+        assert torch.equal(c5, c), fork
+    # under graph capture (no workspace anywhere on this path; never forked)
     cg = torch.full((M, N), float("nan"), dtype=torch.half, device="cuda")
     st = torch.cuda.Stream()
     g = torch.cuda.CUDAGraph()

@@ -48,6 +48,15 @@ for (M, N, K) in shapes:
         try:
             capi.hgemm_kernel_name(M, N, K, lay, capi.HGEMM_RAGGED)
             cands["ragged"] = lambda: capi.hgemm(a, b2, c, layout=lay, variant=capi.HGEMM_RAGGED, swizzle_stride=host.make_block_swizzle_stride(N, K))
+
+            def mk(knob):
+                def f():
+                    capi.tune("hgemm_ragged_fork", knob)
+                    capi.hgemm(a, b2, c, layout=lay, variant=capi.HGEMM_RAGGED, swizzle_stride=host.make_block_swizzle_stride(N, K))
+                    capi.tune("hgemm_ragged_fork", 0)
+                return f
+            cands["ragged_seq"] = mk(1)       # border behind the interior on the caller's stream
+            cands["ragged_fork"] = mk(2)      # border on the side stream
         except capi.LcError:
             pass
         cands["hipBLASLt"] = lambda: capi.hgemm_vendor(a, b2, c, lay)
