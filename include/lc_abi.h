@@ -55,7 +55,7 @@ typedef enum lc_layout { LC_LAYOUT_NN = 0, LC_LAYOUT_TN = 1 } lc_layout;
 typedef enum lc_hgemm_variant {
   LC_HGEMM_AUTO = 0,       /* best available for the shape: the reference's legal shapes (M, N % 128 == 0, K % 32 == 0, K >= 64;
                               hgemm_mma_stage.cu:650,675-676) run MFMA256W4Y when the 256-tileable interior has > 128 tiles (128-wide
-                              border strips on MFMA128 in a second launch), MID / MFMA128 otherwise; every other shape EDGE or GENERIC */
+                              border strips on MFMA128 in a second launch), MID / MFMA128 otherwise; every other shape RAGGED, EDGE or GENERIC */
   LC_HGEMM_MFMA256 = 1,    /* 256x256x64 WG tile, 8 wave64, LDS-DMA double buffer, one barrier / K-tile (simplest)      */
   LC_HGEMM_GENERIC = 3,    /* 64x64x32 edge-predicated MFMA kernel: any M,N,K                                           */
   LC_HGEMM_MFMA256P2 = 4,  /* 8-wave ping-pong, 2 phases of 16 MFMAs per K tile, DMA issued inside the MFMA clusters:
@@ -73,12 +73,12 @@ typedef enum lc_hgemm_variant {
                             /* ring, hand-ordered asm K loop: LC_HGEMM_AUTO's choice between the eight-wave 128-tile kernel (small     */
                             /* grids) and the 256-tile kernel (> 128 tiles of 256 x 256) — n = 1280 .. 2816 square — with the tile that */
                             /* leaves the least work on the busiest CU.  M, N % 64 == 0 (a tile must divide them), K % 32 == 0 (>= 64)  */
-  LC_HGEMM_EDGE = 15,       /* the vectorised edge kernel (hgemm_edge.hip, late round 6): 128 x 128 x 32 tile, any M and N, K % 8 == 0 (NN: */
-                            /* N % 8 == 0), 16-byte chunks with whole-chunk predication: what LC_HGEMM_AUTO runs where no tiled kernel     */
-                            /* divides the shape; every other shape (K % 8, unaligned pointers) stays on LC_HGEMM_GENERIC                   */
-  LC_HGEMM_RAGGED = 16,     /* ragged M / N with K % 32 == 0 (K >= 64), N % 8 == 0: the interior — the largest top-left sub-matrix 256 x 256 (more than  */
-                            /* half a CU's worth of them) or 128 x 128 tiles divide — on hgemm_w4y_kernel / hgemm_mid_kernel, the L-shaped border on   */
-                            /* hgemm_edge_kernel in a second launch; LC_HGEMM_AUTO's choice from 4 edge blocks per CU on (lc_tune_set "hgemm_ragged")  */
+  LC_HGEMM_EDGE = 15,       /* the vectorised edge kernel (hgemm_edge.hip, late round 6): 128 x 128 x 64 tile, any M and N, K % 8 == 0 (NN: */
+                            /* N % 8 == 0), 16-byte chunks from clamped addresses: what LC_HGEMM_AUTO runs where neither a tiled kernel    */
+                            /* nor LC_HGEMM_RAGGED applies (K % 32 != 0, K < 64); K % 8 != 0 / unaligned pointers stay on LC_HGEMM_GENERIC  */
+  LC_HGEMM_RAGGED = 16,     /* ragged M / N with K % 32 == 0 (K >= 64), N % 8 == 0 (LC_HGEMM_AUTO's choice there): more than half a CU's worth of 256 x 256  */
+                            /* tiles: the interior they divide on hgemm_w4y_kernel, the L-shaped border on hgemm_mid_edge_kernel (128 x 128 tiles of the     */
+                            /* mid-size kernel that reach beyond M / N: clamped sources, predicated stores) in a second launch; else all of it on that kernel */
   /* the reference's "CUDA-core" ladder as vector-ALU kernels (hgemm_valu.hip; NN only; v_dot2c_f32_f16, fp32 accumulate);
    * shapes a rung does not tile (and TN) run LC_HGEMM_GENERIC */
   LC_HGEMM_VALU_NAIVE = 20,                  /* one thread per C element, operands from global memory                       */
@@ -168,11 +168,11 @@ const char* lc_build_info(int* is_diag);
  *                  full waves and 128 x 128 blocks the four quadrants of each remaining tile (round 6: on the mid-size kernel, + 4 ... 6 % at 4352 ... 6400); 0 = one launch
  *   "hgemm_tail_tile"  sub-tiles of that tail on the mid-size kernel: 0 = auto (64 x 128 eighths while 8 x the remaining tiles fit one round of the
  *                  CUs, else 128 x 128 quadrants), 1 = eighths, 2 = quadrants (bit-identical results; A/B knob)
- *   "hgemm_ragged" LC_HGEMM_AUTO on ragged M / N with K % 32 == 0: 0 = auto (LC_HGEMM_RAGGED once the shape holds >= 4 blocks of 128 x 128 per CU,
- *                  else the edge kernel alone), 1 = never, 2 = wherever an interior exists (A/B knob)
+ *   "hgemm_ragged" LC_HGEMM_AUTO on ragged M / N with K % 32 == 0 (K >= 64), N % 8 == 0: 0 = LC_HGEMM_RAGGED (the tiled kernels; 128 x 128 tiles with clamped
+ *                  sources and predicated stores on what they do not divide), 1 = never (hgemm_edge_kernel alone; A/B knob)
  *   "hgemm_ragged_fork"  LC_HGEMM_RAGGED's border launch on a per-device side stream forked from / joined to the caller's stream by events (runs beside
- *                  the interior; never while the caller's stream is being captured): 0 = auto (only beside a ragged last round of the 256-tile grid that
- *                  leaves a quarter to a half of the CUs to the mid-size kernel: + 4 ... 7 %; beside full rounds it costs 5 ... 18 %), 1 = never, 2 = always
+ *                  the interior; never while the caller's stream is being captured): 0 = auto (only beside an unsplit last round of the 256-tile grid that
+ *                  leaves >= 3 / 8 of the CUs idle: + 4 %; beside full rounds it costs 2 ... 11 %), 1 = never, 2 = always (same bits)
  *   "hgemm_raster" block -> C tile map of the tiled GEMM kernels: 0 = auto (2 when A + B exceed 272 MiB — the 256 MiB Infinity Cache and a margin,
  *                  else 1), 1 = the reference's block swizzle (N panels of swizzle_stride columns, every XCD a contiguous id
  *                  range), 2 = XCD super-block raster (16 x 16 tile steps shared through the Infinity Cache, 4 x 8 per XCD;

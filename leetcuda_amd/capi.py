@@ -18,7 +18,7 @@ HGEMM_VALU_NAIVE, HGEMM_VALU_SLICED_K, HGEMM_VALU_T8X8_X4, HGEMM_VALU_T16X8_K32 
 HGEMM_MFMA256W4B, HGEMM_MFMA256W4C, HGEMM_MFMA256W4X, HGEMM_MFMA256W4Y = 9, 10, 12, 13
 HGEMM_MID = 14   # the one-round kernel (hgemm_mid.hip)
 HGEMM_EDGE = 15  # the vectorised edge kernel (hgemm_edge.hip): any M, N; K % 8 == 0 (NN: N % 8 == 0)
-HGEMM_RAGGED = 16  # ragged M / N, K % 32 == 0: interior on the tiled kernels + border on the edge kernel
+HGEMM_RAGGED = 16  # ragged M / N, K % 32 == 0, N % 8 == 0: the tiled kernels, clamped 128 x 128 tiles of the mid-size kernel on what they do not divide
 ATTN_SPLIT_Q, ATTN_SHARED_QKV, ATTN_SHARED_KV, ATTN_TILING_QK, ATTN_TILING_QKV, ATTN_SPLIT_KV = range(6)
 
 # every symbol include/lc_abi.h declares: name -> (restype, argtypes)

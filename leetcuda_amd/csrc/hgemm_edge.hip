@@ -1,7 +1,7 @@
 // hgemm_edge.hip — the vectorised edge kernel (late round 6): any M and N, K % 8 == 0 (NN: N % 8 == 0 too), 16-byte aligned pointers.
 // What LC_HGEMM_AUTO runs where no tiled kernel divides the shape (until then hgemm_generic_kernel's element-wise staging, 65 - 75 TFLOP/s
-// at 2880^3 NN / 8192 x 8256 x 4096 NN; the reference's kernels are not legal on such shapes at all, hgemm_mma_stage.cu:675-676), and the
-// BORDER of a ragged shape whose interior a tiled kernel computes (LC_HGEMM_RAGGED, lc_abi.hip launch_ragged).
+// at 2880^3 NN / 8192 x 8256 x 4096 NN; the reference's kernels are not legal on such shapes at all, hgemm_mma_stage.cu:675-676).  Since
+// hgemm_mid_edge_kernel (hgemm_mid.hip EDGE; LC_HGEMM_RAGGED) took the shapes with K % 32 == 0, this kernel serves K % 32 != 0 / K < 64.
 // 128 x 128 x 64 workgroup tile, 4 wave64 as 2 x 2, wave tile 64 x 64 = 4 x 4 blocks of v_mfma_f32_16x16x32_f16 (operands swapped as
 // everywhere: a lane owns 4 consecutive n of one output row).  Global -> registers as 16-byte chunks one K tile ahead (rows / chunks outside the
 // matrix read as zeros), registers -> the other of two LDS buffers behind the MFMAs of the current tile: one barrier per tile.  A (and B as [N][K]): 144-byte LDS rows (conflict-free ds_read_b128).  B as [K][N]: the tile stays k-major in LDS

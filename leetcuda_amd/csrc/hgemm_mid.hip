@@ -104,7 +104,12 @@ LC_DEVINL const char* sgpr_ptr(const void* p) {   // a pointer hipcc can PROVE w
 // range order and rounds once.  For shapes whose one-round tile grid covers at most half the CUs and whose K is long (1024 x 1024 x 8192).
 // (One body, two entry points below: hgemm_mid_kernel<B_KN, TMW, TNW, NS> and hgemm_mid_sk_kernel<B_KN, TMW, NS> — the names rocprofv3 shows
 // and lc_hgemm_kernel_name() reports.)
-template <bool B_KN, int TMW, int TNW, int NS, bool SK>
+// EDGE (late round 6, hgemm_mid_edge_kernel below): tiles that reach beyond M / N.  The DMA sources of rows >= M (columns >= N) are CLAMPED to
+// the last row (the last whole 16-byte chunk) — a row of C depends on its own row of A only, a column on its own column of B, so what those
+// lanes compute is never stored and nothing needs zeroing — and the epilogue stores whole 16-byte chunks inside the matrix only (N % 8 == 0).
+// The block map is the edge kernel's: two strips of C, the right one (all rows, columns Ni .. N) and the bottom one (rows Mi .. M, columns
+// 0 .. Ni); the arguments tiles_m / tiles_n / panel_w / rem_base carry Mi / Ni / blocks of the right strip / its width in blocks.
+template <bool B_KN, int TMW, int TNW, int NS, bool SK, bool EDGE = false>
 LC_DEVINL void hgemm_mid_body(const half_t* __restrict__ A, const half_t* __restrict__ B, half_t* __restrict__ C, int M, int N, int K, int tiles_m,
                               int tiles_n, int panel_w, int rem_base, float* __restrict__ part, int ks) {
   using G = Mid<TMW, TNW, NS>;
@@ -126,7 +131,18 @@ LC_DEVINL void hgemm_mid_body(const half_t* __restrict__ A, const half_t* __rest
     srange = __builtin_amdgcn_readfirstlane(bid / nblk);
     bid -= srange * nblk;
   }
-  if (rem_base < 0) {
+  if constexpr (EDGE) {
+    const int Mi = tiles_m, Ni = tiles_n, nright = panel_w, nrc = rem_base;
+    if (bid < nright) {
+      const int bm = bid / nrc;
+      m0 = bm * TM;
+      n0 = Ni + (bid - bm * nrc) * TN;
+    } else {
+      const int nbc = Ni / TN, r = bid - nright, bm = r / nbc;
+      m0 = Mi + bm * TM;
+      n0 = (r - bm * nbc) * TN;
+    }
+  } else if (rem_base < 0) {
     const TileCoord tc = block_tile(bid, nblk, tiles_m, tiles_n, panel_w);
     m0 = tc.tm * TM;
     n0 = tc.tn * TN;
@@ -152,22 +168,26 @@ LC_DEVINL void hgemm_mid_body(const half_t* __restrict__ A, const half_t* __rest
   const char* b_src = sgpr_ptr(B_KN ? B + n0 + (size_t)kt0 * BK * N : B + (size_t)n0 * K + (size_t)kt0 * BK);
   const uint32_t b_step = B_KN ? (uint32_t)N * (BK * 2) : (uint32_t)(BK * 2);   // bytes between consecutive K tiles of B
   uint32_t va[PA], vb[PB];
+  const int mlim = M - 1 - m0, nlim = N - 1 - n0, clim = N - 8 - n0;   // EDGE: the last row of A / of B as [N][K] / the last whole chunk of B as [K][N], relative to the tile
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     const int row = (4 * i + wave) * 8 + (lane >> 3);
-    va[i] = ((uint32_t)row * (uint32_t)K + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 8)) * 2u;
+    const int srow = EDGE ? min(row, mlim) : row;   // (the LDS slot and its swizzle stay the logical row's)
+    va[i] = ((uint32_t)srow * (uint32_t)K + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 8)) * 2u;
   }
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     if constexpr (!B_KN) {
       const int row = (4 * i + wave) * 8 + (lane >> 3);
-      vb[i] = ((uint32_t)row * (uint32_t)K + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 8)) * 2u;
+      const int srow = EDGE ? min(row, nlim) : row;
+      vb[i] = ((uint32_t)srow * (uint32_t)K + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 8)) * 2u;
     } else {   // sub-image i >> 2 = columns 128 (i >> 2) ..: [64 k][128 n], 256-byte rows = 8 pairs of 16-byte chunks, piece = 4 k rows
       const int p = wave * 4 + (i & 3);
       const int k = p * 4 + (lane >> 4), pp = lane & 15;
       const int h = (k & 3) | (((k >> 3) & 1) << 2);
       const int nc = (((pp >> 1) ^ h) << 1) | (pp & 1);
-      vb[i] = ((uint32_t)k * (uint32_t)N + (uint32_t)((i >> 2) * 128 + nc * 8)) * 2u;
+      const int col = (i >> 2) * 128 + nc * 8;
+      vb[i] = ((uint32_t)k * (uint32_t)N + (uint32_t)(EDGE ? min(col, clim) : col)) * 2u;
     }
   }
   const uint32_t smem32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr32(smem));
@@ -333,14 +353,19 @@ LC_DEVINL void hgemm_mid_body(const half_t* __restrict__ A, const half_t* __rest
     const int k0 = KT_all * BK + 8 * g;
     Frag f;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) f.a[mi] = *(const half8_t*)(A + (size_t)(m0 + wr * (TM / 2) + mi * 16 + i16) * K + k0);
+    for (int mi = 0; mi < MI; ++mi) {
+      const int row = wr * (TM / 2) + mi * 16 + i16;
+      f.a[mi] = *(const half8_t*)(A + (size_t)(m0 + (EDGE ? min(row, mlim) : row)) * K + k0);
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
+      const int col = wc * (TN / 2) + ni * 16 + i16;
+      const int scol = EDGE ? min(col, nlim) : col;
       if constexpr (!B_KN) {
-        f.b[ni] = *(const half8_t*)(B + (size_t)(n0 + wc * (TN / 2) + ni * 16 + i16) * K + k0);
+        f.b[ni] = *(const half8_t*)(B + (size_t)(n0 + scol) * K + k0);
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f.b[ni][e] = B[(size_t)(k0 + e) * N + n0 + wc * (TN / 2) + ni * 16 + i16];
+        for (int e = 0; e < 8; ++e) f.b[ni][e] = B[(size_t)(k0 + e) * N + n0 + scol];
       }
     }
     kstep(f, f0, NONEXT{}, 0u, KS0{}, NODMA{}, 0u, nullptr, nullptr);
@@ -388,7 +413,8 @@ LC_DEVINL void hgemm_mid_body(const half_t* __restrict__ A, const half_t* __rest
     const int idx = it * 64 + lane;
     const int row = idx / CPR, c = idx % CPR;
     const u32x4_t v = *(const u32x4_t*)(stg + row * G::EPI_ROW + c * 16);
-    *(u32x4_t*)(C + (size_t)(m0 + wr * (TM / 2) + row) * N + n0 + wc * (TN / 2) + c * 8) = v;
+    if (!EDGE || (wr * (TM / 2) + row <= mlim && wc * (TN / 2) + c * 8 <= clim))
+      *(u32x4_t*)(C + (size_t)(m0 + wr * (TM / 2) + row) * N + n0 + wc * (TN / 2) + c * 8) = v;
   }
 }
 
@@ -397,6 +423,12 @@ __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kerne
                                                            half_t* __restrict__ C, int M, int N, int K, int tiles_m, int tiles_n,
                                                            int panel_w, int rem_base) {
   hgemm_mid_body<B_KN, TMW, TNW, NS, false>(A, B, C, M, N, K, tiles_m, tiles_n, panel_w, rem_base, nullptr, 1);
+}
+// 128 x 128 tiles that may reach beyond M / N (EDGE above): the border of a ragged shape, or the whole of one (Mi = Ni = 0)
+template <bool B_KN, int NS>
+__global__ __launch_bounds__(256, 2) void hgemm_mid_edge_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B, half_t* __restrict__ C, int M,
+                                                                int N, int K, int Mi, int Ni, int nright, int nrc) {
+  hgemm_mid_body<B_KN, 2, 2, NS, false, true>(A, B, C, M, N, K, Mi, Ni, nright, nrc, nullptr, 1);
 }
 template <bool B_KN, int TMW, int NS>
 __global__ __launch_bounds__(256, 2) void hgemm_mid_sk_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B, int M, int N, int K,

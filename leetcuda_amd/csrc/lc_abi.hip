@@ -55,7 +55,7 @@ tune_t g_tune_hgemm_mid{0};                    // mid-size kernel (hgemm_mid.hip
 tune_t g_tune_hgemm_mid_ns{0};                 // ... its LDS ring slots: 0 = auto (3 for one-round grids, else 2), 2, 3
 tune_t g_tune_hgemm_128w{0};                   // waves of the 128-tile kernel: 0 = auto (eight — intra-workgroup split-K — on grids of <= 0.6 blocks per CU), 1 = always four, 2 = always eight
 tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to 128 x 128 blocks (launch_mfma256: the mid-size kernel; 2 = round 5's 128-tile kernel + split-K), 0 = one launch
-tune_t g_tune_hgemm_ragged{0};                 // LC_HGEMM_AUTO on ragged M / N with K % 32 == 0: 0 = auto (interior on a tiled kernel + border on the edge kernel from 4 edge blocks per CU), 1 = never, 2 = wherever an interior exists
+tune_t g_tune_hgemm_ragged{0};                 // LC_HGEMM_AUTO on ragged M / N with K % 32 == 0: 0 = LC_HGEMM_RAGGED (the tiled kernels, clamped 128 x 128 tiles on what they do not divide), 1 = never (hgemm_edge_kernel)
 tune_t g_tune_hgemm_ragged_fork{0};            // LC_HGEMM_RAGGED's border launch on a side stream, forked from and joined to the caller's (runs beside the interior): 0 = auto (launch_ragged), 1 = never, 2 = always
 tune_t g_tune_hgemm_tail_tile{0};              // sub-tiles of the ragged tail on the mid-size kernel: 0 = auto (launch_mfma256), 1 = 64 x 128 eighths, 2 = 128 x 128 quadrants
 tune_t g_tune_hgemm_mid_splitk{0};             // split-K of the mid-size kernel: 0 = auto (mid_tile_auto), 1 = never, 2 .. 8 = that many K ranges wherever legal (A/B)
@@ -649,31 +649,28 @@ int launch_attn_d(const half_t* Q, const half_t* K, const half_t* V, half_t* O, 
 
 namespace {
 // LC_HGEMM_RAGGED (late round 6): M and / or N are not multiples of the tiles (not legal in the reference, hgemm_mma_stage.cu:675-676), K is
-// (K % 32 == 0, K >= 64) and rows are 16-byte aligned (N % 8 == 0).  The INTERIOR — the largest top-left sub-matrix the tiles divide — runs on a
-// tiled kernel exactly as it would as a problem of its own (the kernels take N as C's / B's row stride and the tile counts separately), the L-shaped
-// BORDER on hgemm_edge_kernel in a second launch: every element of C is computed by exactly one kernel, deterministically.
-//   kind 1  more than half a CU's worth of 256 x 256 tiles: hgemm_w4y_kernel (+ its ragged last round on the mid-size kernel, as launch_mfma256)
-//   kind 2  otherwise: 128 x 128 tiles of hgemm_mid_kernel (three ring slots while they fit one round of the CUs, else two)
-// LC_HGEMM_AUTO takes it (lc_tune_set "hgemm_ragged") once the edge kernel alone would need about two rounds of its own (>= 4 blocks of
-// 128 x 128 per CU): below, one round of edge blocks is over sooner than a tiled launch plus a border launch.
+// (K % 32 == 0, K >= 64) and rows are 16-byte aligned (N % 8 == 0).  The tiled kernels take N as C's / B's row stride and their tile counts
+// separately, and hgemm_mid_edge_kernel (hgemm_mid.hip EDGE) runs 128 x 128 tiles that reach beyond M / N (clamped sources, predicated stores):
+//   kind 1  more than half a CU's worth of 256 x 256 tiles: the INTERIOR — the largest top-left sub-matrix they divide — on hgemm_w4y_kernel exactly
+//           as a problem of its own (+ its ragged last round on the mid-size kernel, as launch_mfma256), the L-shaped BORDER (right strip: all rows x
+//           columns Ni .. N, bottom strip: rows Mi .. M x columns 0 .. Ni) on hgemm_mid_edge_kernel in a second launch
+//   kind 2  otherwise: the whole problem on hgemm_mid_edge_kernel (three ring slots while the tiles fit one round of the CUs, else two)
+// Every element of C is computed by exactly one kernel, deterministically; no workspace.  lc_tune_set "hgemm_ragged" = 1: never (hgemm_edge_kernel).
 struct RaggedPlan { int kind, Mi, Ni, ns; };
 RaggedPlan ragged_plan(int M, int N, int K, bool al, bool b_kn, bool gated) {
   RaggedPlan none{0, 0, 0, 0};
   if (!al || K % 32 != 0 || K < BK || N % 8 != 0 || K >= (1 << 22) || N >= (1 << 22)) return none;
   if (M % BM1 == 0 && N % BN1 == 0) return none;   // (a tiled shape)
-  if (M < BM1 || N < BN1) return none;
-  const int knob = g_tune_hgemm_ragged;
+  if (gated && g_tune_hgemm_ragged == 1) return none;
   const long ncu = rule_cu_count();
-  if (gated) {
-    if (knob == 1) return none;
-    const long eb = (long)((M + EM - 1) / EM) * ((N + EN - 1) / EN);
-    if (knob == 0 && eb < 4 * ncu) return none;
+  const long t256 = (long)(M / BM) * (N / BN);
+  if (2 * t256 > ncu && g_tune_hgemm_auto == LC_HGEMM_MFMA256W4Y && w4_effective_variant(LC_HGEMM_MFMA256W4Y, b_kn, N, K) == LC_HGEMM_MFMA256W4Y) {
+    const int Mi = (M / BM) * BM, Ni = (N / BN) * BN;
+    const long nb = (long)((N - Ni + 127) / 128) * ((M + 127) / 128) + (long)((M - Mi + 127) / 128) * (Ni / 128);   // border blocks
+    return RaggedPlan{1, Mi, Ni, nb <= ncu ? 3 : 2};
   }
-  const long t256 = (long)(M / BM) * (N / BN), t128 = (long)(M / BM1) * (N / BN1);
-  if (2 * t256 > ncu && g_tune_hgemm_auto == LC_HGEMM_MFMA256W4Y && w4_effective_variant(LC_HGEMM_MFMA256W4Y, b_kn, N, K) == LC_HGEMM_MFMA256W4Y)
-    return RaggedPlan{1, (M / BM) * BM, (N / BN) * BN, 0};
-  if (g_tune_hgemm_mid == 1 && gated) return none;
-  return RaggedPlan{2, (M / BM1) * BM1, (N / BN1) * BN1, t128 <= ncu ? 3 : 2};
+  const long eb = (long)((M + 127) / 128) * ((N + 127) / 128);
+  return RaggedPlan{2, 0, 0, eb <= ncu ? 3 : 2};
 }
 
 // The border launch beside the interior (lc_tune_set "hgemm_ragged_fork"): one side stream per device, forked from the caller's stream
@@ -701,38 +698,35 @@ ForkLane* fork_lane(int dev) {   // (call with the device's mutex held)
 }
 
 template <bool B_KN>
-int launch_ragged_interior(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, const RaggedPlan& p, int swizzle_stride, hipStream_t st) {
-  if (p.kind == 1) {
-    const int tiles_m = M / BM, tiles_n = N / BN;
-    const int pw = panel_tiles(swizzle_stride, tiles_n, BN, ((size_t)p.Mi + p.Ni) * K * 2);
-    const int ncu = device_cu_count();
-    const int T = tiles_m * tiles_n, R = T % ncu;
-    const int tail_knob = g_tune_hgemm_tail;
-    const bool split = tail_knob == 1 && T > ncu && R > 0 && 2 * R <= ncu && g_tune_hgemm_mid != 1;   // (launch_mfma256's default rule)
-    if (int rc = launch_w4_family(A, B, C, M, N, K, LC_HGEMM_MFMA256W4Y, B_KN, tiles_m, tiles_n, pw, split ? T - R : -1, st)) return rc;
-    if (split) {
-      const int tmw = 8 * R <= ncu ? 1 : 2;
-      const int blocks = (tmw == 1 ? 8 : 4) * R;
-      return launch_hgemm_mid_rem(A, B, C, M, N, K, B_KN, tmw, blocks <= ncu ? 3 : 2, tiles_m, tiles_n, pw, T - R, R, st);
-    }
-    return LC_OK;
+int launch_ragged_interior(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int swizzle_stride, hipStream_t st) {   // (kind 1)
+  const int tiles_m = M / BM, tiles_n = N / BN;
+  const int pw = panel_tiles(swizzle_stride, tiles_n, BN, ((size_t)tiles_m * BM + (size_t)tiles_n * BN) * K * 2);
+  const int ncu = device_cu_count();
+  const int T = tiles_m * tiles_n, R = T % ncu;
+  const int tail_knob = g_tune_hgemm_tail;
+  const bool split = tail_knob == 1 && T > ncu && R > 0 && 2 * R <= ncu && g_tune_hgemm_mid != 1;   // (launch_mfma256's default rule)
+  if (int rc = launch_w4_family(A, B, C, M, N, K, LC_HGEMM_MFMA256W4Y, B_KN, tiles_m, tiles_n, pw, split ? T - R : -1, st)) return rc;
+  if (split) {
+    const int tmw = 8 * R <= ncu ? 1 : 2;
+    const int blocks = (tmw == 1 ? 8 : 4) * R;
+    return launch_hgemm_mid_rem(A, B, C, M, N, K, B_KN, tmw, blocks <= ncu ? 3 : 2, tiles_m, tiles_n, pw, T - R, R, st);
   }
-  const int pw = panel_tiles(swizzle_stride, N / BN1, BN1, ((size_t)p.Mi + p.Ni) * K * 2);
-  return launch_hgemm_mid_interior(A, B, C, M, N, K, B_KN, p.ns, pw, st);
+  return LC_OK;
 }
 
 template <bool B_KN>
 int launch_ragged(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, const RaggedPlan& p, int swizzle_stride, hipStream_t st) {
-  // Fork rule (profiles/r6ac … r6ae_hgemm_edge_ab.log; the hardware interleaves the two queues whatever their order or priority): beside an interior of
-  // FULL rounds every CU a border block holds costs the interior a round of its own (4100 x 4104 x 4096, 256 tiles: 883 -> 719 TFLOP/s; 8192 x 8256 x
-  // 4096: − 7 %), beside a ragged last round of at least a quarter of the CUs (the tail the mid-size kernel takes) the border fills idle CUs
-  // (5000 x 5000 x 4096, 361 tiles: 957 -> 1000; 777 x 50264 x 4096: 861 -> 920).
+  if (p.kind == 2) return launch_hgemm_mid_edge(A, B, C, M, N, K, B_KN, p.ns, 0, 0, st);
+  // Fork rule (profiles/r6ac … r6af_hgemm_edge_ab*.log; the hardware interleaves the two queues whatever their order or priority): beside an interior of
+  // FULL rounds every CU a border block holds costs the interior a round of its own (4100 x 4104 x 4096, one round of 256 tiles: 1122 -> 995 TFLOP/s;
+  // 12808^2 x 4096: − 5 %); beside an UNSPLIT last round that leaves at least 3 / 8 of the CUs idle the border fills them (5200^2 x 4096, 400 tiles:
+  // 1182 -> 1234); beside a last round the mid-size kernel takes as quadrants it is a wash (5000^2 x 4096 − 4 %, 777 x 50264 x 4096 + 3 %): not forked.
   const int fork_knob = g_tune_hgemm_ragged_fork;
   bool fork = fork_knob == 2;
-  if (fork_knob == 0 && p.kind == 1) {
+  if (fork_knob == 0) {
     const int ncu = device_cu_count(), T = (M / BM) * (N / BN), R = T % ncu;
     const bool split = g_tune_hgemm_tail == 1 && T > ncu && 2 * R <= ncu && g_tune_hgemm_mid != 1;   // (launch_ragged_interior's)
-    fork = split ? 4 * R >= ncu : (R > 0 && 8 * (ncu - R) >= 3 * ncu);   // ... or an unsplit last round that leaves 3 / 8 of the CUs idle (5200 x 5200 x 4096, 400 tiles: 976 -> 1067)
+    fork = !split && R > 0 && 8 * (ncu - R) >= 3 * ncu;
   }
   int dev = 0;
   if (fork && !stream_is_capturing(st) && hipGetDevice(&dev) == hipSuccess) {
@@ -740,8 +734,8 @@ int launch_ragged(const half_t* A, const half_t* B, half_t* C, int M, int N, int
     ForkLane* l = fork_lane(dev);
     if (l && hipEventRecord(l->fork, st) == hipSuccess && hipStreamWaitEvent(l->side, l->fork, 0) == hipSuccess) {
       // (the order of the two launches and the side stream's priority change nothing measurable)
-      int rc = launch_ragged_interior<B_KN>(A, B, C, M, N, K, p, swizzle_stride, st);
-      if (rc == LC_OK) rc = launch_edge<B_KN>(A, B, C, M, N, K, p.Mi, p.Ni, l->side);
+      int rc = launch_ragged_interior<B_KN>(A, B, C, M, N, K, swizzle_stride, st);
+      if (rc == LC_OK) rc = launch_hgemm_mid_edge(A, B, C, M, N, K, B_KN, p.ns, p.Mi, p.Ni, l->side);
       const bool joined = hipEventRecord(l->join, l->side) == hipSuccess;
       if (!joined || hipStreamWaitEvent(st, l->join, 0) != hipSuccess) {   // (cannot order the caller's stream behind the border: wait for it here)
         (void)hipGetLastError();
@@ -751,8 +745,8 @@ int launch_ragged(const half_t* A, const half_t* B, half_t* C, int M, int N, int
     }
     (void)hipGetLastError();
   }
-  if (int rc = launch_ragged_interior<B_KN>(A, B, C, M, N, K, p, swizzle_stride, st)) return rc;
-  return launch_edge<B_KN>(A, B, C, M, N, K, p.Mi, p.Ni, st);
+  if (int rc = launch_ragged_interior<B_KN>(A, B, C, M, N, K, swizzle_stride, st)) return rc;
+  return launch_hgemm_mid_edge(A, B, C, M, N, K, B_KN, p.ns, p.Mi, p.Ni, st);
 }
 }  // namespace
 
@@ -834,7 +828,7 @@ int resolve_hgemm_variant(int variant, int M, int N, int K, bool al, bool b_kn) 
     if (rk == 1) return LC_HGEMM_RAGGED;
     if (tiles64 && mid_tile_auto(M, N, K, b_kn, true).tmw > 0) return LC_HGEMM_MID;   // the tile with the least work on the busiest CU (n = 1280 .. 2816 square)
     if (tiles128) return LC_HGEMM_MFMA128;
-    if (rk) return LC_HGEMM_RAGGED;   // interior on 128 x 128 tiles of the mid-size kernel, border on the edge kernel
+    if (rk) return LC_HGEMM_RAGGED;   // the whole problem on 128 x 128 tiles of the mid-size kernel that may reach beyond M / N
     return edge_ok ? LC_HGEMM_EDGE : LC_HGEMM_GENERIC;
   }
   if (is_valu_variant(variant)) {   // a rung of the vector-ALU ladder: its own tile, else the edge kernel (never an error)
@@ -879,8 +873,8 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
   else if (v == LC_HGEMM_EDGE) snprintf(buf, buflen, "hgemm_edge_kernel<%s>", nn);
   else if (v == LC_HGEMM_RAGGED) {   // interior kernel + the border launch
     const RaggedPlan p = ragged_plan(M, N, K, true, layout == LC_LAYOUT_NN, variant != LC_HGEMM_RAGGED);
-    if (p.kind == 1) snprintf(buf, buflen, "hgemm_w4y_kernel<%s,%d> + hgemm_edge_kernel<%s>", nn, layout == LC_LAYOUT_NN ? 1 : g_tune_w4y_sched.load(), nn);
-    else if (p.kind == 2) snprintf(buf, buflen, "hgemm_mid_kernel<%s,2,2,%d> + hgemm_edge_kernel<%s>", nn, p.ns, nn);
+    if (p.kind == 1) snprintf(buf, buflen, "hgemm_w4y_kernel<%s,%d> + hgemm_mid_edge_kernel<%s,%d>", nn, layout == LC_LAYOUT_NN ? 1 : g_tune_w4y_sched.load(), nn, p.ns);
+    else if (p.kind == 2) snprintf(buf, buflen, "hgemm_mid_edge_kernel<%s,%d>", nn, p.ns);
     else snprintf(buf, buflen, "hgemm_edge_kernel<%s>", nn);   // (the knob changed between the two reads)
   } else snprintf(buf, buflen, "hgemm_generic_kernel<%s>", nn);
   return LC_OK;
@@ -978,7 +972,7 @@ const Knob kKnobs[] = {
     {"hgemm_stagger", &g_tune_hgemm_stagger, 0, ok_stagger, false},
     {"hgemm_tail", &g_tune_hgemm_tail, 1, ok_04, false},
     {"hgemm_tail_tile", &g_tune_hgemm_tail_tile, 0, ok_02, false},
-    {"hgemm_ragged", &g_tune_hgemm_ragged, 0, ok_02, false},
+    {"hgemm_ragged", &g_tune_hgemm_ragged, 0, ok_01, false},
     {"hgemm_ragged_fork", &g_tune_hgemm_ragged_fork, 0, ok_02, false},
     {"hgemm_mid_splitk", &g_tune_hgemm_mid_splitk, 0, ok_08, false},
     {"hgemm_128w", &g_tune_hgemm_128w, 0, ok_02, false},

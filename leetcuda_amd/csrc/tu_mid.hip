@@ -75,10 +75,26 @@ int launch_hgemm_mid(const half_t* A, const half_t* B, half_t* C, int M, int N, 
   return launch_mid_tm<false, 3>(A, B, C, M, N, K, tmw, ns, pw, st);
 }
 
-// The interior of a ragged shape: launch_mid_one's tile counts are floor(M / 128) x floor(N / 128); the kernel uses M and N as strides only.
-int launch_hgemm_mid_interior(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int ns, int pw, hipStream_t st) {
-  if (M < 128 || N < 128 || N % 8 != 0 || K % 32 != 0 || K < BK || K >= (1 << 22) || N >= (1 << 22)) return LC_ERR_SHAPE;
-  return b_kn ? launch_mid_ns<true, 2, 2>(A, B, C, M, N, K, ns, pw, st) : launch_mid_ns<false, 2, 2>(A, B, C, M, N, K, ns, pw, st);
+// 128 x 128 tiles over the right strip (all rows, columns Ni .. N) and the bottom strip (rows Mi .. M, columns 0 .. Ni) of C, tiles that reach
+// beyond M / N clamped and predicated (hgemm_mid_edge_kernel); Mi = Ni = 0: the whole of a ragged problem.  K % 32 == 0, K >= 64, N % 8 == 0, Ni % 128 == 0.
+namespace {
+template <bool B_KN, int NS>
+int launch_mid_edge_one(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int Mi, int Ni, int nright, int nrc, int nblocks, hipStream_t st) {
+  using G = Mid<2, 2, NS>;
+  auto kern = hgemm_mid_edge_kernel<B_KN, NS>;
+  if (int rc = set_dyn_lds(kern, G::LDS)) return rc;
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), G::LDS, st, A, B, C, M, N, K, Mi, Ni, nright, nrc);
+  return check_launch();
+}
+}  // namespace
+int launch_hgemm_mid_edge(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int ns, int Mi, int Ni, hipStream_t st) {
+  if (N % 8 != 0 || K % 32 != 0 || K < BK || K >= (1 << 22) || N >= (1 << 22) || Ni % 128 != 0 || Mi < 0 || Ni < 0 || Mi > M || Ni > N) return LC_ERR_SHAPE;
+  const long nrc = (N - Ni + 127) / 128, nright = nrc * ((M + 127) / 128), nbottom = (long)((M - Mi + 127) / 128) * (Ni / 128);
+  if (nright + nbottom <= 0) return LC_OK;
+  if (nright + nbottom > INT_MAX) return LC_ERR_SHAPE;
+  const int nb = (int)(nright + nbottom), nr = (int)nright, nc = (int)(nrc > 0 ? nrc : 1);
+  if (b_kn) return ns == 3 ? launch_mid_edge_one<true, 3>(A, B, C, M, N, K, Mi, Ni, nr, nc, nb, st) : launch_mid_edge_one<true, 2>(A, B, C, M, N, K, Mi, Ni, nr, nc, nb, st);
+  return ns == 3 ? launch_mid_edge_one<false, 3>(A, B, C, M, N, K, Mi, Ni, nr, nc, nb, st) : launch_mid_edge_one<false, 2>(A, B, C, M, N, K, Mi, Ni, nr, nc, nb, st);
 }
 
 // The ragged last round of hgemm_w4y_kernel's 256 x 256 grid as 128 x 128 quadrants (tmw = 2) or 64 x 128 eighths (tmw = 1) on this kernel

@@ -343,7 +343,7 @@ def test_mid_size_kernels_at_the_sizes_they_serve(oracle, variant, shape, layout
     bb = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
     var = {"mfma128": capi.HGEMM_MFMA128, "generic": capi.HGEMM_GENERIC, "edge": capi.HGEMM_EDGE, "ragged": capi.HGEMM_AUTO}[variant]
     if variant == "ragged":   # what LC_HGEMM_AUTO launches on a large ragged shape with K % 32 == 0: interior on the flagship kernel (K % 64 == 32: its half step) + border
-        assert capi.hgemm_kernel_name(M, N, K, lay).startswith("hgemm_w4y_kernel") and "+ hgemm_edge_kernel" in capi.hgemm_kernel_name(M, N, K, lay)
+        assert capi.hgemm_kernel_name(M, N, K, lay).startswith("hgemm_w4y_kernel") and "+ hgemm_mid_edge_kernel" in capi.hgemm_kernel_name(M, N, K, lay)
     else:
         assert capi.hgemm_kernel_name(M, N, K, lay, var).startswith(f"hgemm_{variant}_kernel")
     if variant in ("generic", "edge"):

@@ -392,7 +392,7 @@ def test_mid_kernel_split_k_and_64_multiples(oracle, layout):
         if layout == "tn" or N % 128 == 0:
             assert name.startswith("hgemm_mid_kernel<"), (M, N, K, name)
         else:
-            assert name.startswith("hgemm_edge_kernel<"), (M, N, K, name)  # (NN has 128-column tiles only: the vectorised edge kernel)
+            assert name.startswith("hgemm_mid_edge_kernel<"), (M, N, K, name)  # (NN has 128-column tiles only: clamped 128 x 128 tiles)
         torch.manual_seed(M + N)
         a = torch.randn(M, K, dtype=torch.half, device="cuda")
         b = torch.randn(K, N, dtype=torch.half, device="cuda")
@@ -484,22 +484,24 @@ def test_edge_kernel_ragged_shapes(oracle, layout, shape):
 
 
 @pytest.mark.parametrize("layout", ["nn", "tn"])
-@pytest.mark.parametrize("shape,kind", [((1000, 3000, 512), "mid3"), ((2888, 2880, 544), "mid2"), ((4100, 4104, 320), "w4y"), ((5000, 5008, 288), "w4y_tail"),
-                                        ((130, 4232, 96), "mid3"), ((4360, 136, 160), "mid3")])
+@pytest.mark.parametrize("shape,kind", [((1000, 3000, 512), "mid3"), ((2888, 2880, 544), "mid2"), ((4100, 4104, 320), "w4y"), ((5000, 5008, 288), "w4y"),
+                                        ((130, 4232, 96), "mid3"), ((4360, 136, 160), "mid3"), ((100, 4096, 128), "mid3"), ((77, 136, 64), "mid3"),
+                                        ((4352, 4104, 96), "w4y"), ((4100, 4352, 352), "w4y")])
 def test_ragged_shapes_interior_on_the_tiled_kernels(oracle, layout, shape, kind):
-    """Late round 6, LC_HGEMM_RAGGED: M / N that no tile divides with K % 32 == 0 and N % 8 == 0 — the interior on hgemm_w4y_kernel (more than
-    half a CU's worth of 256 x 256 tiles; with its ragged last round on the mid-size kernel) or on 128 x 128 tiles of hgemm_mid_kernel (three /
-    two ring slots), the L-shaped border on hgemm_edge_kernel.  Rows across the seam against the oracle, the whole of C against the edge kernel
-    alone and hgemm_generic_kernel (other fp32 orders: one output ulp), bit-identical from run to run, nothing written outside C; what
-    LC_HGEMM_AUTO launches follows "hgemm_ragged" (auto from 4 edge blocks per CU)."""
+    """Late round 6, LC_HGEMM_RAGGED: M / N that no tile divides with K % 32 == 0 and N % 8 == 0 — more than half a CU's worth of 256 x 256 tiles:
+    the interior on hgemm_w4y_kernel (with its ragged last round on the mid-size kernel), the L-shaped border on hgemm_mid_edge_kernel (128 x 128
+    tiles of the mid-size kernel that reach beyond M / N: clamped sources, predicated stores; one strip empty when M or N is a multiple of 256);
+    otherwise the whole problem on that kernel (three / two ring slots; M < 128 too).  Rows across the seam against the oracle, the whole of C
+    against the edge kernel alone and hgemm_generic_kernel (other fp32 orders: one output ulp), bit-identical from run to run, nothing written
+    outside C; what LC_HGEMM_AUTO launches follows "hgemm_ragged"."""
     capi = _capi()
     M, N, K = shape
     lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
     nnn = "true" if layout == "nn" else "false"
     name = capi.hgemm_kernel_name(M, N, K, lay, capi.HGEMM_RAGGED)
     if capi.device_check() == 256:
-        want = {"mid3": f"hgemm_mid_kernel<{nnn},2,2,3>", "mid2": f"hgemm_mid_kernel<{nnn},2,2,2>"}.get(kind, f"hgemm_w4y_kernel<{nnn},")
-        assert name.startswith(want) and name.endswith(f" + hgemm_edge_kernel<{nnn}>"), name
+        want = {"mid3": f"hgemm_mid_edge_kernel<{nnn},3>", "mid2": f"hgemm_mid_edge_kernel<{nnn},2>"}.get(kind, f"hgemm_w4y_kernel<{nnn},")
+        assert name.startswith(want) and name.endswith(f"hgemm_mid_edge_kernel<{nnn},{2 if kind == 'mid2' else 3}>"), name
     torch.manual_seed(M * 7 + N * 3 + K)
     a = torch.randn(M, K, dtype=torch.half, device="cuda")
     b = torch.randn(K, N, dtype=torch.half, device="cuda")
@@ -510,8 +512,8 @@ def test_ragged_shapes_interior_on_the_tiled_kernels(oracle, layout, shape, kind
     capi.hgemm(a, bb, c, layout=lay, variant=capi.HGEMM_RAGGED, swizzle_stride=host.make_block_swizzle_stride(N, K))
     torch.cuda.synchronize()
     assert torch.isnan(buf[:pad]).all() and torch.isnan(buf[pad + M * N:]).all() and torch.isfinite(c).all()
-    mi = M // 128 * 128
-    rows = sorted(r for r in {0, 1, 127, 128, 255, 256, M // 2 + 3, mi - 257, mi - 129, mi - 1, mi, M - 2, M - 1} if 0 <= r < M)
+    mi = M // 256 * 256
+    rows = sorted(r for r in {0, 1, 127, 128, 255, 256, M // 2 + 3, mi - 257, mi - 129, mi - 1, mi, mi + 127, mi + 128, M - 2, M - 1} if 0 <= r < M)
     truth = oracle.hgemm(a[rows].contiguous(), b.contiguous(), len(rows), N, K, 0, "f32")
     ok, mx, ex = tol.hgemm_close(c[rows].float().cpu().numpy(), truth, K)
     assert ok, (mx, ex)
@@ -521,14 +523,14 @@ def test_ragged_shapes_interior_on_the_tiled_kernels(oracle, layout, shape, kind
         assert ((c.float() - co.float()).abs() <= ulp).all(), other
     c2, _ = _run(capi, a, b, lay, capi.HGEMM_RAGGED, host.make_block_swizzle_stride(N, K))
     assert torch.equal(c2, c)
-    for knob, want in ((1, "hgemm_edge_kernel"), (2, name)):
+    for knob, want in ((1, "hgemm_edge_kernel"), (0, name)):
         capi.tune("hgemm_ragged", knob)
         try:
             assert capi.hgemm_kernel_name(M, N, K, lay).startswith(want)
             c3, _ = _run(capi, a, b, lay, capi.HGEMM_AUTO, host.make_block_swizzle_stride(N, K))
         finally:
             capi.tune("hgemm_ragged", 0)
-        if knob == 2:
+        if knob == 0:
             assert torch.equal(c3, c)
     # the border launch on the side stream ("hgemm_ragged_fork" 2) / behind the interior (1): the same bits; on a stream of the caller's with
     # the operands still being produced on it (the fork event orders the border behind them, the join event the caller's next kernel behind it)
@@ -1023,4 +1025,4 @@ def test_random_shapes_through_the_auto_dispatch(oracle):
         truth = oracle.hgemm(a, b, M, N, K, 0, "f32")
         ok, mx, ex = tol.hgemm_close(c.float().cpu().numpy(), truth, K)
         assert ok, (M, N, K, lay, name, mx, ex)
-    assert {"hgemm_mid_kernel", "hgemm_edge_kernel"} <= seen and ({"hgemm_mfma128_kernel", "hgemm_w4y_kernel"} & seen), seen
+    assert {"hgemm_mid_kernel", "hgemm_mid_edge_kernel"} <= seen and ({"hgemm_mfma128_kernel", "hgemm_w4y_kernel"} & seen), seen
