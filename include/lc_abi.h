@@ -170,6 +170,9 @@ const char* lc_build_info(int* is_diag);
  *                  CUs, else 128 x 128 quadrants), 1 = eighths, 2 = quadrants (bit-identical results; A/B knob)
  *   "hgemm_ragged" LC_HGEMM_AUTO on ragged M / N with K % 32 == 0 (K >= 64), N % 8 == 0: 0 = LC_HGEMM_RAGGED (the tiled kernels; 128 x 128 tiles with clamped
  *                  sources and predicated stores on what they do not divide), 1 = never (hgemm_edge_kernel alone; A/B knob)
+ *   "hgemm_ragged_tile"  tile of a ragged problem that runs entirely on hgemm_mid_edge_kernel: 0 = auto (the smallest of 64 x 128, 128 x 128, 128 x 192 (TN) /
+ *                  192 x 128 (NN), 192 x 192 (TN) whose grid fits one round of the CUs, three ring slots; else 128 x 128 with two), 12 / 22 / 23 / 32 / 33 = that
+ *                  tile where the layout has it (A/B knob)
  *   "hgemm_ragged_fork"  LC_HGEMM_RAGGED's border launch on a per-device side stream forked from / joined to the caller's stream by events (runs beside
  *                  the interior; never while the caller's stream is being captured): 0 = auto (only beside an unsplit last round of the 256-tile grid that
  *                  leaves >= 3 / 8 of the CUs idle: + 4 %; beside full rounds it costs 2 ... 11 %), 1 = never, 2 = always (same bits)

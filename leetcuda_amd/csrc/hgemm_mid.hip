@@ -368,6 +368,12 @@ LC_DEVINL void hgemm_mid_body(const half_t* __restrict__ A, const half_t* __rest
         for (int e = 0; e < 8; ++e) f.b[ni][e] = B[(size_t)(k0 + e) * N + n0 + scol];
       }
     }
+    // (hipcc assembles the [K][N] fragments with VALU permutes and does not know the asm MFMAs' wait states behind a VALU write: name them, then two wait states)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) name_vgpr(f.a[mi]);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) name_vgpr(f.b[ni]);
+    asm volatile("s_nop 1" ::: "memory");
     kstep(f, f0, NONEXT{}, 0u, KS0{}, NODMA{}, 0u, nullptr, nullptr);
     mid_acc_settle<MI, NI>(acc);
   }
@@ -389,7 +395,8 @@ LC_DEVINL void hgemm_mid_body(const half_t* __restrict__ A, const half_t* __rest
         const f32x4_t v = acc[mi][ni];
         half4_t h;
         h[0] = (half_t)v[0]; h[1] = (half_t)v[1]; h[2] = (half_t)v[2]; h[3] = (half_t)v[3];
-        *(half4_t*)(P + (size_t)(mi * 16 + i16) * N + ni * 16 + g * 4) = h;
+        if (!EDGE || (wr * (TM / 2) + mi * 16 + i16 <= mlim && wc * (TN / 2) + ni * 16 + g * 4 <= nlim))   // (N % 8 == 0: 4 columns are inside or outside together)
+          *(half4_t*)(P + (size_t)(mi * 16 + i16) * N + ni * 16 + g * 4) = h;
       }
     return;
   }
@@ -425,10 +432,11 @@ __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_kerne
   hgemm_mid_body<B_KN, TMW, TNW, NS, false>(A, B, C, M, N, K, tiles_m, tiles_n, panel_w, rem_base, nullptr, 1);
 }
 // 128 x 128 tiles that may reach beyond M / N (EDGE above): the border of a ragged shape, or the whole of one (Mi = Ni = 0)
-template <bool B_KN, int NS>
-__global__ __launch_bounds__(256, 2) void hgemm_mid_edge_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B, half_t* __restrict__ C, int M,
-                                                                int N, int K, int Mi, int Ni, int nright, int nrc) {
-  hgemm_mid_body<B_KN, 2, 2, NS, false, true>(A, B, C, M, N, K, Mi, Ni, nright, nrc, nullptr, 1);
+template <bool B_KN, int TMW, int TNW, int NS>
+__global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_edge_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B,
+                                                                                        half_t* __restrict__ C, int M, int N, int K, int Mi, int Ni, int nright,
+                                                                                        int nrc) {
+  hgemm_mid_body<B_KN, TMW, TNW, NS, false, true>(A, B, C, M, N, K, Mi, Ni, nright, nrc, nullptr, 1);
 }
 template <bool B_KN, int TMW, int NS>
 __global__ __launch_bounds__(256, 2) void hgemm_mid_sk_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B, int M, int N, int K,

@@ -56,6 +56,7 @@ tune_t g_tune_hgemm_mid_ns{0};                 // ... its LDS ring slots: 0 = au
 tune_t g_tune_hgemm_128w{0};                   // waves of the 128-tile kernel: 0 = auto (eight — intra-workgroup split-K — on grids of <= 0.6 blocks per CU), 1 = always four, 2 = always eight
 tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to 128 x 128 blocks (launch_mfma256: the mid-size kernel; 2 = round 5's 128-tile kernel + split-K), 0 = one launch
 tune_t g_tune_hgemm_ragged{0};                 // LC_HGEMM_AUTO on ragged M / N with K % 32 == 0: 0 = LC_HGEMM_RAGGED (the tiled kernels, clamped 128 x 128 tiles on what they do not divide), 1 = never (hgemm_edge_kernel)
+tune_t g_tune_hgemm_ragged_tile{0};            // tile of a ragged problem that runs entirely on hgemm_mid_edge_kernel: 0 = auto (ragged_plan), 12 / 22 / 23 / 32 / 33 = that tile (rows / 64, columns / 64; A/B)
 tune_t g_tune_hgemm_ragged_fork{0};            // LC_HGEMM_RAGGED's border launch on a side stream, forked from and joined to the caller's (runs beside the interior): 0 = auto (launch_ragged), 1 = never, 2 = always
 tune_t g_tune_hgemm_tail_tile{0};              // sub-tiles of the ragged tail on the mid-size kernel: 0 = auto (launch_mfma256), 1 = 64 x 128 eighths, 2 = 128 x 128 quadrants
 tune_t g_tune_hgemm_mid_splitk{0};             // split-K of the mid-size kernel: 0 = auto (mid_tile_auto), 1 = never, 2 .. 8 = that many K ranges wherever legal (A/B)
@@ -656,9 +657,9 @@ namespace {
 //           columns Ni .. N, bottom strip: rows Mi .. M x columns 0 .. Ni) on hgemm_mid_edge_kernel in a second launch
 //   kind 2  otherwise: the whole problem on hgemm_mid_edge_kernel (three ring slots while the tiles fit one round of the CUs, else two)
 // Every element of C is computed by exactly one kernel, deterministically; no workspace.  lc_tune_set "hgemm_ragged" = 1: never (hgemm_edge_kernel).
-struct RaggedPlan { int kind, Mi, Ni, ns; };
+struct RaggedPlan { int kind, Mi, Ni, ns, tmw, tnw; };
 RaggedPlan ragged_plan(int M, int N, int K, bool al, bool b_kn, bool gated) {
-  RaggedPlan none{0, 0, 0, 0};
+  RaggedPlan none{0, 0, 0, 0, 0, 0};
   if (!al || K % 32 != 0 || K < BK || N % 8 != 0 || K >= (1 << 22) || N >= (1 << 22)) return none;
   if (M % BM1 == 0 && N % BN1 == 0) return none;   // (a tiled shape)
   if (gated && g_tune_hgemm_ragged == 1) return none;
@@ -667,10 +668,24 @@ RaggedPlan ragged_plan(int M, int N, int K, bool al, bool b_kn, bool gated) {
   if (2 * t256 > ncu && g_tune_hgemm_auto == LC_HGEMM_MFMA256W4Y && w4_effective_variant(LC_HGEMM_MFMA256W4Y, b_kn, N, K) == LC_HGEMM_MFMA256W4Y) {
     const int Mi = (M / BM) * BM, Ni = (N / BN) * BN;
     const long nb = (long)((N - Ni + 127) / 128) * ((M + 127) / 128) + (long)((M - Mi + 127) / 128) * (Ni / 128);   // border blocks
-    return RaggedPlan{1, Mi, Ni, nb <= ncu ? 3 : 2};
+    return RaggedPlan{1, Mi, Ni, nb <= ncu ? 3 : 2, 2, 2};
   }
-  const long eb = (long)((M + 127) / 128) * ((N + 127) / 128);
-  return RaggedPlan{2, 0, 0, eb <= ncu ? 3 : 2};
+  // the mid-size kernel's own rule (mid_tile_auto; measured on ragged shapes in profiles/r6ag_hgemm_edge_ab.log): the smallest tile whose grid fits ONE round of
+  // at most one workgroup per CU (most workgroups, least work on the busiest CU; three ring slots) — 64 x 128, 128 x 128, then 128 x 192 (TN) / 192 x 128 (NN:
+  // 128-column tiles only); where 128 x 128 at two per CU needs more than one double round, 192 x 192 (TN; 3000 x 3000 x 3008: 1074 vs 783 TFLOP/s) /
+  // 192 x 128 (NN: 865 vs 724); else 128 x 128 with two slots at two workgroups per CU (2500 x 2504 x 2560 TN: 857 vs 773 on 192 x 192 in one round).
+  const int tile_knob = g_tune_hgemm_ragged_tile;
+  auto blocks_of = [&](int tmw, int tnw) { return (long)((M + 64 * tmw - 1) / (64 * tmw)) * ((N + 64 * tnw - 1) / (64 * tnw)); };
+  if (tile_knob != 0) {
+    const int tmw = tile_knob / 10, tnw = tile_knob % 10;
+    const bool legal = b_kn ? tnw == 2 : !(tmw == 3 && tnw == 2);
+    if (legal) return RaggedPlan{2, 0, 0, (tmw == 2 && tnw == 2 && blocks_of(2, 2) > ncu) ? 2 : 3, tmw, tnw};
+  }
+  if (blocks_of(1, 2) <= ncu) return RaggedPlan{2, 0, 0, 3, 1, 2};
+  if (blocks_of(2, 2) <= ncu) return RaggedPlan{2, 0, 0, 3, 2, 2};
+  if (blocks_of(2, 2) > 2 * ncu) return b_kn ? RaggedPlan{2, 0, 0, 3, 3, 2} : RaggedPlan{2, 0, 0, 3, 3, 3};
+  if (b_kn ? blocks_of(3, 2) <= ncu : blocks_of(2, 3) <= ncu) return b_kn ? RaggedPlan{2, 0, 0, 3, 3, 2} : RaggedPlan{2, 0, 0, 3, 2, 3};
+  return RaggedPlan{2, 0, 0, 2, 2, 2};
 }
 
 // The border launch beside the interior (lc_tune_set "hgemm_ragged_fork"): one side stream per device, forked from the caller's stream
@@ -716,7 +731,7 @@ int launch_ragged_interior(const half_t* A, const half_t* B, half_t* C, int M, i
 
 template <bool B_KN>
 int launch_ragged(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, const RaggedPlan& p, int swizzle_stride, hipStream_t st) {
-  if (p.kind == 2) return launch_hgemm_mid_edge(A, B, C, M, N, K, B_KN, p.ns, 0, 0, st);
+  if (p.kind == 2) return launch_hgemm_mid_edge(A, B, C, M, N, K, B_KN, p.tmw, p.tnw, p.ns, 0, 0, st);
   // Fork rule (profiles/r6ac … r6af_hgemm_edge_ab*.log; the hardware interleaves the two queues whatever their order or priority): beside an interior of
   // FULL rounds every CU a border block holds costs the interior a round of its own (4100 x 4104 x 4096, one round of 256 tiles: 1122 -> 995 TFLOP/s;
   // 12808^2 x 4096: − 5 %); beside an UNSPLIT last round that leaves at least 3 / 8 of the CUs idle the border fills them (5200^2 x 4096, 400 tiles:
@@ -735,7 +750,7 @@ int launch_ragged(const half_t* A, const half_t* B, half_t* C, int M, int N, int
     if (l && hipEventRecord(l->fork, st) == hipSuccess && hipStreamWaitEvent(l->side, l->fork, 0) == hipSuccess) {
       // (the order of the two launches and the side stream's priority change nothing measurable)
       int rc = launch_ragged_interior<B_KN>(A, B, C, M, N, K, swizzle_stride, st);
-      if (rc == LC_OK) rc = launch_hgemm_mid_edge(A, B, C, M, N, K, B_KN, p.ns, p.Mi, p.Ni, l->side);
+      if (rc == LC_OK) rc = launch_hgemm_mid_edge(A, B, C, M, N, K, B_KN, 2, 2, p.ns, p.Mi, p.Ni, l->side);
       const bool joined = hipEventRecord(l->join, l->side) == hipSuccess;
       if (!joined || hipStreamWaitEvent(st, l->join, 0) != hipSuccess) {   // (cannot order the caller's stream behind the border: wait for it here)
         (void)hipGetLastError();
@@ -746,7 +761,7 @@ int launch_ragged(const half_t* A, const half_t* B, half_t* C, int M, int N, int
     (void)hipGetLastError();
   }
   if (int rc = launch_ragged_interior<B_KN>(A, B, C, M, N, K, swizzle_stride, st)) return rc;
-  return launch_hgemm_mid_edge(A, B, C, M, N, K, B_KN, p.ns, p.Mi, p.Ni, st);
+  return launch_hgemm_mid_edge(A, B, C, M, N, K, B_KN, 2, 2, p.ns, p.Mi, p.Ni, st);
 }
 }  // namespace
 
@@ -873,8 +888,8 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
   else if (v == LC_HGEMM_EDGE) snprintf(buf, buflen, "hgemm_edge_kernel<%s>", nn);
   else if (v == LC_HGEMM_RAGGED) {   // interior kernel + the border launch
     const RaggedPlan p = ragged_plan(M, N, K, true, layout == LC_LAYOUT_NN, variant != LC_HGEMM_RAGGED);
-    if (p.kind == 1) snprintf(buf, buflen, "hgemm_w4y_kernel<%s,%d> + hgemm_mid_edge_kernel<%s,%d>", nn, layout == LC_LAYOUT_NN ? 1 : g_tune_w4y_sched.load(), nn, p.ns);
-    else if (p.kind == 2) snprintf(buf, buflen, "hgemm_mid_edge_kernel<%s,%d>", nn, p.ns);
+    if (p.kind == 1) snprintf(buf, buflen, "hgemm_w4y_kernel<%s,%d> + hgemm_mid_edge_kernel<%s,2,2,%d>", nn, layout == LC_LAYOUT_NN ? 1 : g_tune_w4y_sched.load(), nn, p.ns);
+    else if (p.kind == 2) snprintf(buf, buflen, "hgemm_mid_edge_kernel<%s,%d,%d,%d>", nn, p.tmw, p.tnw, p.ns);
     else snprintf(buf, buflen, "hgemm_edge_kernel<%s>", nn);   // (the knob changed between the two reads)
   } else snprintf(buf, buflen, "hgemm_generic_kernel<%s>", nn);
   return LC_OK;
@@ -936,6 +951,7 @@ bool ok_04(int v) { return v >= 0 && v <= 4; }
 bool ok_08(int v) { return v >= 0 && v <= 8; }
 bool ok_rule_cus(int v) { return v == 0 || (v >= 64 && v <= 1024); }
 bool ok_mid_ns(int v) { return v == 0 || v == 2 || v == 3; }
+bool ok_ragged_tile(int v) { return v == 0 || v == 12 || v == 22 || v == 23 || v == 32 || v == 33; }
 bool ok_mid(int v) { return v == 0 || v == 1 || v == 12 || v == 13 || v == 22 || v == 23 || v == 32 || v == 33; }
 bool ok_split(int v) { return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16; }
 bool ok_span8(int v) { return v == 0 || v == 2 || v == 4 || v == 6; }
@@ -974,6 +990,7 @@ const Knob kKnobs[] = {
     {"hgemm_tail_tile", &g_tune_hgemm_tail_tile, 0, ok_02, false},
     {"hgemm_ragged", &g_tune_hgemm_ragged, 0, ok_01, false},
     {"hgemm_ragged_fork", &g_tune_hgemm_ragged_fork, 0, ok_02, false},
+    {"hgemm_ragged_tile", &g_tune_hgemm_ragged_tile, 0, ok_ragged_tile, false},
     {"hgemm_mid_splitk", &g_tune_hgemm_mid_splitk, 0, ok_08, false},
     {"hgemm_128w", &g_tune_hgemm_128w, 0, ok_02, false},
     {"rule_cus", &g_tune_rule_cus, 0, ok_rule_cus, false},

@@ -212,7 +212,7 @@ int w4_effective_variant(int variant, bool b_kn, int N, int K);   // W4C / W4X /
 int launch_hgemm_mid(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int tmw, int tnw, int ns, int pw,
                      hipStream_t st, float* part = nullptr, int ks = 1);
 // 128 x 128 tiles of the mid-size kernel that may reach beyond M / N (hgemm_mid_edge_kernel): strips of C as hgemm_edge_kernel's launcher defines them
-int launch_hgemm_mid_edge(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int ns, int Mi, int Ni, hipStream_t st);
+int launch_hgemm_mid_edge(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int tmw, int tnw, int ns, int Mi, int Ni, hipStream_t st);
 int launch_hgemm_mid_rem(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int tmw, int ns, int tiles_m256,
                          int tiles_n256, int pw256, int rem_base, int rem_tiles, hipStream_t st);   // the 256-tile kernel's ragged last round as 128 x 128 quadrants
 int launch_w4_family(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant, bool b_kn,

@@ -75,26 +75,43 @@ int launch_hgemm_mid(const half_t* A, const half_t* B, half_t* C, int M, int N, 
   return launch_mid_tm<false, 3>(A, B, C, M, N, K, tmw, ns, pw, st);
 }
 
-// 128 x 128 tiles over the right strip (all rows, columns Ni .. N) and the bottom strip (rows Mi .. M, columns 0 .. Ni) of C, tiles that reach
-// beyond M / N clamped and predicated (hgemm_mid_edge_kernel); Mi = Ni = 0: the whole of a ragged problem.  K % 32 == 0, K >= 64, N % 8 == 0, Ni % 128 == 0.
+// Tiles over the right strip (all rows, columns Ni .. N) and the bottom strip (rows Mi .. M, columns 0 .. Ni) of C, tiles that reach beyond M / N
+// clamped and predicated (hgemm_mid_edge_kernel); Mi = Ni = 0: the whole of a ragged problem.  K % 32 == 0, K >= 64, N % 8 == 0, Ni a multiple of
+// the tile width.  Tiles: 128 x 128 with 2 / 3 ring slots; with 3 slots also 64 x 128, 192 x 128 (NN), 128 x 192 and 192 x 192 (TN).
 namespace {
-template <bool B_KN, int NS>
-int launch_mid_edge_one(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int Mi, int Ni, int nright, int nrc, int nblocks, hipStream_t st) {
-  using G = Mid<2, 2, NS>;
-  auto kern = hgemm_mid_edge_kernel<B_KN, NS>;
+template <bool B_KN, int TMW, int TNW, int NS>
+int launch_mid_edge_one(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int Mi, int Ni, hipStream_t st) {
+  using G = Mid<TMW, TNW, NS>;
+  if (Ni % G::TN != 0) return LC_ERR_SHAPE;
+  const long nrc = (N - Ni + G::TN - 1) / G::TN, nright = nrc * ((M + G::TM - 1) / G::TM), nbottom = (long)((M - Mi + G::TM - 1) / G::TM) * (Ni / G::TN);
+  if (nright + nbottom <= 0) return LC_OK;
+  if (nright + nbottom > INT_MAX) return LC_ERR_SHAPE;
+  auto kern = hgemm_mid_edge_kernel<B_KN, TMW, TNW, NS>;
   if (int rc = set_dyn_lds(kern, G::LDS)) return rc;
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), G::LDS, st, A, B, C, M, N, K, Mi, Ni, nright, nrc);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nright + nbottom)), dim3(256), G::LDS, st, A, B, C, M, N, K, Mi, Ni, (int)nright, (int)(nrc > 0 ? nrc : 1));
   return check_launch();
 }
 }  // namespace
-int launch_hgemm_mid_edge(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int ns, int Mi, int Ni, hipStream_t st) {
-  if (N % 8 != 0 || K % 32 != 0 || K < BK || K >= (1 << 22) || N >= (1 << 22) || Ni % 128 != 0 || Mi < 0 || Ni < 0 || Mi > M || Ni > N) return LC_ERR_SHAPE;
-  const long nrc = (N - Ni + 127) / 128, nright = nrc * ((M + 127) / 128), nbottom = (long)((M - Mi + 127) / 128) * (Ni / 128);
-  if (nright + nbottom <= 0) return LC_OK;
-  if (nright + nbottom > INT_MAX) return LC_ERR_SHAPE;
-  const int nb = (int)(nright + nbottom), nr = (int)nright, nc = (int)(nrc > 0 ? nrc : 1);
-  if (b_kn) return ns == 3 ? launch_mid_edge_one<true, 3>(A, B, C, M, N, K, Mi, Ni, nr, nc, nb, st) : launch_mid_edge_one<true, 2>(A, B, C, M, N, K, Mi, Ni, nr, nc, nb, st);
-  return ns == 3 ? launch_mid_edge_one<false, 3>(A, B, C, M, N, K, Mi, Ni, nr, nc, nb, st) : launch_mid_edge_one<false, 2>(A, B, C, M, N, K, Mi, Ni, nr, nc, nb, st);
+int launch_hgemm_mid_edge(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int tmw, int tnw, int ns, int Mi, int Ni, hipStream_t st) {
+  if (N % 8 != 0 || K % 32 != 0 || K < BK || K >= (1 << 22) || N >= (1 << 22) || Mi < 0 || Ni < 0 || Mi > M || Ni > N) return LC_ERR_SHAPE;
+  const int code = 100 * tmw + 10 * tnw + ns;
+  if (b_kn) {
+    switch (code) {
+      case 222: return launch_mid_edge_one<true, 2, 2, 2>(A, B, C, M, N, K, Mi, Ni, st);
+      case 223: return launch_mid_edge_one<true, 2, 2, 3>(A, B, C, M, N, K, Mi, Ni, st);
+      case 123: return launch_mid_edge_one<true, 1, 2, 3>(A, B, C, M, N, K, Mi, Ni, st);
+      case 323: return launch_mid_edge_one<true, 3, 2, 3>(A, B, C, M, N, K, Mi, Ni, st);
+      default: return LC_ERR_ARG;
+    }
+  }
+  switch (code) {
+    case 222: return launch_mid_edge_one<false, 2, 2, 2>(A, B, C, M, N, K, Mi, Ni, st);
+    case 223: return launch_mid_edge_one<false, 2, 2, 3>(A, B, C, M, N, K, Mi, Ni, st);
+    case 123: return launch_mid_edge_one<false, 1, 2, 3>(A, B, C, M, N, K, Mi, Ni, st);
+    case 233: return launch_mid_edge_one<false, 2, 3, 3>(A, B, C, M, N, K, Mi, Ni, st);
+    case 333: return launch_mid_edge_one<false, 3, 3, 3>(A, B, C, M, N, K, Mi, Ni, st);
+    default: return LC_ERR_ARG;
+  }
 }
 
 // The ragged last round of hgemm_w4y_kernel's 256 x 256 grid as 128 x 128 quadrants (tmw = 2) or 64 x 128 eighths (tmw = 1) on this kernel

@@ -280,8 +280,8 @@ def test_hgemm_dispatch_covers_the_reference_legal_shapes(built):
         finally:
             capi.tune("hgemm_mid_splitk", 0)
         # M, N multiples of 64 only (not legal in the reference): a mid-size tile where one divides the shape, else the edge kernel
-        assert capi.hgemm_kernel_name(2880, 2880, 2880, lay) == ("hgemm_mid_kernel<false,3,3,3>" if nn == "false" else "hgemm_mid_edge_kernel<true,2>")
-        assert capi.hgemm_kernel_name(8192, 8256, 8192, lay) == f"hgemm_w4y_kernel<{nn},{sch}> + hgemm_mid_edge_kernel<{nn},3>"   # (a flagship-size interior goes ahead of the 128 x 192 tile)
+        assert capi.hgemm_kernel_name(2880, 2880, 2880, lay) == ("hgemm_mid_kernel<false,3,3,3>" if nn == "false" else "hgemm_mid_edge_kernel<true,3,2,3>")
+        assert capi.hgemm_kernel_name(8192, 8256, 8192, lay) == f"hgemm_w4y_kernel<{nn},{sch}> + hgemm_mid_edge_kernel<{nn},2,2,3>"   # (a flagship-size interior goes ahead of the 128 x 192 tile)
         if nn == "false":
             assert capi.hgemm_kernel_name(8192, 8256, 8192, lay, capi.HGEMM_MID) == "hgemm_mid_kernel<false,2,3,3>"
         # 192 x 192 only where 128 x 128 at two per CU needs more than one double round (3072^3: 576 blocks on 512 slots)
@@ -301,16 +301,23 @@ def test_hgemm_dispatch_covers_the_reference_legal_shapes(built):
             assert capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_MFMA256W4Y) == f"hgemm_w4y_kernel<{nn},{sch}>"
         # ragged M / N with K % 32 == 0 (LC_HGEMM_RAGGED): a flagship-sized interior on hgemm_w4y_kernel + the border on clamped 128 x 128 tiles of the
         # mid-size kernel; smaller problems entirely on those tiles (three ring slots while they fit one round of the CUs)
-        assert capi.hgemm_kernel_name(8192, 8224, 8192, lay) == f"hgemm_w4y_kernel<{nn},{sch}> + hgemm_mid_edge_kernel<{nn},3>"
-        assert capi.hgemm_kernel_name(4100, 4104, 4096, lay) == f"hgemm_w4y_kernel<{nn},{sch}> + hgemm_mid_edge_kernel<{nn},3>"
-        assert capi.hgemm_kernel_name(12808, 12808, 4096, lay) == f"hgemm_w4y_kernel<{nn},{sch}> + hgemm_mid_edge_kernel<{nn},3>"
-        assert capi.hgemm_kernel_name(1000, 3000, 4096, lay) == f"hgemm_mid_edge_kernel<{nn},3>"
-        assert capi.hgemm_kernel_name(100, 4096, 4096, lay) == f"hgemm_mid_edge_kernel<{nn},3>"
-        assert capi.hgemm_kernel_name(2888, 2880, 544, lay, capi.HGEMM_RAGGED) == f"hgemm_mid_edge_kernel<{nn},2>"
+        assert capi.hgemm_kernel_name(8192, 8224, 8192, lay) == f"hgemm_w4y_kernel<{nn},{sch}> + hgemm_mid_edge_kernel<{nn},2,2,3>"
+        assert capi.hgemm_kernel_name(4100, 4104, 4096, lay) == f"hgemm_w4y_kernel<{nn},{sch}> + hgemm_mid_edge_kernel<{nn},2,2,3>"
+        assert capi.hgemm_kernel_name(12808, 12808, 4096, lay) == f"hgemm_w4y_kernel<{nn},{sch}> + hgemm_mid_edge_kernel<{nn},2,2,3>"
+        assert capi.hgemm_kernel_name(1000, 3000, 4096, lay) == f"hgemm_mid_edge_kernel<{nn},2,2,3>"
+        assert capi.hgemm_kernel_name(100, 4096, 4096, lay) == f"hgemm_mid_edge_kernel<{nn},1,2,3>"        # (the smallest tile whose grid fits one round)
+        assert capi.hgemm_kernel_name(2888, 2880, 544, lay, capi.HGEMM_RAGGED) == ("hgemm_mid_edge_kernel<false,3,3,3>" if nn == "false" else "hgemm_mid_edge_kernel<true,3,2,3>")
+        assert capi.hgemm_kernel_name(2500, 2504, 2560, lay) == f"hgemm_mid_edge_kernel<{nn},2,2,2>"      # (128 x 128 at two per CU fits one double round)
+        capi.tune("hgemm_ragged_tile", 22)
+        try:
+            assert capi.hgemm_kernel_name(2888, 2880, 544, lay) == f"hgemm_mid_edge_kernel<{nn},2,2,2>"
+            assert capi.hgemm_kernel_name(100, 4096, 4096, lay) == f"hgemm_mid_edge_kernel<{nn},2,2,3>"
+        finally:
+            capi.tune("hgemm_ragged_tile", 0)
         capi.tune("hgemm_ragged", 1)
         try:
             assert capi.hgemm_kernel_name(8192, 8224, 8192, lay) == f"hgemm_edge_kernel<{nn}>"
-            assert capi.hgemm_kernel_name(8192, 8224, 8192, lay, capi.HGEMM_RAGGED) == f"hgemm_w4y_kernel<{nn},{sch}> + hgemm_mid_edge_kernel<{nn},3>"   # (explicit: whatever the knob)
+            assert capi.hgemm_kernel_name(8192, 8224, 8192, lay, capi.HGEMM_RAGGED) == f"hgemm_w4y_kernel<{nn},{sch}> + hgemm_mid_edge_kernel<{nn},2,2,3>"   # (explicit: whatever the knob)
         finally:
             capi.tune("hgemm_ragged", 0)
         for shp in ((4096, 4096, 4096), (8192, 8192, 8200), (100, 4096, 40), (4100, 4100, 4096)):     # tiled / K % 32 / K < 64 / N % 8: not a ragged-path shape

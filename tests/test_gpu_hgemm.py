@@ -484,7 +484,7 @@ def test_edge_kernel_ragged_shapes(oracle, layout, shape):
 
 
 @pytest.mark.parametrize("layout", ["nn", "tn"])
-@pytest.mark.parametrize("shape,kind", [((1000, 3000, 512), "mid3"), ((2888, 2880, 544), "mid2"), ((4100, 4104, 320), "w4y"), ((5000, 5008, 288), "w4y"),
+@pytest.mark.parametrize("shape,kind", [((1000, 3000, 512), "mid3"), ((2888, 2880, 544), "mid3"), ((2500, 2504, 96), "mid2"), ((4100, 4104, 320), "w4y"), ((5000, 5008, 288), "w4y"),
                                         ((130, 4232, 96), "mid3"), ((4360, 136, 160), "mid3"), ((100, 4096, 128), "mid3"), ((77, 136, 64), "mid3"),
                                         ((4352, 4104, 96), "w4y"), ((4100, 4352, 352), "w4y")])
 def test_ragged_shapes_interior_on_the_tiled_kernels(oracle, layout, shape, kind):
@@ -500,8 +500,10 @@ def test_ragged_shapes_interior_on_the_tiled_kernels(oracle, layout, shape, kind
     nnn = "true" if layout == "nn" else "false"
     name = capi.hgemm_kernel_name(M, N, K, lay, capi.HGEMM_RAGGED)
     if capi.device_check() == 256:
-        want = {"mid3": f"hgemm_mid_edge_kernel<{nnn},3>", "mid2": f"hgemm_mid_edge_kernel<{nnn},2>"}.get(kind, f"hgemm_w4y_kernel<{nnn},")
-        assert name.startswith(want) and name.endswith(f"hgemm_mid_edge_kernel<{nnn},{2 if kind == 'mid2' else 3}>"), name
+        if kind == "w4y":
+            assert name.startswith(f"hgemm_w4y_kernel<{nnn},") and name.endswith(f" + hgemm_mid_edge_kernel<{nnn},2,2,3>"), name
+        else:
+            assert name.startswith(f"hgemm_mid_edge_kernel<{nnn},") and name.endswith(",2,2,2>" if kind == "mid2" else ",3>"), name
     torch.manual_seed(M * 7 + N * 3 + K)
     a = torch.randn(M, K, dtype=torch.half, device="cuda")
     b = torch.randn(K, N, dtype=torch.half, device="cuda")
@@ -532,6 +534,19 @@ def test_ragged_shapes_interior_on_the_tiled_kernels(oracle, layout, shape, kind
             capi.tune("hgemm_ragged", 0)
         if knob == 0:
             assert torch.equal(c3, c)
+    if kind != "w4y":   # every tile the layout has ("hgemm_ragged_tile"): one output ulp from the rule's choice, bit-identical from run to run
+        for tile in (12, 22, 32) if layout == "nn" else (12, 22, 23, 33):
+            capi.tune("hgemm_ragged_tile", tile)
+            try:
+                tname = capi.hgemm_kernel_name(M, N, K, lay)
+                assert tname.startswith(f"hgemm_mid_edge_kernel<{nnn},{tile // 10},{tile % 10},"), (tile, tname)
+                ct, _ = _run(capi, a, b, lay, capi.HGEMM_AUTO, 256)
+                ct2, _ = _run(capi, a, b, lay, capi.HGEMM_AUTO, 1)
+            finally:
+                capi.tune("hgemm_ragged_tile", 0)
+            assert torch.equal(ct, ct2), tile
+            ulp = torch.clamp(c.float().abs(), min=32.0) * 2.0 ** -10
+            assert ((ct.float() - c.float()).abs() <= ulp).all(), tile
     # the border launch on the side stream ("hgemm_ragged_fork" 2) / behind the interior (1): the same bits; on a stream of the caller's with
     # the operands still being produced on it (the fork event orders the border behind them, the join event the caller's next kernel behind it)
     for fork in (1, 2):

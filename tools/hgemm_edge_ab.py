@@ -55,8 +55,18 @@ for (M, N, K) in shapes:
                     capi.hgemm(a, b2, c, layout=lay, variant=capi.HGEMM_RAGGED, swizzle_stride=host.make_block_swizzle_stride(N, K))
                     capi.tune("hgemm_ragged_fork", 0)
                 return f
-            cands["ragged_seq"] = mk(1)       # border behind the interior on the caller's stream
-            cands["ragged_fork"] = mk(2)      # border on the side stream
+            if "+" in capi.hgemm_kernel_name(M, N, K, lay, capi.HGEMM_RAGGED):
+                cands["ragged_seq"] = mk(1)       # border behind the interior on the caller's stream
+                cands["ragged_fork"] = mk(2)      # border on the side stream
+            else:
+                def mkt(tile):
+                    def f():
+                        capi.tune("hgemm_ragged_tile", tile)
+                        capi.hgemm(a, b2, c, layout=lay, variant=capi.HGEMM_RAGGED, swizzle_stride=host.make_block_swizzle_stride(N, K))
+                        capi.tune("hgemm_ragged_tile", 0)
+                    return f
+                for tile in ((12, 22, 32) if lname == "nn" else (12, 22, 23, 33)):
+                    cands[f"t{tile}"] = mkt(tile)
         except capi.LcError:
             pass
         cands["hipBLASLt"] = lambda: capi.hgemm_vendor(a, b2, c, lay)

@@ -48,6 +48,17 @@ if a.what in ("all", "hgemm"):
             capi.hgemm_vendor(A2, bb, C2, layout=lay)
     torch.cuda.synchronize()
     del A2, B2, C2, Bt2
+    # late round 6: a ragged shape (LC_HGEMM_RAGGED; tools/prof_workloads.py "hgemm_ragged"): the whole of 2000 x 2000 x 2048 on hgemm_mid_edge_kernel<.,2,2,3>
+    # (256 clamped tiles, one round).  No flagship-kernel shape and no vendor launch here: their per-launch averages belong to the 8192^3 / 2048^3 workloads.
+    A3 = torch.randn(2000, 2048, dtype=torch.half, device="cuda")
+    B3 = torch.randn(2048, 2000, dtype=torch.half, device="cuda")
+    C3 = torch.zeros(2000, 2000, dtype=torch.half, device="cuda")
+    Bt3 = host.as_col_major(B3)
+    for lay, bb in ((capi.LAYOUT_TN, Bt3), (capi.LAYOUT_NN, B3)):
+        for _ in range(4 * a.iters):
+            capi.hgemm(A3, bb, C3, layout=lay, variant=capi.HGEMM_AUTO, swizzle_stride=1024)
+    torch.cuda.synchronize()
+    del A3, B3, C3, Bt3
 if a.what in ("all", "attn"):
     q, k, v, o, tv = host.get_qkvo(4, 32, 4096, 128, seed=0)
     for nw in (0, 517, 514, 8):     # default (persistent merged-phase kernel, static walk), the dynamic-queue walk, the generated one-statement-per-phase twin, lock-step

@@ -2,7 +2,7 @@
 shortens it) -> workload key.  bench.py prints a committed per-launch byte count only next to the same key
 (roofline(..., workload=...)): a byte count of another shape would be meaningless."""
 WORKLOADS = [
-    ("hgemm_mid_kernel", "hgemm_2048"), ("hipblaslt:Cijk_Alik_Bljk_MT128x128", "hgemm_2048"), ("hipblaslt:Cijk_Ailk_Bljk_MT128x128", "hgemm_2048"),
+    ("hgemm_mid_edge_kernel", "hgemm_ragged"), ("hgemm_edge_kernel", "hgemm_ragged"), ("hgemm_mid_kernel", "hgemm_2048"), ("hipblaslt:Cijk_Alik_Bljk_MT128x128", "hgemm_2048"), ("hipblaslt:Cijk_Ailk_Bljk_MT128x128", "hgemm_2048"),
     ("hgemm_", "hgemm_8192"), ("hipblaslt:", "hgemm_8192"),
     ("gemm_fp8_", "fp8_16384"),
     # attn_fwd_w4u_kernel<D, VT, WALK>: config 3 (N = 4096) runs the static persistent walk (1), config 4 / the D = 64 shape (N = 8192) one
