@@ -79,6 +79,7 @@ typedef enum lc_hgemm_variant {
   LC_HGEMM_RAGGED = 16,     /* ragged M / N with K % 32 == 0 (K >= 64), N % 8 == 0 (LC_HGEMM_AUTO's choice there): more than half a CU's worth of 256 x 256  */
                             /* tiles: the interior they divide on hgemm_w4y_kernel, the L-shaped border on hgemm_mid_edge_kernel (128 x 128 tiles of the     */
                             /* mid-size kernel that reach beyond M / N: clamped sources, predicated stores) in a second launch; else all of it on that kernel */
+                            /* (tile: "hgemm_ragged_tile"; split-K with workspace partials as "hgemm_mid_splitk" says, one K range under graph capture)      */
   /* the reference's "CUDA-core" ladder as vector-ALU kernels (hgemm_valu.hip; NN only; v_dot2c_f32_f16, fp32 accumulate);
    * shapes a rung does not tile (and TN) run LC_HGEMM_GENERIC */
   LC_HGEMM_VALU_NAIVE = 20,                  /* one thread per C element, operands from global memory                       */

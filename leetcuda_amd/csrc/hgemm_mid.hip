@@ -127,7 +127,7 @@ LC_DEVINL void hgemm_mid_body(const half_t* __restrict__ A, const half_t* __rest
   int m0, n0;
   int bid = (int)blockIdx.x, nblk = (int)gridDim.x, srange = 0;
   if constexpr (SK) {
-    nblk = tiles_m * tiles_n;
+    nblk = EDGE ? panel_w : tiles_m * tiles_n;   // (EDGE: the blocks of the right strip = the whole problem)
     srange = __builtin_amdgcn_readfirstlane(bid / nblk);
     bid -= srange * nblk;
   }
@@ -378,11 +378,13 @@ LC_DEVINL void hgemm_mid_body(const half_t* __restrict__ A, const half_t* __rest
     mid_acc_settle<MI, NI>(acc);
   }
   if constexpr (SK) {   // fp32 partials: a lane owns 4 consecutive n of rows mi * 16 + i16 (16-byte stores, 64 B per row and MFMA block)
-    float* P = part + ((size_t)srange * M + (size_t)(m0 + wr * (TM / 2))) * N + n0 + wc * (TN / 2);
+    // (EDGE: the partials of whole tiles, part[ks][Mp][Np] with Mp x Np = the tile grid's extent — nothing to predicate; the reduce kernel reads what lies inside C)
+    const size_t Mp = EDGE ? (size_t)(panel_w / rem_base) * TM : (size_t)M, Np = EDGE ? (size_t)rem_base * TN : (size_t)N;
+    float* P = part + ((size_t)srange * Mp + (size_t)(m0 + wr * (TM / 2))) * Np + n0 + wc * (TN / 2);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) *(f32x4_t*)(P + (size_t)(mi * 16 + i16) * N + ni * 16 + g * 4) = acc[mi][ni];
+      for (int ni = 0; ni < NI; ++ni) *(f32x4_t*)(P + (size_t)(mi * 16 + i16) * Np + ni * 16 + g * 4) = acc[mi][ni];
     return;
   }
   if constexpr (TMW * TNW >= 9) {   // 192 x 192: straight from the accumulators, 8 bytes per lane (the staged epilogue below makes hipcc keep a second
@@ -437,6 +439,31 @@ __global__ __launch_bounds__(256, (TMW * TNW >= 6) ? 1 : 2) void hgemm_mid_edge_
                                                                                         half_t* __restrict__ C, int M, int N, int K, int Mi, int Ni, int nright,
                                                                                         int nrc) {
   hgemm_mid_body<B_KN, TMW, TNW, NS, false, true>(A, B, C, M, N, K, Mi, Ni, nright, nrc, nullptr, 1);
+}
+// ... split-K of a whole ragged problem (64 / 128 x 128 tiles): ks copies of the tile grid, fp32 partials of whole tiles in part[ks][Mp][Np]
+template <bool B_KN, int TMW, int NS>
+__global__ __launch_bounds__(256, 2) void hgemm_mid_edge_sk_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B, int M, int N, int K, int nright,
+                                                                   int nrc, float* __restrict__ part, int ks) {
+  hgemm_mid_body<B_KN, TMW, 2, NS, true, true>(A, B, nullptr, M, N, K, 0, 0, nright, nrc, part, ks);
+}
+// Sum of those partials in range order, rounded once to fp16: 8 elements (one 16-byte chunk of a row of C, N % 8 == 0) per thread.
+__global__ __launch_bounds__(256) void hgemm_mid_reduce_edge_kernel(const float* __restrict__ part, half_t* __restrict__ C, int M, int N, size_t Mp, size_t Np, int ks) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, cpr = (size_t)N / 8;
+  if (i >= (size_t)M * cpr) return;
+  const size_t row = i / cpr, col = (i - row * cpr) * 8;
+  const float* p = part + row * Np + col;
+  f32x4_t s0 = *(const f32x4_t*)p, s1 = *(const f32x4_t*)(p + 4);
+  for (int r = 1; r < ks; ++r) {
+    s0 += *(const f32x4_t*)(p + (size_t)r * Mp * Np);
+    s1 += *(const f32x4_t*)(p + (size_t)r * Mp * Np + 4);
+  }
+  half8_t h;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = (half_t)s0[e];
+    h[4 + e] = (half_t)s1[e];
+  }
+  *(half8_t*)(C + row * (size_t)N + col) = h;
 }
 template <bool B_KN, int TMW, int NS>
 __global__ __launch_bounds__(256, 2) void hgemm_mid_sk_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B, int M, int N, int K,

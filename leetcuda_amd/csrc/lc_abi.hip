@@ -657,9 +657,9 @@ namespace {
 //           columns Ni .. N, bottom strip: rows Mi .. M x columns 0 .. Ni) on hgemm_mid_edge_kernel in a second launch
 //   kind 2  otherwise: the whole problem on hgemm_mid_edge_kernel (three ring slots while the tiles fit one round of the CUs, else two)
 // Every element of C is computed by exactly one kernel, deterministically; no workspace.  lc_tune_set "hgemm_ragged" = 1: never (hgemm_edge_kernel).
-struct RaggedPlan { int kind, Mi, Ni, ns, tmw, tnw; };
+struct RaggedPlan { int kind, Mi, Ni, ns, tmw, tnw, ks; };   // ks > 1: split-K (kind 2, 64 / 128 x 128 tiles; needs the workspace: none under graph capture)
 RaggedPlan ragged_plan(int M, int N, int K, bool al, bool b_kn, bool gated) {
-  RaggedPlan none{0, 0, 0, 0, 0, 0};
+  RaggedPlan none{0, 0, 0, 0, 0, 0, 1};
   if (!al || K % 32 != 0 || K < BK || N % 8 != 0 || K >= (1 << 22) || N >= (1 << 22)) return none;
   if (M % BM1 == 0 && N % BN1 == 0) return none;   // (a tiled shape)
   if (gated && g_tune_hgemm_ragged == 1) return none;
@@ -668,24 +668,35 @@ RaggedPlan ragged_plan(int M, int N, int K, bool al, bool b_kn, bool gated) {
   if (2 * t256 > ncu && g_tune_hgemm_auto == LC_HGEMM_MFMA256W4Y && w4_effective_variant(LC_HGEMM_MFMA256W4Y, b_kn, N, K) == LC_HGEMM_MFMA256W4Y) {
     const int Mi = (M / BM) * BM, Ni = (N / BN) * BN;
     const long nb = (long)((N - Ni + 127) / 128) * ((M + 127) / 128) + (long)((M - Mi + 127) / 128) * (Ni / 128);   // border blocks
-    return RaggedPlan{1, Mi, Ni, nb <= ncu ? 3 : 2, 2, 2};
+    return RaggedPlan{1, Mi, Ni, nb <= ncu ? 3 : 2, 2, 2, 1};
   }
   // the mid-size kernel's own rule (mid_tile_auto; measured on ragged shapes in profiles/r6ag_hgemm_edge_ab.log): the smallest tile whose grid fits ONE round of
   // at most one workgroup per CU (most workgroups, least work on the busiest CU; three ring slots) — 64 x 128, 128 x 128, then 128 x 192 (TN) / 192 x 128 (NN:
   // 128-column tiles only); where 128 x 128 at two per CU needs more than one double round, 192 x 192 (TN; 3000 x 3000 x 3008: 1074 vs 783 TFLOP/s) /
   // 192 x 128 (NN: 865 vs 724); else 128 x 128 with two slots at two workgroups per CU (2500 x 2504 x 2560 TN: 857 vs 773 on 192 x 192 in one round).
   const int tile_knob = g_tune_hgemm_ragged_tile;
+  // split-K as the mid-size kernel's own (mid_tile_auto, "hgemm_mid_splitk"): a one-round grid of 64 / 128 x 128 tiles on at most half the CUs with a long K — as
+  // many K ranges as fill the CUs, each of at least 32 K tiles, at most 8 (100 x 4096 x 4096: 64 workgroups x 2)
+  auto split_k = [&](RaggedPlan p) {
+    const int ksk = g_tune_hgemm_mid_splitk, KT = K / BK;
+    const long wgs = (long)((M + 64 * p.tmw - 1) / (64 * p.tmw)) * ((N + 127) / 128);
+    if (p.tnw != 2 || p.tmw > 2 || p.ns != 3 || ksk == 1 || wgs > ncu) return p;
+    long ks = ksk >= 2 ? ksk : std::min<long>(std::min<long>(ncu / wgs, KT / 32), 8);
+    while (ks > 1 && KT < 2 * ks) --ks;
+    if (ks > 1 && launch_hgemm_mid_edge_sk_floats(M, N, p.tmw, (int)ks) * sizeof(float) <= ((size_t)256 << 20)) p.ks = (int)ks;
+    return p;
+  };
   auto blocks_of = [&](int tmw, int tnw) { return (long)((M + 64 * tmw - 1) / (64 * tmw)) * ((N + 64 * tnw - 1) / (64 * tnw)); };
   if (tile_knob != 0) {
     const int tmw = tile_knob / 10, tnw = tile_knob % 10;
     const bool legal = b_kn ? tnw == 2 : !(tmw == 3 && tnw == 2);
-    if (legal) return RaggedPlan{2, 0, 0, (tmw == 2 && tnw == 2 && blocks_of(2, 2) > ncu) ? 2 : 3, tmw, tnw};
+    if (legal) return split_k(RaggedPlan{2, 0, 0, (tmw == 2 && tnw == 2 && blocks_of(2, 2) > ncu) ? 2 : 3, tmw, tnw, 1});
   }
-  if (blocks_of(1, 2) <= ncu) return RaggedPlan{2, 0, 0, 3, 1, 2};
-  if (blocks_of(2, 2) <= ncu) return RaggedPlan{2, 0, 0, 3, 2, 2};
-  if (blocks_of(2, 2) > 2 * ncu) return b_kn ? RaggedPlan{2, 0, 0, 3, 3, 2} : RaggedPlan{2, 0, 0, 3, 3, 3};
-  if (b_kn ? blocks_of(3, 2) <= ncu : blocks_of(2, 3) <= ncu) return b_kn ? RaggedPlan{2, 0, 0, 3, 3, 2} : RaggedPlan{2, 0, 0, 3, 2, 3};
-  return RaggedPlan{2, 0, 0, 2, 2, 2};
+  if (blocks_of(1, 2) <= ncu) return split_k(RaggedPlan{2, 0, 0, 3, 1, 2, 1});
+  if (blocks_of(2, 2) <= ncu) return split_k(RaggedPlan{2, 0, 0, 3, 2, 2, 1});
+  if (blocks_of(2, 2) > 2 * ncu) return b_kn ? RaggedPlan{2, 0, 0, 3, 3, 2, 1} : RaggedPlan{2, 0, 0, 3, 3, 3, 1};
+  if (b_kn ? blocks_of(3, 2) <= ncu : blocks_of(2, 3) <= ncu) return b_kn ? RaggedPlan{2, 0, 0, 3, 3, 2, 1} : RaggedPlan{2, 0, 0, 3, 2, 3, 1};
+  return RaggedPlan{2, 0, 0, 2, 2, 2, 1};
 }
 
 // The border launch beside the interior (lc_tune_set "hgemm_ragged_fork"): one side stream per device, forked from the caller's stream
@@ -731,7 +742,13 @@ int launch_ragged_interior(const half_t* A, const half_t* B, half_t* C, int M, i
 
 template <bool B_KN>
 int launch_ragged(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, const RaggedPlan& p, int swizzle_stride, hipStream_t st) {
-  if (p.kind == 2) return launch_hgemm_mid_edge(A, B, C, M, N, K, B_KN, p.tmw, p.tnw, p.ns, 0, 0, st);
+  if (p.kind == 2) {
+    if (p.ks > 1 && !stream_is_capturing(st)) {
+      WorkspaceLease lease = stream_workspace(st, launch_hgemm_mid_edge_sk_floats(M, N, p.tmw, p.ks) * sizeof(float));
+      if (lease.ptr) return launch_hgemm_mid_edge_sk(A, B, C, M, N, K, B_KN, p.tmw, p.ks, static_cast<float*>(lease.ptr), st);
+    }
+    return launch_hgemm_mid_edge(A, B, C, M, N, K, B_KN, p.tmw, p.tnw, p.ns, 0, 0, st);   // (no workspace — graph capture, allocation failure: one K range)
+  }
   // Fork rule (profiles/r6ac … r6af_hgemm_edge_ab*.log; the hardware interleaves the two queues whatever their order or priority): beside an interior of
   // FULL rounds every CU a border block holds costs the interior a round of its own (4100 x 4104 x 4096, one round of 256 tiles: 1122 -> 995 TFLOP/s;
   // 12808^2 x 4096: − 5 %); beside an UNSPLIT last round that leaves at least 3 / 8 of the CUs idle the border fills them (5200^2 x 4096, 400 tiles:
@@ -889,6 +906,7 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
   else if (v == LC_HGEMM_RAGGED) {   // interior kernel + the border launch
     const RaggedPlan p = ragged_plan(M, N, K, true, layout == LC_LAYOUT_NN, variant != LC_HGEMM_RAGGED);
     if (p.kind == 1) snprintf(buf, buflen, "hgemm_w4y_kernel<%s,%d> + hgemm_mid_edge_kernel<%s,2,2,%d>", nn, layout == LC_LAYOUT_NN ? 1 : g_tune_w4y_sched.load(), nn, p.ns);
+    else if (p.kind == 2 && p.ks > 1) snprintf(buf, buflen, "hgemm_mid_edge_sk_kernel<%s,%d,3> x%d", nn, p.tmw, p.ks);   // (x K ranges, + hgemm_mid_reduce_edge_kernel; hgemm_mid_edge_kernel under graph capture)
     else if (p.kind == 2) snprintf(buf, buflen, "hgemm_mid_edge_kernel<%s,%d,%d,%d>", nn, p.tmw, p.tnw, p.ns);
     else snprintf(buf, buflen, "hgemm_edge_kernel<%s>", nn);   // (the knob changed between the two reads)
   } else snprintf(buf, buflen, "hgemm_generic_kernel<%s>", nn);

@@ -213,6 +213,9 @@ int launch_hgemm_mid(const half_t* A, const half_t* B, half_t* C, int M, int N, 
                      hipStream_t st, float* part = nullptr, int ks = 1);
 // 128 x 128 tiles of the mid-size kernel that may reach beyond M / N (hgemm_mid_edge_kernel): strips of C as hgemm_edge_kernel's launcher defines them
 int launch_hgemm_mid_edge(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int tmw, int tnw, int ns, int Mi, int Ni, hipStream_t st);
+// ... split-K of a whole ragged problem (tmw 1 / 2 = 64 / 128 x 128 tiles): part holds launch_hgemm_mid_edge_sk_floats(M, N, tmw, ks) floats
+size_t launch_hgemm_mid_edge_sk_floats(int M, int N, int tmw, int ks);
+int launch_hgemm_mid_edge_sk(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int tmw, int ks, float* part, hipStream_t st);
 int launch_hgemm_mid_rem(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int tmw, int ns, int tiles_m256,
                          int tiles_n256, int pw256, int rem_base, int rem_tiles, hipStream_t st);   // the 256-tile kernel's ragged last round as 128 x 128 quadrants
 int launch_w4_family(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, int variant, bool b_kn,

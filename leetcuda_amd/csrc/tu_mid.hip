@@ -114,6 +114,35 @@ int launch_hgemm_mid_edge(const half_t* A, const half_t* B, half_t* C, int M, in
   }
 }
 
+// Split-K of a whole ragged problem on hgemm_mid_edge_sk_kernel (64 / 128 x 128 tiles, three ring slots): part = ks x Mp x Np floats, Mp x Np = the
+// tile grid's extent (launch_hgemm_mid_edge_sk_floats), then the reduce.  ks >= 2, at least two K tiles per range.
+namespace {
+template <bool B_KN, int TMW>
+int launch_mid_edge_sk(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, float* part, int ks, hipStream_t st) {
+  using G = Mid<TMW, 2, 3>;
+  const long tm = (M + G::TM - 1) / G::TM, tn = (N + G::TN - 1) / G::TN;
+  if (tm * tn * ks > INT_MAX) return LC_ERR_SHAPE;
+  auto kern = hgemm_mid_edge_sk_kernel<B_KN, TMW, 3>;
+  if (int rc = set_dyn_lds(kern, G::LDS)) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tm * tn * ks)), dim3(256), G::LDS, st, A, B, M, N, K, (int)(tm * tn), (int)tn, part, ks);
+  if (int rc = check_launch()) return rc;
+  const size_t chunks = (size_t)M * (N / 8);
+  hipLaunchKernelGGL(hgemm_mid_reduce_edge_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const float*)part, C, M, N, (size_t)tm * G::TM,
+                     (size_t)tn * G::TN, ks);
+  return check_launch();
+}
+}  // namespace
+size_t launch_hgemm_mid_edge_sk_floats(int M, int N, int tmw, int ks) {
+  const size_t tm = (size_t)(M + 64 * tmw - 1) / (64 * tmw), tn = (size_t)(N + 127) / 128;
+  return (size_t)ks * tm * (64 * tmw) * tn * 128;
+}
+int launch_hgemm_mid_edge_sk(const half_t* A, const half_t* B, half_t* C, int M, int N, int K, bool b_kn, int tmw, int ks, float* part, hipStream_t st) {
+  if (N % 8 != 0 || K % 32 != 0 || K < BK || K >= (1 << 22) || N >= (1 << 22)) return LC_ERR_SHAPE;
+  if (!part || (tmw != 1 && tmw != 2) || ks < 2 || ks > 16 || K / BK < 2 * ks) return LC_ERR_ARG;
+  if (b_kn) return tmw == 1 ? launch_mid_edge_sk<true, 1>(A, B, C, M, N, K, part, ks, st) : launch_mid_edge_sk<true, 2>(A, B, C, M, N, K, part, ks, st);
+  return tmw == 1 ? launch_mid_edge_sk<false, 1>(A, B, C, M, N, K, part, ks, st) : launch_mid_edge_sk<false, 2>(A, B, C, M, N, K, part, ks, st);
+}
+
 // The ragged last round of hgemm_w4y_kernel's 256 x 256 grid as 128 x 128 quadrants (tmw = 2) or 64 x 128 eighths (tmw = 1) on this kernel
 // (round 6; until then on hgemm_mfma128_kernel with a workspace split-K): rem_tiles 256-tiles from raster id rem_base on, tiles_m256 /
 // tiles_n256 / pw256 = that grid's dimensions and block map.  ns: ring slots (3 when the blocks fit one round of the CUs, else 2).

@@ -305,13 +305,14 @@ def test_hgemm_dispatch_covers_the_reference_legal_shapes(built):
         assert capi.hgemm_kernel_name(4100, 4104, 4096, lay) == f"hgemm_w4y_kernel<{nn},{sch}> + hgemm_mid_edge_kernel<{nn},2,2,3>"
         assert capi.hgemm_kernel_name(12808, 12808, 4096, lay) == f"hgemm_w4y_kernel<{nn},{sch}> + hgemm_mid_edge_kernel<{nn},2,2,3>"
         assert capi.hgemm_kernel_name(1000, 3000, 4096, lay) == f"hgemm_mid_edge_kernel<{nn},2,2,3>"
-        assert capi.hgemm_kernel_name(100, 4096, 4096, lay) == f"hgemm_mid_edge_kernel<{nn},1,2,3>"        # (the smallest tile whose grid fits one round)
+        assert capi.hgemm_kernel_name(100, 4096, 1024, lay) == f"hgemm_mid_edge_kernel<{nn},1,2,3>"        # (the smallest tile whose grid fits one round)
+        assert capi.hgemm_kernel_name(100, 4096, 4096, lay) == f"hgemm_mid_edge_sk_kernel<{nn},1,3> x2"    # (... split-K when that grid covers at most half the CUs and K is long)
         assert capi.hgemm_kernel_name(2888, 2880, 544, lay, capi.HGEMM_RAGGED) == ("hgemm_mid_edge_kernel<false,3,3,3>" if nn == "false" else "hgemm_mid_edge_kernel<true,3,2,3>")
         assert capi.hgemm_kernel_name(2500, 2504, 2560, lay) == f"hgemm_mid_edge_kernel<{nn},2,2,2>"      # (128 x 128 at two per CU fits one double round)
         capi.tune("hgemm_ragged_tile", 22)
         try:
             assert capi.hgemm_kernel_name(2888, 2880, 544, lay) == f"hgemm_mid_edge_kernel<{nn},2,2,2>"
-            assert capi.hgemm_kernel_name(100, 4096, 4096, lay) == f"hgemm_mid_edge_kernel<{nn},2,2,3>"
+            assert capi.hgemm_kernel_name(100, 4096, 1024, lay) == f"hgemm_mid_edge_kernel<{nn},2,2,3>"
         finally:
             capi.tune("hgemm_ragged_tile", 0)
         capi.tune("hgemm_ragged", 1)

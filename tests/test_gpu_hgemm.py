@@ -580,6 +580,78 @@ def test_ragged_shapes_interior_on_the_tiled_kernels(oracle, layout, shape, kind
     assert torch.equal(cg, c)
 
 
+@pytest.mark.parametrize("layout", ["nn", "tn"])
+def test_ragged_split_k(oracle, layout):
+    """Late round 6: split-K of a whole ragged problem (hgemm_mid_edge_sk_kernel + hgemm_mid_reduce_edge_kernel; fp32 partials of whole tiles in the
+    stream's workspace): LC_HGEMM_AUTO picks it for one-round grids of 64 / 128 x 128 tiles on at most half the CUs with a long K ("hgemm_mid_splitk",
+    the mid-size kernel's own rule); every forced factor against the oracle incl. the K % 64 == 32 half step and K ranges of unequal length, equal to the
+    unsplit launch to the rounding of differently grouped fp32 sums, bit-identical from run to run, nothing written outside C; one K range under graph capture."""
+    capi = _capi()
+    lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
+    nnn = "true" if layout == "nn" else "false"
+    if capi.device_check() == 256:
+        assert capi.hgemm_kernel_name(100, 4096, 4096, lay) == f"hgemm_mid_edge_sk_kernel<{nnn},1,3> x2"
+        assert capi.hgemm_kernel_name(100, 4096, 1024, lay) == f"hgemm_mid_edge_kernel<{nnn},1,2,3>"       # (16 K tiles: never split)
+    for (M, N, K) in ((100, 1032, 4096), (77, 136, 8224), (250, 520, 4128)):
+        torch.manual_seed(M + N + K)
+        a = torch.randn(M, K, dtype=torch.half, device="cuda")
+        b = torch.randn(K, N, dtype=torch.half, device="cuda")
+        truth = oracle.hgemm(a, b.contiguous(), M, N, K, 0, "f32")
+        capi.tune("hgemm_mid_splitk", 1)
+        try:
+            assert capi.hgemm_kernel_name(M, N, K, lay).startswith(f"hgemm_mid_edge_kernel<{nnn},")
+            c1, _ = _run(capi, a, b, lay, capi.HGEMM_AUTO, 1)
+        finally:
+            capi.tune("hgemm_mid_splitk", 0)
+        for tile in (12, 22):
+            for ks in (0, 2, 3, 7, 8):
+                capi.tune("hgemm_ragged_tile", tile)
+                capi.tune("hgemm_mid_splitk", ks)
+                try:
+                    name = capi.hgemm_kernel_name(M, N, K, lay)
+                    bb = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
+                    pad = 4096
+                    buf = torch.full((M * N + 2 * pad,), float("nan"), dtype=torch.half, device="cuda")
+                    c = buf[pad:pad + M * N].view(M, N)
+                    capi.hgemm(a, bb, c, layout=lay, variant=capi.HGEMM_AUTO, swizzle_stride=1)
+                    torch.cuda.synchronize()
+                    c2, _ = _run(capi, a, b, lay, capi.HGEMM_AUTO, 256)
+                finally:
+                    capi.tune("hgemm_ragged_tile", 0)
+                    capi.tune("hgemm_mid_splitk", 0)
+                if ks >= 2:
+                    assert name == f"hgemm_mid_edge_sk_kernel<{nnn},{tile // 10},3> x{ks}", name
+                assert torch.isnan(buf[:pad]).all() and torch.isnan(buf[pad + M * N:]).all()
+                assert torch.equal(c, c2), (M, N, K, tile, ks)
+                ok, mx, _ = tol.hgemm_close(c.float().cpu().numpy(), truth, K)
+                assert ok, (M, N, K, tile, ks, mx)
+                ulp = torch.clamp(c1.float().abs(), min=32.0) * 2.0 ** -10
+                assert ((c.float() - c1.float()).abs() <= ulp).all(), (M, N, K, tile, ks)
+    # under graph capture: one K range, no workspace, the unsplit launch's bits
+    M, N, K = 100, 1032, 8192
+    a = torch.randn(M, K, dtype=torch.half, device="cuda")
+    b = torch.randn(K, N, dtype=torch.half, device="cuda")
+    bb = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
+    capi.tune("hgemm_mid_splitk", 1)
+    try:
+        c1, _ = _run(capi, a, b, lay, capi.HGEMM_AUTO, 1)
+    finally:
+        capi.tune("hgemm_mid_splitk", 0)
+    assert " x" in capi.hgemm_kernel_name(M, N, K, lay) or capi.device_check() != 256
+    cg = torch.full((M, N), float("nan"), dtype=torch.half, device="cuda")
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        capi.hgemm(a, bb, cg, layout=lay, variant=capi.HGEMM_AUTO)              # (warm-up on the capture stream: split)
+        torch.cuda.synchronize()
+        cg.fill_(float("nan"))
+        with torch.cuda.graph(g, stream=s):
+            capi.hgemm(a, bb, cg, layout=lay, variant=capi.HGEMM_AUTO)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cg, c1)
+
+
 @pytest.mark.parametrize("variant", ["mfma256", "pingpong2", "w4b", "w4c", "w4x", "w4y", "generic"])
 def test_identity_times_asymmetric_b_detects_transposes(variant):
     capi = _capi()

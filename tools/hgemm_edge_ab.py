@@ -67,6 +67,17 @@ for (M, N, K) in shapes:
                     return f
                 for tile in ((12, 22, 32) if lname == "nn" else (12, 22, 23, 33)):
                     cands[f"t{tile}"] = mkt(tile)
+
+                def mks(ks):
+                    def f():
+                        capi.tune("hgemm_mid_splitk", ks)
+                        capi.hgemm(a, b2, c, layout=lay, variant=capi.HGEMM_RAGGED, swizzle_stride=host.make_block_swizzle_stride(N, K))
+                        capi.tune("hgemm_mid_splitk", 0)
+                    return f
+                if K // 64 >= 8 and (-(-M // 128)) * (-(-N // 128)) <= 128:
+                    for ks in (1, 2, 4, 8):
+                        if K // 64 >= 2 * ks:
+                            cands[f"sk{ks}"] = mks(ks)
         except capi.LcError:
             pass
         cands["hipBLASLt"] = lambda: capi.hgemm_vendor(a, b2, c, lay)
