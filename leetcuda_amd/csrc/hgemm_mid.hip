@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void hgemm_mid_edge_sk_kernel(const half_t*
   hgemm_mid_body<B_KN, TMW, 2, NS, true, true>(A, B, nullptr, M, N, K, 0, 0, nright, nrc, part, ks);
 }
 // Sum of those partials in range order, rounded once to fp16: 8 elements (one 16-byte chunk of a row of C, N % 8 == 0) per thread.
-__global__ __launch_bounds__(256) void hgemm_mid_reduce_edge_kernel(const float* __restrict__ part, half_t* __restrict__ C, int M, int N, size_t Mp, size_t Np, int ks) {
+static __global__ __launch_bounds__(256) void hgemm_mid_reduce_edge_kernel(const float* __restrict__ part, half_t* __restrict__ C, int M, int N, size_t Mp, size_t Np, int ks) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, cpr = (size_t)N / 8;
   if (i >= (size_t)M * cpr) return;
   const size_t row = i / cpr, col = (i - row * cpr) * 8;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void hgemm_mid_sk_kernel(const half_t* __re
 }
 
 // Sum of the split-K partials part[ks][mn] in range order, rounded once to fp16: 8 elements per thread.
-__global__ __launch_bounds__(256) void hgemm_mid_reduce_kernel(const float* __restrict__ part, half_t* __restrict__ C, size_t mn, int ks) {
+static __global__ __launch_bounds__(256) void hgemm_mid_reduce_kernel(const float* __restrict__ part, half_t* __restrict__ C, size_t mn, int ks) {
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
   if (i >= mn) return;
   f32x4_t s0 = *(const f32x4_t*)(part + i), s1 = *(const f32x4_t*)(part + i + 4);
