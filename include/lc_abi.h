@@ -80,6 +80,9 @@ typedef enum lc_hgemm_variant {
                             /* tiles: the interior they divide on hgemm_w4y_kernel, the L-shaped border on hgemm_mid_edge_kernel (128 x 128 tiles of the     */
                             /* mid-size kernel that reach beyond M / N: clamped sources, predicated stores) in a second launch; else all of it on that kernel */
                             /* (tile: "hgemm_ragged_tile"; split-K with workspace partials as "hgemm_mid_splitk" says, one K range under graph capture)      */
+  LC_HGEMM_KPAD = 17,       /* K % 32 != 0 (K % 8 == 0, N % 8 == 0, K >= 256) (LC_HGEMM_AUTO from a quarter of a 128 x 128 block per CU on, "hgemm_kpad"): A and B   */
+                            /* copied into the stream's workspace with K zero-padded to a multiple of 32, then LC_HGEMM_AUTO on the padded problem (exactly the */
+                            /* same result: zeros add nothing); hgemm_edge_kernel under graph capture / without workspace                                      */
   /* the reference's "CUDA-core" ladder as vector-ALU kernels (hgemm_valu.hip; NN only; v_dot2c_f32_f16, fp32 accumulate);
    * shapes a rung does not tile (and TN) run LC_HGEMM_GENERIC */
   LC_HGEMM_VALU_NAIVE = 20,                  /* one thread per C element, operands from global memory                       */
@@ -171,6 +174,8 @@ const char* lc_build_info(int* is_diag);
  *                  CUs, else 128 x 128 quadrants), 1 = eighths, 2 = quadrants (bit-identical results; A/B knob)
  *   "hgemm_ragged" LC_HGEMM_AUTO on ragged M / N with K % 32 == 0 (K >= 64), N % 8 == 0: 0 = LC_HGEMM_RAGGED (the tiled kernels; 128 x 128 tiles with clamped
  *                  sources and predicated stores on what they do not divide), 1 = never (hgemm_edge_kernel alone; A/B knob)
+ *   "hgemm_kpad"   LC_HGEMM_AUTO on K % 32 != 0 (K % 8 == 0, N % 8 == 0): 0 = auto (LC_HGEMM_KPAD once the shape holds a quarter of a 128 x 128 block per CU), 1 = never
+ *                  (hgemm_edge_kernel), 2 = wherever legal (A/B knob)
  *   "hgemm_ragged_tile"  tile of a ragged problem that runs entirely on hgemm_mid_edge_kernel: 0 = auto (the smallest of 64 x 128, 128 x 128, 128 x 192 (TN) /
  *                  192 x 128 (NN), 192 x 192 (TN) whose grid fits one round of the CUs, three ring slots; else 128 x 128 with two), 12 / 22 / 23 / 32 / 33 = that
  *                  tile where the layout has it (A/B knob)

@@ -19,6 +19,7 @@ HGEMM_MFMA256W4B, HGEMM_MFMA256W4C, HGEMM_MFMA256W4X, HGEMM_MFMA256W4Y = 9, 10, 
 HGEMM_MID = 14   # the one-round kernel (hgemm_mid.hip)
 HGEMM_EDGE = 15  # the vectorised edge kernel (hgemm_edge.hip): any M, N; K % 8 == 0 (NN: N % 8 == 0)
 HGEMM_RAGGED = 16  # ragged M / N, K % 32 == 0, N % 8 == 0: the tiled kernels, clamped 128 x 128 tiles of the mid-size kernel on what they do not divide
+HGEMM_KPAD = 17    # K % 32 != 0 on a large problem: zero-padded operand copies in the workspace + the tuned kernels
 ATTN_SPLIT_Q, ATTN_SHARED_QKV, ATTN_SHARED_KV, ATTN_TILING_QK, ATTN_TILING_QKV, ATTN_SPLIT_KV = range(6)
 
 # every symbol include/lc_abi.h declares: name -> (restype, argtypes)

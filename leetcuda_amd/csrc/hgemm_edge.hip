@@ -176,4 +176,16 @@ __global__ __launch_bounds__(256, 2) void hgemm_edge_kernel(const half_t* __rest
   }
 }
 
+// dst[r][c] (dst_rows x dst_cols) = r < src_rows && c < src_cols ? src[r][c] : 0, in 16-byte chunks (src_cols, dst_cols % 8 == 0): the zero-padded operand
+// copies of LC_HGEMM_KPAD (lc_abi.hip: K % 32 != 0 on a large problem — the padded K runs the tuned kernels, zeros add nothing to a sum)
+static __global__ __launch_bounds__(256) void hgemm_pad_copy_kernel(const half_t* __restrict__ src, half_t* __restrict__ dst, int src_rows, int src_cols,
+                                                                     int dst_rows, int dst_cols) {
+  const size_t cpr = (size_t)dst_cols / 8, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)dst_rows * cpr) return;
+  const size_t r = i / cpr, c = (i - r * cpr) * 8;
+  half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (r < (size_t)src_rows && c < (size_t)src_cols) v = *(const half8_t*)(src + r * (size_t)src_cols + c);
+  *(half8_t*)(dst + r * (size_t)dst_cols + c) = v;
+}
+
 }  // namespace lc

@@ -56,6 +56,7 @@ tune_t g_tune_hgemm_mid_ns{0};                 // ... its LDS ring slots: 0 = au
 tune_t g_tune_hgemm_128w{0};                   // waves of the 128-tile kernel: 0 = auto (eight — intra-workgroup split-K — on grids of <= 0.6 blocks per CU), 1 = always four, 2 = always eight
 tune_t g_tune_hgemm_tail{1};                   // 1 = hand the ragged last wave of the 256-tile kernel to 128 x 128 blocks (launch_mfma256: the mid-size kernel; 2 = round 5's 128-tile kernel + split-K), 0 = one launch
 tune_t g_tune_hgemm_ragged{0};                 // LC_HGEMM_AUTO on ragged M / N with K % 32 == 0: 0 = LC_HGEMM_RAGGED (the tiled kernels, clamped 128 x 128 tiles on what they do not divide), 1 = never (hgemm_edge_kernel)
+tune_t g_tune_hgemm_kpad{0};                   // LC_HGEMM_AUTO on K % 32 != 0 (K % 8 == 0): 0 = auto (zero-padded operand copies + the tuned kernels from a quarter of a 128 x 128 block per CU on), 1 = never (hgemm_edge_kernel), 2 = wherever legal
 tune_t g_tune_hgemm_ragged_tile{0};            // tile of a ragged problem that runs entirely on hgemm_mid_edge_kernel: 0 = auto (ragged_plan), 12 / 22 / 23 / 32 / 33 = that tile (rows / 64, columns / 64; A/B)
 tune_t g_tune_hgemm_ragged_fork{0};            // LC_HGEMM_RAGGED's border launch on a side stream, forked from and joined to the caller's (runs beside the interior): 0 = auto (launch_ragged), 1 = never, 2 = always
 tune_t g_tune_hgemm_tail_tile{0};              // sub-tiles of the ragged tail on the mid-size kernel: 0 = auto (launch_mfma256), 1 = 64 x 128 eighths, 2 = 128 x 128 quadrants
@@ -649,6 +650,22 @@ int launch_attn_d(const half_t* Q, const half_t* K, const half_t* V, half_t* O, 
 }  // namespace
 
 namespace {
+// LC_HGEMM_KPAD (late round 6): K is not a multiple of 32 (K % 8 == 0, N % 8 == 0) on a problem large enough that hgemm_edge_kernel's 0.5 ... 0.66 x of the
+// vendor hurts: A and B are copied into this stream's workspace with K padded to the next multiple of 32 by zeros (products with zero add nothing to an
+// fp32 sum: the result is what the tuned kernels would produce on the padded problem, exactly), and the padded problem runs LC_HGEMM_AUTO's choice —
+// tiled or LC_HGEMM_RAGGED, in its workspace-free form (the operands hold the workspace).  Costs two copies (8192 x 8192 x 8200: 0.54 GB of traffic).
+// Not under graph capture, not beyond the workspace cap: the edge kernel then.  Kp = 0: not this path.
+int kpad_plan(int M, int N, int K, bool al, bool gated) {
+  if (!al || K % 8 != 0 || K % 32 == 0 || N % 8 != 0 || K < 256 || K >= (1 << 22) - 32 || N >= (1 << 22)) return 0;
+  const int knob = g_tune_hgemm_kpad;
+  if (gated && knob == 1) return 0;
+  const long eb = (long)((M + 127) / 128) * ((N + 127) / 128);
+  if (gated && knob == 0 && 4 * eb < rule_cu_count()) return 0;   // (below a quarter of a block per CU three launches cost more than the edge kernel's slower K walk; 1000^3: + 20 %, 8192 x 8192 x 8200: + 75 %)
+  const int Kp = (K + 31) / 32 * 32;
+  if (((size_t)M + N) * Kp * 2 > kWorkspaceCapBytes) return 0;
+  return Kp;
+}
+
 // LC_HGEMM_RAGGED (late round 6): M and / or N are not multiples of the tiles (not legal in the reference, hgemm_mma_stage.cu:675-676), K is
 // (K % 32 == 0, K >= 64) and rows are 16-byte aligned (N % 8 == 0).  The tiled kernels take N as C's / B's row stride and their tile counts
 // separately, and hgemm_mid_edge_kernel (hgemm_mid.hip EDGE) runs 128 x 128 tiles that reach beyond M / N (clamped sources, predicated stores):
@@ -761,7 +778,7 @@ int launch_ragged(const half_t* A, const half_t* B, half_t* C, int M, int N, int
     fork = !split && R > 0 && 8 * (ncu - R) >= 3 * ncu;
   }
   int dev = 0;
-  if (fork && !stream_is_capturing(st) && hipGetDevice(&dev) == hipSuccess) {
+  if (fork && !workspace_held_by_this_thread() && !stream_is_capturing(st) && hipGetDevice(&dev) == hipSuccess) {
     std::unique_lock<std::mutex> lock(workspace_pool(dev).mu);
     ForkLane* l = fork_lane(dev);
     if (l && hipEventRecord(l->fork, st) == hipSuccess && hipStreamWaitEvent(l->side, l->fork, 0) == hipSuccess) {
@@ -819,7 +836,7 @@ namespace {
 bool is_tile256_variant(int v) { return v == LC_HGEMM_MFMA256 || v == LC_HGEMM_MFMA256P2 || is_w4_variant(v); }
 bool is_valu_variant(int v) { return v >= LC_HGEMM_VALU_NAIVE && v <= LC_HGEMM_VALU_T16X8_K32; }
 bool is_hgemm_variant(int v) {
-  return v == LC_HGEMM_AUTO || v == LC_HGEMM_GENERIC || v == LC_HGEMM_EDGE || v == LC_HGEMM_RAGGED || v == LC_HGEMM_MFMA128 || v == LC_HGEMM_MID || is_tile256_variant(v) || is_valu_variant(v);
+  return v == LC_HGEMM_AUTO || v == LC_HGEMM_GENERIC || v == LC_HGEMM_EDGE || v == LC_HGEMM_RAGGED || v == LC_HGEMM_KPAD || v == LC_HGEMM_MFMA128 || v == LC_HGEMM_MID || is_tile256_variant(v) || is_valu_variant(v);
 }
 }  // namespace
 
@@ -861,6 +878,7 @@ int resolve_hgemm_variant(int variant, int M, int N, int K, bool al, bool b_kn) 
     if (tiles64 && mid_tile_auto(M, N, K, b_kn, true).tmw > 0) return LC_HGEMM_MID;   // the tile with the least work on the busiest CU (n = 1280 .. 2816 square)
     if (tiles128) return LC_HGEMM_MFMA128;
     if (rk) return LC_HGEMM_RAGGED;   // the whole problem on 128 x 128 tiles of the mid-size kernel that may reach beyond M / N
+    if (kpad_plan(M, N, K, al, true)) return LC_HGEMM_KPAD;   // K % 32 != 0 on a large problem: zero-padded operand copies + the tuned kernels
     return edge_ok ? LC_HGEMM_EDGE : LC_HGEMM_GENERIC;
   }
   if (is_valu_variant(variant)) {   // a rung of the vector-ALU ladder: its own tile, else the edge kernel (never an error)
@@ -875,6 +893,7 @@ int resolve_hgemm_variant(int variant, int M, int N, int K, bool al, bool b_kn) 
   if (variant == LC_HGEMM_MID && !(al && mid_tile_auto(M, N, K, b_kn, false).tmw > 0)) return LC_ERR_SHAPE;
   if (variant == LC_HGEMM_EDGE && !edge_ok) return LC_ERR_SHAPE;
   if (variant == LC_HGEMM_RAGGED && !ragged_plan(M, N, K, al, b_kn, false).kind) return LC_ERR_SHAPE;
+  if (variant == LC_HGEMM_KPAD && !kpad_plan(M, N, K, al, false)) return LC_ERR_SHAPE;
   return variant;
 }
 }  // namespace
@@ -903,7 +922,12 @@ int lc_hgemm_kernel_name(int M, int N, int K, int layout, int variant, char* buf
     else snprintf(buf, buflen, "hgemm_mid_kernel<%s,%d,%d,%d>", nn, t.tmw, t.tnw, t.ns);
   } else if (v == LC_HGEMM_MFMA128) snprintf(buf, buflen, "hgemm_mfma128_kernel<%s,%d>", nn, mfma128_ksw((long)(M / BM1) * (N / BN1)));
   else if (v == LC_HGEMM_EDGE) snprintf(buf, buflen, "hgemm_edge_kernel<%s>", nn);
-  else if (v == LC_HGEMM_RAGGED) {   // interior kernel + the border launch
+  else if (v == LC_HGEMM_KPAD) {   // the copies + whatever the padded problem runs
+    const int Kp = kpad_plan(M, N, K, true, variant != LC_HGEMM_KPAD);
+    char inner[160];
+    if (Kp <= 0 || lc_hgemm_kernel_name(M, N, Kp, layout, LC_HGEMM_AUTO, inner, (int)sizeof(inner)) != LC_OK) snprintf(buf, buflen, "hgemm_edge_kernel<%s>", nn);
+    else snprintf(buf, buflen, "hgemm_pad_copy_kernel + %s", inner);
+  } else if (v == LC_HGEMM_RAGGED) {   // interior kernel + the border launch
     const RaggedPlan p = ragged_plan(M, N, K, true, layout == LC_LAYOUT_NN, variant != LC_HGEMM_RAGGED);
     if (p.kind == 1) snprintf(buf, buflen, "hgemm_w4y_kernel<%s,%d> + hgemm_mid_edge_kernel<%s,2,2,%d>", nn, layout == LC_LAYOUT_NN ? 1 : g_tune_w4y_sched.load(), nn, p.ns);
     else if (p.kind == 2 && p.ks > 1) snprintf(buf, buflen, "hgemm_mid_edge_sk_kernel<%s,%d,3> x%d", nn, p.tmw, p.ks);   // (x K ranges, + hgemm_mid_reduce_edge_kernel; hgemm_mid_edge_kernel under graph capture)
@@ -1009,6 +1033,7 @@ const Knob kKnobs[] = {
     {"hgemm_ragged", &g_tune_hgemm_ragged, 0, ok_01, false},
     {"hgemm_ragged_fork", &g_tune_hgemm_ragged_fork, 0, ok_02, false},
     {"hgemm_ragged_tile", &g_tune_hgemm_ragged_tile, 0, ok_ragged_tile, false},
+    {"hgemm_kpad", &g_tune_hgemm_kpad, 0, ok_02, false},
     {"hgemm_mid_splitk", &g_tune_hgemm_mid_splitk, 0, ok_08, false},
     {"hgemm_128w", &g_tune_hgemm_128w, 0, ok_02, false},
     {"rule_cus", &g_tune_rule_cus, 0, ok_rule_cus, false},
@@ -1083,7 +1108,7 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   const half_t* b = static_cast<const half_t*>(B);
   half_t* c = static_cast<half_t*>(C);
   const bool al = aligned16(A) && aligned16(B) && aligned16(C);
-  const bool mid_forced = variant == LC_HGEMM_MID, ragged_forced = variant == LC_HGEMM_RAGGED;
+  const bool mid_forced = variant == LC_HGEMM_MID, ragged_forced = variant == LC_HGEMM_RAGGED, kpad_forced = variant == LC_HGEMM_KPAD;
   variant = resolve_hgemm_variant(variant, M, N, K, al, layout == LC_LAYOUT_NN);
   if (variant < 0) return variant;
   if (int rc = launch_guard()) return rc;   // a sticky HIP error of an earlier call: report it, launch nothing
@@ -1104,6 +1129,28 @@ int lc_hgemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int
   if (variant == LC_HGEMM_MFMA128) {
     return layout == LC_LAYOUT_NN ? launch_mfma128<true>(a, b, c, M, N, K, swizzle_stride, st)
                                   : launch_mfma128<false>(a, b, c, M, N, K, swizzle_stride, st);
+  }
+  if (variant == LC_HGEMM_KPAD) {
+    const int Kp = kpad_plan(M, N, K, al, !kpad_forced);
+    if (Kp > 0 && !workspace_held_by_this_thread() && !stream_is_capturing(st)) {
+      WorkspaceLease lease = stream_workspace(st, ((size_t)M + N) * Kp * 2);
+      if (lease.ptr) {
+        half_t* ap = static_cast<half_t*>(lease.ptr);
+        half_t* bp = ap + (size_t)M * Kp;
+        const bool nn = layout == LC_LAYOUT_NN;
+        // A [M][K] -> [M][Kp]; B as [N][K] -> [N][Kp], as [K][N] -> [Kp][N] (zero rows behind the last k)
+        const size_t ca = (size_t)M * (Kp / 8), cb = nn ? (size_t)Kp * (N / 8) : (size_t)N * (Kp / 8);
+        hipLaunchKernelGGL(hgemm_pad_copy_kernel, dim3((unsigned)((ca + 255) / 256)), dim3(256), 0, st, a, ap, M, K, M, Kp);
+        if (nn) hipLaunchKernelGGL(hgemm_pad_copy_kernel, dim3((unsigned)((cb + 255) / 256)), dim3(256), 0, st, b, bp, K, N, Kp, N);
+        else hipLaunchKernelGGL(hgemm_pad_copy_kernel, dim3((unsigned)((cb + 255) / 256)), dim3(256), 0, st, b, bp, N, K, N, Kp);
+        if (int rc = check_launch()) return rc;
+        workspace_held_by_this_thread() = true;   // the padded problem's launch: workspace-free forms, no fork
+        const int rc = lc_hgemm_f16(ap, bp, C, M, N, Kp, layout, LC_HGEMM_AUTO, stages, swizzle_stride, stream);
+        workspace_held_by_this_thread() = false;
+        return rc;
+      }
+    }
+    variant = LC_HGEMM_EDGE;   // (graph capture, no workspace, the knob changed between the two reads: every LC_HGEMM_KPAD shape is an edge-kernel shape)
   }
   if (variant == LC_HGEMM_RAGGED) {
     const RaggedPlan p = ragged_plan(M, N, K, al, layout == LC_LAYOUT_NN, !ragged_forced);

@@ -87,8 +87,15 @@ struct RelaxedCaptureMode {   // hipMalloc / hipFree while another thread's glob
   RelaxedCaptureMode() { ok = hipThreadExchangeStreamCaptureMode(&prev) == hipSuccess; if (!ok) (void)hipGetLastError(); }
   ~RelaxedCaptureMode() { if (ok) (void)hipThreadExchangeStreamCaptureMode(&prev); }
 };
+// A launch sequence that already holds this thread's lease (the K-padding path of lc_hgemm_f16 keeps padded operands in the workspace while the
+// inner launch is enqueued) marks the thread: nested requests get no workspace — their callers run their workspace-free forms — and take no lock.
+inline bool& workspace_held_by_this_thread() {
+  static thread_local bool held = false;
+  return held;
+}
 inline WorkspaceLease stream_workspace(hipStream_t st, size_t bytes) {
   WorkspaceLease lease;
+  if (workspace_held_by_this_thread()) return lease;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) {
     (void)hipGetLastError();

@@ -217,7 +217,7 @@ def test_status_strings_and_argument_errors(built):
     assert lib.lc_hgemm_f16(None, None, None, 256, 256, 256, 0, 0, 2, 1, None) == capi.LC_ERR_ARG
     one = C.c_void_p(16)
     assert lib.lc_hgemm_f16(one, one, one, 256, 256, 256, 7, 0, 2, 1, None) == capi.LC_ERR_ARG
-    for retired in (2, 5, 7, 8, 11, 17, 19, 31):       # round-1 experiment variants / out of range (14 = LC_HGEMM_MID, 15 = LC_HGEMM_EDGE, 16 = LC_HGEMM_RAGGED since round 6)
+    for retired in (2, 5, 7, 8, 11, 18, 19, 31):       # round-1 experiment variants / out of range (14 = LC_HGEMM_MID, 15 = LC_HGEMM_EDGE, 16 = LC_HGEMM_RAGGED, 17 = LC_HGEMM_KPAD since round 6)
         assert lib.lc_hgemm_f16(one, one, one, 256, 256, 256, 0, retired, 2, 1, None) == capi.LC_ERR_ARG
     assert lib.lc_hgemm_f16(one, one, one, 0, 256, 256, 0, 0, 2, 1, None) == capi.LC_ERR_SHAPE
     assert lib.lc_hgemm_f16(one, one, one, 128, 256, 256, 0, capi.HGEMM_MFMA256, 2, 1, None) == capi.LC_ERR_SHAPE
@@ -324,7 +324,20 @@ def test_hgemm_dispatch_covers_the_reference_legal_shapes(built):
         for shp in ((4096, 4096, 4096), (8192, 8192, 8200), (100, 4096, 40), (4100, 4100, 4096)):     # tiled / K % 32 / K < 64 / N % 8: not a ragged-path shape
             with pytest.raises(capi.LcError, match="Tensor size mismatch"):
                 capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_RAGGED)
-        for shp in ((256, 256, 32), (8192, 8192, 8200), (128, 128, 48), (1000, 3000, 4104)):     # K < 64, K % 32: the vectorised edge kernel
+        # K % 32 != 0 (K % 8 == 0) on a large problem: zero-padded operand copies in the workspace + whatever the padded problem runs (LC_HGEMM_KPAD)
+        assert capi.hgemm_kernel_name(8192, 8192, 8200, lay) == f"hgemm_pad_copy_kernel + hgemm_w4y_kernel<{nn},{sch}>"
+        assert capi.hgemm_kernel_name(8200, 8200, 8200, lay) == f"hgemm_pad_copy_kernel + hgemm_w4y_kernel<{nn},{sch}> + hgemm_mid_edge_kernel<{nn},2,2,3>"
+        assert capi.hgemm_kernel_name(2000, 2000, 2056, lay, capi.HGEMM_KPAD) == f"hgemm_pad_copy_kernel + hgemm_mid_edge_kernel<{nn},2,2,3>"
+        capi.tune("hgemm_kpad", 1)
+        try:
+            assert capi.hgemm_kernel_name(8192, 8192, 8200, lay) == f"hgemm_edge_kernel<{nn}>"
+        finally:
+            capi.tune("hgemm_kpad", 0)
+        for shp in ((8192, 8192, 8192), (8192, 8192, 8196), (8192, 8196, 8200), (4096, 4096, 40)):    # K % 32 == 0 / K % 8 / N % 8 / K < 256: not this path
+            with pytest.raises(capi.LcError, match="Tensor size mismatch"):
+                capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_KPAD)
+        assert capi.hgemm_kernel_name(2000, 2000, 2056, lay) == f"hgemm_pad_copy_kernel + hgemm_mid_edge_kernel<{nn},2,2,3>"
+        for shp in ((256, 256, 32), (640, 640, 2056), (128, 128, 48), (1000, 3000, 200)):     # K < 64, K % 32 on small problems / with a short K: the vectorised edge kernel
             assert capi.hgemm_kernel_name(*shp, lay) == f"hgemm_edge_kernel<{nn}>", shp
             assert capi.hgemm_kernel_name(*shp, lay, capi.HGEMM_GENERIC) == f"hgemm_generic_kernel<{nn}>", shp     # ... the element-wise one when asked for
             with pytest.raises(capi.LcError, match="Tensor size mismatch"):

@@ -652,6 +652,82 @@ def test_ragged_split_k(oracle, layout):
     assert torch.equal(cg, c1)
 
 
+@pytest.mark.parametrize("layout", ["nn", "tn"])
+@pytest.mark.parametrize("shape", [(1000, 3000, 520), (2888, 2880, 264), (512, 1024, 4104), (130, 136, 296)])
+def test_k_padding_path(oracle, layout, shape):
+    """Late round 6, LC_HGEMM_KPAD: K % 32 != 0 (K % 8 == 0, N % 8 == 0) — A and B copied into the stream's workspace with K zero-padded to a multiple of
+    32, the padded problem on LC_HGEMM_AUTO's choice (tiled, ragged; their workspace-free forms).  Zeros add nothing to an fp32 sum: the result equals
+    what the same kernel computes on explicitly padded operands BIT FOR BIT; against the oracle and the edge kernel (one output ulp); the source operands
+    are not touched; two streams back to back (one buffer per stream); hgemm_edge_kernel under graph capture."""
+    capi = _capi()
+    M, N, K = shape
+    lay = capi.LAYOUT_NN if layout == "nn" else capi.LAYOUT_TN
+    Kp = (K + 31) // 32 * 32
+    name = capi.hgemm_kernel_name(M, N, K, lay, capi.HGEMM_KPAD)
+    assert name == "hgemm_pad_copy_kernel + " + capi.hgemm_kernel_name(M, N, Kp, lay), name
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, dtype=torch.half, device="cuda")
+    b = torch.randn(K, N, dtype=torch.half, device="cuda")
+    a0, b0 = a.clone(), b.clone()
+    c, _ = _run(capi, a, b, lay, capi.HGEMM_KPAD, 256)
+    assert torch.equal(a, a0) and torch.equal(b, b0) and torch.isfinite(c).all()
+    apad = torch.zeros(M, Kp, dtype=torch.half, device="cuda")
+    bpad = torch.zeros(Kp, N, dtype=torch.half, device="cuda")
+    apad[:, :K] = a
+    bpad[:K] = b
+    capi.tune("hgemm_mid_splitk", 1)       # (the padded problem runs its workspace-free form: the operands hold the workspace)
+    capi.tune("hgemm_splitk", 1)
+    try:
+        cp, _ = _run(capi, apad, bpad, lay, capi.HGEMM_AUTO, 256)
+    finally:
+        capi.tune("hgemm_mid_splitk", 0)
+        capi.tune("hgemm_splitk", 0)
+    if " x" not in capi.hgemm_kernel_name(M, N, Kp, lay):
+        assert torch.equal(c, cp)
+    else:   # (the padded problem would split K through the workspace: inside LC_HGEMM_KPAD it runs the unsplit launch of the same tile, the knob = 1 launch above may be another kernel)
+        ulp = torch.clamp(cp.float().abs(), min=32.0) * 2.0 ** -10
+        assert ((c.float() - cp.float()).abs() <= ulp).all()
+    truth = oracle.hgemm(a, b.contiguous(), M, N, K, 0, "f32") if M * N * K <= 1 << 31 else None
+    if truth is not None:
+        ok, mx, ex = tol.hgemm_close(c.float().cpu().numpy(), truth, K)
+        assert ok, (mx, ex)
+    ce, _ = _run(capi, a, b, lay, capi.HGEMM_EDGE)
+    ulp = torch.clamp(ce.float().abs(), min=32.0) * 2.0 ** -10
+    assert ((c.float() - ce.float()).abs() <= ulp).all()
+    # two streams, several launches each, operands rewritten between launches
+    outs = []
+    bb = host.as_col_major(b) if lay == capi.LAYOUT_TN else b
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for it in range(3):
+        for st in streams:
+            with torch.cuda.stream(st):
+                ci = torch.full((M, N), float("nan"), dtype=torch.half, device="cuda")
+                capi.hgemm(a, bb, ci, layout=lay, variant=capi.HGEMM_KPAD, swizzle_stride=256)
+                outs.append(ci)
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, c) for o in outs)
+    # LC_HGEMM_AUTO follows "hgemm_kpad" (2 = wherever legal); under graph capture: no workspace -> the edge kernel
+    capi.tune("hgemm_kpad", 2)
+    try:
+        assert capi.hgemm_kernel_name(M, N, K, lay) == name
+        c2, _ = _run(capi, a, b, lay, capi.HGEMM_AUTO, 256)
+        cg = torch.full((M, N), float("nan"), dtype=torch.half, device="cuda")
+        s = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            capi.hgemm(a, bb, cg, layout=lay, variant=capi.HGEMM_AUTO)
+            torch.cuda.synchronize()
+            cg.fill_(float("nan"))
+            with torch.cuda.graph(g, stream=s):
+                capi.hgemm(a, bb, cg, layout=lay, variant=capi.HGEMM_AUTO)
+        g.replay()
+        torch.cuda.synchronize()
+    finally:
+        capi.tune("hgemm_kpad", 0)
+    assert torch.equal(c2, c) and torch.equal(cg, ce)
+
+
 @pytest.mark.parametrize("variant", ["mfma256", "pingpong2", "w4b", "w4c", "w4x", "w4y", "generic"])
 def test_identity_times_asymmetric_b_detects_transposes(variant):
     capi = _capi()

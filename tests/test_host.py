@@ -373,7 +373,8 @@ def test_bench_traffic_keys_exist_in_committed_pmc_summary(built):
     assert capi.hgemm_kernel_name(1024, 1024, 1024, capi.LAYOUT_NN) == "hgemm_mid_kernel<true,1,2,3>"       # (round 6: 64 x 128 tiles, one round)
     assert capi.hgemm_kernel_name(512, 512, 512, capi.LAYOUT_NN) == "hgemm_mfma128_kernel<true,2>"
     assert capi.hgemm_kernel_name(1000, 1024, 1024, capi.LAYOUT_NN) == "hgemm_mid_edge_kernel<true,1,2,3>"       # (late round 6: clamped tiles of the mid-size kernel; K % 32: hgemm_edge_kernel; K % 8: hgemm_generic_kernel)
-    assert capi.hgemm_kernel_name(1000, 1024, 1032, capi.LAYOUT_NN) == "hgemm_edge_kernel<true>"
+    assert capi.hgemm_kernel_name(1000, 1024, 200, capi.LAYOUT_NN) == "hgemm_edge_kernel<true>"
+    assert capi.hgemm_kernel_name(1000, 1024, 1032, capi.LAYOUT_NN) == "hgemm_pad_copy_kernel + hgemm_mid_edge_kernel<true,1,2,3>"   # (K % 32 != 0, K >= 256: zero-padded copies + the tuned kernels)
     assert capi.hgemm_kernel_name(1000, 1024, 1028, capi.LAYOUT_NN) == "hgemm_generic_kernel<true>"
     assert capi.attn_kernel_name(4096, 128) == "attn_fwd_w4u_kernel<128,false,1>"            # config 3: the persistent workgroup, static walk
     assert capi.attn_kernel_name(8192, 128) == "attn_fwd_w4u_kernel<128,false,0>"            # config 4: one block per workgroup (the dispatcher balances 16+ blocks per CU best)

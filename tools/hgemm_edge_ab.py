@@ -80,6 +80,11 @@ for (M, N, K) in shapes:
                             cands[f"sk{ks}"] = mks(ks)
         except capi.LcError:
             pass
+        try:
+            capi.hgemm_kernel_name(M, N, K, lay, capi.HGEMM_KPAD)
+            cands["kpad"] = lambda: capi.hgemm(a, b2, c, layout=lay, variant=capi.HGEMM_KPAD, swizzle_stride=host.make_block_swizzle_stride(N, K))
+        except capi.LcError:
+            pass
         cands["hipBLASLt"] = lambda: capi.hgemm_vendor(a, b2, c, lay)
         for f in cands.values():
             burst(f, 2)
@@ -96,6 +101,7 @@ for (M, N, K) in shapes:
         print(f"{M}x{N}x{K} {lname} auto={capi.hgemm_kernel_name(M, N, K, lay)} " + " ".join(f"{k} {v:7.1f}" for k, v in rate.items())
               + (f" | edge / generic {rate['edge'] / rate['generic']:.2f}, edge / vendor {rate['edge'] / rate['hipBLASLt']:.3f}" if "edge" in rate else "")
               + (f", ragged / edge {rate['ragged'] / rate['edge']:.2f}" if "ragged" in rate and "edge" in rate else "")
+              + (f", kpad / edge {rate['kpad'] / rate['edge']:.2f}" if "kpad" in rate and "edge" in rate else "")
               + f", auto / vendor {rate['auto'] / rate['hipBLASLt']:.3f}",
               flush=True)
 capi.vendor_destroy()
