@@ -55,7 +55,7 @@ typedef enum lc_layout { LC_LAYOUT_NN = 0, LC_LAYOUT_TN = 1 } lc_layout;
 typedef enum lc_hgemm_variant {
   LC_HGEMM_AUTO = 0,       /* best available for the shape: the reference's legal shapes (M, N % 128 == 0, K % 32 == 0, K >= 64;
                               hgemm_mma_stage.cu:650,675-676) run MFMA256W4Y when the 256-tileable interior has > 128 tiles (128-wide
-                              border strips on MFMA128 in a second launch), MID / MFMA128 otherwise; every other shape RAGGED, EDGE or GENERIC */
+                              border strips on MFMA128 in a second launch), MID / MFMA128 otherwise; every other shape RAGGED, KPAD, EDGE or GENERIC */
   LC_HGEMM_MFMA256 = 1,    /* 256x256x64 WG tile, 8 wave64, LDS-DMA double buffer, one barrier / K-tile (simplest)      */
   LC_HGEMM_GENERIC = 3,    /* 64x64x32 edge-predicated MFMA kernel: any M,N,K                                           */
   LC_HGEMM_MFMA256P2 = 4,  /* 8-wave ping-pong, 2 phases of 16 MFMAs per K tile, DMA issued inside the MFMA clusters:
@@ -82,7 +82,8 @@ typedef enum lc_hgemm_variant {
                             /* (tile: "hgemm_ragged_tile"; split-K with workspace partials as "hgemm_mid_splitk" says, one K range under graph capture)      */
   LC_HGEMM_KPAD = 17,       /* K % 32 != 0 (K % 8 == 0, N % 8 == 0, K >= 256) (LC_HGEMM_AUTO from a quarter of a 128 x 128 block per CU on, "hgemm_kpad"): A and B   */
                             /* copied into the stream's workspace with K zero-padded to a multiple of 32, then LC_HGEMM_AUTO on the padded problem (exactly the */
-                            /* same result: zeros add nothing); hgemm_edge_kernel under graph capture / without workspace                                      */
+                            /* same result: zeros add nothing; the padded problem runs its workspace-free form — lc_hgemm_kernel_name reports its default launch, */
+                            /* a split-K suffix " xN" there does not apply); hgemm_edge_kernel under graph capture / without workspace                          */
   /* the reference's "CUDA-core" ladder as vector-ALU kernels (hgemm_valu.hip; NN only; v_dot2c_f32_f16, fp32 accumulate);
    * shapes a rung does not tile (and TN) run LC_HGEMM_GENERIC */
   LC_HGEMM_VALU_NAIVE = 20,                  /* one thread per C element, operands from global memory                       */
